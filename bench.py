@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- element operator-applies/s of the MiMSEM hot path on MI355X (BASELINE.json metric).
+
+A "step" = one application of the 1-form mass operator (Umat, SURVEY row B1: gather -> interpolate ->
+Jacobian/thickness-weighted scale -> project -> deterministic scatter-add) to EVERY (element, level) pair of
+the p=3, 24x24x6 cubed sphere with 30 levels (BASELINE config 4 grid, 103 680 pairs), inputs resident in HBM.
+N>1: the 24 patches (12x12 elements) are dealt to the ranks (strong scaling) and each step ends with the
+halo reduce (RCCL send/recv over xGMI) that replaces the reference's VecScatter REVERSE/ADD.
+
+Prints ONE JSON line (rank 0).  roofline: dominant kernel k_elem_apply<3,UMAT>, HIP-event timed inside the
+timed region.  cpu_baseline: the oracle's reference-structure (assemble CSR + SpMV) path on host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PN, NE, NPATCH, NK = 3, 24, 24, 30
+SCALE = 1.0e8
+# algorithmic bytes per (element, level) unit, p=3 (DESIGN.md "Roofline accounting")
+BYTES_OP_B1 = 1440          # whole B1 apply incl. y read-modify-write and 96 B of indices
+BYTES_K1_B1 = 1248          # the element kernel alone: 120 dbl in + 24 dbl out + 96 B indices
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_worker(args):
+    """one host core: reference-structure assemble+MatMult on a 12x12-element patch for ~`budget` seconds"""
+    budget, seed = args
+    from oracle import pyoracle
+    from tests.helpers import make_patch
+    cs, topo, geom, P, rng = make_patch(pyoracle, PN, 12, 6, 0, nk=2, seed=seed)
+    x = rng.standard_normal(P.n1)
+    sec, _ = P.bench_assemble_mult("UMAT", x, 2, lev=1, scale=SCALE, flag=1)
+    reps = max(2, int(budget / (sec / 2)))
+    sec, _ = P.bench_assemble_mult("UMAT", x, reps, lev=1, scale=SCALE, flag=1)
+    return P.nEl * reps, sec
+
+
+def cpu_baseline(budget=12.0):
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    with mp.get_context("spawn").Pool(cores) as pool:
+        t0 = time.time()
+        res = pool.map(cpu_worker, [(budget, s) for s in range(cores)])
+        wall = time.time() - t0
+    units = sum(u for u, _ in res)
+    slowest = max(s for _, s in res)
+    return {"value": units / slowest, "unit": "element operator-applies/s", "cores": cores, "kind": "port",
+            "per_core": units / slowest / cores,
+            "sample": f"Umat assemble(CSR)+MatMult, reference cost structure, one 12x12-element p=3 patch per core, "
+                      f"{units // cores} element-applies per core in {slowest:.1f}s (gcc -O3)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
+    from mimsem_amd.topo import Topo
+    from tests.helpers import z_levels
+
+    cs = CubedSphere(PN, NE, NPATCH)
+    coords = sphere_coords(PN, NE)
+    pids = patches_of_rank(NPATCH, world, rank)
+    topos = [Topo(cs, p, NK) for p in pids]
+    geoms = [Geom(t, cs, coords, NK) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(NK, g.n0))
+    dm = DeviceMesh(topos, geoms, nk=NK, numbering="global")
+    eng = Engine(dm, device=local_rank)
+    rng = np.random.default_rng(20241024 + rank)
+    x = eng.tensor(rng.standard_normal((NK, dm.n1)))
+    y = eng.zeros(NK, dm.n1)
+    halo = None
+    if world > 1:
+        plan1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)[1]
+        halo = HaloExchanger(plan1, engine=eng)
+
+    def step():
+        eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)
+        if halo is not None:
+            halo.reverse_add(y)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms1, ms2, nl = eng.profile_read()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    units_total = cs.ne * cs.ne * 6 * NK            # all ranks together
+    units_rank = dm.nEl * NK
+    value = units_total * a.steps / dt
+    out = {
+        "metric": "element operator-applies/sec", "value": value, "unit": "element operator-applies/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Umat (B1, 1-form mass) matrix-free apply over every (element, level) pair of the "
+                               "p=3 24x24x6 cubed sphere x 30 levels (BASELINE config 4 grid); N>1 adds the xGMI halo reduce",
+                   "order": PN, "elements": cs.ne * cs.ne * 6, "levels": NK, "units_per_step": units_total,
+                   "patches": NPATCH, "patches_per_gpu": len(pids), "scale": SCALE},
+    }
+    if nl:
+        k1 = ms1 / nl * 1e-3
+        k12 = (ms1 + ms2) / nl * 1e-3
+        a1 = units_rank * BYTES_K1_B1 / k1 / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_elem_apply<3,UMAT>", "achieved": a1, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic": None,
+                           "avg_kernel_us": k1 * 1e6, "bytes_per_unit": BYTES_K1_B1, "units_per_launch": units_rank}
+        a12 = units_rank * BYTES_OP_B1 / k12 / 1e9
+        out["roofline_op"] = {"bound": "hbm", "kernels": "k_elem_apply<3,UMAT> + k_gather_sum<2>", "achieved": a12,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a12 / HBM_PEAK_GBS,
+                              "avg_us": k12 * 1e6, "bytes_per_unit": BYTES_OP_B1}
+    if a.families and rank == 0 and world == 1:
+        fam = {}
+        h = eng.tensor(rng.uniform(1, 2, (NK, dm.n2)) * 1e3)
+        q0 = eng.tensor(rng.standard_normal((NK, dm.n0)) * 1e-4)
+        x2 = eng.tensor(rng.standard_normal((NK, dm.n2)))
+        x0 = eng.tensor(rng.standard_normal((NK, dm.n0)))
+        cases = [("UMAT", x, None, 1), ("UHMAT", x, h, 1), ("ROTMAT", x, q0, 0), ("WTQUMAT", x, x, 0), ("WMAT", x2, None, 1),
+                 ("WHMAT", x2, h, 1), ("PMAT", x0, None, 0), ("UTQWMAT", x2, x, 0)]
+        for op, xin, f, fl in cases:
+            for _ in range(5):
+                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(50):
+                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl)
+            torch.cuda.synchronize()
+            fam[op] = units_rank * 50 / (time.perf_counter() - t1)
+        out["families"] = fam
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+/*
+ * include/mimsem_hip.h -- C ABI of libmimsem_hip.so: the MI355X (gfx950) element-operator engine
+ * for the MiMSEM per-element assemble/apply layer and the per-column (HEVI) vertical operators.
+ *
+ * Drop-in boundary.  The reference has no FFI; its boundary is the C++ class surface
+ * of eul/Assembly.h, eul/VertOps.h, eul/L2Vecs.h over PETSc Vec/Mat.  Each entry point below names
+ * the reference interface it replaces; INTEGRATION.md shows the reference-side binding.  The
+ * reference idiom
+ *       X->assemble(<fields>, lev, scale, ...);  MatMult(X->M, x, y);        (e.g. eul/HorizSolve.cpp:216-221)
+ * becomes ONE call  mimsem_op_apply(ctx, MIMSEM_OP_X, ...)  -- matrix-free, batched over levels --
+ * and callers that still need the assembled PETSc Mat get the dense element blocks that the
+ * reference hands to MatSetValues from  mimsem_op_element_matrices().
+ *
+ * Conventions: plain pointers and sizes only.  All arithmetic IEEE FP64, all indices int32.
+ * "dev" pointers are device (HBM) addresses (hipMalloc / torch tensor data_ptr / mimsem_malloc);
+ * "host" pointers are ordinary memory.  Vectors follow the PETSc layout the reference reads through
+ * VecGetArray: contiguous doubles; a multi-level field is addressed as base + k*lev_stride.
+ * Every function returns 0 on success or a negative MIMSEM_ERR_* code (the reference itself has no
+ * error convention: PETSc codes are ignored and Inv's error int is dropped, eul/VertOps.cpp:434).
+ * Launches are asynchronous on the context's stream; nothing here synchronises unless it says so.
+ */
+#ifndef MIMSEM_HIP_H
+#define MIMSEM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMSEM_ABI_VERSION 1
+
+enum {
+    MIMSEM_OK = 0,
+    MIMSEM_ERR_ARG = -1,          /* null / out-of-range argument                              */
+    MIMSEM_ERR_UNSUPPORTED = -2,  /* order outside 1..7 or quadrature order != element order   */
+    MIMSEM_ERR_HIP = -3,          /* a HIP runtime call failed (see mimsem_last_hip_error)     */
+    MIMSEM_ERR_STATE = -4,        /* call needs data not yet given (e.g. levels not set)       */
+    MIMSEM_ERR_SINGULAR = -5      /* a block inverse hit |pivot| < 1e-12 (LinAlg.cpp:243)      */
+};
+
+typedef struct mimsem_ctx mimsem_ctx;
+
+/* What one device holds: any set of cubed-sphere patches flattened to element -> vector-slot tables.
+ * Host pointers, copied at creation.  Replaces the per-rank Topo/Geom members the operator classes
+ * read (eul/Topo.h:5-51, eul/Geom.h:8-36): pass Topo::elInds*_l for a single reference rank, or
+ * device-global slots (loc* composed with a compaction) when several patches share one GPU. */
+typedef struct mimsem_mesh_desc {
+    int elOrd;            /* Topo::elOrd                                                        */
+    int quadOrd;          /* Geom::quad->n  (must equal elOrd)                       */
+    int nEl;              /* elements on this device                                            */
+    int nk;               /* Geom::nk vertical levels (>= 1; 1 for the shallow-water stack)     */
+    int n0, n1, n2;       /* lengths of 0/1/2-form vectors per level (Topo::n0,n1,n2)           */
+    const int* inds0;     /* [nEl][(n+1)^2]  Topo::elInds0_l   eul/Topo.cpp:200-212             */
+    const int* inds1x;    /* [nEl][(n+1)n]   Topo::elInds1x_l  :214-226                         */
+    const int* inds1y;    /* [nEl][n(n+1)]   Topo::elInds1y_l  :228-240                         */
+    const int* inds2;     /* [nEl][n^2] or NULL = element-contiguous e*n^2+i (Topo::elInds2_l :242-251) */
+    const double* det;    /* [nEl][(m+1)^2]      Geom::det   eul/Geom.cpp:726-741               */
+    const double* J;      /* [nEl][(m+1)^2][4]   Geom::J  as J00 J01 J10 J11                    */
+    const double* thick;    /* [nk][nEl][(m+1)^2] layer thickness AT each element's quad points
+                               (Geom::thick[k][Geom::elInds0_l(e)[q]]), or NULL -> 1            */
+    const double* thickInv; /* same shape, Geom::thickInv; NULL -> 1/thick (or 1)               */
+} mimsem_mesh_desc;
+
+/* horizontal operator classes, eul/Assembly.h (src/Assembly.h twins: scale=1, no thickness) */
+enum mimsem_op {
+    MIMSEM_OP_UMAT = 0,     /* Umat::assemble(lev,scale,vert_scale)         Assembly.cpp:66-153    1-form -> 1-form */
+    MIMSEM_OP_WMAT = 1,     /* Wmat::assemble(lev,scale,vert_scale)         :324-373               2 -> 2           */
+    MIMSEM_OP_UHMAT = 2,    /* Uhmat::assemble(h2,lev,const_vert,scale)     :416-474   f=h2 (2-form)  1 -> 1        */
+    MIMSEM_OP_PMAT = 3,     /* Pmat::assemble(lev,scale)                    :2004-2046             0 -> 0           */
+    MIMSEM_OP_PHMAT = 4,    /* Pmat::assemble_h(lev,scale,h2)               :2048-2098 f=h2           0 -> 0        */
+    MIMSEM_OP_WTQUMAT = 5,  /* WtQUmat::assemble(u1,lev,scale)              :933-986   f=u1 (1-form)  1 -> 2        */
+    MIMSEM_OP_ROTMAT = 6,   /* RotMat::assemble(q0,lev,scale)               :1030-1083 f=q0 (0-form)  1 -> 1        */
+    MIMSEM_OP_WHMAT = 7,    /* Whmat::assemble(rho,lev,scale,vert_scale_rho):1243-1299 f=rho (2-form) 2 -> 2        */
+    MIMSEM_OP_UTMAT = 8,    /* Ut_mat::assemble(lev,scale)                  :1338-1386 (needs lev+1 < nk) 1 -> 1    */
+    MIMSEM_OP_UTMAT_H = 9,  /* Ut_mat::assemble_h(lev,scale,rho)            :1388-1438 f=rho          1 -> 1        */
+    MIMSEM_OP_UTQWMAT = 10, /* UtQWmat::assemble(u1,scale)                  :1490-1538 f=u1           2 -> 1        */
+    MIMSEM_OP_WTQDUDZ = 11, /* WtQdUdz_mat::assemble(u1,scale)              :1581-1640 f=u1           1 -> 2        */
+    MIMSEM_OP_WMATINV = 12, /* WmatInv::assemble(lev,scale)                 :1673-1722 element-wise inverse 2 -> 2  */
+    MIMSEM_OP_WHMATINV = 13,/* WhmatInv::assemble(rho,lev,scale)            :1744-1802 f=rho          2 -> 2        */
+    MIMSEM_OP_COUNT
+};
+/* op flag: the boolean the reference method takes (vert_scale / const_vert / vert_scale_rho) */
+#define MIMSEM_FLAG_VERT   1u
+/* y += result instead of y = result (Uvec::assemble_hu(..., zero_and_scatter=false, ...), :2198-2279) */
+#define MIMSEM_FLAG_ACCUM  2u
+
+/* ---- context ------------------------------------------------------------------------------- */
+int  mimsem_abi_version(void);
+const char* mimsem_strerror(int code);
+const char* mimsem_last_hip_error(void);
+int  mimsem_device_count(void);
+
+/* device = HIP ordinal.  Builds GLL/edge tables (eul/Basis.cpp), copies the mesh, builds the
+ * deterministic scatter-add plans.  Replaces: Topo+Geom+LagrangeNode/Edge ctor arguments of every
+ * Assembly.h class (eul/Assembly.cpp:26-30). */
+int  mimsem_ctx_create(const mimsem_mesh_desc* desc, int device, mimsem_ctx** out);
+void mimsem_ctx_destroy(mimsem_ctx* ctx);
+/* run all subsequent launches on this hipStream_t (NULL = default stream) */
+int  mimsem_ctx_set_stream(mimsem_ctx* ctx, void* hip_stream);
+int  mimsem_ctx_sync(mimsem_ctx* ctx);
+/* refresh thickness after Geom::initTopog (eul/Geom.cpp:743-764); host arrays [nk][nEl][(m+1)^2] */
+int  mimsem_ctx_set_levels(mimsem_ctx* ctx, const double* thick, const double* thickInv);
+/* bytes of device workspace the context currently holds */
+long long mimsem_ctx_workspace_bytes(const mimsem_ctx* ctx);
+/* Measurement hook (bench.py): when on, mimsem_op_apply brackets its element kernel (pass 1) and its
+ * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
+ * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */
+int  mimsem_ctx_set_profiling(mimsem_ctx* ctx, int on);
+int  mimsem_ctx_profile_read(mimsem_ctx* ctx, double* ms_pass1, double* ms_pass2, long long* launches);
+
+/* plain device memory helpers so a C/C++ host (PETSc VecGetArray side) needs no HIP headers */
+int  mimsem_malloc(void** dev, long long bytes);
+int  mimsem_free(void* dev);
+int  mimsem_memcpy_h2d(mimsem_ctx* ctx, void* dev, const void* host, long long bytes);
+int  mimsem_memcpy_d2h(mimsem_ctx* ctx, void* host, const void* dev, long long bytes);
+int  mimsem_memset(mimsem_ctx* ctx, void* dev, int byte, long long bytes);
+
+/* ---- horizontal operators (rows B1..B17) ---------------------------------------------------- */
+/* y_k = A_op(geometry, level k, f_k) x_k   for k = lev0 .. lev0+nlev-1, all on device vectors with
+ * the "local" (ghost-in-place) layout.  Replaces X->assemble(...) + MatMult(X->M, x, y) for the
+ * enum's class, and Uvec::assemble/assemble_hu/assemble_wxu (Assembly.cpp:2124-2430), which are
+ * UMAT/UHMAT/ROTMAT applied to the velocity (fac -> `alpha`).
+ *   f, f_stride : coefficient field of the op (NULL when it takes none), level stride in doubles
+ *   x, y        : input / output device vectors, sizes by the op's spaces, level strides in doubles
+ *   alpha       : result is scaled by alpha (1.0 for MatMult semantics; Uvec's `fac`)
+ *   geom_lev0   : geometry level of the first vector level (normally == lev0; the shallow-water
+ *                 stack passes 0 with nk = 1)                                                   */
+int mimsem_op_apply(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                    const double* f, long long f_stride,
+                    const double* x, long long x_stride,
+                    double* y, long long y_stride, double alpha);
+
+/* The dense element blocks the reference passes to MatSetValues (row-major, block order as in the
+ * reference: UMAT-like [4][n1e][n1e] = UtQU UtQV VtQU VtQV; ROTMAT [2] = UtQV VtQU; WTQU-like [2];
+ * UTQW [2]; 2-form [n2e][n2e]; 0-form [n0e][n0e]).  out: device, [nEl][esz].                     */
+int mimsem_op_elmat_size(const mimsem_ctx* ctx, int op);
+int mimsem_op_element_matrices(mimsem_ctx* ctx, int op, int geom_lev, double scale, unsigned flags,
+                               const double* f, double* out);
+
+/* Pvec::assemble / Phvec::assemble (Assembly.cpp:602-689): lumped 0-form mass as a vector */
+int mimsem_pvec(mimsem_ctx* ctx, int geom_lev0, int nlev, double scale,
+                const double* h2, long long h_stride, double* y, long long y_stride);
+
+/* incidence matrices (E10mat :1102-1162, E21mat :1170-1220) applied as stencils.
+ * which: 0 = E10 (0->1, own west/south edges), 1 = E21 (1->2), 2 = E12 = -E21^T (2->1), 3 = E01 = -E10^T (1->0) */
+int mimsem_incidence_apply(mimsem_ctx* ctx, int which, int nlev,
+                           const double* x, long long x_stride, double* y, long long y_stride);
+
+/* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
+enum mimsem_colop {
+    MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,
+    MIMSEM_V_CONST_THETA = 4, MIMSEM_V_EOS_BLOCK = 5, MIMSEM_V_LINEAR = 6, MIMSEM_V_LINEAR_INV = 7,
+    MIMSEM_V_LINEAR_RT = 8, MIMSEM_V_LINEAR_THETA = 9, MIMSEM_V_LINEAR_RHO2 = 10, MIMSEM_V_RAYLEIGH = 11,
+    MIMSEM_V_LINCON = 12, MIMSEM_V_LINCON2 = 13, MIMSEM_V_CONLIN = 14, MIMSEM_V_CONLIN_W = 15,
+    MIMSEM_V_CONLIN_RHODPI = 16, MIMSEM_V_COUNT
+};
+/* L2Vecs::HorizToVert (dir=0) / VertToHoriz (dir=1), eul/L2Vecs.cpp:55-101:
+ * vh[k*h_stride + e*n2e + i] <-> vz[e*nkv*n2e + k*n2e + i], nkv levels (nk, nk-1 or nk+1)        */
+int mimsem_l2_transpose(mimsem_ctx* ctx, int dir, int nkv, double* vh, long long h_stride, double* vz);
+
+/* Block structure of a column operator for ALL columns: the (block-diagonal or block-bidiagonal)
+ * n2e x n2e blocks VertOps::Assemble*(ex,ey,[Vec..],Mat) would MatSetValues.  Fields are "vertical"
+ * vectors vz[e][k*n2e+i] (L2Vecs::vz).  out: device [nEl][nblk][n2e][n2e], nblk from
+ * mimsem_colop_nblocks (block order documented in DESIGN.md).                                     */
+int mimsem_colop_nblocks(const mimsem_ctx* ctx, int colop);
+int mimsem_colop_blocks(mimsem_ctx* ctx, int colop, unsigned flags,
+                        const double* f1, const double* f2, double* out);
+/* y_e = A_colop(e) x_e for every column (MatMult(vo->VX, x, y) after vo->AssembleX(ex,ey,..)),
+ * transpose != 0 applies A^T (MatMultTranspose, eul/VertSolve.cpp:486)                           */
+int mimsem_colop_apply(mimsem_ctx* ctx, int colop, unsigned flags, int transpose,
+                       const double* f1, const double* f2, const double* x, double* y);
+
+/* EOS / log / exp column vectors (C7), eul/VertOps.cpp:732-787, :987-1047, :1204-1305.
+ * which: 0 = Assemble_EOS_Residual(rt=a, exner=b) ; 1 = Assemble_EOS_RHS(rt=a, factor=p0, exponent=p1) ;
+ *        2 = AssembleConstWithLogThetaPlusEta(theta=a, eta=b or NULL) ; 3 = AssembleConstWithRhoExpEta(rho=a, eta=b) */
+int mimsem_column_eos(mimsem_ctx* ctx, int which, const double* a, const double* b,
+                      double p0, double p1, double* out);
+
+/* C6: theta diagnosis per column.  which: 0 = diagTheta_L2 (eul/VertSolve.cpp:322-352),
+ * 1 = diagTheta2 (:289-319; theta has nk+1 levels).  rho, rt, theta: vertical vectors.            */
+int mimsem_column_diag_theta(mimsem_ctx* ctx, int which, const double* rho, const double* rt, double* theta);
+
+/* C5: VertSolve::solve_schur_column_eta for every column (eul/VertSolve.cpp:677-823): builds the
+ * block-tridiagonal Helmholtz operator L_pi analytically from its block-(bi)diagonal factors, solves
+ * it with a batched block-Thomas sweep, back-substitutes.  F_* are updated in place exactly as the
+ * reference does (they are read afterwards, :1868-1894); d_* are outputs.  All vertical vectors:
+ * theta/rho/eta/pi/F_rho/F_eta/F_pi/d_rho/d_eta/d_pi [nEl][nk*n2e], F_u/d_u [nEl][(nk-1)*n2e].      */
+int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
+        const double* theta, const double* rho, const double* eta, const double* pi,
+        double* F_u, double* F_rho, double* F_eta, double* F_pi,
+        double* d_u, double* d_rho, double* d_eta, double* d_pi);
+/* the assembled block-tridiagonal L_pi itself: out [nEl][nk][3][n2e][n2e] (sub, diag, super)       */
+int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
+        const double* theta, const double* rho, const double* eta, const double* pi, double* out);
+
+/* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
+/* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer
+ * (torch.distributed / ncclSend-ncclRecv) on the buffers these calls fill.
+ * idx: device int32 list of vector slots; buf: device [nlev][count].                              */
+int mimsem_halo_pack(mimsem_ctx* ctx, const int* idx, int count, int nlev,
+                     const double* v, long long v_stride, double* buf);
+/* mode 0 = INSERT_VALUES (SCATTER_FORWARD ghost fill), 1 = ADD_VALUES (SCATTER_REVERSE reduce)     */
+int mimsem_halo_unpack(mimsem_ctx* ctx, const int* idx, int count, int nlev, int mode,
+                       const double* buf, double* v, long long v_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

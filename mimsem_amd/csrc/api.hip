@@ -1,0 +1,332 @@
+// mimsem_amd/csrc/api.hip -- C-ABI entry points of libmimsem_hip.so (include/mimsem_hip.h):
+// context lifetime, HBM layout, scatter-add plans, horizontal-operator dispatch.
+#include <algorithm>
+#include <cstring>
+#include "ctx.hpp"
+
+namespace mimsem {
+thread_local std::string g_last_hip_error;
+int hip_fail(hipError_t e, const char* what) {
+    g_last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return MIMSEM_ERR_HIP;
+}
+}  // namespace mimsem
+
+namespace {
+
+template <class T>
+int upload(T** dst, const T* src, size_t count, mimsem_ctx* c) {
+    MIMSEM_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(count, 1)*sizeof(T)));
+    c->bytes += (long long)(count*sizeof(T));
+    if (count) MIMSEM_HIP_TRY(hipMemcpy(*dst, src, count*sizeof(T), hipMemcpyHostToDevice));
+    return MIMSEM_OK;
+}
+
+// slot -> list of element-local result positions, ascending element order (deterministic sums)
+int build_plan(int nslots, int nEl, int per_el, const std::vector<const int*>& maps, const std::vector<int>& offs,
+               int counts, int K, std::vector<int>& plan) {
+    plan.assign((size_t)nslots*K, -1);
+    std::vector<int> fill(nslots, 0);
+    for (int e = 0; e < nEl; e++)
+        for (size_t m = 0; m < maps.size(); m++)
+            for (int j = 0; j < counts; j++) {
+                const int s = maps[m][(size_t)e*counts + j];
+                if (s < 0 || s >= nslots) return MIMSEM_ERR_ARG;
+                if (fill[s] >= K) return MIMSEM_ERR_UNSUPPORTED;
+                plan[(size_t)s*K + fill[s]++] = e*per_el + offs[m] + j;
+            }
+    return MIMSEM_OK;
+}
+
+int op_spaces(int op, int* in, int* cf, int* out) {
+    switch (op) {
+    case MIMSEM_OP_UMAT: case MIMSEM_OP_UTMAT:   *in = 1; *cf = -1; *out = 1; return 0;
+    case MIMSEM_OP_UHMAT: case MIMSEM_OP_UTMAT_H: *in = 1; *cf = 2; *out = 1; return 0;
+    case MIMSEM_OP_ROTMAT:  *in = 1; *cf = 0; *out = 1; return 0;
+    case MIMSEM_OP_WMAT: case MIMSEM_OP_WMATINV:  *in = 2; *cf = -1; *out = 2; return 0;
+    case MIMSEM_OP_WHMAT: case MIMSEM_OP_WHMATINV: *in = 2; *cf = 2; *out = 2; return 0;
+    case MIMSEM_OP_PMAT:    *in = 0; *cf = -1; *out = 0; return 0;
+    case MIMSEM_OP_PHMAT:   *in = 0; *cf = 2; *out = 0; return 0;
+    case MIMSEM_OP_WTQUMAT: case MIMSEM_OP_WTQDUDZ: *in = 1; *cf = 1; *out = 2; return 0;
+    case MIMSEM_OP_UTQWMAT: *in = 2; *cf = 1; *out = 1; return 0;
+    }
+    return 1;
+}
+
+}  // namespace
+
+int mimsem_ctx::ensure_ye(long long doubles) {
+    if (doubles <= ye_doubles) return MIMSEM_OK;
+    if (d_ye) { MIMSEM_HIP_TRY(hipFree(d_ye)); bytes -= ye_doubles*8; d_ye = nullptr; ye_doubles = 0; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_ye, (size_t)doubles*sizeof(double)));
+    ye_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
+int mimsem_ctx::ensure_col(long long doubles) {
+    if (doubles <= col_doubles) return MIMSEM_OK;
+    if (d_col) { MIMSEM_HIP_TRY(hipFree(d_col)); bytes -= col_doubles*8; d_col = nullptr; col_doubles = 0; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_col, (size_t)doubles*sizeof(double)));
+    col_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
+
+hipEvent_t mimsem_ctx::next_event() {
+    if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+    return ev_pool[ev_used++];
+}
+
+extern "C" {
+
+int mimsem_ctx_set_profiling(mimsem_ctx* c, int on) {
+    if (!c) return MIMSEM_ERR_ARG;
+    c->profiling = on != 0; c->ev_used = 0;
+    return MIMSEM_OK;
+}
+int mimsem_ctx_profile_read(mimsem_ctx* c, double* ms1, double* ms2, long long* launches) {
+    if (!c) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    double a = 0.0, b = 0.0;
+    for (size_t i = 0; i + 2 < c->ev_used; i += 3) {
+        float t = 0.f;
+        MIMSEM_HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1])); a += t;
+        MIMSEM_HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i + 1], c->ev_pool[i + 2])); b += t;
+    }
+    if (ms1) *ms1 = a;
+    if (ms2) *ms2 = b;
+    if (launches) *launches = (long long)(c->ev_used/3);
+    c->ev_used = 0;
+    return MIMSEM_OK;
+}
+
+int mimsem_abi_version(void) { return MIMSEM_ABI_VERSION; }
+
+const char* mimsem_strerror(int code) {
+    switch (code) {
+    case MIMSEM_OK: return "ok";
+    case MIMSEM_ERR_ARG: return "invalid argument";
+    case MIMSEM_ERR_UNSUPPORTED: return "unsupported configuration (order must be 1..7 with quadrature order == element order)";
+    case MIMSEM_ERR_HIP: return "HIP runtime error";
+    case MIMSEM_ERR_STATE: return "context state does not allow this call";
+    case MIMSEM_ERR_SINGULAR: return "singular block";
+    }
+    return "unknown error";
+}
+const char* mimsem_last_hip_error(void) { return mimsem::g_last_hip_error.c_str(); }
+
+int mimsem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
+    if (!d || !out) return MIMSEM_ERR_ARG;
+    *out = nullptr;
+    if (d->elOrd < 1 || d->elOrd > 7 || d->quadOrd != d->elOrd) return MIMSEM_ERR_UNSUPPORTED;
+    if (d->nEl < 0 || d->nk < 1 || d->n0 < 0 || d->n1 < 0 || d->n2 < 0) return MIMSEM_ERR_ARG;
+    if (!d->inds0 || !d->inds1x || !d->inds1y || !d->det || !d->J) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipSetDevice(device));
+
+    mimsem_ctx* c = new mimsem_ctx();
+    c->device = device;
+    c->es = ElemSizes(d->elOrd);
+    c->nEl = d->nEl; c->nk = d->nk; c->n0 = d->n0; c->n1 = d->n1; c->n2 = d->n2;
+    const ElemSizes& es = c->es;
+    if (!c->tab.init(d->elOrd, d->quadOrd) || !c->tab.collocated) { delete c; return MIMSEM_ERR_UNSUPPORTED; }
+    if (d->n2 < d->nEl*es.n2e && !d->inds2) { delete c; return MIMSEM_ERR_ARG; }
+
+    int rc = MIMSEM_OK;
+    auto fail = [&](int code) { mimsem_ctx_destroy(c); return code; };
+    if ((rc = upload(&c->d_E, c->tab.E.data(), c->tab.E.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_w, c->tab.quad.w.data(), c->tab.quad.w.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_U, c->tab.U.data(), c->tab.U.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_V, c->tab.V.data(), c->tab.V.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_W, c->tab.W.data(), c->tab.W.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_P, c->tab.P.data(), c->tab.P.size(), c))) return fail(rc);
+
+    // metric: [e][q][4] -> component-major [e][4][q] so that one lane-per-point load is contiguous
+    {
+        std::vector<double> Js((size_t)d->nEl*4*es.mp12);
+        for (int e = 0; e < d->nEl; e++)
+            for (int q = 0; q < es.mp12; q++)
+                for (int k = 0; k < 4; k++)
+                    Js[((size_t)e*4 + k)*es.mp12 + q] = d->J[((size_t)e*es.mp12 + q)*4 + k];
+        if ((rc = upload(&c->d_J, Js.data(), Js.size(), c))) return fail(rc);
+    }
+    if ((rc = upload(&c->d_det, d->det, (size_t)d->nEl*es.mp12, c))) return fail(rc);
+    if ((rc = upload(&c->d_i0, d->inds0, (size_t)d->nEl*es.n0e, c))) return fail(rc);
+    if ((rc = upload(&c->d_i1x, d->inds1x, (size_t)d->nEl*es.n1e, c))) return fail(rc);
+    if ((rc = upload(&c->d_i1y, d->inds1y, (size_t)d->nEl*es.n1e, c))) return fail(rc);
+    if (d->inds2) {
+        bool contig = true;
+        for (size_t i = 0; i < (size_t)d->nEl*es.n2e && contig; i++) contig = (d->inds2[i] == (int)i);
+        for (size_t i = 0; i < (size_t)d->nEl*es.n2e; i++) if (d->inds2[i] < 0 || d->inds2[i] >= d->n2) return fail(MIMSEM_ERR_ARG);
+        c->inds2_contig = contig;
+        if (!contig && (rc = upload(&c->d_i2, d->inds2, (size_t)d->nEl*es.n2e, c))) return fail(rc);
+    }
+
+    // scatter-add plans
+    {
+        std::vector<int> plan;
+        rc = build_plan(d->n1, d->nEl, 2*es.n1e, {d->inds1x, d->inds1y}, {0, es.n1e}, es.n1e, 2, plan);
+        if (rc) return fail(rc);
+        if ((rc = upload(&c->d_g1, plan.data(), plan.size(), c))) return fail(rc);
+        c->G0 = 4;
+        rc = build_plan(d->n0, d->nEl, es.n0e, {d->inds0}, {0}, es.n0e, 4, plan);
+        if (rc == MIMSEM_ERR_UNSUPPORTED) { c->G0 = 8; rc = build_plan(d->n0, d->nEl, es.n0e, {d->inds0}, {0}, es.n0e, 8, plan); }
+        if (rc) return fail(rc);
+        if ((rc = upload(&c->d_g0, plan.data(), plan.size(), c))) return fail(rc);
+    }
+    {
+        const size_t cnt = (size_t)d->nk*d->nEl*es.mp12;
+        MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double)));
+        MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_tI, std::max<size_t>(cnt, 1)*sizeof(double)));
+        c->bytes += 2*(long long)cnt*8;
+    }
+    if ((rc = mimsem_ctx_set_levels(c, d->thick, d->thickInv))) return fail(rc);
+    if ((rc = c->ensure_ye((long long)d->nk*d->nEl*std::max(2*es.n1e, es.n0e)))) return fail(rc);
+    *out = c;
+    return MIMSEM_OK;
+}
+
+void mimsem_ctx_destroy(mimsem_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_g1, c->d_g0, c->d_ye, c->d_col};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) { if (!c) return MIMSEM_ERR_ARG; c->stream = (hipStream_t)s; return MIMSEM_OK; }
+int mimsem_ctx_sync(mimsem_ctx* c) { if (!c) return MIMSEM_ERR_ARG; MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream)); return MIMSEM_OK; }
+long long mimsem_ctx_workspace_bytes(const mimsem_ctx* c) { return c ? c->bytes : 0; }
+
+int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thickInv) {
+    if (!c) return MIMSEM_ERR_ARG;
+    const size_t cnt = (size_t)c->nk*c->nEl*c->es.mp12;
+    std::vector<double> th(cnt, 1.0), ti(cnt, 1.0);
+    if (thick) std::memcpy(th.data(), thick, cnt*sizeof(double));
+    if (thickInv) std::memcpy(ti.data(), thickInv, cnt*sizeof(double));
+    else if (thick) for (size_t i = 0; i < cnt; i++) ti[i] = 1.0/th[i];     // Geom.cpp:761
+    else if (false) {}
+    if (cnt) {
+        MIMSEM_HIP_TRY(hipMemcpy(c->d_th, th.data(), cnt*sizeof(double), hipMemcpyHostToDevice));
+        MIMSEM_HIP_TRY(hipMemcpy(c->d_tI, ti.data(), cnt*sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->have_levels = (thick != nullptr) || (thickInv != nullptr);
+    return MIMSEM_OK;
+}
+
+int mimsem_malloc(void** dev, long long bytes) {
+    if (!dev || bytes < 0) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipMalloc(dev, (size_t)std::max<long long>(bytes, 8)));
+    return MIMSEM_OK;
+}
+int mimsem_free(void* dev) { if (dev) MIMSEM_HIP_TRY(hipFree(dev)); return MIMSEM_OK; }
+int mimsem_memcpy_h2d(mimsem_ctx* c, void* dev, const void* host, long long bytes) {
+    if (!c || !dev || !host || bytes < 0) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIMSEM_OK;
+}
+int mimsem_memcpy_d2h(mimsem_ctx* c, void* host, const void* dev, long long bytes) {
+    if (!c || !dev || !host || bytes < 0) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIMSEM_OK;
+}
+int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
+    if (!c || !dev || bytes < 0) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipMemsetAsync(dev, byte, (size_t)bytes, c->stream));
+    return MIMSEM_OK;
+}
+
+// ---- horizontal operators --------------------------------------------------------------------
+int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                    const double* f, long long fs, const double* x, long long xs,
+                    double* y, long long ys, double alpha) {
+    if (!c || !x || !y || nlev < 0) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
+    if (cf >= 0 && !f) return MIMSEM_ERR_ARG;
+    if (geom_lev0 < 0 || geom_lev0 + nlev > c->nk) return MIMSEM_ERR_ARG;
+    if (op == MIMSEM_OP_UTMAT && geom_lev0 + nlev > c->nk - 1) return MIMSEM_ERR_ARG;   // needs thick[lev+1]
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (op == MIMSEM_OP_WMATINV || op == MIMSEM_OP_WHMATINV)
+        return mimsem_colop_block_inverse_apply(c, op, geom_lev0, nlev, scale, flags, f, fs, x, xs, y, ys, alpha);
+
+    const ElemSizes& es = c->es;
+    ElemArgs a;
+    a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
+    a.flags = flags; a.scale = scale; a.alpha = alpha;
+    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
+    a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2;
+    a.f = f; a.fs = fs; a.x = x; a.xs = xs;
+    int rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (c->profiling) { e0 = c->next_event(); e1 = c->next_event(); e2 = c->next_event(); MIMSEM_HIP_TRY(hipEventRecord(e0, c->stream)); }
+    if (outsp == 2) {
+        a.out = y; a.os = ys;
+        rc = launch_elem_apply(c, op, a);
+        if (c->profiling) { MIMSEM_HIP_TRY(hipEventRecord(e1, c->stream)); MIMSEM_HIP_TRY(hipEventRecord(e2, c->stream)); }
+        return rc;
+    }
+    const long long per = (long long)c->nEl*(outsp == 1 ? 2*es.n1e : es.n0e);
+    if ((rc = c->ensure_ye(per*nlev))) return rc;
+    a.out = c->d_ye; a.os = per;
+    a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+    if ((rc = launch_elem_apply(c, op, a))) return rc;
+    if (c->profiling) MIMSEM_HIP_TRY(hipEventRecord(e1, c->stream));
+    rc = launch_gather_sum(c, outsp, nlev, c->d_ye, per, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, y, ys);
+    if (c->profiling) MIMSEM_HIP_TRY(hipEventRecord(e2, c->stream));
+    return rc;
+}
+
+int mimsem_op_elmat_size(const mimsem_ctx* c, int op) {
+    if (!c) return MIMSEM_ERR_ARG;
+    const ElemSizes& es = c->es;
+    switch (op) {
+    case MIMSEM_OP_UMAT: case MIMSEM_OP_UHMAT: case MIMSEM_OP_UTMAT: case MIMSEM_OP_UTMAT_H: return 4*es.n1e*es.n1e;
+    case MIMSEM_OP_ROTMAT: return 2*es.n1e*es.n1e;
+    case MIMSEM_OP_WMAT: case MIMSEM_OP_WHMAT: case MIMSEM_OP_WMATINV: case MIMSEM_OP_WHMATINV: return es.n2e*es.n2e;
+    case MIMSEM_OP_PMAT: case MIMSEM_OP_PHMAT: return es.n0e*es.n0e;
+    case MIMSEM_OP_WTQUMAT: case MIMSEM_OP_WTQDUDZ: case MIMSEM_OP_UTQWMAT: return 2*es.n2e*es.n1e;
+    }
+    return MIMSEM_ERR_ARG;
+}
+
+int mimsem_op_element_matrices(mimsem_ctx* c, int op, int geom_lev, double scale, unsigned flags,
+                               const double* f, double* out) {
+    if (!c || !out) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
+    if (cf >= 0 && !f) return MIMSEM_ERR_ARG;
+    if (geom_lev < 0 || geom_lev >= c->nk) return MIMSEM_ERR_ARG;
+    if (op == MIMSEM_OP_UTMAT && geom_lev + 1 >= c->nk) return MIMSEM_ERR_ARG;
+    if (op == MIMSEM_OP_WMATINV || op == MIMSEM_OP_WHMATINV) {
+        // Wmat/Whmat blocks with the inverse ops' fixed flags, then batched Gauss-Jordan (LinAlg.cpp:186-269)
+        const int base = (op == MIMSEM_OP_WMATINV) ? MIMSEM_OP_WMAT : MIMSEM_OP_WHMAT;
+        int rc = launch_elmats(c, base, geom_lev, scale, MIMSEM_FLAG_VERT, f, out);
+        if (rc) return rc;
+        return mimsem_block_inverse_inplace(c, c->nEl, c->es.n2e, out);
+    }
+    return launch_elmats(c, op, geom_lev, scale, flags, f, out);
+}
+
+int mimsem_incidence_apply(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys) {
+    if (!c || !x || !y || which < 0 || which > 3 || nlev < 0) return MIMSEM_ERR_ARG;
+    return launch_incidence(c, which, nlev, x, xs, y, ys);
+}
+
+int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
+    if (!c || !idx || !v || !buf || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    return launch_halo_pack(c, idx, count, nlev, v, vs, buf);
+}
+int mimsem_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs) {
+    if (!c || !idx || !v || !buf || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    return launch_halo_unpack(c, idx, count, nlev, mode, buf, v, vs);
+}
+
+}  // extern "C"

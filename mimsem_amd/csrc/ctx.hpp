@@ -1,0 +1,94 @@
+// mimsem_amd/csrc/ctx.hpp -- device context shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/mimsem_hip.h"
+#include "basis_host.hpp"
+
+namespace mimsem {
+extern thread_local std::string g_last_hip_error;
+int hip_fail(hipError_t e, const char* what);
+}
+
+#define MIMSEM_HIP_TRY(call)                                                        \
+    do { hipError_t e__ = (call);                                                   \
+         if (e__ != hipSuccess) return mimsem::hip_fail(e__, #call); } while (0)
+
+// element sizes for order n (quadrature collocated: m == n)
+struct ElemSizes {
+    int n, np1, mp1, mp12, n0e, n1e, n2e;
+    explicit ElemSizes(int order = 1)
+        : n(order), np1(order + 1), mp1(order + 1), mp12((order + 1)*(order + 1)),
+          n0e((order + 1)*(order + 1)), n1e((order + 1)*order), n2e(order*order) {}
+};
+
+struct mimsem_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ElemSizes es;
+    int nEl = 0, nk = 0, n0 = 0, n1 = 0, n2 = 0;
+    bool inds2_contig = true;
+    mimsem::BasisTables tab;
+
+    // ---- HBM-resident data (layout: DESIGN.md "Data layout in HBM") ----
+    double* d_E = nullptr;      // [mp1][n]   edge basis at quad points
+    double* d_w = nullptr;      // [mp1]      GLL weights
+    double* d_U = nullptr;      // dense tables for the element-matrix kernels
+    double* d_V = nullptr;
+    double* d_W = nullptr;
+    double* d_P = nullptr;
+    double* d_J = nullptr;      // [nEl][4][mp12]  component-major per element (coalesced per component)
+    double* d_det = nullptr;    // [nEl][mp12]
+    double* d_th = nullptr;     // [nk][nEl][mp12] thickness at the element's own quad points
+    double* d_tI = nullptr;     // [nk][nEl][mp12] inverse thickness
+    bool have_levels = false;
+    int* d_i0 = nullptr;        // [nEl][n0e]
+    int* d_i1x = nullptr;       // [nEl][n1e]
+    int* d_i1y = nullptr;       // [nEl][n1e]
+    int* d_i2 = nullptr;        // [nEl][n2e] or null (contiguous)
+    // deterministic scatter-add plans: vector slot -> up to K element-local result slots (-1 = none)
+    int* d_g1 = nullptr;        // [n1][2]   into ye1[e*2*n1e + j]  (j<n1e: x edge, else y edge)
+    int* d_g0 = nullptr;        // [n0][G0]  into ye0[e*n0e + j]
+    int G0 = 4;
+    // workspace
+    double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
+    long long ye_doubles = 0;
+    double* d_col = nullptr;    // column-solver workspace
+    long long col_doubles = 0;
+    long long bytes = 0;
+    // measurement hook: event triples (start, mid, end) around pass 1 / pass 2 of mimsem_op_apply
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t next_event();
+
+    int ensure_ye(long long doubles);
+    int ensure_col(long long doubles);
+};
+
+// kernels (elem_kernels.hip / column_kernels.hip) ---------------------------------------------------
+struct ElemArgs {
+    int nEl, nlev, lev0, total;
+    unsigned flags;
+    double scale, alpha;
+    const double *J, *det, *tI, *th, *E, *w;
+    const int *i0, *i1x, *i1y, *i2;
+    const double* f; long long fs;
+    const double* x; long long xs;
+    double* out; long long os;     // element-local results (or the 2-form output vector itself)
+};
+
+int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
+int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
+                      double* y, long long ys);
+int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out);
+int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys);
+int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf);
+int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);
+
+// column_kernels.hip internals used by api.hip
+int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks);
+int mimsem_colop_block_inverse_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                     const double* f, long long fs, const double* x, long long xs,
+                                     double* y, long long ys, double alpha);

@@ -1,0 +1,222 @@
+"""Device-resident mesh + operator engine: thin Python layer over the C ABI (include/mimsem_hip.h).
+PyTorch supplies device memory, streams and torch.distributed -- plumbing, not the product."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import COLOPS, FLAG_ACCUM, FLAG_VERT, OPS, MeshDesc, check
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.dtype in (torch.float64, torch.int32) and t.is_contiguous() and t.is_cuda, "device float64/int32 contiguous tensor required"
+    return t.data_ptr()
+
+
+class DeviceMesh:
+    """Flattens any set of patches (Topo+Geom pairs) into the element->slot tables of mimsem_mesh_desc.
+
+    numbering="local": exactly one patch, vectors have the reference's per-rank LOCAL (ghosted) layout
+                       (Topo::elInds*_l) -- what VecGetArray on the reference's `*l` vectors gives.
+    numbering="global": any number of patches; vector slots are the compacted global ids touched by the
+                        patches (all of them => the concatenated PETSc global Vec)."""
+
+    def __init__(self, topos, geoms, nk=1, numbering="global"):
+        t0 = topos[0]
+        self.n, self.m, self.nk = t0.elOrd, geoms[0].quad_ord, nk
+        self.topos, self.geoms = topos, geoms
+        n2e = self.n * self.n
+        if numbering == "local":
+            assert len(topos) == 1
+            self.inds0, self.inds1x, self.inds1y = t0.all_inds0_l(), t0.all_inds1x_l(), t0.all_inds1y_l()
+            self.n0, self.n1, self.n2 = t0.n0, t0.n1, t0.n2
+            self.gid0 = self.gid1 = self.gid2 = None
+        else:
+            g0 = np.concatenate([t.all_inds0_g() for t in topos])
+            g1x = np.concatenate([t.all_inds1x_g() for t in topos])
+            g1y = np.concatenate([t.all_inds1y_g() for t in topos])
+            self.gid0, inv0 = np.unique(g0, return_inverse=True)
+            self.gid1, inv1 = np.unique(np.concatenate([g1x.ravel(), g1y.ravel()]), return_inverse=True)
+            self.inds0 = inv0.reshape(g0.shape).astype(np.int32)
+            self.inds1x = inv1[:g1x.size].reshape(g1x.shape).astype(np.int32)
+            self.inds1y = inv1[g1x.size:].reshape(g1y.shape).astype(np.int32)
+            self.gid2 = np.concatenate([t.all_inds2_g().ravel() for t in topos])
+            self.n0, self.n1 = self.gid0.size, self.gid1.size
+            self.n2 = self.gid2.size
+        self.nEl = self.inds0.shape[0]
+        self.inds2 = np.arange(self.nEl * n2e, dtype=np.int32).reshape(self.nEl, n2e)
+        self.det = np.ascontiguousarray(np.concatenate([g.det for g in geoms]))
+        self.J = np.ascontiguousarray(np.concatenate([g.J for g in geoms]))
+        th = [g.thick_at_elements() for g in geoms]
+        self.thick = np.ascontiguousarray(np.concatenate([a for a, _ in th], axis=1))
+        self.thickInv = np.ascontiguousarray(np.concatenate([b for _, b in th], axis=1))
+
+    def desc(self):
+        d = MeshDesc()
+        d.elOrd, d.quadOrd, d.nEl, d.nk = self.n, self.m, self.nEl, self.nk
+        d.n0, d.n1, d.n2 = self.n0, self.n1, self.n2
+        keep = []
+        for name in ("inds0", "inds1x", "inds1y", "inds2"):
+            a = np.ascontiguousarray(getattr(self, name), dtype=np.int32); keep.append(a)
+            setattr(d, name, a.ctypes.data)
+        for name in ("det", "J", "thick", "thickInv"):
+            a = np.ascontiguousarray(getattr(self, name), dtype=np.float64); keep.append(a)
+            setattr(d, name, a.ctypes.data)
+        d._keep = keep
+        return d
+
+
+class Engine:
+    """One mimsem_ctx on one GPU."""
+
+    def __init__(self, dmesh, device=0):
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.MimsemError("no GPU visible: the operator engine has no CPU fallback")
+        self.mesh = dmesh
+        self.device = torch.device("cuda", device)
+        self.ctx = C.c_void_p()
+        d = dmesh.desc()
+        torch.cuda.set_device(self.device)
+        check(self.L.mimsem_ctx_create(C.byref(d), device, C.byref(self.ctx)), "mimsem_ctx_create")
+        self.use_stream(torch.cuda.current_stream(self.device))
+        n = dmesh.n
+        self.n0e, self.n1e, self.n2e, self.mp12 = (n + 1) ** 2, (n + 1) * n, n * n, (n + 1) ** 2
+        self.nEl, self.nk = dmesh.nEl, dmesh.nk
+        self.sizes = {0: dmesh.n0, 1: dmesh.n1, 2: dmesh.n2}
+
+    def __del__(self):
+        try:
+            if self.ctx:
+                self.L.mimsem_ctx_destroy(self.ctx); self.ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    def use_stream(self, stream):
+        check(self.L.mimsem_ctx_set_stream(self.ctx, C.c_void_p(stream.cuda_stream)), "set_stream")
+
+    def sync(self):
+        check(self.L.mimsem_ctx_sync(self.ctx), "sync")
+
+    def set_profiling(self, on):
+        check(self.L.mimsem_ctx_set_profiling(self.ctx, int(on)), "set_profiling")
+
+    def profile_read(self):
+        """(ms in element kernels, ms in gather-sum kernels, launches) since the last read"""
+        a, b, n = C.c_double(), C.c_double(), C.c_longlong()
+        check(self.L.mimsem_ctx_profile_read(self.ctx, C.byref(a), C.byref(b), C.byref(n)), "profile_read")
+        return a.value, b.value, n.value
+
+    def tensor(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device).contiguous()
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64, device=self.device)
+
+    # ---- horizontal operators ---------------------------------------------------------------
+    _SPACES = dict(UMAT=(1, None, 1), UTMAT=(1, None, 1), UHMAT=(1, 2, 1), UTMAT_H=(1, 2, 1), ROTMAT=(1, 0, 1),
+                   WMAT=(2, None, 2), WMATINV=(2, None, 2), WHMAT=(2, 2, 2), WHMATINV=(2, 2, 2), PMAT=(0, None, 0),
+                   PHMAT=(0, 2, 0), WTQUMAT=(1, 1, 2), WTQDUDZ=(1, 1, 2), UTQWMAT=(2, 1, 1))
+
+    def apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
+        """y_k = A_op(level lev0+k, f_k) x_k ; x: [nlev, n_in] (or [n_in]) device tensor"""
+        sin, sf, sout = self._SPACES[op]
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        nlev = x2.shape[0]
+        assert x2.shape[1] == self.sizes[sin], (x2.shape, self.sizes[sin])
+        f2 = None
+        if sf is not None:
+            f2 = f if f.dim() == 2 else f.unsqueeze(0)
+            assert f2.shape == (nlev, self.sizes[sf])
+        y = out if out is not None else torch.empty(nlev, self.sizes[sout], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        check(self.L.mimsem_op_apply(self.ctx, OPS[op], lev0, nlev, scale, flags,
+                                     _ptr(f2), f2.stride(0) if f2 is not None else 0,
+                                     _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply(%s)" % op)
+        return y if x.dim() == 2 else y2[0]
+
+    def element_matrices(self, op, f=None, lev=0, scale=1.0, flags=0):
+        esz = self.L.mimsem_op_elmat_size(self.ctx, OPS[op])
+        out = torch.empty(self.nEl, esz, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_op_element_matrices(self.ctx, OPS[op], lev, scale, flags, _ptr(f), _ptr(out)),
+              "mimsem_op_element_matrices(%s)" % op)
+        return out
+
+    def pvec(self, lev0=0, nlev=1, scale=1.0, h2=None):
+        y = torch.empty(nlev, self.sizes[0], dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_pvec(self.ctx, lev0, nlev, scale, _ptr(h2), h2.stride(0) if h2 is not None else 0,
+                                 _ptr(y), y.stride(0)), "mimsem_pvec")
+        return y
+
+    def incidence(self, which, x):
+        """which: 'E10','E21','E12','E01'"""
+        w = dict(E10=0, E21=1, E12=2, E01=3)[which]
+        nout = {0: self.sizes[1], 1: self.sizes[2], 2: self.sizes[1], 3: self.sizes[0]}[w]
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        y = torch.zeros(x2.shape[0], nout, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_incidence_apply(self.ctx, w, x2.shape[0], _ptr(x2), x2.stride(0), _ptr(y), y.stride(0)), "incidence")
+        return y if x.dim() == 2 else y[0]
+
+    # ---- column operators -------------------------------------------------------------------
+    def l2_horiz_to_vert(self, vh):
+        nkv = vh.shape[0]
+        vz = torch.empty(self.nEl, nkv * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_l2_transpose(self.ctx, 0, nkv, _ptr(vh), vh.stride(0), _ptr(vz)), "l2_transpose")
+        return vz
+
+    def l2_vert_to_horiz(self, vz, nkv):
+        vh = torch.empty(nkv, self.sizes[2], dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_l2_transpose(self.ctx, 1, nkv, _ptr(vh), vh.stride(0), _ptr(vz)), "l2_transpose")
+        return vh
+
+    def colop_blocks(self, colop, f1=None, f2=None, flags=0):
+        nb = self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])
+        out = torch.empty(self.nEl, nb, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_colop_blocks(self.ctx, COLOPS[colop], flags, _ptr(f1), _ptr(f2), _ptr(out)), "colop_blocks(%s)" % colop)
+        return out
+
+    def colop_apply(self, colop, x, f1=None, f2=None, flags=0, transpose=False, nout_slots=None):
+        y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_colop_apply(self.ctx, COLOPS[colop], flags, int(transpose), _ptr(f1), _ptr(f2), _ptr(x), _ptr(y)),
+              "colop_apply(%s)" % colop)
+        return y
+
+    def column_eos(self, which, a, b=None, p0=0.0, p1=0.0):
+        out = torch.empty(self.nEl, self.nk * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_eos(self.ctx, which, _ptr(a), _ptr(b), p0, p1, _ptr(out)), "column_eos")
+        return out
+
+    def diag_theta(self, which, rho, rt):
+        nl = self.nk + (1 if which == 1 else 0)
+        th = torch.empty(self.nEl, nl * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_diag_theta(self.ctx, which, _ptr(rho), _ptr(rt), _ptr(th)), "diag_theta")
+        return th
+
+    def helmholtz_blocks(self, dt, theta, rho, eta, pi):
+        out = torch.empty(self.nEl, self.nk, 3, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_helmholtz_blocks(self.ctx, dt, _ptr(theta), _ptr(rho), _ptr(eta), _ptr(pi), _ptr(out)), "helmholtz_blocks")
+        return out
+
+    def solve_schur_eta(self, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi):
+        """F_* are updated in place (as the reference does); returns d_u, d_rho, d_eta, d_pi"""
+        N, Nm = self.nk * self.n2e, (self.nk - 1) * self.n2e
+        mk = lambda n: torch.empty(self.nEl, n, dtype=torch.float64, device=self.device)
+        d_u, d_rho, d_eta, d_pi = mk(Nm), mk(N), mk(N), mk(N)
+        check(self.L.mimsem_column_solve_schur_eta(self.ctx, dt, _ptr(theta), _ptr(rho), _ptr(eta), _ptr(pi),
+                                                   _ptr(F_u), _ptr(F_rho), _ptr(F_eta), _ptr(F_pi),
+                                                   _ptr(d_u), _ptr(d_rho), _ptr(d_eta), _ptr(d_pi)), "solve_schur_eta")
+        return d_u, d_rho, d_eta, d_pi
+
+    # ---- halo pack / unpack ---------------------------------------------------------------------
+    def halo_pack(self, idx, v):
+        v2 = v if v.dim() == 2 else v.unsqueeze(0)
+        buf = torch.empty(v2.shape[0], idx.numel(), dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_halo_pack(self.ctx, _ptr(idx), idx.numel(), v2.shape[0], _ptr(v2), v2.stride(0), _ptr(buf)), "halo_pack")
+        return buf
+
+    def halo_unpack(self, idx, buf, v, add):
+        v2 = v if v.dim() == 2 else v.unsqueeze(0)
+        check(self.L.mimsem_halo_unpack(self.ctx, _ptr(idx), idx.numel(), v2.shape[0], int(add), _ptr(buf), _ptr(v2), v2.stride(0)), "halo_unpack")

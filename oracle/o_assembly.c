@@ -403,3 +403,61 @@ void orc_csr_mult(const orc_csr* A, const double* x, double* y) {
         y[r] = s;
     }
 }
+
+/* ---- timed CPU baseline: the reference's per-call cost structure (SURVEY 8(a) "today's cost", BASELINE.md
+ * variant A): per call  rebuild nothing cached -> per-element coefficient loop + Mult_FD_IP/Mult_IP triple
+ * products -> MatSetValues(ADD)-style insertion with per-entry column search -> SpMV.  The CSR pattern is
+ * preallocated outside the timed loop (PETSc preallocation happens in the operator constructors).
+ * Returns elapsed seconds for `reps` (assemble + MatMult) calls of `op` at level `lev` on this patch. */
+#include <time.h>
+double orc_bench_assemble_mult(const orc_patch* p, int op, int lev, double scale, int flag,
+                               const double* f1, const double* x, double* y, int reps) {
+    int e, r, n1e = p->n1e, n2e = p->n2e, n0e = p->n0e, nEl = p->nEl, esz = orc_op_elmat_size(p, op);
+    int *i0 = (int*)malloc(sizeof(int)*nEl*n0e), *i1 = (int*)malloc(sizeof(int)*nEl*2*n1e), *i2 = (int*)malloc(sizeof(int)*nEl*n2e);
+    double* em = (double*)malloc(sizeof(double)*(size_t)nEl*esz);
+    orc_csr* A = NULL;
+    struct timespec t0, t1;
+    int rows_n = 0, cols_n = 0, nr = 0, nc = 0; const int *rows = NULL, *cols = NULL;
+    for (e = 0; e < nEl; e++) {
+        int ex = e%p->nElsX, ey = e/p->nElsX;
+        orc_elinds0_l(p, ex, ey, i0 + e*n0e);
+        orc_elinds1x_l(p, ex, ey, i1 + e*2*n1e); orc_elinds1y_l(p, ex, ey, i1 + e*2*n1e + n1e);
+        orc_elinds2_l(p, ex, ey, i2 + e*n2e);
+    }
+    switch (op) {
+    case ORC_UMAT: case ORC_UHMAT: case ORC_UTMAT: case ORC_UTMAT_H: case ORC_ROTMAT:
+        rows = cols = i1; nr = nc = 2*n1e; rows_n = cols_n = p->n1; break;
+    case ORC_WMAT: case ORC_WHMAT: rows = cols = i2; nr = nc = n2e; rows_n = cols_n = p->n2; break;
+    case ORC_PMAT: case ORC_PHMAT: rows = cols = i0; nr = nc = n0e; rows_n = cols_n = p->n0; break;
+    case ORC_WTQUMAT: case ORC_WTQDUDZ: rows = i2; nr = n2e; rows_n = p->n2; cols = i1; nc = 2*n1e; cols_n = p->n1; break;
+    case ORC_UTQWMAT: rows = i1; nr = 2*n1e; rows_n = p->n1; cols = i2; nc = n2e; cols_n = p->n2; break;
+    default: free(i0); free(i1); free(i2); free(em); return -1.0;
+    }
+    A = orc_csr_create(rows_n, cols_n, nEl, nr, rows, nc, cols);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (r = 0; r < reps; r++) {
+        orc_csr_zero(A);                                           /* MatZeroEntries */
+        orc_op_elmats(p, op, lev, scale, flag, f1, em);            /* coefficient loops + triple products */
+        for (e = 0; e < nEl; e++) {                                /* MatSetValues(ADD_VALUES) per block */
+            const double* M = em + (size_t)e*esz;
+            const int *ix = i1 + e*2*n1e, *iy = ix + n1e, *j2 = i2 + e*n2e, *j0 = i0 + e*n0e;
+            switch (op) {
+            case ORC_UMAT: case ORC_UHMAT: case ORC_UTMAT: case ORC_UTMAT_H:
+                orc_csr_add(A, n1e, ix, n1e, ix, M); orc_csr_add(A, n1e, ix, n1e, iy, M + n1e*n1e);
+                orc_csr_add(A, n1e, iy, n1e, ix, M + 2*n1e*n1e); orc_csr_add(A, n1e, iy, n1e, iy, M + 3*n1e*n1e); break;
+            case ORC_ROTMAT:
+                orc_csr_add(A, n1e, ix, n1e, iy, M); orc_csr_add(A, n1e, iy, n1e, ix, M + n1e*n1e); break;
+            case ORC_WMAT: case ORC_WHMAT: orc_csr_add(A, n2e, j2, n2e, j2, M); break;
+            case ORC_PMAT: case ORC_PHMAT: orc_csr_add(A, n0e, j0, n0e, j0, M); break;
+            case ORC_WTQUMAT: case ORC_WTQDUDZ:
+                orc_csr_add(A, n2e, j2, n1e, ix, M); orc_csr_add(A, n2e, j2, n1e, iy, M + n2e*n1e); break;
+            case ORC_UTQWMAT:
+                orc_csr_add(A, n1e, ix, n2e, j2, M); orc_csr_add(A, n1e, iy, n2e, j2, M + n1e*n2e); break;
+            }
+        }
+        orc_csr_mult(A, x, y);                                     /* MatMult */
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    orc_csr_destroy(A); free(i0); free(i1); free(i2); free(em);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9*(double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -148,6 +148,9 @@ void orc_csr_destroy(orc_csr* A);
 void orc_csr_zero(orc_csr* A);
 void orc_csr_add(orc_csr* A, int nr, const int* rows, int nc, const int* cols, const double* vals);
 void orc_csr_mult(const orc_csr* A, const double* x, double* y);
+/* timed "assemble + MatMult" loop with the reference's cost structure; returns seconds (bench.py cpu_baseline) */
+double orc_bench_assemble_mult(const orc_patch* p, int op, int lev, double scale, int flag,
+                               const double* f1, const double* x, double* y, int reps);
 
 /* ---- vertical (column) operators, eul/VertOps.cpp; vectors indexed k*n2e+i ------------ */
 enum orc_colop {

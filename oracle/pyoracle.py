@@ -64,6 +64,7 @@ def lib():
         _lib.orc_node_deriv.restype = C.c_double
         _lib.orc_edge_eval.restype = C.c_double
         _lib.orc_csr_create.restype = C.c_void_p
+        _lib.orc_bench_assemble_mult.restype = C.c_double
     return _lib
 
 
@@ -212,6 +213,14 @@ class Patch:
         """assemble(...) then MatMult on local vectors: the reference's two-call idiom."""
         em = self.op_elmats(op, lev, scale, flag, f1)
         return self.op_apply(op, em, x, self.out_size(op))
+
+    def bench_assemble_mult(self, op, x, reps, lev=0, scale=1.0, flag=0, f1=None):
+        """seconds for `reps` x (assemble + MatMult) with the reference's CSR cost structure; also returns y"""
+        y = np.zeros(self.out_size(op))
+        sec = self.L.orc_bench_assemble_mult(self.p, OPS[op], lev, C.c_double(scale), int(flag), _dp(f1),
+                                             _dp(np.ascontiguousarray(x)), _dp(y), int(reps))
+        assert sec >= 0
+        return sec, y
 
     def pvec(self, lev, scale):
         v = np.zeros(self.n0); self.L.orc_pvec(self.p, lev, C.c_double(scale), _dp(v)); return v

@@ -1,0 +1,142 @@
+"""GPU parity for the vertical (column) operators and the column Schur solve, rows C1..C9."""
+import numpy as np
+import pytest
+
+from tests.helpers import make_patch, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module", params=[(3, 2, 6, 1, 6), (4, 1, 6, 0, 5), (2, 2, 6, 3, 4)], ids=lambda p: "p%d_ne%d_np%d_pi%d_nk%d" % p)
+def setup(request, oracle):
+    from mimsem_amd.device import DeviceMesh, Engine
+    pn, ne, nprocs, pi, nk = request.param
+    cs, topo, geom, P, rng = make_patch(oracle, pn, ne, nprocs, pi, nk=nk, seed=7 * pn + nk)
+    eng = Engine(DeviceMesh([topo], [geom], nk=nk, numbering="local"))
+    return eng, P
+
+
+def _col_fields(P, seed=3):
+    """physically scaled column fields: 2-form dofs are cell integrals ~ value * det * thick"""
+    r = np.random.default_rng(seed)
+    nEl, nk, n2 = P.nEl, P.nk, P.n2e
+    area = P.det.mean() * 4.0 / n2              # ~ dof scale of a unit density (sum_q w_q = 4)
+    dz = P.thick.mean()
+    lev = lambda nl, lo, hi: r.uniform(lo, hi, (nEl, nl * n2)) * area * dz
+    return dict(rho=lev(nk, 0.5, 1.2), rt=lev(nk, 250.0, 400.0), theta=lev(nk + 1, 280.0, 320.0) / dz,
+                pi=lev(nk, 700.0, 1000.0), eta=lev(nk, 5.0, 6.0), velz=lev(nk - 1, -1.0, 1.0) / dz,
+                thetaL=lev(nk, 280.0, 320.0))
+
+
+def _dense_from_blocks(P, colop, blk):
+    """stored blocks of one column -> dense matrix in the oracle's layout"""
+    nk, n2 = P.nk, P.n2e
+    rows, cols = P.colop_dims(colop)
+    M = np.zeros((rows, cols))
+    nb = blk.shape[0]
+    if colop in ("LINCON", "LINCON2", "CONLIN", "CONLIN_W", "CONLIN_RHODPI"):
+        off = 0 if colop == "LINCON" else -1
+        for r in range(nb // 2):
+            for w in range(2):
+                c = r + off + w
+                if 0 <= c < cols // n2 and r < rows // n2:
+                    M[r*n2:(r+1)*n2, c*n2:(c+1)*n2] = blk[2*r + w]
+    else:
+        for r in range(nb):
+            M[r*n2:(r+1)*n2, r*n2:(r+1)*n2] = blk[r]
+    return M
+
+
+COLCASES = [("CONST", None, None, 0), ("CONST_INV", None, None, 0), ("CONST_RHO", "rho", None, 0), ("CONST_RHO_INV", "rho", None, 0),
+            ("CONST_THETA", "theta", None, 0), ("EOS_BLOCK", "rt", None, 0), ("LINEAR", None, None, 0), ("LINEAR_INV", None, None, 0),
+            ("LINEAR_RT", "rt", None, 1), ("LINEAR_RT", "rt", None, 0), ("LINEAR_THETA", "theta", None, 0), ("LINEAR_RHO2", "rho", None, 0),
+            ("RAYLEIGH", None, None, 0), ("LINCON", None, None, 0), ("LINCON2", None, None, 0), ("CONLIN", None, None, 0),
+            ("CONLIN_W", "velz", None, 0), ("CONLIN_RHODPI", "thetaL", "velz", 0)]
+
+
+@pytest.mark.parametrize("colop,k1,k2,flag", COLCASES, ids=[f"{c[0]}_{c[3]}" for c in COLCASES])
+def test_colop_blocks_and_apply(setup, colop, k1, k2, flag):
+    eng, P = setup
+    F = _col_fields(P)
+    f1 = F[k1] if k1 else None; f2 = F[k2] if k2 else None
+    t = lambda a: eng.tensor(a) if a is not None else None
+    blk = eng.colop_blocks(colop, f1=t(f1), f2=t(f2), flags=flag).cpu().numpy()
+    rows, cols = P.colop_dims(colop)
+    r = np.random.default_rng(5)
+    x = r.standard_normal((P.nEl, cols)); xt = r.standard_normal((P.nEl, rows))
+    y = eng.colop_apply(colop, eng.tensor(x), f1=t(f1), f2=t(f2), flags=flag, nout_slots=rows // P.n2e).cpu().numpy()
+    yt = eng.colop_apply(colop, eng.tensor(xt), f1=t(f1), f2=t(f2), flags=flag, transpose=True, nout_slots=cols // P.n2e).cpu().numpy()
+    for e in (0, P.nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        want = P.colop_dense(colop, ex, ey, flag=flag, f1=None if f1 is None else f1[e], f2=None if f2 is None else f2[e])
+        got = _dense_from_blocks(P, colop, blk[e])
+        assert rel_l2(got, want) < TOL, colop
+        assert rel_l2(y[e], want @ x[e]) < TOL, colop
+        assert rel_l2(yt[e], want.T @ xt[e]) < TOL, colop
+
+
+def test_l2_transpose_roundtrip_and_layout(setup):
+    import torch
+    eng, P = setup
+    vh = np.random.default_rng(1).standard_normal((P.nk, P.n2))
+    vz = eng.l2_horiz_to_vert(eng.tensor(vh))
+    assert np.array_equal(vz.cpu().numpy(), P.horiz_to_vert(vh))            # pure data movement: bit-exact
+    back = eng.l2_vert_to_horiz(vz, P.nk)
+    assert torch.equal(back, eng.tensor(vh))                                # VertToHoriz o HorizToVert = id
+
+
+def test_eos_vectors(setup):
+    eng, P = setup
+    F = _col_fields(P)
+    t = eng.tensor
+    got = [eng.column_eos(0, t(F["rt"]), t(F["pi"])), eng.column_eos(1, t(F["rt"]), None, 1004.5 * (287.0 / 1e5) ** (287.0 / 717.5), 287.0 / 717.5),
+           eng.column_eos(2, t(F["thetaL"]), None), eng.column_eos(2, t(F["thetaL"]), t(F["eta"])), eng.column_eos(3, t(F["rho"]), t(F["eta"] * 1e-3))]
+    for e in (0, P.nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        want = [P.eos_residual(ex, ey, F["rt"][e], F["pi"][e]),
+                P.eos_rhs(ex, ey, F["rt"][e], 1004.5 * (287.0 / 1e5) ** (287.0 / 717.5), 287.0 / 717.5),
+                P.const_log_theta_plus_eta(ex, ey, F["thetaL"][e]), P.const_log_theta_plus_eta(ex, ey, F["thetaL"][e], F["eta"][e]),
+                P.const_rho_exp_eta(ex, ey, F["rho"][e], F["eta"][e] * 1e-3)]
+        for g, w in zip(got, want):
+            assert rel_l2(g[e].cpu().numpy(), w) < TOL
+
+
+def test_diag_theta(setup):
+    eng, P = setup
+    F = _col_fields(P)
+    th0 = eng.diag_theta(0, eng.tensor(F["rho"]), eng.tensor(F["rt"])).cpu().numpy()
+    th1 = eng.diag_theta(1, eng.tensor(F["rho"]), eng.tensor(F["rt"])).cpu().numpy()
+    for e in (0, P.nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        assert rel_l2(th0[e], P.diag_theta_L2(ex, ey, F["rho"][e], F["rt"][e])) < 1e-9
+        assert rel_l2(th1[e], P.diag_theta2(ex, ey, F["rho"][e], F["rt"][e])) < 1e-9
+
+
+def test_schur_column_solve(setup):
+    """solve_schur_column_eta: analytically assembled block-tridiagonal L_pi + block Thomas vs the oracle's dense
+    restatement of the reference's MatMatMult chain + LU (eul/VertSolve.cpp:677-823)"""
+    eng, P = setup
+    F = _col_fields(P)
+    r = np.random.default_rng(9)
+    nEl, N, Nm = P.nEl, P.nk * P.n2e, (P.nk - 1) * P.n2e
+    dt = 75.0
+    Fu, Frho, Feta, Fpi = (r.standard_normal((nEl, n)) * 1e8 for n in (Nm, N, N, N))
+    t = eng.tensor
+    L = eng.helmholtz_blocks(dt, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"])).cpu().numpy()
+    dFu, dFrho, dFeta, dFpi = t(Fu), t(Frho), t(Feta), t(Fpi)
+    d_u, d_rho, d_eta, d_pi = eng.solve_schur_eta(dt, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]), dFu, dFrho, dFeta, dFpi)
+    n2, nk = P.n2e, P.nk
+    for e in (0, nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        ref = P.solve_schur_column_eta(ex, ey, dt, F["thetaL"][e], F["rho"][e], F["eta"][e], F["pi"][e], Fu[e], Frho[e], Feta[e], Fpi[e])
+        Ld = np.zeros((N, N))
+        for k in range(nk):
+            for w, c in ((0, k - 1), (1, k), (2, k + 1)):
+                if 0 <= c < nk:
+                    Ld[k*n2:(k+1)*n2, c*n2:(c+1)*n2] = L[e, k, w]
+        # the operator itself (incl. exact zeros outside the three block diagonals of the reference's product)
+        assert rel_l2(Ld, ref["L_pi"]) < 1e-9
+        for name, got in (("d_pi", d_pi), ("d_u", d_u), ("d_eta", d_eta), ("d_rho", d_rho),
+                          ("F_u", dFu), ("F_rho", dFrho), ("F_eta", dFeta), ("F_pi", dFpi)):
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name
