@@ -101,7 +101,7 @@ int  mimsem_ctx_sync(mimsem_ctx* ctx);
 int  mimsem_ctx_set_levels(mimsem_ctx* ctx, const double* thick, const double* thickInv);
 /* bytes of device workspace the context currently holds */
 long long mimsem_ctx_workspace_bytes(const mimsem_ctx* ctx);
-/* Measurement hook (bench.py): when on, mimsem_op_apply brackets its element kernel (pass 1) and its
+/* Measurement hook (bench.py): when on = n > 0, every n-th mimsem_op_apply brackets its element kernel (pass 1) and its
  * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
  * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */
 int  mimsem_ctx_set_profiling(mimsem_ctx* ctx, int on);

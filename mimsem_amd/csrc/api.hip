@@ -1,6 +1,7 @@
 // mimsem_amd/csrc/api.hip -- C-ABI entry points of libmimsem_hip.so (include/mimsem_hip.h):
 // context lifetime, HBM layout, scatter-add plans, horizontal-operator dispatch.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "ctx.hpp"
 
@@ -79,21 +80,22 @@ extern "C" {
 
 int mimsem_ctx_set_profiling(mimsem_ctx* c, int on) {
     if (!c) return MIMSEM_ERR_ARG;
-    c->profiling = on != 0; c->ev_used = 0;
+    // on = n > 0: time every n-th mimsem_op_apply (n = 1: all of them); 0 = off
+    c->profiling = on != 0; c->prof_every = on > 0 ? on : 1; c->prof_count = 0; c->ev_used = 0;
     return MIMSEM_OK;
 }
 int mimsem_ctx_profile_read(mimsem_ctx* c, double* ms1, double* ms2, long long* launches) {
     if (!c) return MIMSEM_ERR_ARG;
     MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     double a = 0.0, b = 0.0;
-    for (size_t i = 0; i + 2 < c->ev_used; i += 3) {
+    for (size_t i = 0; i + 3 < c->ev_used; i += 4) {
         float t = 0.f;
         MIMSEM_HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1])); a += t;
-        MIMSEM_HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i + 1], c->ev_pool[i + 2])); b += t;
+        if (hipEventElapsedTime(&t, c->ev_pool[i + 2], c->ev_pool[i + 3]) == hipSuccess) b += t;   // unset when the op has no pass 2
     }
     if (ms1) *ms1 = a;
     if (ms2) *ms2 = b;
-    if (launches) *launches = (long long)(c->ev_used/3);
+    if (launches) *launches = (long long)(c->ev_used/4);
     c->ev_used = 0;
     return MIMSEM_OK;
 }
@@ -129,6 +131,8 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
 
     mimsem_ctx* c = new mimsem_ctx();
     c->device = device;
+    if (const char* ev = getenv("MIMSEM_LCH")) c->lch_override = atoi(ev);
+    if (const char* ev = getenv("MIMSEM_NOSWZ")) c->swz = atoi(ev) ? 0 : 1;
     c->es = ElemSizes(d->elOrd);
     c->nEl = d->nEl; c->nk = d->nk; c->n0 = d->n0; c->n1 = d->n1; c->n2 = d->n2;
     const ElemSizes& es = c->es;
@@ -264,23 +268,33 @@ int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
     a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2;
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;
+    {   // levels per work item: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible
+        const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
+        const long long blocks1 = ((long long)c->nEl + epb - 1)/epb;          // workgroups per single level
+        long long lch = (blocks1*nlev)/(256*6);
+        if (lch < 1) lch = 1;
+        if (lch > nlev) lch = nlev;
+        if (lch > 8) lch = 8;
+        if (c->lch_override > 0) lch = std::min(c->lch_override, nlev);
+        a.lch = (int)lch;
+        a.swz = 0;   // pass 1: the natural order already keeps all level-chunks of an element on one XCD (profiles/r01_swizzle_ab.txt)
+    }
     int rc;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (c->profiling) { e0 = c->next_event(); e1 = c->next_event(); e2 = c->next_event(); MIMSEM_HIP_TRY(hipEventRecord(e0, c->stream)); }
+    c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+    if (c->profiling && (c->prof_count++ % c->prof_every) == 0) { c->ev_k1[0] = c->next_event(); c->ev_k1[1] = c->next_event(); c->ev_k2[0] = c->next_event(); c->ev_k2[1] = c->next_event(); }
     if (outsp == 2) {
         a.out = y; a.os = ys;
         rc = launch_elem_apply(c, op, a);
-        if (c->profiling) { MIMSEM_HIP_TRY(hipEventRecord(e1, c->stream)); MIMSEM_HIP_TRY(hipEventRecord(e2, c->stream)); }
+        c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }
     const long long per = (long long)c->nEl*(outsp == 1 ? 2*es.n1e : es.n0e);
     if ((rc = c->ensure_ye(per*nlev))) return rc;
     a.out = c->d_ye; a.os = per;
     a.flags = flags & ~MIMSEM_FLAG_ACCUM;
-    if ((rc = launch_elem_apply(c, op, a))) return rc;
-    if (c->profiling) MIMSEM_HIP_TRY(hipEventRecord(e1, c->stream));
-    rc = launch_gather_sum(c, outsp, nlev, c->d_ye, per, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, y, ys);
-    if (c->profiling) MIMSEM_HIP_TRY(hipEventRecord(e2, c->stream));
+    rc = launch_elem_apply(c, op, a);
+    if (!rc) rc = launch_gather_sum(c, outsp, nlev, c->d_ye, per, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, y, ys);
+    c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
     return rc;
 }
 

@@ -172,59 +172,59 @@ int block_pass(mimsem_ctx* c, long long nb, const double* cq, double* M) {
 
 // ---- batched Gauss-Jordan with full pivoting: one thread per block, private copy in LDS ------------
 // (thread-minor layout => conflict-free; pivot search / swaps / elimination exactly as LinAlg.cpp:186-269)
-__global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, double* blocks, int* errcount) {
+__global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, int T, double* blocks, int* errcount) {
     extern __shared__ double lds[];
     const int t = threadIdx.x;
-    const long long b = (long long)blockIdx.x*64 + t;
-    double* A = lds;                                   // A[(i*n+j)*64 + t]
-    int* ipiv = (int*)(lds + (size_t)n*n*64);          // [n][64]
-    int* indxr = ipiv + n*64;
-    int* indxc = indxr + n*64;
-    if (b >= nb) return;
+    const long long b = (long long)blockIdx.x*T + t;
+    double* A = lds;                                   // A[(i*n+j)*T + t]
+    int* ipiv = (int*)(lds + (size_t)n*n*T);           // [n][T]
+    int* indxr = ipiv + n*T;
+    int* indxc = indxr + n*T;
+    if (t >= T || b >= nb) return;
     double* src = blocks + b*n*n;
-    for (int k = 0; k < n*n; k++) A[k*64 + t] = src[k];
-    for (int j = 0; j < n; j++) ipiv[j*64 + t] = 0;
+    for (int k = 0; k < n*n; k++) A[k*T + t] = src[k];
+    for (int j = 0; j < n; j++) ipiv[j*T + t] = 0;
     int err = 0, irow = 0, icol = 0;
     for (int i = 0; i < n; i++) {
         double big = 0.0;
         for (int j = 0; j < n; j++) {
-            if (ipiv[j*64 + t] == 1) continue;
+            if (ipiv[j*T + t] == 1) continue;
             for (int k = 0; k < n; k++) {
-                if (ipiv[k*64 + t] == 0) {
-                    const double v = fabs(A[(j*n + k)*64 + t]);
+                if (ipiv[k*T + t] == 0) {
+                    const double v = fabs(A[(j*n + k)*T + t]);
                     if (v >= big) { big = v; irow = j; icol = k; }
-                } else if (ipiv[k*64 + t] > 1) err = 1;
+                } else if (ipiv[k*T + t] > 1) err = 1;
             }
         }
-        ++ipiv[icol*64 + t];
+        ++ipiv[icol*T + t];
         if (irow != icol)
             for (int l = 0; l < n; l++) {
-                const double tmp = A[(irow*n + l)*64 + t];
-                A[(irow*n + l)*64 + t] = A[(icol*n + l)*64 + t];
-                A[(icol*n + l)*64 + t] = tmp;
+                const double tmp = A[(irow*n + l)*T + t];
+                A[(irow*n + l)*T + t] = A[(icol*n + l)*T + t];
+                A[(icol*n + l)*T + t] = tmp;
             }
-        indxr[i*64 + t] = irow; indxc[i*64 + t] = icol;
-        if (fabs(A[(icol*n + icol)*64 + t]) < 1.0e-12) err = 2;
-        const double pivinv = 1.0/A[(icol*n + icol)*64 + t];
-        A[(icol*n + icol)*64 + t] = 1.0;
-        for (int l = 0; l < n; l++) A[(icol*n + l)*64 + t] *= pivinv;
+        indxr[i*T + t] = irow; indxc[i*T + t] = icol;
+        if (fabs(A[(icol*n + icol)*T + t]) < 1.0e-12) err = 2;
+        const double pivinv = 1.0/A[(icol*n + icol)*T + t];
+        A[(icol*n + icol)*T + t] = 1.0;
+        for (int l = 0; l < n; l++) A[(icol*n + l)*T + t] *= pivinv;
         for (int ll = 0; ll < n; ll++) {
             if (ll == icol) continue;
-            const double dum = A[(ll*n + icol)*64 + t];
-            A[(ll*n + icol)*64 + t] = 0.0;
-            for (int l = 0; l < n; l++) A[(ll*n + l)*64 + t] -= A[(icol*n + l)*64 + t]*dum;
+            const double dum = A[(ll*n + icol)*T + t];
+            A[(ll*n + icol)*T + t] = 0.0;
+            for (int l = 0; l < n; l++) A[(ll*n + l)*T + t] -= A[(icol*n + l)*T + t]*dum;
         }
     }
     for (int l = n - 1; l >= 0; l--) {
-        const int ir = indxr[l*64 + t], ic = indxc[l*64 + t];
+        const int ir = indxr[l*T + t], ic = indxc[l*T + t];
         if (ir == ic) continue;
         for (int k = 0; k < n; k++) {
-            const double tmp = A[(k*n + ir)*64 + t];
-            A[(k*n + ir)*64 + t] = A[(k*n + ic)*64 + t];
-            A[(k*n + ic)*64 + t] = tmp;
+            const double tmp = A[(k*n + ir)*T + t];
+            A[(k*n + ir)*T + t] = A[(k*n + ic)*T + t];
+            A[(k*n + ic)*T + t] = tmp;
         }
     }
-    for (int k = 0; k < n*n; k++) src[k] = A[k*64 + t];
+    for (int k = 0; k < n*n; k++) src[k] = A[k*T + t];
     if (err && errcount) atomicAdd(errcount, 1);
 }
 
@@ -232,12 +232,16 @@ __global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, doubl
 
 int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks) {
     if (nblocks <= 0) return MIMSEM_OK;
-    const size_t lds = (size_t)n*n*64*sizeof(double) + (size_t)3*n*64*sizeof(int);
+    // matrices per workgroup: as many as fit a 144 KiB LDS budget (64 for n<=16, fewer for the 25..49-wide blocks of p>=5)
+    int T = 64;
+    auto need = [&](int t) { return (size_t)n*n*t*sizeof(double) + (size_t)3*n*t*sizeof(int); };
+    while (T > 1 && need(T) > 144*1024) T >>= 1;
+    const size_t lds = need(T);
     if (lds > 160*1024) return MIMSEM_ERR_UNSUPPORTED;
     if (lds > 64*1024)
         MIMSEM_HIP_TRY(hipFuncSetAttribute((const void*)k_block_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)((nblocks + 63)/64)), dim3(64), lds, c->stream,
-                       nblocks, n, blocks, (int*)nullptr);
+    hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)((nblocks + T - 1)/T)), dim3(64), lds, c->stream,
+                       nblocks, n, T, blocks, (int*)nullptr);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

@@ -57,11 +57,16 @@ struct mimsem_ctx {
     double* d_col = nullptr;    // column-solver workspace
     long long col_doubles = 0;
     long long bytes = 0;
+    int swz = 1;                   // MIMSEM_NOSWZ=1 disables the XCD-aware block order (tuning)
+    int lch_override = 0;          // MIMSEM_LCH environment override (tuning)
     // measurement hook: event triples (start, mid, end) around pass 1 / pass 2 of mimsem_op_apply
     bool profiling = false;
+    int prof_every = 1; long long prof_count = 0;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     hipEvent_t next_event();
+    hipEvent_t ev_k1[2] = {nullptr, nullptr};   // start/stop events of the next element kernel (null = not profiling)
+    hipEvent_t ev_k2[2] = {nullptr, nullptr};   // ... of the next gather-sum kernel
 
     int ensure_ye(long long doubles);
     int ensure_col(long long doubles);
@@ -70,6 +75,8 @@ struct mimsem_ctx {
 // kernels (elem_kernels.hip / column_kernels.hip) ---------------------------------------------------
 struct ElemArgs {
     int nEl, nlev, lev0, total;
+    int swz;                       // XCD-aware work-item order on/off
+    int lch;                       // levels handled by one work item (level-invariant data stays in registers)
     unsigned flags;
     double scale, alpha;
     const double *J, *det, *tI, *th, *E, *w;

@@ -16,6 +16,7 @@
 //    element-local results contiguously, pass 2 (k_gather_sum) sums each vector slot's <=2 (edges)
 //    or <=4 (nodes) contributions in a fixed order => bitwise run-to-run reproducible.
 //  * HBM-bound by construction (1.5-3.5 flop/B against a ~10 flop/B FP64 ridge): no MFMA here.
+#include <hip/hip_ext.h>
 #include "ctx.hpp"
 
 namespace {
@@ -139,20 +140,52 @@ __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigne
     }
 }
 
-// load one element's DoFs of space SP into LDS row `dst` (lanes q < count participate)
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a CONTIGUOUS range of
+// work items so that neighbouring elements (which share edge/node DoFs and plan lines) hit the same L2.
+// Placement-independent for correctness: a different dispatch order only changes speed.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nb, int on = 1) {
+    constexpr unsigned NX = 8;
+    if (!on) return bid;
+    const unsigned per = nb/NX, full = per*NX;
+    if (bid >= full) return bid;                 // ragged tail keeps its natural position
+    return (bid%NX)*per + bid/NX;
+}
+
+// Lanes of one element never span wavefronts (LPE divides 64), so the LDS hand-offs between the lanes of
+// an element need only wave-level ordering, not s_barrier: LDS operations of one wave execute in order.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// per-lane gather addresses of one space: lane q fetches DoF q (and n1e+q for 1-forms); -1 = lane idle
+template <int N, Space SP>
+__device__ __forceinline__ void dof_slots(const ElemArgs& a, int e, int q, bool act, int& s0, int& s1) {
+    using D = Dims<N>;
+    s0 = -1; s1 = -1;
+    if (!act) return;
+    if constexpr (SP == S1) {
+        if (q < D::n1e) { s0 = a.i1x[e*D::n1e + q]; s1 = a.i1y[e*D::n1e + q]; }
+    } else if constexpr (SP == S2) {
+        if (q < D::n2e) s0 = a.i2 ? a.i2[e*D::n2e + q] : e*D::n2e + q;
+    } else if constexpr (SP == S0) {
+        if (q < D::n0e) s0 = a.i0[e*D::n0e + q];
+    }
+}
+template <int N, Space SP>
+__device__ __forceinline__ void dof_store(double v0, double v1, int s0, int s1, int q, double* dst) {
+    using D = Dims<N>;
+    if (s0 >= 0) dst[q] = v0;
+    if constexpr (SP == S1) { if (s1 >= 0) dst[D::n1e + q] = v1; }
+}
+
+// used by the element-matrix kernel: load one element's DoFs of space SP into LDS row `dst`
 template <int N, Space SP>
 __device__ __forceinline__ void stage_dofs(const ElemArgs& a, const double* vec, int e, int q, double* dst) {
-    using D = Dims<N>;
-    if constexpr (SP == S1) {
-        if (q < D::n1e) {
-            dst[q]          = vec[a.i1x[e*D::n1e + q]];
-            dst[D::n1e + q] = vec[a.i1y[e*D::n1e + q]];
-        }
-    } else if constexpr (SP == S2) {
-        if (q < D::n2e) dst[q] = vec[a.i2 ? a.i2[e*D::n2e + q] : e*D::n2e + q];
-    } else if constexpr (SP == S0) {
-        if (q < D::n0e) dst[q] = vec[a.i0[e*D::n0e + q]];
-    }
+    int s0, s1;
+    dof_slots<N, SP>(a, e, q, true, s0, s1);
+    dof_store<N, SP>(s0 >= 0 ? vec[s0] : 0.0, s1 >= 0 ? vec[s1] : 0.0, s0, s1, q, dst);
 }
 
 // value(s) of a staged field at quad point (qx,qy): collocated tables => short 1-D sums
@@ -178,6 +211,9 @@ __device__ __forceinline__ void interp_point(const double* dofs, const double* s
     }
 }
 
+// Work item = (element, chunk of `lch` consecutive levels).  Level-invariant data (metric, quadrature weight,
+// gather slots) is loaded ONCE into registers; the level loop prefetches the next level's DoFs and thickness
+// while the current level is interpolated / scaled / projected.
 template <int N, int OP>
 __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     using D = Dims<N>;
@@ -190,16 +226,18 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     __shared__ double s_b[EPB][LPE];
 
     const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
-    const long long eg = (long long)blockIdx.x*EPB + el;
-    const bool act = eg < a.total;
-    const int lev = act ? (int)(eg/a.nEl) : 0;
-    const int e = act ? (int)(eg%a.nEl) : 0;
+    const int nchunk = (a.nlev + a.lch - 1)/a.lch;
+    const long long item = (long long)xcd_swizzle(blockIdx.x, gridDim.x, a.swz)*EPB + el;   // item = chunk*nEl + e
+    const bool act = item < (long long)a.nEl*nchunk;
+    const int e = act ? (int)(item%a.nEl) : 0;
+    const int lbeg = act ? (int)(item/a.nEl)*a.lch : 0;
+    const int lend = act ? min(a.nlev, lbeg + a.lch) : 0;
     const int qx = q%D::mp1, qy = q/D::mp1;
     const bool qact = act && q < D::mp12;
 
     if (tid < D::mp1*N) sE[tid] = a.E[tid];
 
-    // ---- issue every independent global load first (latency overlap) ----
+    // ---- level-invariant registers ----
     QPoint g;
     g.J00 = g.J01 = g.J10 = g.J11 = 0.0; g.det = 1.0; g.Q = 0.0; g.tI = 1.0; g.th0 = g.th1 = 1.0;
     if (qact) {
@@ -207,78 +245,110 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
         g.J00 = Je[0*D::mp12 + q]; g.J01 = Je[1*D::mp12 + q];
         g.J10 = Je[2*D::mp12 + q]; g.J11 = Je[3*D::mp12 + q];
         g.det = a.det[(size_t)e*D::mp12 + q];
-        const size_t gl = ((size_t)(a.lev0 + lev)*a.nEl + e)*D::mp12 + q;
-        g.tI = a.tI[gl];
-        if constexpr (OP == MIMSEM_OP_UTMAT) { g.th0 = a.th[gl]; g.th1 = a.th[gl + (size_t)a.nEl*D::mp12]; }
         g.Q = a.w[qx]*a.w[qy];
     }
-    if (act) {
-        stage_dofs<N, T::in>(a, a.x + (size_t)lev*a.xs, e, q, s_x[el]);
-        if constexpr (T::cf != SN) stage_dofs<N, T::cf>(a, a.f + (size_t)lev*a.fs, e, q, s_f[el]);
-    }
-    __syncthreads();
+    int xs0, xs1, fs0 = -1, fs1 = -1;
+    dof_slots<N, T::in>(a, e, q, act, xs0, xs1);
+    if constexpr (T::cf != SN) dof_slots<N, T::cf>(a, e, q, act, fs0, fs1);
+    const size_t lstride = (size_t)a.nEl*D::mp12;
+    const size_t gq = (size_t)e*D::mp12 + q;
 
-    double ra = 0.0, rb = 0.0;
-    if (qact) {
-        double u, v, fu = 0.0, fv = 0.0;
-        interp_point<N, T::in>(s_x[el], sE, q, qx, qy, u, v);
-        if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f[el], sE, q, qx, qy, fu, fv);
-        qpoint_op<OP>(g, a.scale, a.flags, u, v, fu, fv, ra, rb);
-    }
+    // ---- prefetch level lbeg ----
+    double nx0 = 0.0, nx1 = 0.0, nf0 = 0.0, nf1 = 0.0, ntI = 1.0, nth0 = 1.0, nth1 = 1.0;
+    auto fetch = [&](int lev) {
+        const double* xv = a.x + (size_t)lev*a.xs;
+        if (xs0 >= 0) nx0 = xv[xs0];
+        if constexpr (T::in == S1) { if (xs1 >= 0) nx1 = xv[xs1]; }
+        if constexpr (T::cf != SN) {
+            const double* fv = a.f + (size_t)lev*a.fs;
+            if (fs0 >= 0) nf0 = fv[fs0];
+            if constexpr (T::cf == S1) { if (fs1 >= 0) nf1 = fv[fs1]; }
+        }
+        if (qact) {
+            const size_t gl = (size_t)(a.lev0 + lev)*lstride + gq;
+            ntI = a.tI[gl];
+            if constexpr (OP == MIMSEM_OP_UTMAT) { nth0 = a.th[gl]; nth1 = a.th[gl + lstride]; }
+        }
+    };
+    if (lbeg < lend) fetch(lbeg);
+    __syncthreads();                 // sE visible to every wave (the only block-level barrier)
 
-    if constexpr (T::out == S0) {
-        // collocated 0-form projection is the identity: P^T diag(c) P = diag(c)
-        if (qact) a.out[(size_t)lev*a.os + (size_t)e*D::n0e + q] = a.alpha*ra;
-    } else {
-        if (q < LPE) { s_a[el][q] = ra; s_b[el][q] = rb; }
-        __syncthreads();
-        if constexpr (T::out == S1) {
-            if (act && q < D::n1e) {
-                double yx = 0.0, yy = 0.0;
-                const int ixx = q%D::np1, iyx = q/D::np1;     // x-normal edge: node in x, edge fn in y
-                const int ixy = q%N,      iyy = q/N;          // y-normal edge: edge fn in x, node in y
+    for (int lev = lbeg; lev < lend; lev++) {
+        dof_store<N, T::in>(nx0, nx1, xs0, xs1, q, s_x[el]);
+        if constexpr (T::cf != SN) dof_store<N, T::cf>(nf0, nf1, fs0, fs1, q, s_f[el]);
+        g.tI = ntI; g.th0 = nth0; g.th1 = nth1;
+        if (lev + 1 < lend) fetch(lev + 1);
+        wave_lds_sync();
+
+        double ra = 0.0, rb = 0.0;
+        if (qact) {
+            double u, v, fu = 0.0, fv = 0.0;
+            interp_point<N, T::in>(s_x[el], sE, q, qx, qy, u, v);
+            if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f[el], sE, q, qx, qy, fu, fv);
+            qpoint_op<OP>(g, a.scale, a.flags, u, v, fu, fv, ra, rb);
+        }
+
+        if constexpr (T::out == S0) {
+            // collocated 0-form projection is the identity: P^T diag(c) P = diag(c)
+            if (qact) a.out[(size_t)lev*a.os + (size_t)e*D::n0e + q] = a.alpha*ra;
+            wave_lds_sync();
+        } else {
+            s_a[el][q] = ra; s_b[el][q] = rb;
+            wave_lds_sync();
+            if constexpr (T::out == S1) {
+                if (act && q < D::n1e) {
+                    double yx = 0.0, yy = 0.0;
+                    const int ixx = q%D::np1, iyx = q/D::np1;     // x-normal edge: node in x, edge fn in y
+                    const int ixy = q%N,      iyy = q/N;          // y-normal edge: edge fn in x, node in y
 #pragma unroll
-                for (int k = 0; k < D::mp1; k++) {
-                    yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
-                    yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
+                    for (int k = 0; k < D::mp1; k++) {
+                        yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
+                        yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
+                    }
+                    double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
+                    o[q] = a.alpha*yx;
+                    o[D::n1e + q] = a.alpha*yy;
                 }
-                double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
-                o[q] = a.alpha*yx;
-                o[D::n1e + q] = a.alpha*yy;
-            }
-        } else {   // S2: written straight into the output vector (faces are never shared)
-            if (act && q < D::n2e) {
-                const int ix = q%N, iy = q/N;
-                double y2 = 0.0;
+            } else {   // S2: written straight into the output vector (faces are never shared)
+                if (act && q < D::n2e) {
+                    const int ix = q%N, iy = q/N;
+                    double y2 = 0.0;
 #pragma unroll
-                for (int ky = 0; ky < D::mp1; ky++)
+                    for (int ky = 0; ky < D::mp1; ky++)
 #pragma unroll
-                    for (int kx = 0; kx < D::mp1; kx++)
-                        y2 += (sE[kx*N + ix]*sE[ky*N + iy])*s_a[el][ky*D::mp1 + kx];
-                double* o = a.out + (size_t)lev*a.os + (a.i2 ? a.i2[e*D::n2e + q] : e*D::n2e + q);
-                if (a.flags & MIMSEM_FLAG_ACCUM) *o += a.alpha*y2; else *o = a.alpha*y2;
+                        for (int kx = 0; kx < D::mp1; kx++)
+                            y2 += (sE[kx*N + ix]*sE[ky*N + iy])*s_a[el][ky*D::mp1 + kx];
+                    double* o = a.out + (size_t)lev*a.os + (a.i2 ? a.i2[e*D::n2e + q] : e*D::n2e + q);
+                    if (a.flags & MIMSEM_FLAG_ACCUM) *o += a.alpha*y2; else *o = a.alpha*y2;
+                }
             }
+            wave_lds_sync();         // projection reads done before the next level overwrites s_a/s_b
         }
     }
 }
 
-// pass 2: y[slot] = (+=) sum of its element-local contributions, fixed order.  One thread per slot.
+// pass 2: y[slot] = (+=) sum of its element-local contributions, fixed order.  One thread per slot and
+// chunk of LC levels: the plan entry is read once per chunk, level reads/writes are coalesced across slots.
+constexpr int GS_LC = 4;
 template <int K>
 __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ ye, long long ye_stride,
                                                     const int* __restrict__ plan, int nslots, int nlev,
                                                     int accum, double* __restrict__ y, long long ys) {
-    const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
-    if (t >= (long long)nslots*nlev) return;
-    const int lev = (int)(t/nslots), s = (int)(t%nslots);
-    const double* src = ye + (size_t)lev*ye_stride;
-    double acc = 0.0;
+    const int s = xcd_swizzle(blockIdx.x, gridDim.x, accum >> 8)*256 + threadIdx.x;
+    accum &= 1;
+    if (s >= nslots) return;
+    int j[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int j = plan[(size_t)s*K + k];
-        if (j >= 0) acc += src[j];
+    for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
+    const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);
+    for (int lev = l0; lev < l1; lev++) {
+        const double* src = ye + (size_t)lev*ye_stride;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
+        double* o = y + (size_t)lev*ys + s;
+        if (accum) *o += acc; else *o = acc;
     }
-    double* o = y + (size_t)lev*ys + s;
-    if (accum) *o += acc; else *o = acc;
 }
 
 // ---- dense element blocks for MatSetValues callers: out[e][blk][i][j] = sum_q Bt[i][q] c[q] B[q][j] ----
@@ -478,9 +548,14 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const int* __restrict__ idx
 template <int N>
 int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     using D = Dims<N>;
-    const unsigned grid = (unsigned)((a.total + D::EPB - 1)/D::EPB);
+    const long long items = (long long)a.nEl*((a.nlev + a.lch - 1)/a.lch);
+    const unsigned grid = (unsigned)((items + D::EPB - 1)/D::EPB);
     if (grid == 0) return MIMSEM_OK;
-#define MIMSEM_CASE(OPV) case OPV: hipLaunchKernelGGL((k_elem_apply<N, OPV>), dim3(grid), dim3(256), 0, c->stream, a); break;
+    // measurement hook: hipExtLaunchKernelGGL ties the events to the dispatch's own begin/end timestamps
+#define MIMSEM_CASE(OPV) case OPV: \
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_elem_apply<N, OPV>), dim3(grid), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_elem_apply<N, OPV>), dim3(grid), dim3(256), 0, c->stream, a); \
+        break;
     switch (op) {
         MIMSEM_CASE(MIMSEM_OP_UMAT) MIMSEM_CASE(MIMSEM_OP_WMAT) MIMSEM_CASE(MIMSEM_OP_UHMAT)
         MIMSEM_CASE(MIMSEM_OP_PMAT) MIMSEM_CASE(MIMSEM_OP_PHMAT) MIMSEM_CASE(MIMSEM_OP_WTQUMAT)
@@ -530,15 +605,16 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys) {
     const int nslots = form == 1 ? c->n1 : c->n0;
-    const long long total = (long long)nslots*nlev;
-    if (total == 0) return MIMSEM_OK;
-    const unsigned grid = (unsigned)((total + 255)/256);
-    if (form == 1)
-        hipLaunchKernelGGL((k_gather_sum<2>), dim3(grid), dim3(256), 0, c->stream, ye, ye_stride, c->d_g1, nslots, nlev, accum, y, ys);
-    else if (c->G0 == 4)
-        hipLaunchKernelGGL((k_gather_sum<4>), dim3(grid), dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, accum, y, ys);
-    else
-        hipLaunchKernelGGL((k_gather_sum<8>), dim3(grid), dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, accum, y, ys);
+    if (nslots == 0 || nlev == 0) return MIMSEM_OK;
+    const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
+    hipEvent_t s0 = c->ev_k2[0], s1 = c->ev_k2[1];
+#define MIMSEM_GS(K, PLAN) \
+    if (s0) hipExtLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, s0, s1, 0, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys); \
+    else hipLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys)
+    if (form == 1) { MIMSEM_GS(2, c->d_g1); }
+    else if (c->G0 == 4) { MIMSEM_GS(4, c->d_g0); }
+    else { MIMSEM_GS(8, c->d_g0); }
+#undef MIMSEM_GS
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

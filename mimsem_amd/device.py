@@ -101,8 +101,9 @@ class Engine:
     def sync(self):
         check(self.L.mimsem_ctx_sync(self.ctx), "sync")
 
-    def set_profiling(self, on):
-        check(self.L.mimsem_ctx_set_profiling(self.ctx, int(on)), "set_profiling")
+    def set_profiling(self, every):
+        """0 = off; n > 0 = time every n-th op_apply with hipExtLaunchKernelGGL start/stop events"""
+        check(self.L.mimsem_ctx_set_profiling(self.ctx, int(every)), "set_profiling")
 
     def profile_read(self):
         """(ms in element kernels, ms in gather-sum kernels, launches) since the last read"""
@@ -137,6 +138,32 @@ class Engine:
                                      _ptr(f2), f2.stride(0) if f2 is not None else 0,
                                      _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply(%s)" % op)
         return y if x.dim() == 2 else y2[0]
+
+    def prepare_apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
+        """Validate once, return (call, y): `call()` re-issues the same mimsem_op_apply with pre-marshalled
+        arguments (the buffers are fixed) -- the host-side fast path for time-step loops and bench.py."""
+        sin, sf, sout = self._SPACES[op]
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        nlev = x2.shape[0]
+        assert x2.shape[1] == self.sizes[sin]
+        f2 = None
+        if sf is not None:
+            f2 = f if f.dim() == 2 else f.unsqueeze(0)
+            assert f2.shape == (nlev, self.sizes[sf])
+        y = out if out is not None else torch.empty(nlev, self.sizes[sout], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        fn = self.L.mimsem_op_apply
+        args = (self.ctx, C.c_int(OPS[op]), C.c_int(lev0), C.c_int(nlev), C.c_double(scale), C.c_uint(flags),
+                C.c_void_p(_ptr(f2)), C.c_longlong(f2.stride(0) if f2 is not None else 0),
+                C.c_void_p(_ptr(x2)), C.c_longlong(x2.stride(0)), C.c_void_p(_ptr(y2)), C.c_longlong(y2.stride(0)),
+                C.c_double(alpha))
+        keep = (x2, f2, y2)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc:
+                check(rc, "mimsem_op_apply(%s)" % op)
+        return call, y
 
     def element_matrices(self, op, f=None, lev=0, scale=1.0, flags=0):
         esz = self.L.mimsem_op_elmat_size(self.ctx, OPS[op])
