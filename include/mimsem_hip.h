@@ -76,6 +76,10 @@ enum mimsem_op {
     MIMSEM_OP_WTQDUDZ = 11, /* WtQdUdz_mat::assemble(u1,scale)              :1581-1640 f=u1           1 -> 2        */
     MIMSEM_OP_WMATINV = 12, /* WmatInv::assemble(lev,scale)                 :1673-1722 element-wise inverse 2 -> 2  */
     MIMSEM_OP_WHMATINV = 13,/* WhmatInv::assemble(rho,lev,scale)            :1744-1802 f=rho          2 -> 2        */
+    /* upwinded operators of the shallow-water stack (src/ flavour: scale = 1, no thickness), applied through
+     * mimsem_op_apply_up: f = the op's field, u = local 1-form velocity that defines the departure points */
+    MIMSEM_OP_PHMAT_UP = 14, /* Phmat::assemble_up(ul,hl,fac,dt)  src/Assembly.cpp:499-567   f=hl (2-form)  0 -> 0 */
+    MIMSEM_OP_ROTMAT_UP = 15,/* RotMat_up::assemble(q0,ul,fac,dt) src/Assembly.cpp:1784-1853 f=q0 (0-form)  1 -> 1 */
     MIMSEM_OP_COUNT
 };
 /* op flag: the boolean the reference method takes (vert_scale / const_vert / vert_scale_rho) */
@@ -128,6 +132,12 @@ int mimsem_op_apply(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double sca
                     const double* f, long long f_stride,
                     const double* x, long long x_stride,
                     double* y, long long y_stride, double alpha);
+
+/* Upwinded variants: the 0-form (trial function resp. vorticity) is evaluated at the departure points
+ * x_q - tau*u_local(x_q), tau = 1/(1/(fac*dt)) as in the reference.  u: local 1-form velocity per level. */
+int mimsem_op_apply_up(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double fac, double dt, unsigned flags,
+                       const double* f, long long f_stride, const double* u, long long u_stride,
+                       const double* x, long long x_stride, double* y, long long y_stride, double alpha);
 
 /* The dense element blocks the reference passes to MatSetValues (row-major, block order as in the
  * reference: UMAT-like [4][n1e][n1e] = UtQU UtQV VtQU VtQV; ROTMAT [2] = UtQV VtQU; WTQU-like [2];

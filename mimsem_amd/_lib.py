@@ -43,6 +43,8 @@ _SIGS = {
     "mimsem_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_ll]),
     "mimsem_op_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint,
                                   c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
+    "mimsem_op_apply_up": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
+                                     c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_elmat_size": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_op_element_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_dp]),
     "mimsem_pvec": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_dp, c_ll, c_dp, c_ll]),
@@ -60,7 +62,7 @@ _SIGS = {
 }
 
 OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=7, UTMAT=8,
-           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13)
+           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15)
 COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4, EOS_BLOCK=5,
               LINEAR=6, LINEAR_INV=7, LINEAR_RT=8, LINEAR_THETA=9, LINEAR_RHO2=10, RAYLEIGH=11,
               LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16)

@@ -50,6 +50,8 @@ int op_spaces(int op, int* in, int* cf, int* out) {
     case MIMSEM_OP_PHMAT:   *in = 0; *cf = 2; *out = 0; return 0;
     case MIMSEM_OP_WTQUMAT: case MIMSEM_OP_WTQDUDZ: *in = 1; *cf = 1; *out = 2; return 0;
     case MIMSEM_OP_UTQWMAT: *in = 2; *cf = 1; *out = 1; return 0;
+    case MIMSEM_OP_PHMAT_UP:  *in = 0; *cf = 2; *out = 0; return 0;
+    case MIMSEM_OP_ROTMAT_UP: *in = 1; *cf = 0; *out = 1; return 0;
     }
     return 1;
 }
@@ -143,6 +145,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     auto fail = [&](int code) { mimsem_ctx_destroy(c); return code; };
     if ((rc = upload(&c->d_E, c->tab.E.data(), c->tab.E.size(), c))) return fail(rc);
     if ((rc = upload(&c->d_w, c->tab.quad.w.data(), c->tab.quad.w.size(), c))) return fail(rc);
+    if ((rc = upload(&c->d_xn, c->tab.nodes.x.data(), c->tab.nodes.x.size(), c))) return fail(rc);
     if ((rc = upload(&c->d_U, c->tab.U.data(), c->tab.U.size(), c))) return fail(rc);
     if ((rc = upload(&c->d_V, c->tab.V.data(), c->tab.V.size(), c))) return fail(rc);
     if ((rc = upload(&c->d_W, c->tab.W.data(), c->tab.W.size(), c))) return fail(rc);
@@ -196,7 +199,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
 void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
+    void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
                     c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_g1, c->d_g0, c->d_ye, c->d_col};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -248,9 +251,31 @@ int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
 }
 
 // ---- horizontal operators --------------------------------------------------------------------
+static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                         const double* f, long long fs, const double* f2, long long f2s, double param,
+                         const double* x, long long xs, double* y, long long ys, double alpha);
+
 int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                     const double* f, long long fs, const double* x, long long xs,
                     double* y, long long ys, double alpha) {
+    if (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP) return MIMSEM_ERR_ARG;   // need mimsem_op_apply_up
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, y, ys, alpha);
+}
+
+int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double fac, double dt, unsigned flags,
+                       const double* f, long long fs, const double* u, long long us,
+                       const double* x, long long xs, double* y, long long ys, double alpha) {
+    if (op != MIMSEM_OP_PHMAT_UP && op != MIMSEM_OP_ROTMAT_UP) return MIMSEM_ERR_ARG;
+    if (!u) return MIMSEM_ERR_ARG;
+    const double tau = 1.0/(1.0/(fac*dt));               // src/Assembly.cpp:541, :1812
+    return op_apply_core(c, op, geom_lev0, nlev, 1.0, flags, f, fs, u, us, tau, x, xs, y, ys, alpha);
+}
+
+}  // extern "C"
+
+static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                         const double* f, long long fs, const double* f2, long long f2s, double param,
+                         const double* x, long long xs, double* y, long long ys, double alpha) {
     if (!c || !x || !y || nlev < 0) return MIMSEM_ERR_ARG;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
@@ -268,6 +293,7 @@ int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
     a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2;
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;
+    a.f2 = f2; a.f2s = f2s; a.param = param; a.xn = c->d_xn;
     {   // levels per work item: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible
         const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
         const long long blocks1 = ((long long)c->nEl + epb - 1)/epb;          // workgroups per single level
@@ -297,6 +323,8 @@ int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale
     c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
     return rc;
 }
+
+extern "C" {
 
 int mimsem_op_elmat_size(const mimsem_ctx* c, int op) {
     if (!c) return MIMSEM_ERR_ARG;

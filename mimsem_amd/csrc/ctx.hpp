@@ -34,6 +34,7 @@ struct mimsem_ctx {
     // ---- HBM-resident data (layout: DESIGN.md "Data layout in HBM") ----
     double* d_E = nullptr;      // [mp1][n]   edge basis at quad points
     double* d_w = nullptr;      // [mp1]      GLL weights
+    double* d_xn = nullptr;     // [np1]      nodal (GLL) points, for Lagrange evaluation at departure points
     double* d_U = nullptr;      // dense tables for the element-matrix kernels
     double* d_V = nullptr;
     double* d_W = nullptr;
@@ -82,6 +83,9 @@ struct ElemArgs {
     const double *J, *det, *tI, *th, *E, *w;
     const int *i0, *i1x, *i1y, *i2;
     const double* f; long long fs;
+    const double* f2; long long f2s;   // second coefficient field (velocity of the upwinded operators)
+    double param;                       // tau of the upwinded operators
+    const double* xn;                   // nodal points
     const double* x; long long xs;
     double* out; long long os;     // element-local results (or the 2-form output vector itself)
 };

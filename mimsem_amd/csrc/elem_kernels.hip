@@ -32,7 +32,8 @@ enum Space { S0 = 0, S1 = 1, S2 = 2, SN = 3 };
 
 template <int OP> struct OpTraits;
 #define MIMSEM_TRAIT(op, in_, cf_, out_) \
-    template <> struct OpTraits<op> { static constexpr Space in = in_, cf = cf_, out = out_; }
+    template <> struct OpTraits<op> { static constexpr Space in = in_, cf = cf_, out = out_; \
+        static constexpr bool up = (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP); }
 MIMSEM_TRAIT(MIMSEM_OP_UMAT,    S1, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_WMAT,    S2, SN, S2);
 MIMSEM_TRAIT(MIMSEM_OP_UHMAT,   S1, S2, S1);
@@ -45,6 +46,8 @@ MIMSEM_TRAIT(MIMSEM_OP_UTMAT,   S1, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_UTMAT_H, S1, S2, S1);
 MIMSEM_TRAIT(MIMSEM_OP_UTQWMAT, S2, S1, S1);
 MIMSEM_TRAIT(MIMSEM_OP_WTQDUDZ, S1, S1, S2);
+MIMSEM_TRAIT(MIMSEM_OP_PHMAT_UP,  S0, S2, S0);   // + velocity (1-form) as second field
+MIMSEM_TRAIT(MIMSEM_OP_ROTMAT_UP, S1, S0, S1);   // + velocity (1-form) as second field
 
 // ---- per-quadrature-point coefficient: the fused restatement of each assemble()'s Q?? loop --------
 // in : interpolated input (u,v for a 1-form, h for a 0/2-form in .u)
@@ -131,6 +134,13 @@ __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigne
         const double caa = (ux0*g.J00 + ux1*g.J10)*g.Q*sd;
         const double cab = (ux0*g.J01 + ux1*g.J11)*g.Q*sd;
         a = caa*u + cab*v; b = 0.0;
+    } else if constexpr (OP == MIMSEM_OP_PHMAT_UP) {                 // src/Assembly.cpp:546-548 (u = trial value at the
+        a = fu*g.Q*u; b = 0.0;                                       //  departure point, fu = interp2_l(h): dets cancel)
+    } else if constexpr (OP == MIMSEM_OP_ROTMAT_UP) {                // src/Assembly.cpp:1825-1826 (fu = upwinded vorticity)
+        const double cab = fu*(-g.J00*g.J11 + g.J01*g.J10)*g.Q/g.det;
+        const double cba = fu*(+g.J00*g.J11 - g.J01*g.J10)*g.Q/g.det;
+        a = cab*v;
+        b = cba*u;
     } else if constexpr (OP == MIMSEM_OP_UTQWMAT) {                  // :1504-1517
         const double ux0 = (g.J00*fu + g.J01*fv)/g.det;
         const double ux1 = (g.J10*fu + g.J11*fv)/g.det;
@@ -224,6 +234,8 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     __shared__ double s_f[EPB][2*LPE];
     __shared__ double s_a[EPB][LPE];
     __shared__ double s_b[EPB][LPE];
+    __shared__ double s_g[T::up ? EPB : 1][2*LPE];     // velocity DoFs of the upwinded operators
+    __shared__ double sXn[D::np1];
 
     const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
     const int nchunk = (a.nlev + a.lch - 1)/a.lch;
@@ -236,6 +248,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     const bool qact = act && q < D::mp12;
 
     if (tid < D::mp1*N) sE[tid] = a.E[tid];
+    if (T::up && tid < D::np1) sXn[tid] = a.xn[tid];
 
     // ---- level-invariant registers ----
     QPoint g;
@@ -250,11 +263,13 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     int xs0, xs1, fs0 = -1, fs1 = -1;
     dof_slots<N, T::in>(a, e, q, act, xs0, xs1);
     if constexpr (T::cf != SN) dof_slots<N, T::cf>(a, e, q, act, fs0, fs1);
+    int us0 = -1, us1 = -1;
+    if constexpr (T::up) dof_slots<N, S1>(a, e, q, act, us0, us1);
     const size_t lstride = (size_t)a.nEl*D::mp12;
     const size_t gq = (size_t)e*D::mp12 + q;
 
     // ---- prefetch level lbeg ----
-    double nx0 = 0.0, nx1 = 0.0, nf0 = 0.0, nf1 = 0.0, ntI = 1.0, nth0 = 1.0, nth1 = 1.0;
+    double nx0 = 0.0, nx1 = 0.0, nf0 = 0.0, nf1 = 0.0, ng0 = 0.0, ng1 = 0.0, ntI = 1.0, nth0 = 1.0, nth1 = 1.0;
     auto fetch = [&](int lev) {
         const double* xv = a.x + (size_t)lev*a.xs;
         if (xs0 >= 0) nx0 = xv[xs0];
@@ -263,6 +278,11 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
             const double* fv = a.f + (size_t)lev*a.fs;
             if (fs0 >= 0) nf0 = fv[fs0];
             if constexpr (T::cf == S1) { if (fs1 >= 0) nf1 = fv[fs1]; }
+        }
+        if constexpr (T::up) {
+            const double* uv = a.f2 + (size_t)lev*a.f2s;
+            if (us0 >= 0) ng0 = uv[us0];
+            if (us1 >= 0) ng1 = uv[us1];
         }
         if (qact) {
             const size_t gl = (size_t)(a.lev0 + lev)*lstride + gq;
@@ -276,6 +296,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     for (int lev = lbeg; lev < lend; lev++) {
         dof_store<N, T::in>(nx0, nx1, xs0, xs1, q, s_x[el]);
         if constexpr (T::cf != SN) dof_store<N, T::cf>(nf0, nf1, fs0, fs1, q, s_f[el]);
+        if constexpr (T::up) dof_store<N, S1>(ng0, ng1, us0, us1, q, s_g[el]);
         g.tI = ntI; g.th0 = nth0; g.th1 = nth1;
         if (lev + 1 < lend) fetch(lev + 1);
         wave_lds_sync();
@@ -285,6 +306,35 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
             double u, v, fu = 0.0, fv = 0.0;
             interp_point<N, T::in>(s_x[el], sE, q, qx, qy, u, v);
             if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f[el], sE, q, qx, qy, fu, fv);
+            if constexpr (T::up) {
+                // departure point of this quadrature point: x_q - tau * (velocity in element coordinates)
+                double gu, gv;
+                interp_point<N, S1>(s_g[el], sE, q, qx, qy, gu, gv);
+                const double ux0 = (g.J00*gu + g.J01*gv)/g.det, ux1 = (g.J10*gu + g.J11*gv)/g.det;   // interp1_g
+                const double ul0 = +g.J11*ux0/g.det - g.J01*ux1/g.det;
+                const double ul1 = -g.J10*ux0/g.det + g.J00*ux1/g.det;
+                const double px = sXn[qx] - a.param*ul0, py = sXn[qy] - a.param*ul1;   // quad points == nodes (m == n)
+                double lx[D::np1], ly[D::np1];
+#pragma unroll
+                for (int i = 0; i < D::np1; i++) {                    // LagrangeNode::eval_q eul/Basis.cpp:180-187
+                    double yx_ = 1.0, yy_ = 1.0;
+#pragma unroll
+                    for (int j = 0; j < D::np1; j++) {
+                        if (j == i) continue;
+                        yx_ *= (px - sXn[j])/(sXn[i] - sXn[j]);
+                        yy_ *= (py - sXn[j])/(sXn[i] - sXn[j]);
+                    }
+                    lx[i] = yx_; ly[i] = yy_;
+                }
+                const double* nod = (OP == MIMSEM_OP_PHMAT_UP) ? s_x[el] : s_f[el];   // the 0-form evaluated upwind
+                double val = 0.0;
+#pragma unroll
+                for (int jy = 0; jy < D::np1; jy++)
+#pragma unroll
+                    for (int jx = 0; jx < D::np1; jx++)
+                        val += nod[jy*D::np1 + jx]*lx[jx]*ly[jy];
+                if constexpr (OP == MIMSEM_OP_PHMAT_UP) u = val; else fu = val;
+            }
             qpoint_op<OP>(g, a.scale, a.flags, u, v, fu, fv, ra, rb);
         }
 
@@ -561,6 +611,7 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_PMAT) MIMSEM_CASE(MIMSEM_OP_PHMAT) MIMSEM_CASE(MIMSEM_OP_WTQUMAT)
         MIMSEM_CASE(MIMSEM_OP_ROTMAT) MIMSEM_CASE(MIMSEM_OP_WHMAT) MIMSEM_CASE(MIMSEM_OP_UTMAT)
         MIMSEM_CASE(MIMSEM_OP_UTMAT_H) MIMSEM_CASE(MIMSEM_OP_UTQWMAT) MIMSEM_CASE(MIMSEM_OP_WTQDUDZ)
+        MIMSEM_CASE(MIMSEM_OP_PHMAT_UP) MIMSEM_CASE(MIMSEM_OP_ROTMAT_UP)
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE

@@ -461,3 +461,50 @@ double orc_bench_assemble_mult(const orc_patch* p, int op, int lev, double scale
     orc_csr_destroy(A); free(i0); free(i1); free(i2); free(em);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9*(double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- upwinded operators of the shallow-water stack (src/ flavour: scale = 1, no thickness) ------------
+ * ORC_PHMAT_UP : Phmat::assemble_up(ul, hl, fac, dt)   src/Assembly.cpp:499-567  out [nEl][n0e][n0e]
+ *                trial functions evaluated at the departure points x_q - tau*u_local, tau = 1/(1/(fac*dt))
+ * ORC_ROTMAT_UP: RotMat_up::assemble(q0, ul, fac, dt)  src/Assembly.cpp:1784-1853 out [nEl][2][n1e][n1e]
+ *                the vorticity is interpolated at the departure points
+ * f1 = hl (2-form) resp. q0 (0-form), ul = local 1-form velocity.                                      */
+int orc_op_elmats_up(const orc_patch* p, int which, double fac, double dt, const double* f1, const double* ul, double* out) {
+    int ex, ey, ei, ii, jj, mp1 = p->mp1, mp12 = p->mp12, np1 = p->np1, np12 = p->n0e, n1e = p->n1e, i0[128];
+    double lx[16], ly[16], ux[2], ux2[2], hx, tau, vort;
+    double *QP = (double*)malloc(sizeof(double)*mp12*np12), *ca = (double*)malloc(sizeof(double)*mp12),
+           *cb = (double*)malloc(sizeof(double)*mp12), *tmp = (double*)malloc(sizeof(double)*128*mp12);
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        ei = ey*p->nElsX + ex;
+        orc_elinds0_l(p, ex, ey, i0);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+            orc_interp1_g(p, ex, ey, ii%mp1, ii/mp1, ul, ux);
+            ux2[0] = +J11*ux[0]/det - J01*ux[1]/det;
+            ux2[1] = -J10*ux[0]/det + J00*ux[1]/det;
+            tau = 1.0/(1.0/(fac*dt));
+            for (jj = 0; jj < np1; jj++) {
+                lx[jj] = orc_node_eval(p->n, p->nx, p->qx[ii%mp1] - tau*ux2[0], jj);
+                ly[jj] = orc_node_eval(p->n, p->nx, p->qx[ii/mp1] - tau*ux2[1], jj);
+            }
+            if (which == 0) {                                   /* Phmat::assemble_up :538-548 */
+                orc_interp2_l(p, ex, ey, ii%mp1, ii/mp1, f1, &hx);
+                for (jj = 0; jj < np12; jj++) QP[ii*np12 + jj] = hx*p->Q[ii]*lx[jj%np1]*ly[jj/np1];
+            } else {                                            /* RotMat_up::assemble :1816-1826 */
+                vort = 0.0;
+                for (jj = 0; jj < np12; jj++) vort += f1[i0[jj]]*lx[jj%np1]*ly[jj/np1];
+                ca[ii] = vort*(-J00*J11 + J01*J10)*p->Q[ii]/det;
+                cb[ii] = vort*(+J00*J11 - J01*J10)*p->Q[ii]/det;
+            }
+        }
+        if (which == 0) {
+            orc_la->mult(np12, np12, mp12, p->Pt, QP, out + (size_t)ei*np12*np12);     /* Pt . QP :551 */
+        } else {
+            double* M = out + (size_t)ei*2*n1e*n1e;
+            triple(p, n1e, n1e, p->Ut, ca, p->V, tmp, M);
+            triple(p, n1e, n1e, p->Vt, cb, p->U, tmp, M + n1e*n1e);
+        }
+    }
+    free(QP); free(ca); free(cb); free(tmp);
+    return 0;
+}

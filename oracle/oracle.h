@@ -127,6 +127,11 @@ int orc_op_elmats(const orc_patch* p, int op, int lev, double scale, int flag,
  * content of MatSetValues(ADD)+MatMult.  x,y sized by the op's col/row space. */
 int orc_op_apply(const orc_patch* p, int op, const double* elmats, const double* x, double* y);
 
+/* upwinded shallow-water operators (src/ flavour): which 0 = Phmat::assemble_up src/Assembly.cpp:499-567
+ * (f1 = hl, out [nEl][n0e][n0e], apply with ORC_PMAT), 1 = RotMat_up::assemble :1784-1853 (f1 = q0, out like
+ * ORC_ROTMAT).  ul = local 1-form velocity; tau = 1/(1/(fac*dt)). */
+int orc_op_elmats_up(const orc_patch* p, int which, double fac, double dt, const double* f1, const double* ul, double* out);
+
 /* matrix-free vectors, eul/Assembly.cpp */
 void orc_pvec(const orc_patch* p, int lev, double scale, double* vl);                       /* B5 Pvec  :602-632 (local part) */
 void orc_phvec(const orc_patch* p, int lev, double scale, const double* h2, double* vl);    /* B5 Phvec :654-689 */

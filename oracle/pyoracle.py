@@ -214,6 +214,14 @@ class Patch:
         em = self.op_elmats(op, lev, scale, flag, f1)
         return self.op_apply(op, em, x, self.out_size(op))
 
+    def apply_up(self, which, x, fac, dt, f1, ul):
+        """Phmat::assemble_up (which=0) / RotMat_up::assemble (which=1) followed by MatMult, local vectors"""
+        op = "PMAT" if which == 0 else "ROTMAT"
+        em = np.zeros((self.nEl, self.elmat_size(op)))
+        rc = self.L.orc_op_elmats_up(self.p, which, C.c_double(fac), C.c_double(dt), _dp(f1), _dp(ul), _dp(em))
+        assert rc == 0
+        return self.op_apply(op, em, x, self.out_size(op)), em
+
     def bench_assemble_mult(self, op, x, reps, lev=0, scale=1.0, flag=0, f1=None):
         """seconds for `reps` x (assemble + MatMult) with the reference's CSR cost structure; also returns y"""
         y = np.zeros(self.out_size(op))

@@ -120,3 +120,20 @@ def test_incidence(setup):
     a1, b0 = eng.tensor(x1), eng.tensor(x0)
     lhs = torch.dot(eng.incidence("E01", a1), b0).item(); rhs = -torch.dot(a1, eng.incidence("E10", b0)).item()
     assert abs(lhs - rhs) <= 1e-12 * max(1.0, abs(rhs))
+
+
+@pytest.mark.parametrize("which,op", [(0, "PHMAT_UP"), (1, "ROTMAT_UP")])
+def test_upwinded_sw_operators(setup, which, op):
+    """Phmat::assemble_up / RotMat_up::assemble (src/Assembly.cpp:499-567, :1784-1853): the 0-form evaluated at
+    departure points x_q - tau*u; shift kept at ~0.2 of the reference element as in the SW runs (UP_TAU=0.5)"""
+    eng, P, rng = setup
+    r = np.random.default_rng(21)
+    fac, dt = 0.5, 600.0
+    ul = r.uniform(-1, 1, P.n1) * P.det.mean() * 0.2 / (fac * dt)
+    if which == 0:
+        f1 = r.uniform(0.5, 1.5, P.n2) * 1e4; x = r.standard_normal(P.n0)
+    else:
+        f1 = r.standard_normal(P.n0) * 1e-4; x = r.standard_normal(P.n1)
+    want, _ = P.apply_up(which, x, fac, dt, f1, ul)
+    got = eng.apply_up(op, eng.tensor(x), eng.tensor(f1), eng.tensor(ul), fac, dt, lev0=0)
+    assert rel_l2(got.cpu().numpy(), want) < TOL
