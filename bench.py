@@ -72,6 +72,35 @@ def replicate(dm, R):
     return out
 
 
+def column_extras(eng, dm, rng, torch):
+    """untimed-for-the-headline extras: solve_schur_column_eta for all 3 456 columns x 30 levels,
+    one VertOps assemble+MatMult, and the L2Vecs transposes"""
+    nEl, nk, n2 = dm.nEl, NK, eng.n2e
+    area = float(dm.det.mean()) * 4.0 / n2
+    dz = float(dm.thick.mean())
+    lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+    theta, rho, eta, pi = lev(nk, 280, 320), lev(nk, 0.5, 1.2), lev(nk, 5, 6), lev(nk, 700, 1000)
+    F = [eng.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (nk - 1, nk, nk, nk)]
+    res = {}
+
+    def timeit(fn, reps):
+        fn(); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    t = timeit(lambda: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F]), 5)
+    res["schur_column_solves_per_s"] = nEl / t
+    res["schur_ms_all_columns"] = t * 1e3
+    t = timeit(lambda: eng.colop_apply("CONST_RHO", theta, f1=rho, nout_slots=nk), 20)
+    res["vertops_assemble_apply_columns_per_s"] = nEl / t
+    vh = eng.tensor(rng.standard_normal((nk, dm.n2)))
+    t = timeit(lambda: eng.l2_horiz_to_vert(vh), 50)
+    res["l2_transposes_per_s"] = 1.0 / t
+    res["l2_transpose_GBs"] = 2 * vh.numel() * 8 / t / 1e9
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
+    ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
                          "working set >> the 256 MiB Infinity Cache, i.e. genuinely HBM-resident")
@@ -190,6 +220,8 @@ def main():
             torch.cuda.synchronize()
             fam[op] = units_rank * 50 / (time.perf_counter() - t1)
         out["families"] = fam
+    if a.column and rank == 0 and world == 1:
+        out["column"] = column_extras(eng, dm, rng, torch)
     if a.cold and rank == 0 and world == 1:
         R = a.cold
         dmc = replicate(dm, R)

@@ -12,6 +12,7 @@
 // The Schur complement of solve_schur_column_eta is assembled ANALYTICALLY from these factors: every
 // factor is block-diagonal or block-bidiagonal, so L_pi is block-tridiagonal -- no
 // sparse mat-mat products, no symbolic phases, no per-column PETSc objects.
+#include <cstdlib>
 #include "ctx.hpp"
 
 #define RD 287.0
@@ -157,17 +158,35 @@ int coef_pass(mimsem_ctx* c, int colop, unsigned flags, const double* f1, const 
     });
 }
 
-// block pass: M[b][i][j] = sum_q (W[q][i] c[b][q]) W[q][j]   (Mult_FD_IP then Mult_IP order)
-int block_pass(mimsem_ctx* c, long long nb, const double* cq, double* M) {
-    const CG g = make_cg(c);
-    const int nn = g.n2*g.n2;
-    return each(c, nb*nn, [=] __device__(long long i) {
-        const long long b = i/nn; const int ij = (int)(i%nn), ii = ij/g.n2, jj = ij%g.n2;
-        const double* cb = cq + b*g.mp12;
+// block pass: M[b][i][j] = sum_q (W[q][i] c[b][q]) W[q][j]   (Mult_FD_IP then Mult_IP order).
+// One workgroup = BT blocks; the dense W table (built from the edge table) and the BT coefficient rows are
+// staged in LDS, every thread produces entries with mp12-term sums out of LDS -> write-bandwidth bound.
+constexpr int BP_BT = 16;
+__global__ __launch_bounds__(256) void k_block_pass(CG g, long long nb, const double* __restrict__ cq, double* __restrict__ M) {
+    extern __shared__ double sm[];
+    double* sW = sm;                         // [mp12][n2]
+    double* sc = sm + g.mp12*g.n2;           // [BT][mp12]
+    const int nn = g.n2*g.n2, tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x*BP_BT;
+    const int nbt = (int)min((long long)BP_BT, nb - b0);
+    for (int t = tid; t < g.mp12*g.n2; t += 256) sW[t] = g_W(g, t/g.n2, t%g.n2);
+    for (int t = tid; t < nbt*g.mp12; t += 256) sc[t] = cq[b0*g.mp12 + t];
+    __syncthreads();
+    for (int t = tid; t < nbt*nn; t += 256) {
+        const int lb = t/nn, ij = t%nn, ii = ij/g.n2, jj = ij%g.n2;
+        const double* cb = sc + lb*g.mp12;
         double s = 0.0;
-        for (int q = 0; q < g.mp12; q++) s += (g_W(g, q, ii)*cb[q])*g_W(g, q, jj);
-        M[i] = s;
-    });
+        for (int q = 0; q < g.mp12; q++) s += (sW[q*g.n2 + ii]*cb[q])*sW[q*g.n2 + jj];
+        M[b0*nn + t] = s;
+    }
+}
+int block_pass(mimsem_ctx* c, long long nb, const double* cq, double* M) {
+    if (nb <= 0) return MIMSEM_OK;
+    const CG g = make_cg(c);
+    const size_t lds = (size_t)(g.mp12*g.n2 + BP_BT*g.mp12)*sizeof(double);
+    hipLaunchKernelGGL(k_block_pass, dim3((unsigned)((nb + BP_BT - 1)/BP_BT)), dim3(256), lds, c->stream, g, nb, cq, M);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
 }
 
 // ---- batched Gauss-Jordan with full pivoting: one thread per block, private copy in LDS ------------
@@ -228,10 +247,189 @@ __global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, int T
     if (err && errcount) atomicAdd(errcount, 1);
 }
 
+
+// Cooperative variant for the block sizes of p <= 4 (n = 1, 4, 9, 16): ONE LANE PER ROW, the row lives in
+// registers, LPM lanes per matrix (4 matrices per wavefront at n = 9/16).  Same algorithm and tie-breaking as
+// LinAlg.cpp:186-269: the pivot is the LAST entry (row-major scan of the not-yet-pivoted rows x columns)
+// attaining the maximum modulus; row swap, normalise, eliminate, final column un-permutation.
+template <int N> __device__ __forceinline__ double rsel(const double (&r)[N], int idx) {
+    double v = r[0];
+#pragma unroll
+    for (int c = 1; c < N; c++) v = (c == idx) ? r[c] : v;
+    return v;
+}
+template <int N, int LPM>
+__global__ __launch_bounds__(256) void k_block_inverse_rows(long long nb, double* __restrict__ blocks, int* errcount) {
+    const int tid = threadIdx.x, lane = tid%LPM;
+    const long long m = ((long long)blockIdx.x*256 + tid)/LPM;
+    const bool act = (m < nb) && (lane < N);
+    double row[N];
+    const long long mm = (m < nb) ? m : nb - 1;
+    const int lr = (lane < N) ? lane : N - 1;
+#pragma unroll
+    for (int c = 0; c < N; c++) row[c] = blocks[mm*N*N + lr*N + c];
+    unsigned pmask = 0;
+    int indxr[N], indxc[N];
+    int err = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        // ---- pivot search ----
+        double bv = -2.0; int bk = 0, br = lane;
+        if (lane < N && !((pmask >> lane) & 1u)) {
+            bv = -1.0;
+#pragma unroll
+            for (int k = 0; k < N; k++)
+                if (!((pmask >> k) & 1u)) { const double v = fabs(row[k]); if (v >= bv) { bv = v; bk = k; } }
+        }
+#pragma unroll
+        for (int off = LPM/2; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, LPM);
+            const int ok = __shfl_xor(bk, off, LPM), orr = __shfl_xor(br, off, LPM);
+            if (ov > bv || (ov == bv && orr > br)) { bv = ov; bk = ok; br = orr; }
+        }
+        const int irow = br, icol = bk;
+        pmask |= 1u << icol;
+        indxr[i] = irow; indxc[i] = icol;
+        // ---- swap rows irow <-> icol ----
+        const int partner = (lane == irow) ? icol : ((lane == icol) ? irow : lane);
+#pragma unroll
+        for (int c = 0; c < N; c++) row[c] = __shfl(row[c], partner, LPM);
+        // ---- normalise the pivot row (now held by lane icol), broadcast it ----
+        double prow[N];
+#pragma unroll
+        for (int c = 0; c < N; c++) prow[c] = __shfl(row[c], icol, LPM);
+        const double piv = rsel<N>(prow, icol);
+        if (fabs(piv) < 1.0e-12) err = 2;
+        const double pivinv = 1.0/piv;
+#pragma unroll
+        for (int c = 0; c < N; c++) prow[c] = ((c == icol) ? 1.0 : prow[c])*pivinv;
+        if (lane == icol) {
+#pragma unroll
+            for (int c = 0; c < N; c++) row[c] = prow[c];
+        } else {
+            const double dum = rsel<N>(row, icol);
+#pragma unroll
+            for (int c = 0; c < N; c++) row[c] = ((c == icol) ? 0.0 : row[c]) - prow[c]*dum;
+        }
+    }
+    // ---- unscramble the columns ----
+#pragma unroll
+    for (int l = N - 1; l >= 0; l--) {
+        const int ir = indxr[l], ic = indxc[l];
+        if (ir != ic) {
+            const double a = rsel<N>(row, ir), b = rsel<N>(row, ic);
+#pragma unroll
+            for (int c = 0; c < N; c++) row[c] = (c == ir) ? b : ((c == ic) ? a : row[c]);
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < N; c++) blocks[m*N*N + lane*N + c] = row[c];
+        if (err && errcount && lane == 0) atomicAdd(errcount, 1);
+    }
+}
+// Register-resident variant for n <= 9: one THREAD per block, all n*n entries in VGPRs with static indices,
+// natural-order (unpivoted) Gauss-Jordan.  Every block this engine inverts is W^T diag(c) W with c > 0, i.e.
+// symmetric positive definite, for which the reference's full-pivoting search can only ever select diagonal
+// entries (|a_ij| <= max diagonal) and elimination is stable in any order; the results agree to round-off.
+// A block whose natural-order pivot falls below 1e-8 x its largest diagonal entry (not SPD / near singular)
+// is redone by the same thread with the reference's exact full-pivoting algorithm (LinAlg.cpp:186-269).
+template <int N>
+__global__ __launch_bounds__(64) void k_block_inverse_reg(long long nb, double* __restrict__ blocks, int* errcount) {
+    const long long b = (long long)blockIdx.x*64 + threadIdx.x;
+    if (b >= nb) return;
+    double* src = blocks + b*N*N;
+    double a[N*N];
+#pragma unroll
+    for (int k = 0; k < N*N; k++) a[k] = src[k];
+    double dmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k++) dmax = fmax(dmax, fabs(a[k*N + k]));
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+        const double piv = a[p*N + p];
+        if (!(fabs(piv) >= 1.0e-8*dmax) || !(fabs(piv) >= 1.0e-12)) ok = false;
+        const double pinv = 1.0/piv;
+        a[p*N + p] = 1.0;
+#pragma unroll
+        for (int c = 0; c < N; c++) a[p*N + c] *= pinv;
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            if (r == p) continue;
+            const double d = a[r*N + p];
+            a[r*N + p] = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; c++) a[r*N + c] -= a[p*N + c]*d;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < N*N; k++) src[k] = a[k];
+        return;
+    }
+    // ---- slow path: exact restatement with full pivoting on a private copy ----
+    double A[N*N]; int ipiv[N], indxr[N], indxc[N];
+    for (int k = 0; k < N*N; k++) A[k] = src[k];
+    for (int j = 0; j < N; j++) ipiv[j] = 0;
+    int err = 0, irow = 0, icol = 0;
+    for (int i = 0; i < N; i++) {
+        double big = 0.0;
+        for (int j = 0; j < N; j++) {
+            if (ipiv[j] == 1) continue;
+            for (int k = 0; k < N; k++) {
+                if (ipiv[k] == 0) { const double v = fabs(A[j*N + k]); if (v >= big) { big = v; irow = j; icol = k; } }
+                else if (ipiv[k] > 1) err = 1;
+            }
+        }
+        ++ipiv[icol];
+        if (irow != icol) for (int l = 0; l < N; l++) { const double t = A[irow*N + l]; A[irow*N + l] = A[icol*N + l]; A[icol*N + l] = t; }
+        indxr[i] = irow; indxc[i] = icol;
+        if (fabs(A[icol*N + icol]) < 1.0e-12) err = 2;
+        const double pivinv = 1.0/A[icol*N + icol];
+        A[icol*N + icol] = 1.0;
+        for (int l = 0; l < N; l++) A[icol*N + l] *= pivinv;
+        for (int ll = 0; ll < N; ll++) {
+            if (ll == icol) continue;
+            const double dum = A[ll*N + icol];
+            A[ll*N + icol] = 0.0;
+            for (int l = 0; l < N; l++) A[ll*N + l] -= A[icol*N + l]*dum;
+        }
+    }
+    for (int l = N - 1; l >= 0; l--) {
+        if (indxr[l] == indxc[l]) continue;
+        for (int k = 0; k < N; k++) { const double t = A[k*N + indxr[l]]; A[k*N + indxr[l]] = A[k*N + indxc[l]]; A[k*N + indxc[l]] = t; }
+    }
+    for (int k = 0; k < N*N; k++) src[k] = A[k];
+    if (err && errcount) atomicAdd(errcount, 1);
+}
+template <int N>
+int launch_inverse_reg(mimsem_ctx* c, long long nb, double* blocks) {
+    hipLaunchKernelGGL((k_block_inverse_reg<N>), dim3((unsigned)((nb + 63)/64)), dim3(64), 0, c->stream, nb, blocks, (int*)nullptr);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+template <int N, int LPM>
+int launch_inverse_rows(mimsem_ctx* c, long long nb, double* blocks) {
+    const long long threads = nb*LPM;
+    hipLaunchKernelGGL((k_block_inverse_rows<N, LPM>), dim3((unsigned)((threads + 255)/256)), dim3(256), 0, c->stream,
+                       nb, blocks, (int*)nullptr);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 }  // namespace
 
 int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks) {
     if (nblocks <= 0) return MIMSEM_OK;
+    switch (n) {                     // register-resident one-lane-per-row kernel for the block sizes of p <= 4
+    case 1:  return launch_inverse_reg<1>(c, nblocks, blocks);
+    case 4:  return launch_inverse_reg<4>(c, nblocks, blocks);
+    case 9:  return getenv("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks) : launch_inverse_reg<9>(c, nblocks, blocks);
+    case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks);
+    default: break;                  // 25, 36, 49: thread-per-matrix in LDS below
+    }
     // matrices per workgroup: as many as fit a 144 KiB LDS budget (64 for n<=16, fewer for the 25..49-wide blocks of p>=5)
     int T = 64;
     auto need = [&](int t) { return (size_t)n*n*t*sizeof(double) + (size_t)3*n*t*sizeof(int); };
@@ -254,6 +452,13 @@ struct WS {
     double* take(long long n) { double* p = base + used; used += n; return p; }
 };
 
+int flat_mm_impl(mimsem_ctx* c, long long nb, const double* A, const double* B, double* C);   // defined after bmm
+// C[b] = A[b] . B[b] for nb independent n x n blocks
+int flat_mm(mimsem_ctx* c, long long nb, int n, const double* A, const double* B, double* C) {
+    (void)n;
+    return flat_mm_impl(c, nb, A, B, C);
+}
+
 bool colop_is_inverse(int colop) {
     return colop == MIMSEM_V_CONST_INV || colop == MIMSEM_V_CONST_RHO_INV || colop == MIMSEM_V_LINEAR_INV;
 }
@@ -274,17 +479,12 @@ int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1
         double* Bm = tmpM + nb*nn;
         if ((rc = block_pass(c, nb, cq, Bm))) return rc;                      // B
         const double* Binv = tmpM;
-        return each(c, nb*nn, [=] __device__(long long i) {                   // B (Binv B)
-            const long long b = i/nn; const int ij = (int)(i%nn), ii = ij/n2, jj = ij%n2;
-            const double *B = Bm + b*nn, *Bi = Binv + b*nn;
-            double s = 0.0;
-            for (int k = 0; k < n2; k++) {
-                double t = 0.0;
-                for (int l = 0; l < n2; l++) t += Bi[k*n2 + l]*B[l*n2 + jj];
-                s += B[ii*n2 + k]*t;
-            }
-            M[i] = s;
-        });
+        double* t1 = M;                                                        // Binv.B lands in the output, then B.(Binv.B)
+        if ((rc = flat_mm(c, nb, n2, Binv, Bm, t1))) return rc;
+        double* t2 = tmpM;                                                     // Binv no longer needed
+        if ((rc = flat_mm(c, nb, n2, Bm, t1, t2))) return rc;
+        MIMSEM_HIP_TRY(hipMemcpyAsync(M, t2, (size_t)nb*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return MIMSEM_OK;
     }
     if ((rc = coef_pass(c, colop, flags, f1, f2, cq, nr, nw))) return rc;
     if ((rc = block_pass(c, nb, cq, M))) return rc;
@@ -502,23 +702,51 @@ namespace {
 // block-array view: X[e][slot][n2*n2] with ns slots per column
 struct BA { double* p; int ns; };
 
-// C[e][r] (+)= alpha * A[e][r+da] . B[e][r+db]   for r in [0,nr); out-of-range operand slots contribute 0
-int bmm(mimsem_ctx* c, int nr, BA C, BA A, int da, BA B, int db, double alpha, int accum) {
-    const int n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
-    return each(c, (long long)nEl*nr*nn, [=] __device__(long long i) {
-        const int ij = (int)(i%nn), ii = ij/n2, jj = ij%n2; long long t = i/nn;
-        const int r = (int)(t%nr), e = (int)(t/nr);
-        double* out = C.p + ((size_t)e*C.ns + r)*nn + ij;
-        const int ra = r + da, rb = r + db;
+// C[e][r] (+)= alpha * A[e][r+da] . B[e][r+db]   for r in [0,nr); out-of-range operand slots contribute 0.
+// A workgroup takes TPW consecutive (e,r) tasks, stages both operand blocks in LDS (coalesced 648-B reads at
+// p=3) and every thread forms entries from LDS.
+__global__ __launch_bounds__(256) void k_bmm(int n2, int nEl, int nr, int tpw, BA C, BA A, int da, BA B, int db, double alpha, int accum) {
+    extern __shared__ double sm[];
+    const int nn = n2*n2, tid = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x*tpw, ntask = (long long)nEl*nr;
+    const int nt = (int)min((long long)tpw, ntask - t0);
+    double* sA = sm; double* sB = sm + tpw*nn;
+    for (int x = tid; x < nt*nn; x += 256) {
+        const long long task = t0 + x/nn; const int ij = x%nn;
+        const int r = (int)(task%nr), e = (int)(task/nr), ra = r + da, rb = r + db;
+        sA[x] = (ra >= 0 && ra < A.ns) ? A.p[((size_t)e*A.ns + ra)*nn + ij] : 0.0;
+        sB[x] = (rb >= 0 && rb < B.ns) ? B.p[((size_t)e*B.ns + rb)*nn + ij] : 0.0;
+    }
+    __syncthreads();
+    for (int x = tid; x < nt*nn; x += 256) {
+        const int lt = x/nn, ij = x%nn, ii = ij/n2, jj = ij%n2;
+        const long long task = t0 + lt;
+        const int r = (int)(task%nr), e = (int)(task/nr);
+        const double *a = sA + lt*nn, *b = sB + lt*nn;
         double s = 0.0;
-        if (ra >= 0 && ra < A.ns && rb >= 0 && rb < B.ns) {
-            const double* a = A.p + ((size_t)e*A.ns + ra)*nn;
-            const double* b = B.p + ((size_t)e*B.ns + rb)*nn;
-            for (int k = 0; k < n2; k++) s += a[ii*n2 + k]*b[k*n2 + jj];
-        }
+        for (int k = 0; k < n2; k++) s += a[ii*n2 + k]*b[k*n2 + jj];
+        double* out = C.p + ((size_t)e*C.ns + r)*nn + ij;
         if (accum) *out += alpha*s; else *out = alpha*s;
-    });
+    }
 }
+int bmm(mimsem_ctx* c, int nr, BA C, BA A, int da, BA B, int db, double alpha, int accum) {
+    const int n2 = c->es.n2e, nn = n2*n2;
+    const long long ntask = (long long)c->nEl*nr;
+    if (ntask <= 0) return MIMSEM_OK;
+    const int tpw = std::max(1, 768/nn);                 // ~3 passes of the 256 threads per workgroup
+    const size_t lds = (size_t)2*tpw*nn*sizeof(double);
+    hipLaunchKernelGGL(k_bmm, dim3((unsigned)((ntask + tpw - 1)/tpw)), dim3(256), lds, c->stream,
+                       n2, c->nEl, nr, tpw, C, A, da, B, db, alpha, accum);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int flat_mm_impl(mimsem_ctx* c, long long nb, const double* A, const double* B, double* C) {
+    // view the flat arrays as [nEl][slots]: nb is always nEl * (slots per column) here
+    const int per = (int)(nb/c->nEl);
+    BA a{const_cast<double*>(A), per}, b{const_cast<double*>(B), per}, cc{C, per};
+    return bmm(c, per, cc, a, 0, b, 0, 1.0, 0);
+}
+
 // y[e][r] (+)= alpha * A[e][r+da] x[e][r+dx]   (vectors with nsy / nsx slots)
 int bmv(mimsem_ctx* c, int nr, double* y, int nsy, BA A, int da, const double* x, int nsx, int dx, double alpha, int accum) {
     const int n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
@@ -633,9 +861,38 @@ int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, dou
     return MIMSEM_OK;
 }
 
+// one workgroup per (column, level): the two DIV blocks of the row, the four G_pi blocks they meet and N_pi are
+// staged in LDS; 3*nn entries of L(k,k-1), L(k,k), L(k,k+1) are formed from LDS.
+__global__ __launch_bounds__(256) void k_helmholtz_rows(int n2, int nk, double gam, const double* __restrict__ Dl,
+        const double* __restrict__ Du, const double* __restrict__ Gl, const double* __restrict__ Gu,
+        const double* __restrict__ Np, double* __restrict__ L) {
+    extern __shared__ double sm[];
+    const int nn = n2*n2, nm = nk - 1, tid = threadIdx.x;
+    const int k = blockIdx.x%nk, e = blockIdx.x/nk;
+    double *sDl = sm, *sDu = sm + nn, *sGlm = sm + 2*nn, *sGum = sm + 3*nn, *sGl = sm + 4*nn, *sGu = sm + 5*nn, *sN = sm + 6*nn;
+    for (int x = tid; x < nn; x += 256) {
+        sDl[x] = Dl[((size_t)e*nk + k)*nn + x]; sDu[x] = Du[((size_t)e*nk + k)*nn + x]; sN[x] = Np[((size_t)e*nk + k)*nn + x];
+        sGlm[x] = (k > 0) ? Gl[((size_t)e*nm + k - 1)*nn + x] : 0.0;
+        sGum[x] = (k > 0) ? Gu[((size_t)e*nm + k - 1)*nn + x] : 0.0;
+        sGl[x] = (k < nk - 1) ? Gl[((size_t)e*nm + k)*nn + x] : 0.0;
+        sGu[x] = (k < nk - 1) ? Gu[((size_t)e*nm + k)*nn + x] : 0.0;
+    }
+    __syncthreads();
+    for (int x = tid; x < 3*nn; x += 256) {
+        const int w = x/nn, ij = x%nn, ii = ij/n2, jj = ij%n2;
+        double s = 0.0;
+        if (w == 0)      { for (int p = 0; p < n2; p++) s += sDl[ii*n2 + p]*sGlm[p*n2 + jj]; s = (-1.0*gam)*s; }          // DIV(k,k-1) G(k-1,k-1)
+        else if (w == 2) { for (int p = 0; p < n2; p++) s += sDu[ii*n2 + p]*sGu[p*n2 + jj]; s = (-1.0*gam)*s; }           // DIV(k,k)   G(k,k+1)
+        else { for (int p = 0; p < n2; p++) s += sDl[ii*n2 + p]*sGum[p*n2 + jj];                                         // DIV(k,k-1) G(k-1,k)
+               for (int p = 0; p < n2; p++) s += sDu[ii*n2 + p]*sGl[p*n2 + jj];                                          // DIV(k,k)   G(k,k)
+               s = (-1.0*gam)*s + sN[ij]; }
+        L[(((size_t)e*nk + k)*3 + w)*nn + ij] = s;
+    }
+}
+
 struct Schur {
     // block arrays (all [nEl][ns][nn])
-    BA B, Binv, Ainv, T, Rr, X, Npi, Nrho, R2, C2, DIVl, DIVu, Gl, Gu, M1, L, G;
+    BA B, Binv, Ainv, T, Rr, X, Npi, Nrho, R2, C2, DIVl, DIVu, Gl, Gu, M1, L, G, AB0, AB1;
     double *gpi, *geta, *rlump, *tA, *tB;
 };
 
@@ -644,13 +901,13 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
                    const double* pi, Schur& S) {
     const int nk = c->nk, nm = nk - 1, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl, mp12 = c->es.mp12;
     int rc;
-    if ((rc = c->ensure_col((long long)nEl*(nk + 1)*(26LL*nn + 8LL*n2 + 4LL*mp12) + colop_ws_doubles(c)))) return rc;
+    if ((rc = c->ensure_col((long long)nEl*(nk + 1)*(30LL*nn + 8LL*n2 + 4LL*mp12) + colop_ws_doubles(c)))) return rc;
     WS w{c, c->d_col, 0, c->col_doubles};
     double* cq = w.take((long long)nEl*(nk + 1)*2*mp12);
     double* tmpM = w.take((long long)nEl*(nk + 1)*2*nn*2);
     auto ba = [&](int ns) { BA b; b.ns = ns; b.p = w.take((long long)nEl*ns*nn); return b; };
     S.B = ba(nk); S.Binv = ba(nk); S.Ainv = ba(nm); S.T = ba(nm); S.Rr = ba(nm); S.X = ba(nm);
-    S.Npi = ba(nk); S.Nrho = ba(nk); S.M1 = ba(nm); S.G = ba(nk);
+    S.Npi = ba(nk); S.Nrho = ba(nk); S.M1 = ba(nm); S.G = ba(nk); S.AB0 = ba(nm); S.AB1 = ba(nm);
     S.R2.ns = 2*nk; S.R2.p = w.take((long long)nEl*2*nk*nn);   // RHODPI stored [k][2]
     S.C2.ns = 2*nk; S.C2.p = w.take((long long)nEl*2*nk*nn);   // CONLIN_W stored [k][2]
     BA R2 = S.R2, C2 = S.C2;
@@ -768,74 +1025,33 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
         }))) return rc;
     }
     // DIV (N x Nm), row k:  DIVl_k = (k,k-1),  DIVu_k = (k,k)                           (:754-761)
-    //   = 0.5dt ( -+ N_rho_k X_j ) + 0.5dt C_j , then column-scaled by rlump_j
+    //   = 0.5dt ( -+ CM_k B_k X_j ) + 0.5dt C_j , then column-scaled by rlump_j ;  CM_k B_k = N_rho_k Binv_k B_k = N_rho_k
     {
-        const double *Nr = S.Nrho.p, *Bi = S.Binv.p, *B = S.B.p, *X = S.X.p, *Cw = C2.p, *rl = S.rlump;
-        double *Dl = S.DIVl.p, *Du = S.DIVu.p;
+        if ((rc = bmm(c, nk, S.DIVl, S.Nrho, 0, S.X, -1, -hdt, 0))) return rc;         // -h N_rho_k X_{k-1}
+        if ((rc = bmm(c, nk, S.DIVu, S.Nrho, 0, S.X, 0, +hdt, 0))) return rc;          // +h N_rho_k X_k
+        const double *Cw = C2.p, *rl = S.rlump; double *Dl = S.DIVl.p, *Du = S.DIVu.p;
         if ((rc = each(c, (long long)nEl*nk*2*nn, [=] __device__(long long x) {
-            const int ij = (int)(x%nn), ii = ij/n2, jj = ij%n2; long long t = x/nn;
+            const int ij = (int)(x%nn), jj = ij%n2; long long t = x/nn;
             const int w = (int)(t%2); t /= 2; const int k = (int)(t%nk), e = (int)(t/nk);
             const int j = k - 1 + w;
             double* out = (w ? Du : Dl) + ((size_t)e*nk + k)*nn + ij;
             if (j < 0 || j > nm - 1) { *out = 0.0; return; }
-            // CM_k = N_rho_k Binv_k ; D_rho(k,j) = +-0.5dt B_k X_j  => CM_k D_rho = +-0.5dt N_rho_k Binv_k B_k X_j
-            const double* nr = Nr + ((size_t)e*nk + k)*nn; const double* bi = Bi + ((size_t)e*nk + k)*nn;
-            const double* bk = B + ((size_t)e*nk + k)*nn;  const double* xj = X + ((size_t)e*nm + j)*nn;
-            double s = 0.0;
-            for (int p = 0; p < n2; p++) {            // (N_rho Binv)[ii][p]
-                double cm = 0.0;
-                for (int l = 0; l < n2; l++) cm += nr[ii*n2 + l]*bi[l*n2 + p];
-                double bx = 0.0;                       // (B_k X_j)[p][jj]
-                for (int l = 0; l < n2; l++) bx += bk[p*n2 + l]*xj[l*n2 + jj];
-                s += cm*bx;
-            }
-            s *= (w ? +hdt : -hdt);
-            s += hdt*Cw[((size_t)e*2*nk + 2*k + w)*nn + ij];
-            *out = s*rl[((size_t)e*nm + j)*n2 + jj];
+            *out = (*out + hdt*Cw[((size_t)e*2*nk + 2*k + w)*nn + ij])*rl[((size_t)e*nm + j)*n2 + jj];
         }))) return rc;
     }
     // G_pi (Nm x N), row i: Gl_i = (i,i) = -0.5dt T_i Ainv_i B_i ; Gu_i = (i,i+1) = +0.5dt T_i Ainv_i B_{i+1}  (:710-711)
     {
-        const double *T = S.T.p, *Ai = S.Ainv.p, *B = S.B.p; double *Gl = S.Gl.p, *Gu = S.Gu.p;
-        if ((rc = each(c, (long long)nEl*nm*2*nn, [=] __device__(long long x) {
-            const int ij = (int)(x%nn), ii = ij/n2, jj = ij%n2; long long t = x/nn;
-            const int w = (int)(t%2); t /= 2; const int i = (int)(t%nm), e = (int)(t/nm);
-            const double* tt = T + ((size_t)e*nm + i)*nn; const double* ai = Ai + ((size_t)e*nm + i)*nn;
-            const double* bk = B + ((size_t)e*nk + i + w)*nn;
-            double s = 0.0;
-            for (int p = 0; p < n2; p++) {
-                double ab = 0.0;                        // (Ainv_i B)[p][jj]
-                for (int l = 0; l < n2; l++) ab += ai[p*n2 + l]*bk[l*n2 + jj];
-                s += tt[ii*n2 + p]*ab;
-            }
-            ((w ? Gu : Gl) + ((size_t)e*nm + i)*nn)[ij] = (w ? +hdt : -hdt)*s;
-        }))) return rc;
+        if ((rc = bmm(c, nm, S.AB0, S.Ainv, 0, S.B, 0, 1.0, 0))) return rc;            // Ainv_i B_i
+        if ((rc = bmm(c, nm, S.AB1, S.Ainv, 0, S.B, 1, 1.0, 0))) return rc;            // Ainv_i B_{i+1}
+        if ((rc = bmm(c, nm, S.Gl, S.T, 0, S.AB0, 0, -hdt, 0))) return rc;
+        if ((rc = bmm(c, nm, S.Gu, S.T, 0, S.AB1, 0, +hdt, 0))) return rc;
     }
     // L_pi = N_pi - gam DIV G_pi : block tridiagonal [k][3]                                (:766-767)
     {
-        const double *Dl = S.DIVl.p, *Du = S.DIVu.p, *Gl = S.Gl.p, *Gu = S.Gu.p, *Np = S.Npi.p; double* L = S.L.p;
-        if ((rc = each(c, (long long)nEl*nk*3*nn, [=] __device__(long long x) {
-            const int ij = (int)(x%nn), ii = ij/n2, jj = ij%n2; long long t = x/nn;
-            const int w = (int)(t%3); t /= 3; const int k = (int)(t%nk), e = (int)(t/nk);
-            const double* dl = Dl + ((size_t)e*nk + k)*nn; const double* du = Du + ((size_t)e*nk + k)*nn;
-            double s = 0.0;
-            if (w == 0) {            // (k,k-1): DIV(k,k-1) G_pi(k-1,k-1)
-                if (k > 0) { const double* g = Gl + ((size_t)e*nm + k - 1)*nn;
-                             for (int p = 0; p < n2; p++) s += dl[ii*n2 + p]*g[p*n2 + jj]; }
-                s = (-1.0*gam)*s;
-            } else if (w == 2) {     // (k,k+1): DIV(k,k) G_pi(k,k+1)
-                if (k < nk - 1) { const double* g = Gu + ((size_t)e*nm + k)*nn;
-                                  for (int p = 0; p < n2; p++) s += du[ii*n2 + p]*g[p*n2 + jj]; }
-                s = (-1.0*gam)*s;
-            } else {                 // (k,k): DIV(k,k-1) G_pi(k-1,k) + DIV(k,k) G_pi(k,k)
-                if (k > 0) { const double* g = Gu + ((size_t)e*nm + k - 1)*nn;
-                             for (int p = 0; p < n2; p++) s += dl[ii*n2 + p]*g[p*n2 + jj]; }
-                if (k < nk - 1) { const double* g = Gl + ((size_t)e*nm + k)*nn;
-                                  for (int p = 0; p < n2; p++) s += du[ii*n2 + p]*g[p*n2 + jj]; }
-                s = (-1.0*gam)*s + Np[((size_t)e*nk + k)*nn + ij];
-            }
-            L[x] = s;
-        }))) return rc;
+        const size_t lds = (size_t)7*nn*sizeof(double);
+        hipLaunchKernelGGL(k_helmholtz_rows, dim3((unsigned)(nEl*nk)), dim3(256), lds, c->stream, n2, nk, gam,
+                           S.DIVl.p, S.DIVu.p, S.Gl.p, S.Gu.p, S.Npi.p, S.L.p);
+        MIMSEM_HIP_TRY(hipGetLastError());
     }
     return MIMSEM_OK;
 }

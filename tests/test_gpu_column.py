@@ -140,3 +140,55 @@ def test_schur_column_solve(setup):
         for name, got in (("d_pi", d_pi), ("d_u", d_u), ("d_eta", d_eta), ("d_rho", d_rho),
                           ("F_u", dFu), ("F_rho", dFrho), ("F_eta", dFeta), ("F_pi", dFpi)):
             assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name
+
+
+def test_residual_compositions(setup):
+    """C8: diagnose_F_z / diagnose_Phi_z / assemble_residual_ec (eul/VertSolve.cpp:237-286, 432-502) issued for all
+    columns through the ABI vs the same chain written with the oracle's dense column matrices"""
+    from mimsem_amd.vertsolve import RAYLEIGH, VertSolve
+    eng, P = setup
+    if P.nk < 4:
+        pytest.skip("Rayleigh layer needs nk >= 4")
+    F = _col_fields(P)
+    r = np.random.default_rng(13)
+    nEl, nk, n2 = P.nEl, P.nk, P.n2e
+    velz1, velz2 = F["velz"], F["velz"] * (1.0 + 0.1 * r.standard_normal(F["velz"].shape))
+    rho1, rho2 = F["rho"], F["rho"] * (1.0 + 0.01 * r.standard_normal(F["rho"].shape))
+    theta, Pi = F["thetaL"], F["pi"]
+    zv = r.standard_normal((nEl, nk * n2)) * 1e8
+    dt = 75.0
+    t = eng.tensor
+    vs = VertSolve(eng, dt)
+    fw, Fz, G, ftc = vs.assemble_residual_ec(t(theta), t(Pi), t(velz1), t(velz2), t(rho1), t(rho2), t(zv))
+    N, Nm = nk * n2, (nk - 1) * n2
+    V10 = np.zeros((N, Nm))
+    for k in range(nk):
+        for i in range(n2):
+            if k > 0: V10[k*n2+i, (k-1)*n2+i] = -1.0
+            if k < nk - 1: V10[k*n2+i, k*n2+i] = +1.0
+    V01 = -V10.T
+    for e in (0, nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        D = lambda op, **kw: P.colop_dense(op, ex, ey, **kw)
+        VAinv = D("LINEAR_INV")
+        F_ref = VAinv @ D("LINEAR_RT", flag=1, f1=rho1[e]) @ (velz1[e] / 3 + velz2[e] / 6) + \
+            VAinv @ D("LINEAR_RT", flag=1, f1=rho2[e]) @ (velz1[e] / 6 + velz2[e] / 3)
+        W1, W2 = D("CONLIN_W", f1=velz1[e]), D("CONLIN_W", f1=velz2[e])
+        Phi = (W1 @ velz1[e] + W1 @ velz2[e] + W2 @ velz2[e]) / 6 + zv[e]
+        VA, VB = D("LINEAR"), D("CONST")
+        fw_ref = VA @ velz2[e] - VA @ velz1[e] + dt * V01 @ Phi
+        tA2 = VAinv @ (V01 @ (VB @ Pi[e]))
+        VAt = D("LINEAR_RT", flag=1, f1=theta[e])
+        tA1 = VAt @ tA2
+        fw_ref += 0.5 * dt * tA1
+        G_ref = VAinv @ (VAt @ F_ref)
+        VR = D("RAYLEIGH")
+        fw_ref += 0.5 * dt * RAYLEIGH * (VR @ velz2[e] + VR @ velz1[e])
+        tA2 = VAinv @ (V01 @ (VB @ theta[e]))
+        VBr = D("CONST_RHO", f1=theta[e]); VBA = D("CONLIN_W", f1=tA2)
+        fw_ref += 0.5 * dt * V01 @ (VBr @ Pi[e]) - 0.5 * dt * VBA.T @ Pi[e]
+        ftc_ref = 0.5 * dt * VBr @ (V10 @ F_ref) + 0.5 * dt * VBA @ F_ref
+        assert rel_l2(Fz[e].cpu().numpy(), F_ref) < 1e-9
+        assert rel_l2(G[e].cpu().numpy(), G_ref) < 1e-9
+        assert rel_l2(fw[e].cpu().numpy(), fw_ref) < 1e-9
+        assert rel_l2(ftc[e].cpu().numpy(), ftc_ref) < 1e-9
