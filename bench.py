@@ -123,9 +123,11 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MIMSEM_BENCH_FORCE_DIST") == "1"     # FORCE: rehearse the RCCL set-up on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mimsem_amd.device import DeviceMesh, Engine
     from mimsem_amd.geom import Geom
@@ -147,7 +149,7 @@ def main():
     x = eng.tensor(rng.standard_normal((NK, dm.n1)))
     y = eng.zeros(NK, dm.n1)
     halo = None
-    if world > 1:
+    if use_dist:
         plan1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)[1]
         halo = HaloExchanger(plan1, engine=eng)
 
@@ -160,7 +162,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +177,7 @@ def main():
     dt = time.perf_counter() - t0
     ms1, ms2, nl = eng.profile_read()
     eng.set_profiling(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -246,7 +248,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

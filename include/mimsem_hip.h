@@ -58,6 +58,9 @@ typedef struct mimsem_mesh_desc {
     const double* thick;    /* [nk][nEl][(m+1)^2] layer thickness AT each element's quad points
                                (Geom::thick[k][Geom::elInds0_l(e)[q]]), or NULL -> 1            */
     const double* thickInv; /* same shape, Geom::thickInv; NULL -> 1/thick (or 1)               */
+    const int* indsq;     /* [nEl][(m+1)^2] Geom::elInds0_l (eul/Geom.cpp:799-811): slots of the quad-point
+                             grid vectors the projection operators read; NULL if they are not used */
+    int nq;               /* length of a quad-point grid vector (Geom::n0)                        */
 } mimsem_mesh_desc;
 
 /* horizontal operator classes, eul/Assembly.h (src/Assembly.h twins: scale=1, no thickness) */
@@ -80,6 +83,10 @@ enum mimsem_op {
      * mimsem_op_apply_up: f = the op's field, u = local 1-form velocity that defines the departure points */
     MIMSEM_OP_PHMAT_UP = 14, /* Phmat::assemble_up(ul,hl,fac,dt)  src/Assembly.cpp:499-567   f=hl (2-form)  0 -> 0 */
     MIMSEM_OP_ROTMAT_UP = 15,/* RotMat_up::assemble(q0,ul,fac,dt) src/Assembly.cpp:1784-1853 f=q0 (0-form)  1 -> 1 */
+    /* projections from the quadrature-point grid (initial conditions, Coriolis): x lives on the quad grid */
+    MIMSEM_OP_WTQ = 16,      /* WtQmat::assemble  Assembly.cpp:707-751   quad scalar -> 2-form                        */
+    MIMSEM_OP_PTQ = 17,      /* PtQmat::assemble  :766-808               quad scalar -> 0-form                        */
+    MIMSEM_OP_UTQ = 18,      /* UtQmat::assemble  :824-902               quad vector [nq][2] -> 1-form                */
     MIMSEM_OP_COUNT
 };
 /* op flag: the boolean the reference method takes (vert_scale / const_vert / vert_scale_rho) */

@@ -16,7 +16,8 @@ class MeshDesc(C.Structure):
     _fields_ = [("elOrd", C.c_int), ("quadOrd", C.c_int), ("nEl", C.c_int), ("nk", C.c_int),
                 ("n0", C.c_int), ("n1", C.c_int), ("n2", C.c_int),
                 ("inds0", C.c_void_p), ("inds1x", C.c_void_p), ("inds1y", C.c_void_p), ("inds2", C.c_void_p),
-                ("det", C.c_void_p), ("J", C.c_void_p), ("thick", C.c_void_p), ("thickInv", C.c_void_p)]
+                ("det", C.c_void_p), ("J", C.c_void_p), ("thick", C.c_void_p), ("thickInv", C.c_void_p),
+                ("indsq", C.c_void_p), ("nq", C.c_int)]
 
 
 class MimsemError(RuntimeError):
@@ -62,7 +63,7 @@ _SIGS = {
 }
 
 OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=7, UTMAT=8,
-           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15)
+           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18)
 COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4, EOS_BLOCK=5,
               LINEAR=6, LINEAR_INV=7, LINEAR_RT=8, LINEAR_THETA=9, LINEAR_RHO2=10, RAYLEIGH=11,
               LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16)

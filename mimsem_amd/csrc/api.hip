@@ -50,6 +50,9 @@ int op_spaces(int op, int* in, int* cf, int* out) {
     case MIMSEM_OP_PHMAT:   *in = 0; *cf = 2; *out = 0; return 0;
     case MIMSEM_OP_WTQUMAT: case MIMSEM_OP_WTQDUDZ: *in = 1; *cf = 1; *out = 2; return 0;
     case MIMSEM_OP_UTQWMAT: *in = 2; *cf = 1; *out = 1; return 0;
+    case MIMSEM_OP_WTQ: *in = 3; *cf = -1; *out = 2; return 0;
+    case MIMSEM_OP_PTQ: *in = 3; *cf = -1; *out = 0; return 0;
+    case MIMSEM_OP_UTQ: *in = 3; *cf = -1; *out = 1; return 0;
     case MIMSEM_OP_PHMAT_UP:  *in = 0; *cf = 2; *out = 0; return 0;
     case MIMSEM_OP_ROTMAT_UP: *in = 1; *cf = 0; *out = 1; return 0;
     }
@@ -172,6 +175,12 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         if (!contig && (rc = upload(&c->d_i2, d->inds2, (size_t)d->nEl*es.n2e, c))) return fail(rc);
     }
 
+    if (d->indsq) {
+        if (d->nq <= 0) return fail(MIMSEM_ERR_ARG);
+        for (size_t i = 0; i < (size_t)d->nEl*es.mp12; i++) if (d->indsq[i] < 0 || d->indsq[i] >= d->nq) return fail(MIMSEM_ERR_ARG);
+        c->nq = d->nq;
+        if ((rc = upload(&c->d_iq, d->indsq, (size_t)d->nEl*es.mp12, c))) return fail(rc);
+    }
     // scatter-add plans
     {
         std::vector<int> plan;
@@ -200,7 +209,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_g1, c->d_g0, c->d_ye, c->d_col};
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_g1, c->d_g0, c->d_ye, c->d_col};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -291,7 +300,8 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
     a.flags = flags; a.scale = scale; a.alpha = alpha;
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
-    a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2;
+    a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2; a.iq = c->d_iq;
+    if (in == 3 && !c->d_iq) return MIMSEM_ERR_STATE;     // projection operators need mimsem_mesh_desc::indsq
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;
     a.f2 = f2; a.f2s = f2s; a.param = param; a.xn = c->d_xn;
     {   // levels per work item: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible

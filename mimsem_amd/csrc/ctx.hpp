@@ -48,6 +48,8 @@ struct mimsem_ctx {
     int* d_i1x = nullptr;       // [nEl][n1e]
     int* d_i1y = nullptr;       // [nEl][n1e]
     int* d_i2 = nullptr;        // [nEl][n2e] or null (contiguous)
+    int* d_iq = nullptr;        // [nEl][mp12] quad-grid slots (projection operators), may be null
+    int nq = 0;
     // deterministic scatter-add plans: vector slot -> up to K element-local result slots (-1 = none)
     int* d_g1 = nullptr;        // [n1][2]   into ye1[e*2*n1e + j]  (j<n1e: x edge, else y edge)
     int* d_g0 = nullptr;        // [n0][G0]  into ye0[e*n0e + j]
@@ -81,7 +83,7 @@ struct ElemArgs {
     unsigned flags;
     double scale, alpha;
     const double *J, *det, *tI, *th, *E, *w;
-    const int *i0, *i1x, *i1y, *i2;
+    const int *i0, *i1x, *i1y, *i2, *iq;
     const double* f; long long fs;
     const double* f2; long long f2s;   // second coefficient field (velocity of the upwinded operators)
     double param;                       // tau of the upwinded operators

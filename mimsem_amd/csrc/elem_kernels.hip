@@ -28,7 +28,7 @@ template <int N> struct Dims {
     static constexpr int BLOCK = 256, EPB = BLOCK/LPE;
 };
 
-enum Space { S0 = 0, S1 = 1, S2 = 2, SN = 3 };
+enum Space { S0 = 0, S1 = 1, S2 = 2, SN = 3, SQ = 4, SQ2 = 5 };   // SQ/SQ2: scalar / interleaved vector on the quad-point grid
 
 template <int OP> struct OpTraits;
 #define MIMSEM_TRAIT(op, in_, cf_, out_) \
@@ -46,6 +46,9 @@ MIMSEM_TRAIT(MIMSEM_OP_UTMAT,   S1, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_UTMAT_H, S1, S2, S1);
 MIMSEM_TRAIT(MIMSEM_OP_UTQWMAT, S2, S1, S1);
 MIMSEM_TRAIT(MIMSEM_OP_WTQDUDZ, S1, S1, S2);
+MIMSEM_TRAIT(MIMSEM_OP_WTQ, SQ,  SN, S2);
+MIMSEM_TRAIT(MIMSEM_OP_PTQ, SQ,  SN, S0);
+MIMSEM_TRAIT(MIMSEM_OP_UTQ, SQ2, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_PHMAT_UP,  S0, S2, S0);   // + velocity (1-form) as second field
 MIMSEM_TRAIT(MIMSEM_OP_ROTMAT_UP, S1, S0, S1);   // + velocity (1-form) as second field
 
@@ -134,6 +137,13 @@ __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigne
         const double caa = (ux0*g.J00 + ux1*g.J10)*g.Q*sd;
         const double cab = (ux0*g.J01 + ux1*g.J11)*g.Q*sd;
         a = caa*u + cab*v; b = 0.0;
+    } else if constexpr (OP == MIMSEM_OP_WTQ) {                      // :727-731
+        a = g.Q*u; b = 0.0;
+    } else if constexpr (OP == MIMSEM_OP_PTQ) {                      // :789-792
+        a = (g.Q*g.det)*u; b = 0.0;
+    } else if constexpr (OP == MIMSEM_OP_UTQ) {                      // :858-882
+        a = (g.J00*g.Q)*u + (g.J10*g.Q)*v;
+        b = (g.J01*g.Q)*u + (g.J11*g.Q)*v;
     } else if constexpr (OP == MIMSEM_OP_PHMAT_UP) {                 // src/Assembly.cpp:546-548 (u = trial value at the
         a = fu*g.Q*u; b = 0.0;                                       //  departure point, fu = interp2_l(h): dets cancel)
     } else if constexpr (OP == MIMSEM_OP_ROTMAT_UP) {                // src/Assembly.cpp:1825-1826 (fu = upwinded vorticity)
@@ -181,6 +191,10 @@ __device__ __forceinline__ void dof_slots(const ElemArgs& a, int e, int q, bool 
         if (q < D::n2e) s0 = a.i2 ? a.i2[e*D::n2e + q] : e*D::n2e + q;
     } else if constexpr (SP == S0) {
         if (q < D::n0e) s0 = a.i0[e*D::n0e + q];
+    } else if constexpr (SP == SQ) {
+        if (q < D::mp12) s0 = a.iq[e*D::mp12 + q];
+    } else if constexpr (SP == SQ2) {
+        if (q < D::mp12) { s0 = 2*a.iq[e*D::mp12 + q]; s1 = s0 + 1; }
     }
 }
 template <int N, Space SP>
@@ -188,6 +202,7 @@ __device__ __forceinline__ void dof_store(double v0, double v1, int s0, int s1, 
     using D = Dims<N>;
     if (s0 >= 0) dst[q] = v0;
     if constexpr (SP == S1) { if (s1 >= 0) dst[D::n1e + q] = v1; }
+    if constexpr (SP == SQ2) { if (s1 >= 0) dst[D::mp12 + q] = v1; }
 }
 
 // used by the element-matrix kernel: load one element's DoFs of space SP into LDS row `dst`
@@ -216,8 +231,10 @@ __device__ __forceinline__ void interp_point(const double* dofs, const double* s
 #pragma unroll
             for (int jx = 0; jx < N; jx++)
                 u += dofs[jy*N + jx]*(sE[qx*N + jx]*sE[qy*N + jy]);
-    } else if constexpr (SP == S0) {    // Geom::interp0 :328-340
+    } else if constexpr (SP == S0 || SP == SQ) {    // Geom::interp0 :328-340 (collocated) / a quad-grid value
         u = dofs[q];
+    } else if constexpr (SP == SQ2) {
+        u = dofs[q]; v = dofs[D::mp12 + q];
     }
 }
 
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     auto fetch = [&](int lev) {
         const double* xv = a.x + (size_t)lev*a.xs;
         if (xs0 >= 0) nx0 = xv[xs0];
-        if constexpr (T::in == S1) { if (xs1 >= 0) nx1 = xv[xs1]; }
+        if constexpr (T::in == S1 || T::in == SQ2) { if (xs1 >= 0) nx1 = xv[xs1]; }
         if constexpr (T::cf != SN) {
             const double* fv = a.f + (size_t)lev*a.fs;
             if (fs0 >= 0) nf0 = fv[fs0];
@@ -612,6 +629,7 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_ROTMAT) MIMSEM_CASE(MIMSEM_OP_WHMAT) MIMSEM_CASE(MIMSEM_OP_UTMAT)
         MIMSEM_CASE(MIMSEM_OP_UTMAT_H) MIMSEM_CASE(MIMSEM_OP_UTQWMAT) MIMSEM_CASE(MIMSEM_OP_WTQDUDZ)
         MIMSEM_CASE(MIMSEM_OP_PHMAT_UP) MIMSEM_CASE(MIMSEM_OP_ROTMAT_UP)
+        MIMSEM_CASE(MIMSEM_OP_WTQ) MIMSEM_CASE(MIMSEM_OP_PTQ) MIMSEM_CASE(MIMSEM_OP_UTQ)
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE

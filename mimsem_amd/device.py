@@ -33,7 +33,8 @@ class DeviceMesh:
             assert len(topos) == 1
             self.inds0, self.inds1x, self.inds1y = t0.all_inds0_l(), t0.all_inds1x_l(), t0.all_inds1y_l()
             self.n0, self.n1, self.n2 = t0.n0, t0.n1, t0.n2
-            self.gid0 = self.gid1 = self.gid2 = None
+            self.gid0 = self.gid1 = self.gid2 = self.gidq = None
+            self.indsq, self.nq = geoms[0].all_inds0_l(), geoms[0].n0
         else:
             g0 = np.concatenate([t.all_inds0_g() for t in topos])
             g1x = np.concatenate([t.all_inds1x_g() for t in topos])
@@ -44,6 +45,9 @@ class DeviceMesh:
             self.inds1x = inv1[:g1x.size].reshape(g1x.shape).astype(np.int32)
             self.inds1y = inv1[g1x.size:].reshape(g1y.shape).astype(np.int32)
             self.gid2 = np.concatenate([t.all_inds2_g().ravel() for t in topos])
+            gq = np.concatenate([g.loc0[g.all_inds0_l()] for g in geoms])
+            self.gidq, invq = np.unique(gq, return_inverse=True)
+            self.indsq, self.nq = invq.reshape(gq.shape).astype(np.int32), self.gidq.size
             self.n0, self.n1 = self.gid0.size, self.gid1.size
             self.n2 = self.gid2.size
         self.nEl = self.inds0.shape[0]
@@ -59,7 +63,8 @@ class DeviceMesh:
         d.elOrd, d.quadOrd, d.nEl, d.nk = self.n, self.m, self.nEl, self.nk
         d.n0, d.n1, d.n2 = self.n0, self.n1, self.n2
         keep = []
-        for name in ("inds0", "inds1x", "inds1y", "inds2"):
+        d.nq = self.nq
+        for name in ("inds0", "inds1x", "inds1y", "inds2", "indsq"):
             a = np.ascontiguousarray(getattr(self, name), dtype=np.int32); keep.append(a)
             setattr(d, name, a.ctypes.data)
         for name in ("det", "J", "thick", "thickInv"):
@@ -86,7 +91,7 @@ class Engine:
         n = dmesh.n
         self.n0e, self.n1e, self.n2e, self.mp12 = (n + 1) ** 2, (n + 1) * n, n * n, (n + 1) ** 2
         self.nEl, self.nk = dmesh.nEl, dmesh.nk
-        self.sizes = {0: dmesh.n0, 1: dmesh.n1, 2: dmesh.n2}
+        self.sizes = {0: dmesh.n0, 1: dmesh.n1, 2: dmesh.n2, "q": dmesh.nq, "q2": 2 * dmesh.nq}
 
     def __del__(self):
         try:
@@ -121,7 +126,7 @@ class Engine:
     _SPACES = dict(UMAT=(1, None, 1), UTMAT=(1, None, 1), UHMAT=(1, 2, 1), UTMAT_H=(1, 2, 1), ROTMAT=(1, 0, 1),
                    WMAT=(2, None, 2), WMATINV=(2, None, 2), WHMAT=(2, 2, 2), WHMATINV=(2, 2, 2), PMAT=(0, None, 0),
                    PHMAT=(0, 2, 0), WTQUMAT=(1, 1, 2), WTQDUDZ=(1, 1, 2), UTQWMAT=(2, 1, 1),
-                   PHMAT_UP=(0, 2, 0), ROTMAT_UP=(1, 0, 1))
+                   PHMAT_UP=(0, 2, 0), ROTMAT_UP=(1, 0, 1), WTQ=("q", None, 2), PTQ=("q", None, 0), UTQ=("q2", None, 1))
 
     def apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
         """y_k = A_op(level lev0+k, f_k) x_k ; x: [nlev, n_in] (or [n_in]) device tensor"""

@@ -508,3 +508,47 @@ int orc_op_elmats_up(const orc_patch* p, int which, double fac, double dt, const
     free(QP); free(ca); free(cb); free(tmp);
     return 0;
 }
+
+
+/* ---- B7: projections from the quadrature-point grid, built once for initial conditions / Coriolis -------------
+ * WtQmat::assemble :707-751   y2 = W^T (Q xq)                     xq[n0q]
+ * PtQmat::assemble :766-808   y0 = P^T (Q det xq)                 (added into the local 0-form vector)
+ * UtQmat::assemble :824-902   y1 = [U^T (J00 Q vx + J10 Q vy) ; V^T (J01 Q vx + J11 Q vy)], xq interleaved [n0q][2]
+ * which = 0, 1, 2.  The element blocks WtQ / PtQ / UtQ are formed with Mult_FD_IP exactly as the reference does and
+ * applied to the quad-grid values gathered through Geom::elInds0_l. */
+int orc_project_from_quad(const orc_patch* p, int which, const double* xq, double* y) {
+    int ex, ey, ei, ii, k, mp12 = p->mp12, n1e = p->n1e, n2e = p->n2e, n0e = p->n0e;
+    int iq[128], i0[128], ix[128], iy[128], i2[128];
+    double c0[128], c1[128], v0[128], v1[128], rhs[128];
+    double* BtQ = (double*)malloc(sizeof(double)*128*mp12);
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        ei = ey*p->nElsX + ex;
+        orc_elindsq_l(p, ex, ey, iq); orc_elinds0_l(p, ex, ey, i0); orc_elinds1x_l(p, ex, ey, ix);
+        orc_elinds1y_l(p, ex, ey, iy); orc_elinds2_l(p, ex, ey, i2);
+        if (which == 0) {
+            for (ii = 0; ii < mp12; ii++) { c0[ii] = p->Q[ii]; v0[ii] = xq[iq[ii]]; }
+            orc_la->mult_fd(n2e, mp12, mp12, p->Wt, c0, BtQ);
+            orc_la->axb(n2e, mp12, BtQ, v0, rhs);
+            for (k = 0; k < n2e; k++) y[i2[k]] += rhs[k];
+        } else if (which == 1) {
+            for (ii = 0; ii < mp12; ii++) { c0[ii] = p->Q[ii]*p->det[(size_t)ei*mp12 + ii]; v0[ii] = xq[iq[ii]]; }
+            orc_la->mult_fd(n0e, mp12, mp12, p->Pt, c0, BtQ);
+            orc_la->axb(n0e, mp12, BtQ, v0, rhs);
+            for (k = 0; k < n0e; k++) y[i0[k]] += rhs[k];
+        } else {
+            for (ii = 0; ii < mp12; ii++) { v0[ii] = xq[2*iq[ii]]; v1[ii] = xq[2*iq[ii] + 1]; }
+            for (ii = 0; ii < mp12; ii++) { const double* jac = &p->J[((size_t)ei*mp12 + ii)*4]; c0[ii] = J00*p->Q[ii]; c1[ii] = J10*p->Q[ii]; }
+            orc_la->mult_fd(n1e, mp12, mp12, p->Ut, c0, BtQ); orc_la->axb(n1e, mp12, BtQ, v0, rhs);
+            for (k = 0; k < n1e; k++) y[ix[k]] += rhs[k];
+            orc_la->mult_fd(n1e, mp12, mp12, p->Ut, c1, BtQ); orc_la->axb(n1e, mp12, BtQ, v1, rhs);
+            for (k = 0; k < n1e; k++) y[ix[k]] += rhs[k];
+            for (ii = 0; ii < mp12; ii++) { const double* jac = &p->J[((size_t)ei*mp12 + ii)*4]; c0[ii] = J01*p->Q[ii]; c1[ii] = J11*p->Q[ii]; }
+            orc_la->mult_fd(n1e, mp12, mp12, p->Vt, c0, BtQ); orc_la->axb(n1e, mp12, BtQ, v0, rhs);
+            for (k = 0; k < n1e; k++) y[iy[k]] += rhs[k];
+            orc_la->mult_fd(n1e, mp12, mp12, p->Vt, c1, BtQ); orc_la->axb(n1e, mp12, BtQ, v1, rhs);
+            for (k = 0; k < n1e; k++) y[iy[k]] += rhs[k];
+        }
+    }
+    free(BtQ);
+    return 0;
+}

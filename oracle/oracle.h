@@ -132,6 +132,10 @@ int orc_op_apply(const orc_patch* p, int op, const double* elmats, const double*
  * ORC_ROTMAT).  ul = local 1-form velocity; tau = 1/(1/(fac*dt)). */
 int orc_op_elmats_up(const orc_patch* p, int which, double fac, double dt, const double* f1, const double* ul, double* out);
 
+/* B7 projections from the quad-point grid: which 0 = WtQmat :707-751, 1 = PtQmat :766-808, 2 = UtQmat :824-902
+ * (xq interleaved [n0q][2]); y is ACCUMULATED into (local 2/0/1-form vector). */
+int orc_project_from_quad(const orc_patch* p, int which, const double* xq, double* y);
+
 /* matrix-free vectors, eul/Assembly.cpp */
 void orc_pvec(const orc_patch* p, int lev, double scale, double* vl);                       /* B5 Pvec  :602-632 (local part) */
 void orc_phvec(const orc_patch* p, int lev, double scale, const double* h2, double* vl);    /* B5 Phvec :654-689 */

@@ -222,6 +222,12 @@ class Patch:
         assert rc == 0
         return self.op_apply(op, em, x, self.out_size(op)), em
 
+    def project_from_quad(self, which, xq):
+        """WtQmat / PtQmat / UtQmat applied to a quad-grid field (B7)"""
+        y = np.zeros([self.n2, self.n0, self.n1][which])
+        rc = self.L.orc_project_from_quad(self.p, which, _dp(np.ascontiguousarray(xq)), _dp(y)); assert rc == 0
+        return y
+
     def bench_assemble_mult(self, op, x, reps, lev=0, scale=1.0, flag=0, f1=None):
         """seconds for `reps` x (assemble + MatMult) with the reference's CSR cost structure; also returns y"""
         y = np.zeros(self.out_size(op))

@@ -137,3 +137,14 @@ def test_upwinded_sw_operators(setup, which, op):
     want, _ = P.apply_up(which, x, fac, dt, f1, ul)
     got = eng.apply_up(op, eng.tensor(x), eng.tensor(f1), eng.tensor(ul), fac, dt, lev0=0)
     assert rel_l2(got.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("which,op", [(0, "WTQ"), (1, "PTQ"), (2, "UTQ")])
+def test_quad_grid_projections(setup, which, op):
+    """B7: WtQmat / PtQmat / UtQmat (eul/Assembly.cpp:707-902) applied to a quad-point-grid field"""
+    eng, P, rng = setup
+    r = np.random.default_rng(31)
+    xq = r.standard_normal(P.n0q * (2 if which == 2 else 1))
+    want = P.project_from_quad(which, xq)
+    got = eng.apply(op, eng.tensor(xq), lev0=0, scale=1.0)
+    assert rel_l2(got.cpu().numpy(), want) < TOL
