@@ -189,6 +189,42 @@ int block_pass(mimsem_ctx* c, long long nb, const double* cq, double* M) {
     return MIMSEM_OK;
 }
 
+// coefficient pass + block pass fused: the BT coefficient rows of a workgroup's blocks are evaluated straight
+// into LDS (one thread per quadrature point), never touching HBM.
+__global__ __launch_bounds__(256) void k_coef_block(CG g, int colop, unsigned flags, int nr, int nw,
+        const double* __restrict__ f1, const double* __restrict__ f2, double* __restrict__ M) {
+    extern __shared__ double sm[];
+    double* sW = sm;                         // [mp12][n2]
+    double* sc = sm + g.mp12*g.n2;           // [BT][mp12]
+    const int nn = g.n2*g.n2, tid = threadIdx.x;
+    const long long nb = (long long)g.nEl*nr*nw, b0 = (long long)blockIdx.x*BP_BT;
+    const int nbt = (int)min((long long)BP_BT, nb - b0);
+    for (int t = tid; t < g.mp12*g.n2; t += 256) sW[t] = g_W(g, t/g.n2, t%g.n2);
+    for (int t = tid; t < nbt*g.mp12; t += 256) {
+        const long long b = b0 + t/g.mp12; const int q = t%g.mp12;
+        const int w = (int)(b%nw); long long r2 = b/nw;
+        const int r = (int)(r2%nr), e = (int)(r2/nr);
+        sc[t] = colop_coef(g, colop, flags, e, r, w, q, f1, f2);
+    }
+    __syncthreads();
+    for (int t = tid; t < nbt*nn; t += 256) {
+        const int lb = t/nn, ij = t%nn, ii = ij/g.n2, jj = ij%g.n2;
+        const double* cb = sc + lb*g.mp12;
+        double s = 0.0;
+        for (int q = 0; q < g.mp12; q++) s += (sW[q*g.n2 + ii]*cb[q])*sW[q*g.n2 + jj];
+        M[b0*nn + t] = s;
+    }
+}
+int coef_block_pass(mimsem_ctx* c, int colop, unsigned flags, const double* f1, const double* f2, double* M, int nr, int nw) {
+    const CG g = make_cg(c);
+    const long long nb = (long long)c->nEl*nr*nw;
+    if (nb <= 0) return MIMSEM_OK;
+    const size_t lds = (size_t)(g.mp12*g.n2 + BP_BT*g.mp12)*sizeof(double);
+    hipLaunchKernelGGL(k_coef_block, dim3((unsigned)((nb + BP_BT - 1)/BP_BT)), dim3(256), lds, c->stream, g, colop, flags, nr, nw, f1, f2, M);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 // ---- batched Gauss-Jordan with full pivoting: one thread per block, private copy in LDS ------------
 // (thread-minor layout => conflict-free; pivot search / swaps / elimination exactly as LinAlg.cpp:186-269)
 __global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, int T, double* blocks, int* errcount) {
@@ -472,12 +508,10 @@ int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1
     const int n2 = c->es.n2e, nn = n2*n2;
     int rc;
     if (colop == MIMSEM_V_EOS_BLOCK) {        // B . B(rt)^-1 . B   VertOps.cpp:1162-1196
-        if ((rc = coef_pass(c, MIMSEM_V_CONST_RHO, 0, f1, nullptr, cq, nr, 1))) return rc;
-        if ((rc = block_pass(c, nb, cq, tmpM))) return rc;                    // B(rt)
+        if ((rc = coef_block_pass(c, MIMSEM_V_CONST_RHO, 0, f1, nullptr, tmpM, nr, 1))) return rc;   // B(rt)
         if ((rc = mimsem_block_inverse_inplace(c, nb, n2, tmpM))) return rc;
-        if ((rc = coef_pass(c, MIMSEM_V_CONST, 0, nullptr, nullptr, cq, nr, 1))) return rc;
         double* Bm = tmpM + nb*nn;
-        if ((rc = block_pass(c, nb, cq, Bm))) return rc;                      // B
+        if ((rc = coef_block_pass(c, MIMSEM_V_CONST, 0, nullptr, nullptr, Bm, nr, 1))) return rc;     // B
         const double* Binv = tmpM;
         double* t1 = M;                                                        // Binv.B lands in the output, then B.(Binv.B)
         if ((rc = flat_mm(c, nb, n2, Binv, Bm, t1))) return rc;
@@ -486,8 +520,7 @@ int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1
         MIMSEM_HIP_TRY(hipMemcpyAsync(M, t2, (size_t)nb*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return MIMSEM_OK;
     }
-    if ((rc = coef_pass(c, colop, flags, f1, f2, cq, nr, nw))) return rc;
-    if ((rc = block_pass(c, nb, cq, M))) return rc;
+    if ((rc = coef_block_pass(c, colop, flags, f1, f2, M, nr, nw))) return rc;
     if (colop_is_inverse(colop)) return mimsem_block_inverse_inplace(c, nb, n2, M);
     return MIMSEM_OK;
 }
@@ -852,8 +885,138 @@ __global__ void k_block_thomas(int nk, int n2, const double* __restrict__ L, con
     }
 }
 
+// Wave-per-column variant (n2 <= 16): the whole sweep of a column is carried by ONE wavefront, so the
+// level-to-level dependency chain needs only wave-level LDS ordering (no s_barrier); the previous level's
+// G_{k-1} = D'^{-1} sup and y_{k-1} stay in LDS.  Gauss-Jordan with partial pivoting on the running diagonal block.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int N2>
+__global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* __restrict__ L, const double* __restrict__ f,
+                                                          double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws) {
+    constexpr int nn = N2*N2, EPL = (nn + 63)/64;           // entries per lane
+    __shared__ double D[nn], Di[nn], Gp[nn], S[nn], U[nn], v[N2], yp[N2], dn[N2];
+    const int lane = threadIdx.x, e = blockIdx.x;
+    const double* Le = L + (size_t)e*nk*3*nn;
+    double* G = Gws + (size_t)e*nk*nn;
+    double* yv = yws + (size_t)e*nk*N2;
+    for (int k = 0; k < nk; k++) {
+        const double* sub = Le + ((size_t)k*3 + 0)*nn;
+        const double* dia = Le + ((size_t)k*3 + 1)*nn;
+        const double* sup = Le + ((size_t)k*3 + 2)*nn;
+#pragma unroll
+        for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) { S[t] = sub[t]; U[t] = sup[t]; } }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            const int t = lane + 64*r;
+            if (t < nn) {
+                const int i = t/N2, j = t%N2;
+                double s = dia[t];
+                if (k > 0) {
+#pragma unroll
+                    for (int m = 0; m < N2; m++) s -= S[i*N2 + m]*Gp[m*N2 + j];
+                }
+                D[t] = s; Di[t] = (i == j) ? 1.0 : 0.0;
+            }
+        }
+        if (lane < N2) {
+            double s = f[((size_t)e*nk + k)*N2 + lane];
+            if (k > 0) {
+#pragma unroll
+                for (int m = 0; m < N2; m++) s -= S[lane*N2 + m]*yp[m];
+            }
+            v[lane] = s;
+        }
+        wsync();
+        // Gauss-Jordan on [D | Di], partial pivoting (every lane finds the same pivot row from LDS)
+        for (int col = 0; col < N2; col++) {
+            int p = col; double big = fabs(D[col*N2 + col]);
+            for (int r = col + 1; r < N2; r++) { const double a = fabs(D[r*N2 + col]); if (a > big) { big = a; p = r; } }
+            if (p != col) {
+                double t0[EPL], t1[EPL];
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {      // lanes < 2*N2 swap one entry of D or Di each
+                    const int t = lane + 64*r;
+                    if (t < 2*N2) { double* M = (t < N2) ? D : Di; const int j = t%N2; t0[r] = M[col*N2 + j]; t1[r] = M[p*N2 + j]; }
+                }
+                wsync();
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {
+                    const int t = lane + 64*r;
+                    if (t < 2*N2) { double* M = (t < N2) ? D : Di; const int j = t%N2; M[col*N2 + j] = t1[r]; M[p*N2 + j] = t0[r]; }
+                }
+                wsync();
+            }
+            const double pinv = 1.0/D[col*N2 + col];
+            // new values from old ones, then one sync: row col scaled, other rows eliminated
+            double nd[EPL], ni[EPL];
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                const int t = lane + 64*r;
+                if (t < nn) {
+                    const int i = t/N2, j = t%N2;
+                    const double dcj = D[col*N2 + j]*pinv, icj = Di[col*N2 + j]*pinv;
+                    if (i == col) { nd[r] = dcj; ni[r] = icj; }
+                    else { const double u = D[i*N2 + col]; nd[r] = D[t] - u*dcj; ni[r] = Di[t] - u*icj; }
+                }
+            }
+            wsync();
+#pragma unroll
+            for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) { D[t] = nd[r]; Di[t] = ni[r]; } }
+            wsync();
+        }
+        // G_k = Di . sup ; y_k = Di . v
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            const int t = lane + 64*r;
+            if (t < nn) {
+                const int i = t/N2, j = t%N2; double s = 0.0;
+                if (k < nk - 1) {
+#pragma unroll
+                    for (int m = 0; m < N2; m++) s += Di[i*N2 + m]*U[m*N2 + j];
+                }
+                G[(size_t)k*nn + t] = s; Gp[t] = s;
+            }
+        }
+        if (lane < N2) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += Di[lane*N2 + m]*v[m];
+            yv[(size_t)k*N2 + lane] = s; yp[lane] = s;
+        }
+        wsync();
+    }
+    // back substitution: d_k = y_k - G_k d_{k+1}; G re-read from this wave's own global writes
+    __threadfence_block();
+    for (int k = nk - 1; k >= 0; k--) {
+        if (lane < N2) {
+            double s = yv[(size_t)k*N2 + lane];
+            if (k < nk - 1) { const double* Gk = G + (size_t)k*nn;
+#pragma unroll
+                for (int m = 0; m < N2; m++) s -= Gk[lane*N2 + m]*dn[m]; }
+            d[((size_t)e*nk + k)*N2 + lane] = s;
+            v[lane] = s;
+        }
+        wsync();
+        if (lane < N2) dn[lane] = v[lane];
+        wsync();
+    }
+}
+
 int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws) {
     const int n2 = c->es.n2e, nn = n2*n2;
+    if (!getenv("MIMSEM_THOMAS_WG")) {
+        switch (n2) {
+#define MIMSEM_TW(N) case N: hipLaunchKernelGGL((k_block_thomas_wave<N>), dim3(c->nEl), dim3(64), 0, c->stream, c->nk, L, f, d, Gws, yws); \
+                     MIMSEM_HIP_TRY(hipGetLastError()); return MIMSEM_OK;
+        MIMSEM_TW(1) MIMSEM_TW(4) MIMSEM_TW(9) MIMSEM_TW(16)
+#undef MIMSEM_TW
+        default: break;
+        }
+    }
     const int nt = std::min(256, ((nn + 63)/64)*64);
     const size_t lds = (size_t)(3*nn + 2*n2)*sizeof(double);
     hipLaunchKernelGGL(k_block_thomas, dim3(c->nEl), dim3(nt), lds, c->stream, c->nk, n2, L, f, d, Gws, yws);
