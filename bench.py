@@ -67,6 +67,7 @@ def replicate(dm, R):
     out.nEl = dm.nEl * R
     out.inds2 = np.arange(out.nEl * dm.n * dm.n, dtype=np.int32).reshape(out.nEl, -1)
     out.n0, out.n1, out.n2 = dm.n0 * R, dm.n1 * R, dm.n2 * R
+    out.indsq = np.concatenate([dm.indsq + r * dm.nq for r in range(R)]).astype(np.int32); out.nq = dm.nq * R
     out.det = np.tile(dm.det, (R, 1)); out.J = np.tile(dm.J, (R, 1, 1))
     out.thick = np.tile(dm.thick, (1, R, 1)); out.thickInv = np.tile(dm.thickInv, (1, R, 1))
     return out
@@ -194,17 +195,27 @@ def main():
                    "order": PN, "elements": cs.ne * cs.ne * 6, "levels": NK, "units_per_step": units_total,
                    "patches": NPATCH, "patches_per_gpu": len(pids), "scale": SCALE},
     }
+    traffic1 = traffic12 = None
+    try:        # HBM-side bytes per launch from the committed PMC passes (scripts/pmc_to_json.py), same 103 680-unit launch
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if world == 1:
+            traffic1 = min(pj["kernels"]["k_elem_apply<3,UMAT>"], key=lambda r: r["grid_threads"])["total_bytes"]
+            traffic12 = traffic1 + min(pj["kernels"]["k_gather_sum<2>"], key=lambda r: r["grid_threads"])["total_bytes"]
+    except Exception:
+        pass
     if nl:
         k1 = ms1 / nl * 1e-3
         k12 = (ms1 + ms2) / nl * 1e-3
         a1 = units_rank * BYTES_K1_B1 / k1 / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_elem_apply<3,UMAT>", "achieved": a1, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS, "traffic": traffic1,
+                           "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/pmc_traffic.json",
+                           "algorithmic_bytes_per_launch": units_rank * BYTES_K1_B1,
                            "avg_kernel_us": k1 * 1e6, "bytes_per_unit": BYTES_K1_B1, "units_per_launch": units_rank}
         a12 = units_rank * BYTES_OP_B1 / k12 / 1e9
         out["roofline_op"] = {"bound": "hbm", "kernels": "k_elem_apply<3,UMAT> + k_gather_sum<2>", "achieved": a12,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a12 / HBM_PEAK_GBS,
-                              "avg_us": k12 * 1e6, "bytes_per_unit": BYTES_OP_B1}
+                              "avg_us": k12 * 1e6, "bytes_per_unit": BYTES_OP_B1, "traffic": traffic12}
     if a.families and rank == 0 and world == 1:
         fam = {}
         h = eng.tensor(rng.uniform(1, 2, (NK, dm.n2)) * 1e3)
