@@ -1,6 +1,7 @@
 // mimsem_amd/csrc/api.hip -- C-ABI entry points of libmimsem_hip.so (include/mimsem_hip.h):
 // context lifetime, HBM layout, scatter-add plans, horizontal-operator dispatch.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "ctx.hpp"
@@ -36,6 +37,72 @@ int build_plan(int nslots, int nEl, int per_el, const std::vector<const int*>& m
                 if (fill[s] >= K) return MIMSEM_ERR_UNSUPPORTED;
                 plan[(size_t)s*K + fill[s]++] = e*per_el + offs[m] + j;
             }
+    return MIMSEM_OK;
+}
+
+// Element groups (= workgroups of the fused kernel) grown greedily over shared edge slots, and the group-local
+// slot tables: a slot whose every contributor sits in one group is summed in LDS and written once; the others
+// ("perimeter") leave one partial sum per group and are finished by k_gather_perim.
+struct FusedPlan {
+    int ngroups = 0, lmax = 0, nps = 0, npart = 0;
+    std::vector<int> perm, fslot, fcnt, pslot, ppart;
+    std::vector<unsigned short> lid;
+};
+int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* iy, FusedPlan& P) {
+    const int nd = 2*n1e;
+    auto slot_of = [&](int e, int j) { return j < n1e ? ix[(size_t)e*n1e + j] : iy[(size_t)e*n1e + j - n1e]; };
+    std::vector<int> own((size_t)n1*2, -1), cnt(n1, 0);
+    for (int e = 0; e < nEl; e++) for (int j = 0; j < nd; j++) {
+        const int s = slot_of(e, j);
+        if (cnt[s] >= 2) return MIMSEM_ERR_UNSUPPORTED;
+        own[(size_t)s*2 + cnt[s]++] = e;
+    }
+    P.ngroups = (nEl + G - 1)/G; P.lmax = G*nd;
+    P.perm.assign((size_t)P.ngroups*G, -1);
+    std::vector<char> assigned(nEl, 0);
+    std::vector<int> score(nEl, 0), touched;
+    int next_seed = 0;
+    for (int g = 0; g < P.ngroups; g++) {
+        for (int t : touched) score[t] = 0;
+        touched.clear();
+        for (int k = 0; k < G; k++) {
+            int best = -1;
+            for (int t : touched) if (!assigned[t] && (best < 0 || score[t] > score[best] || (score[t] == score[best] && t < best))) best = t;
+            if (best < 0) { while (next_seed < nEl && assigned[next_seed]) next_seed++; if (next_seed >= nEl) break; best = next_seed; }
+            assigned[best] = 1; P.perm[(size_t)g*G + k] = best;
+            for (int j = 0; j < nd; j++) {
+                const int s = slot_of(best, j);
+                for (int w = 0; w < 2; w++) { const int o = own[(size_t)s*2 + w]; if (o >= 0 && o != best && !assigned[o]) { if (!score[o]) touched.push_back(o); score[o]++; } }
+            }
+        }
+    }
+    // per group: its distinct slots in ASCENDING slot order (coalesced write-out); for each the one or two
+    // element-local result positions (k*nd + j inside the group) that feed it, in element order
+    P.lid.assign((size_t)P.ngroups*P.lmax*2, 0xFFFF);
+    P.fslot.assign((size_t)P.ngroups*P.lmax, 0); P.fcnt.assign(P.ngroups, 0);
+    std::vector<int> part((size_t)n1*2, -1);
+    std::vector<int> ingroup(n1, 0);
+    for (int g = 0; g < P.ngroups; g++) {
+        std::vector<std::pair<int, int>> contrib;                      // (slot, position in group)
+        for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
+            for (int j = 0; j < nd; j++) { const int s = slot_of(e, j); ingroup[s]++; contrib.push_back({s, k*nd + j}); } }
+        std::sort(contrib.begin(), contrib.end());
+        int nl = 0;
+        for (size_t i = 0; i < contrib.size(); ) {
+            const int s = contrib[i].first;
+            size_t j = i; while (j < contrib.size() && contrib[j].first == s) j++;
+            P.lid[((size_t)g*P.lmax + nl)*2 + 0] = (unsigned short)contrib[i].second;
+            if (j - i > 1) P.lid[((size_t)g*P.lmax + nl)*2 + 1] = (unsigned short)contrib[i + 1].second;
+            if (ingroup[s] == cnt[s]) P.fslot[(size_t)g*P.lmax + nl] = s;
+            else { const int pi = P.npart++; P.fslot[(size_t)g*P.lmax + nl] = -(pi + 1);
+                   if (part[(size_t)s*2] < 0) part[(size_t)s*2] = pi; else part[(size_t)s*2 + 1] = pi; }
+            nl++; i = j;
+        }
+        P.fcnt[g] = nl;
+        for (auto& c2 : contrib) ingroup[c2.first] = 0;
+    }
+    for (int s = 0; s < n1; s++) if (part[(size_t)s*2] >= 0) { P.pslot.push_back(s); P.ppart.push_back(part[(size_t)s*2]); P.ppart.push_back(part[(size_t)s*2 + 1]); }
+    P.nps = (int)P.pslot.size();
     return MIMSEM_OK;
 }
 
@@ -193,6 +260,27 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         if (rc) return fail(rc);
         if ((rc = upload(&c->d_g0, plan.data(), plan.size(), c))) return fail(rc);
     }
+    // Fused single-barrier scatter-add (group-local sums in LDS + perimeter pass): measured SLOWER than the two-pass
+    // form on MI355X in round 1 (profiles/r01_fused_scatter_ab.txt), so it is opt-in (MIMSEM_FUSE=1) for further tuning.
+    if (getenv("MIMSEM_FUSE")) {
+        FusedPlan P;
+        const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
+        rc = build_fused_plan(d->n1, d->nEl, es.n1e, epb, d->inds1x, d->inds1y, P);
+        if (rc == MIMSEM_OK && P.lmax < 0x8000) {
+            if ((rc = upload(&c->d_fperm, P.perm.data(), P.perm.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_flid, P.lid.data(), P.lid.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_fslot, P.fslot.data(), P.fslot.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_fcnt, P.fcnt.data(), P.fcnt.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_pslot, P.pslot.data(), P.pslot.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_ppart, P.ppart.data(), P.ppart.size(), c))) return fail(rc);
+            c->f_ngroups = P.ngroups; c->f_lmax = P.lmax; c->f_nps = P.nps; c->f_npart = P.npart; c->fused1 = true;
+            if (getenv("MIMSEM_VERBOSE")) {
+                long long tot = 0; for (int v : P.fcnt) tot += v;
+                fprintf(stderr, "[mimsem] fused plan: %d groups of %d elements, %.1f local slots/group, %d perimeter slots (%d partials) of %d\n",
+                        P.ngroups, epb, (double)tot/std::max(P.ngroups, 1), P.nps, P.npart, d->n1);
+            }
+        }
+    }
     {
         const size_t cnt = (size_t)d->nk*d->nEl*es.mp12;
         MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double)));
@@ -209,7 +297,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_g1, c->d_g0, c->d_ye, c->d_col};
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -321,6 +409,19 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     if (outsp == 2) {
         a.out = y; a.os = ys;
         rc = launch_elem_apply(c, op, a);
+        c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+        return rc;
+    }
+    a.fperm = nullptr; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0;
+    if (outsp == 1 && c->fused1) {
+        // fused path: group-local sums in LDS, complete slots written straight to y, perimeter partials to the workspace
+        if ((rc = c->ensure_ye((long long)std::max(c->f_npart, 1)*nlev))) return rc;
+        a.fperm = c->d_fperm; a.flid = c->d_flid; a.fslot = c->d_fslot; a.fcnt = c->d_fcnt;
+        a.ngroups = c->f_ngroups; a.lmax = c->f_lmax;
+        a.y = y; a.ys = ys; a.out = c->d_ye; a.os = c->f_npart;
+        a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+        rc = launch_elem_apply(c, op, a);
+        if (!rc) rc = launch_gather_perim(c, nlev, c->d_ye, c->f_npart, a.accum, y, ys);
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }

@@ -54,6 +54,15 @@ struct mimsem_ctx {
     int* d_g1 = nullptr;        // [n1][2]   into ye1[e*2*n1e + j]  (j<n1e: x edge, else y edge)
     int* d_g0 = nullptr;        // [n0][G0]  into ye0[e*n0e + j]
     int G0 = 4;
+    // fused scatter-add of 1-form results: element groups = workgroups, group-local slot ids
+    bool fused1 = false;
+    int f_ngroups = 0, f_lmax = 0, f_nps = 0, f_npart = 0;
+    int* d_fperm = nullptr;             // [ngroups][EPB] element of each lane group (-1 = padding)
+    unsigned short* d_flid = nullptr;   // [ngroups][lmax][2] positions (el*2*n1e + dof) of the 1-2 contributions of each local slot
+    int* d_fslot = nullptr;             // [ngroups][lmax] vector slot (>=0, complete in group) or -(partial index+1)
+    int* d_fcnt = nullptr;              // [ngroups] local ids in use
+    int* d_pslot = nullptr;             // [nps] perimeter slots
+    int* d_ppart = nullptr;             // [nps][2] their partial-sum indices (-1 = none)
     // workspace
     double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
     long long ye_doubles = 0;
@@ -89,10 +98,14 @@ struct ElemArgs {
     double param;                       // tau of the upwinded operators
     const double* xn;                   // nodal points
     const double* x; long long xs;
-    double* out; long long os;     // element-local results (or the 2-form output vector itself)
+    double* out; long long os;     // element-local results (or the 2-form output vector itself); fused: partial sums
+    // fused 1-form scatter-add
+    const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
+    double* y; long long ys; int accum;
 };
 
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
+int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys);
 int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out);

@@ -241,11 +241,13 @@ __device__ __forceinline__ void interp_point(const double* dofs, const double* s
 // Work item = (element, chunk of `lch` consecutive levels).  Level-invariant data (metric, quadrature weight,
 // gather slots) is loaded ONCE into registers; the level loop prefetches the next level's DoFs and thickness
 // while the current level is interpolated / scaled / projected.
-template <int N, int OP>
+template <int N, int OP, bool FUSED>
 __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     using D = Dims<N>;
     using T = OpTraits<OP>;
     constexpr int LPE = D::LPE, EPB = D::EPB;
+    static_assert(!FUSED || T::out == S1, "the fused scatter-add exists for 1-form results only");
+    __shared__ double s_acc[FUSED ? 2 : 1][FUSED ? EPB*2*D::n1e : 1];   // the group's element-local results, double-buffered by level parity
     __shared__ double sE[D::mp1*N];
     __shared__ double s_x[EPB][2*LPE];
     __shared__ double s_f[EPB][2*LPE];
@@ -256,11 +258,20 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
 
     const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
     const int nchunk = (a.nlev + a.lch - 1)/a.lch;
-    const long long item = (long long)xcd_swizzle(blockIdx.x, gridDim.x, a.swz)*EPB + el;   // item = chunk*nEl + e
-    const bool act = item < (long long)a.nEl*nchunk;
-    const int e = act ? (int)(item%a.nEl) : 0;
-    const int lbeg = act ? (int)(item/a.nEl)*a.lch : 0;
-    const int lend = act ? min(a.nlev, lbeg + a.lch) : 0;
+    bool act; int e, lbeg, lend, grp = 0;
+    if constexpr (FUSED) {
+        // one workgroup = one element group x one level chunk; every lane runs the same number of levels
+        grp = blockIdx.x%a.ngroups;
+        const int pe = a.fperm[grp*EPB + el];
+        act = pe >= 0; e = act ? pe : 0;
+        lbeg = (blockIdx.x/a.ngroups)*a.lch; lend = min(a.nlev, lbeg + a.lch);
+    } else {
+        const long long item = (long long)xcd_swizzle(blockIdx.x, gridDim.x, a.swz)*EPB + el;   // item = chunk*nEl + e
+        act = item < (long long)a.nEl*nchunk;
+        e = act ? (int)(item%a.nEl) : 0;
+        lbeg = act ? (int)(item/a.nEl)*a.lch : 0;
+        lend = act ? min(a.nlev, lbeg + a.lch) : 0;
+    }
     const int qx = q%D::mp1, qy = q/D::mp1;
     const bool qact = act && q < D::mp12;
 
@@ -284,6 +295,8 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     if constexpr (T::up) dof_slots<N, S1>(a, e, q, act, us0, us1);
     const size_t lstride = (size_t)a.nEl*D::mp12;
     const size_t gq = (size_t)e*D::mp12 + q;
+    int fcnt = 0;
+    if constexpr (FUSED) fcnt = a.fcnt[grp];
 
     // ---- prefetch level lbeg ----
     double nx0 = 0.0, nx1 = 0.0, nf0 = 0.0, nf1 = 0.0, ng0 = 0.0, ng1 = 0.0, ntI = 1.0, nth0 = 1.0, nth1 = 1.0;
@@ -372,9 +385,27 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
                         yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
                         yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
                     }
-                    double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
-                    o[q] = a.alpha*yx;
-                    o[D::n1e + q] = a.alpha*yy;
+                    if constexpr (!FUSED) {
+                        double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
+                        o[q] = a.alpha*yx;
+                        o[D::n1e + q] = a.alpha*yy;
+                    } else {                 // park the element-local results in LDS (conflict-free, no branching)
+                        double* st = s_acc[lev & 1] + el*2*D::n1e;
+                        st[q] = a.alpha*yx; st[D::n1e + q] = a.alpha*yy;
+                    }
+                }
+                if constexpr (FUSED) {
+                    __syncthreads();         // the only workgroup barrier per level (buffers alternate with level parity)
+                    const double* st = s_acc[lev & 1];
+                    for (int t = tid; t < fcnt; t += 256) {       // one thread per distinct slot of the group, ascending slots
+                        const size_t gi = (size_t)grp*a.lmax + t;
+                        const int sl = a.fslot[gi];
+                        const unsigned short p0 = a.flid[2*gi], p1 = a.flid[2*gi + 1];
+                        double val = st[p0];
+                        if (p1 != 0xFFFF) val += st[p1];
+                        if (sl >= 0) { double* o = a.y + (size_t)lev*a.ys + sl; if (a.accum) *o += val; else *o = val; }
+                        else a.out[(size_t)lev*a.os + (-sl - 1)] = val;
+                    }
                 }
             } else {   // S2: written straight into the output vector (faces are never shared)
                 if (act && q < D::n2e) {
@@ -413,6 +444,22 @@ __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ y
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
+        double* o = y + (size_t)lev*ys + s;
+        if (accum) *o += acc; else *o = acc;
+    }
+}
+
+// perimeter pass of the fused scatter-add: slots shared by two element groups sum their two partials
+__global__ __launch_bounds__(256) void k_gather_perim(const double* __restrict__ yp, long long yps, const int* __restrict__ pslot,
+        const int* __restrict__ ppart, int nps, int nlev, int accum, double* __restrict__ y, long long ys) {
+    const int i = blockIdx.x*256 + threadIdx.x;
+    if (i >= nps) return;
+    const int s = pslot[i], p0 = ppart[2*i], p1 = ppart[2*i + 1];
+    const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);
+    for (int lev = l0; lev < l1; lev++) {
+        const double* src = yp + (size_t)lev*yps;
+        double acc = src[p0];
+        if (p1 >= 0) acc += src[p1];
         double* o = y + (size_t)lev*ys + s;
         if (accum) *o += acc; else *o = acc;
     }
@@ -617,11 +664,15 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     using D = Dims<N>;
     const long long items = (long long)a.nEl*((a.nlev + a.lch - 1)/a.lch);
     const unsigned grid = (unsigned)((items + D::EPB - 1)/D::EPB);
+    const unsigned fgrid = a.fperm ? (unsigned)(a.ngroups*((a.nlev + a.lch - 1)/a.lch)) : 0u;
     if (grid == 0) return MIMSEM_OK;
     // measurement hook: hipExtLaunchKernelGGL ties the events to the dispatch's own begin/end timestamps
+#define MIMSEM_LAUNCH(OPV, FU, GRID) \
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_elem_apply<N, OPV, FU>), dim3(GRID), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_elem_apply<N, OPV, FU>), dim3(GRID), dim3(256), 0, c->stream, a)
 #define MIMSEM_CASE(OPV) case OPV: \
-        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_elem_apply<N, OPV>), dim3(grid), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
-        else hipLaunchKernelGGL((k_elem_apply<N, OPV>), dim3(grid), dim3(256), 0, c->stream, a); \
+        if constexpr (OpTraits<OPV>::out == S1) { if (a.fperm) { MIMSEM_LAUNCH(OPV, true, fgrid); break; } } \
+        MIMSEM_LAUNCH(OPV, false, grid); \
         break;
     switch (op) {
         MIMSEM_CASE(MIMSEM_OP_UMAT) MIMSEM_CASE(MIMSEM_OP_WMAT) MIMSEM_CASE(MIMSEM_OP_UHMAT)
@@ -633,6 +684,7 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE
+#undef MIMSEM_LAUNCH
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
@@ -669,6 +721,16 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     case 7: return dispatch_apply<7>(c, op, a);
     default: return MIMSEM_ERR_UNSUPPORTED;
     }
+}
+
+int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys) {
+    if (c->f_nps == 0 || nlev == 0) return MIMSEM_OK;
+    const dim3 grid((unsigned)((c->f_nps + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
+    if (c->ev_k2[0]) hipExtLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0,
+                                           yp, yps, c->d_pslot, c->d_ppart, c->f_nps, nlev, accum, y, ys);
+    else hipLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, yp, yps, c->d_pslot, c->d_ppart, c->f_nps, nlev, accum, y, ys);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
 }
 
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
