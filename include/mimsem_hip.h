@@ -83,6 +83,10 @@ enum mimsem_op {
      * mimsem_op_apply_up: f = the op's field, u = local 1-form velocity that defines the departure points */
     MIMSEM_OP_PHMAT_UP = 14, /* Phmat::assemble_up(ul,hl,fac,dt)  src/Assembly.cpp:499-567   f=hl (2-form)  0 -> 0 */
     MIMSEM_OP_ROTMAT_UP = 15,/* RotMat_up::assemble(q0,ul,fac,dt) src/Assembly.cpp:1784-1853 f=q0 (0-form)  1 -> 1 */
+    /* eul-flavour operators whose TEST functions are evaluated at departure points (mimsem_op_apply_up; p <= 6) */
+    MIMSEM_OP_UMAT_UP = 19,   /* Umat::assemble_up(lev,scale,tau,ui,uj)      Assembly.cpp:156-279  f=ui, u=uj (local 1-forms) 1 -> 1 */
+    MIMSEM_OP_UHMAT_UP = 20,  /* Uhmat::assemble_up(h2,lev,scale,dt,u1)      :477-560              f=h2, u=u1, tau=dt        1 -> 1 */
+    MIMSEM_OP_UVEC_HU_UP = 21,/* Uvec::assemble_hu_up(lev,scale,vel,rho,fac,tau,vel2) :2281-2373   x=vel, f=rho, u=vel2, alpha=fac */
     /* projections from the quadrature-point grid (initial conditions, Coriolis): x lives on the quad grid */
     MIMSEM_OP_WTQ = 16,      /* WtQmat::assemble  Assembly.cpp:707-751   quad scalar -> 2-form                        */
     MIMSEM_OP_PTQ = 17,      /* PtQmat::assemble  :766-808               quad scalar -> 0-form                        */
@@ -140,9 +144,10 @@ int mimsem_op_apply(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double sca
                     const double* x, long long x_stride,
                     double* y, long long y_stride, double alpha);
 
-/* Upwinded variants: the 0-form (trial function resp. vorticity) is evaluated at the departure points
- * x_q - tau*u_local(x_q), tau = 1/(1/(fac*dt)) as in the reference.  u: local 1-form velocity per level. */
-int mimsem_op_apply_up(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double fac, double dt, unsigned flags,
+/* Upwinded variants.  PHMAT_UP / ROTMAT_UP: the 0-form (trial function resp. vorticity) is evaluated at the departure
+ * points x_q - tau*u_local(x_q) (the reference's tau = 1/(1/(fac*dt)) is formed by the caller).  UMAT_UP / UHMAT_UP /
+ * UVEC_HU_UP: the test functions are evaluated at x_q + (op-specific shift).  u: second field (velocity) per level. */
+int mimsem_op_apply_up(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
                        const double* f, long long f_stride, const double* u, long long u_stride,
                        const double* x, long long x_stride, double* y, long long y_stride, double alpha);
 

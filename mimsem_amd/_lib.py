@@ -63,7 +63,7 @@ _SIGS = {
 }
 
 OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=7, UTMAT=8,
-           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18)
+           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18, UMAT_UP=19, UHMAT_UP=20, UVEC_HU_UP=21)
 COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4, EOS_BLOCK=5,
               LINEAR=6, LINEAR_INV=7, LINEAR_RT=8, LINEAR_THETA=9, LINEAR_RHO2=10, RAYLEIGH=11,
               LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16)

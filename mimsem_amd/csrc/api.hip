@@ -122,6 +122,8 @@ int op_spaces(int op, int* in, int* cf, int* out) {
     case MIMSEM_OP_UTQ: *in = 3; *cf = -1; *out = 1; return 0;
     case MIMSEM_OP_PHMAT_UP:  *in = 0; *cf = 2; *out = 0; return 0;
     case MIMSEM_OP_ROTMAT_UP: *in = 1; *cf = 0; *out = 1; return 0;
+    case MIMSEM_OP_UMAT_UP:   *in = 1; *cf = 1; *out = 1; return 0;
+    case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP: *in = 1; *cf = 2; *out = 1; return 0;
     }
     return 1;
 }
@@ -351,21 +353,25 @@ int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
                          const double* x, long long xs, double* y, long long ys, double alpha);
+static bool is_up_op(int op);
 
 int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                     const double* f, long long fs, const double* x, long long xs,
                     double* y, long long ys, double alpha) {
-    if (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP) return MIMSEM_ERR_ARG;   // need mimsem_op_apply_up
+    if (is_up_op(op)) return MIMSEM_ERR_ARG;   // need mimsem_op_apply_up
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, y, ys, alpha);
 }
 
-int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double fac, double dt, unsigned flags,
+static bool is_up_op(int op) {
+    return op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP || op == MIMSEM_OP_UMAT_UP || op == MIMSEM_OP_UHMAT_UP ||
+           op == MIMSEM_OP_UVEC_HU_UP;
+}
+int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
                        const double* f, long long fs, const double* u, long long us,
                        const double* x, long long xs, double* y, long long ys, double alpha) {
-    if (op != MIMSEM_OP_PHMAT_UP && op != MIMSEM_OP_ROTMAT_UP) return MIMSEM_ERR_ARG;
-    if (!u) return MIMSEM_ERR_ARG;
-    const double tau = 1.0/(1.0/(fac*dt));               // src/Assembly.cpp:541, :1812
-    return op_apply_core(c, op, geom_lev0, nlev, 1.0, flags, f, fs, u, us, tau, x, xs, y, ys, alpha);
+    if (!is_up_op(op) || !u) return MIMSEM_ERR_ARG;
+    if (c && c->es.n > 6 && op >= MIMSEM_OP_UMAT_UP) return MIMSEM_ERR_UNSUPPORTED;    // LDS budget of the test-upwind kernels
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, y, ys, alpha);
 }
 
 }  // extern "C"
@@ -413,7 +419,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         return rc;
     }
     a.fperm = nullptr; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0;
-    if (outsp == 1 && c->fused1) {
+    if (outsp == 1 && c->fused1 && op < MIMSEM_OP_UMAT_UP) {
         // fused path: group-local sums in LDS, complete slots written straight to y, perimeter partials to the workspace
         if ((rc = c->ensure_ye((long long)std::max(c->f_npart, 1)*nlev))) return rc;
         a.fperm = c->d_fperm; a.flid = c->d_flid; a.fslot = c->d_fslot; a.fcnt = c->d_fcnt;

@@ -33,7 +33,9 @@ enum Space { S0 = 0, S1 = 1, S2 = 2, SN = 3, SQ = 4, SQ2 = 5 };   // SQ/SQ2: sca
 template <int OP> struct OpTraits;
 #define MIMSEM_TRAIT(op, in_, cf_, out_) \
     template <> struct OpTraits<op> { static constexpr Space in = in_, cf = cf_, out = out_; \
-        static constexpr bool up = (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP); }
+        /* tup: test functions at departure points: 1 nodal factor via two local velocities, 2 via (x+u), 3 nodal+edge factors */ \
+        static constexpr int tup = (op == MIMSEM_OP_UMAT_UP) ? 1 : (op == MIMSEM_OP_UVEC_HU_UP ? 2 : (op == MIMSEM_OP_UHMAT_UP ? 3 : 0)); \
+        static constexpr bool up = (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP) || tup != 0; }
 MIMSEM_TRAIT(MIMSEM_OP_UMAT,    S1, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_WMAT,    S2, SN, S2);
 MIMSEM_TRAIT(MIMSEM_OP_UHMAT,   S1, S2, S1);
@@ -49,6 +51,9 @@ MIMSEM_TRAIT(MIMSEM_OP_WTQDUDZ, S1, S1, S2);
 MIMSEM_TRAIT(MIMSEM_OP_WTQ, SQ,  SN, S2);
 MIMSEM_TRAIT(MIMSEM_OP_PTQ, SQ,  SN, S0);
 MIMSEM_TRAIT(MIMSEM_OP_UTQ, SQ2, SN, S1);
+MIMSEM_TRAIT(MIMSEM_OP_UMAT_UP,    S1, S1, S1);   // f = ui, second field uj
+MIMSEM_TRAIT(MIMSEM_OP_UHMAT_UP,   S1, S2, S1);   // f = h2, second field u1
+MIMSEM_TRAIT(MIMSEM_OP_UVEC_HU_UP, S1, S2, S1);   // f = rho, second field vel2
 MIMSEM_TRAIT(MIMSEM_OP_PHMAT_UP,  S0, S2, S0);   // + velocity (1-form) as second field
 MIMSEM_TRAIT(MIMSEM_OP_ROTMAT_UP, S1, S0, S1);   // + velocity (1-form) as second field
 
@@ -66,9 +71,22 @@ __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigne
                                           double& a, double& b) {
     const double sd = scale/g.det;
     const bool vert = (flags & MIMSEM_FLAG_VERT) != 0;
-    if constexpr (OP == MIMSEM_OP_UMAT || OP == MIMSEM_OP_UHMAT || OP == MIMSEM_OP_UTMAT || OP == MIMSEM_OP_UTMAT_H) {
+    if constexpr (OP == MIMSEM_OP_UMAT || OP == MIMSEM_OP_UHMAT || OP == MIMSEM_OP_UTMAT || OP == MIMSEM_OP_UTMAT_H ||
+                  OP == MIMSEM_OP_UMAT_UP || OP == MIMSEM_OP_UHMAT_UP || OP == MIMSEM_OP_UVEC_HU_UP) {
         double caa, cab, cbb;
-        if constexpr (OP == MIMSEM_OP_UMAT) {                       // Assembly.cpp:99-113
+        if constexpr (OP == MIMSEM_OP_UMAT_UP) {                    // Assembly.cpp:225-232 (thickness always applied)
+            caa = (g.J00*g.J00 + g.J10*g.J10)*g.Q*sd;
+            cab = (g.J00*g.J01 + g.J10*g.J11)*g.Q*sd;
+            cbb = (g.J01*g.J01 + g.J11*g.J11)*g.Q*sd;
+            caa *= g.tI; cab *= g.tI; cbb *= g.tI;
+        } else if constexpr (OP == MIMSEM_OP_UHMAT_UP || OP == MIMSEM_OP_UVEC_HU_UP) {   // :521-530 / :2310-2329
+            double hi = fu/g.det;
+            if constexpr (OP == MIMSEM_OP_UVEC_HU_UP) hi *= g.tI;     // rho is piecewise constant in the vertical
+            caa = hi*(g.J00*g.J00 + g.J10*g.J10)*g.Q*sd;
+            cab = hi*(g.J00*g.J01 + g.J10*g.J11)*g.Q*sd;
+            cbb = hi*(g.J01*g.J01 + g.J11*g.J11)*g.Q*sd;
+            caa *= g.tI; cab *= g.tI; cbb *= g.tI;
+        } else if constexpr (OP == MIMSEM_OP_UMAT) {                // Assembly.cpp:99-113
             caa = (g.J00*g.J00 + g.J10*g.J10)*g.Q*sd;
             cab = (g.J00*g.J01 + g.J10*g.J11)*g.Q*sd;
             cbb = (g.J01*g.J01 + g.J11*g.J11)*g.Q*sd;
@@ -255,6 +273,9 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     __shared__ double s_b[EPB][LPE];
     __shared__ double s_g[T::up ? EPB : 1][2*LPE];     // velocity DoFs of the upwinded operators
     __shared__ double sXn[D::np1];
+    constexpr int TUP = T::tup;
+    __shared__ double s_lx[TUP ? EPB : 1][TUP ? D::mp12*D::np1 : 1], s_ly[TUP ? EPB : 1][TUP ? D::mp12*D::np1 : 1];
+    __shared__ double s_ex[TUP == 3 ? EPB : 1][TUP == 3 ? D::mp12*N : 1], s_ey[TUP == 3 ? EPB : 1][TUP == 3 ? D::mp12*N : 1];
 
     const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
     const int nchunk = (a.nlev + a.lch - 1)/a.lch;
@@ -336,7 +357,58 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
             double u, v, fu = 0.0, fv = 0.0;
             interp_point<N, T::in>(s_x[el], sE, q, qx, qy, u, v);
             if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f[el], sE, q, qx, qy, fu, fv);
-            if constexpr (T::up) {
+            if constexpr (TUP != 0) {
+                // test functions of this point evaluated at its departure point (rows B2 / B4 / B17)
+                double gu, gv, px, py;
+                interp_point<N, S1>(s_g[el], sE, q, qx, qy, gu, gv);
+                if constexpr (TUP == 1) {            // Umat::assemble_up :206-216  (fu,fv) = ui, (gu,gv) = uj, local components
+                    const double ui0 = fu*(g.tI/g.det), ui1 = fv*(g.tI/g.det), uj0 = gu*(g.tI/g.det), uj1 = gv*(g.tI/g.det);
+                    px = sXn[qx] + 0.5*a.param*ui0 + 0.5*a.param*uj0;
+                    py = sXn[qy] + 0.5*a.param*ui1 + 0.5*a.param*uj1;
+                } else if constexpr (TUP == 2) {     // Uvec::assemble_hu_up :2331-2340  uh = (vel2 + vel) * 0.5 tI/det
+                    double uh0 = gu + u, uh1 = gv + v;
+                    uh0 *= 0.5*g.tI/g.det; uh1 *= 0.5*g.tI/g.det;
+                    px = sXn[qx] + 0.5*a.param*uh0; py = sXn[qy] + 0.5*a.param*uh1;
+                } else {                             // Uhmat::assemble_up :504-513
+                    double ug0 = (g.J00*gu + g.J01*gv)/g.det, ug1 = (g.J10*gu + g.J11*gv)/g.det;
+                    ug0 *= g.tI; ug1 *= g.tI;
+                    const double ul0 = (+g.J11*ug0 - g.J01*ug1)/g.det, ul1 = (-g.J10*ug0 + g.J00*ug1)/g.det;
+                    px = sXn[qx] + a.param*ul0; py = sXn[qy] + a.param*ul1;
+                }
+                double dxs[D::np1], dys[D::np1];
+#pragma unroll
+                for (int i = 0; i < D::np1; i++) {
+                    double yx_ = 1.0, yy_ = 1.0;
+#pragma unroll
+                    for (int j = 0; j < D::np1; j++) {
+                        if (j == i) continue;
+                        yx_ *= (px - sXn[j])/(sXn[i] - sXn[j]);
+                        yy_ *= (py - sXn[j])/(sXn[i] - sXn[j]);
+                    }
+                    s_lx[el][q*D::np1 + i] = yx_; s_ly[el][q*D::np1 + i] = yy_;
+                    if constexpr (TUP == 3) {        // l_i'(p) (LagrangeNode::evalDeriv eul/Basis.cpp:189-210)
+                        double bx = 0.0, by = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D::np1; j++) {
+                            if (j == i) continue;
+                            double ax = 1.0, ay = 1.0;
+#pragma unroll
+                            for (int k = 0; k < D::np1; k++) {
+                                if (k == i || k == j) continue;
+                                ax *= (px - sXn[k])/(sXn[i] - sXn[k]);
+                                ay *= (py - sXn[k])/(sXn[i] - sXn[k]);
+                            }
+                            bx += ax/(sXn[i] - sXn[j]); by += ay/(sXn[i] - sXn[j]);
+                        }
+                        dxs[i] = bx; dys[i] = by;
+                    }
+                }
+                if constexpr (TUP == 3) {            // e_i = -sum_{j<=i} l_j'  (LagrangeEdge::eval :274-283)
+                    double cx = 0.0, cy = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; i++) { cx -= dxs[i]; cy -= dys[i]; s_ex[el][q*N + i] = cx; s_ey[el][q*N + i] = cy; }
+                }
+            } else if constexpr (T::up) {
                 // departure point of this quadrature point: x_q - tau * (velocity in element coordinates)
                 double gu, gv;
                 interp_point<N, S1>(s_g[el], sE, q, qx, qy, gu, gv);
@@ -380,10 +452,20 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
                     double yx = 0.0, yy = 0.0;
                     const int ixx = q%D::np1, iyx = q/D::np1;     // x-normal edge: node in x, edge fn in y
                     const int ixy = q%N,      iyy = q/N;          // y-normal edge: edge fn in x, node in y
+                    if constexpr (TUP == 0) {
 #pragma unroll
-                    for (int k = 0; k < D::mp1; k++) {
-                        yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
-                        yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
+                        for (int k = 0; k < D::mp1; k++) {
+                            yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
+                            yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
+                        }
+                    } else {                 // rows Ut[i][q] = lx_q[ix] * (e_iy at q or at its departure point), all q contribute
+                        for (int qq = 0; qq < D::mp12; qq++) {
+                            const int kx = qq%D::mp1, ky = qq/D::mp1;
+                            const double ty = (TUP == 3) ? s_ey[el][qq*N + iyx] : sE[ky*N + iyx];
+                            const double sx = (TUP == 3) ? s_ex[el][qq*N + ixy] : sE[kx*N + ixy];
+                            yx += (s_lx[el][qq*D::np1 + ixx]*ty)*s_a[el][qq];
+                            yy += (sx*s_ly[el][qq*D::np1 + iyy])*s_b[el][qq];
+                        }
                     }
                     if constexpr (!FUSED) {
                         double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
@@ -681,6 +763,9 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_UTMAT_H) MIMSEM_CASE(MIMSEM_OP_UTQWMAT) MIMSEM_CASE(MIMSEM_OP_WTQDUDZ)
         MIMSEM_CASE(MIMSEM_OP_PHMAT_UP) MIMSEM_CASE(MIMSEM_OP_ROTMAT_UP)
         MIMSEM_CASE(MIMSEM_OP_WTQ) MIMSEM_CASE(MIMSEM_OP_PTQ) MIMSEM_CASE(MIMSEM_OP_UTQ)
+        case MIMSEM_OP_UMAT_UP: case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP:
+            if constexpr (N <= 6) { switch (op) { MIMSEM_CASE(MIMSEM_OP_UMAT_UP) MIMSEM_CASE(MIMSEM_OP_UHMAT_UP) MIMSEM_CASE(MIMSEM_OP_UVEC_HU_UP) } break; }
+            else return MIMSEM_ERR_UNSUPPORTED;
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE

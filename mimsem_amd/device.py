@@ -126,7 +126,7 @@ class Engine:
     _SPACES = dict(UMAT=(1, None, 1), UTMAT=(1, None, 1), UHMAT=(1, 2, 1), UTMAT_H=(1, 2, 1), ROTMAT=(1, 0, 1),
                    WMAT=(2, None, 2), WMATINV=(2, None, 2), WHMAT=(2, 2, 2), WHMATINV=(2, 2, 2), PMAT=(0, None, 0),
                    PHMAT=(0, 2, 0), WTQUMAT=(1, 1, 2), WTQDUDZ=(1, 1, 2), UTQWMAT=(2, 1, 1),
-                   PHMAT_UP=(0, 2, 0), ROTMAT_UP=(1, 0, 1), WTQ=("q", None, 2), PTQ=("q", None, 0), UTQ=("q2", None, 1))
+                   PHMAT_UP=(0, 2, 0), ROTMAT_UP=(1, 0, 1), UMAT_UP=(1, 1, 1), UHMAT_UP=(1, 2, 1), UVEC_HU_UP=(1, 2, 1), WTQ=("q", None, 2), PTQ=("q", None, 0), UTQ=("q2", None, 1))
 
     def apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
         """y_k = A_op(level lev0+k, f_k) x_k ; x: [nlev, n_in] (or [n_in]) device tensor"""
@@ -145,15 +145,18 @@ class Engine:
                                      _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply(%s)" % op)
         return y if x.dim() == 2 else y2[0]
 
-    def apply_up(self, op, x, f, u, fac, dt, lev0=0, alpha=1.0, flags=0, out=None):
-        """upwinded SW operators (PHMAT_UP / ROTMAT_UP): f = the op's field, u = local velocity 1-form"""
+    def apply_up(self, op, x, f, u, fac=None, dt=None, lev0=0, alpha=1.0, flags=0, out=None, scale=1.0, tau=None):
+        """upwinded operators: f = the op's field, u = second (velocity) field.  SW ops (PHMAT_UP / ROTMAT_UP) pass fac, dt
+        (tau = 1/(1/(fac*dt)), src/Assembly.cpp:541); the eul ops (UMAT_UP / UHMAT_UP / UVEC_HU_UP) pass scale and tau."""
+        if tau is None:
+            tau = 1.0 / (1.0 / (fac * dt))
         sin, sf, sout = self._SPACES[op]
         x2 = x if x.dim() == 2 else x.unsqueeze(0); f2 = f if f.dim() == 2 else f.unsqueeze(0); u2 = u if u.dim() == 2 else u.unsqueeze(0)
         nlev = x2.shape[0]
         assert x2.shape[1] == self.sizes[sin] and f2.shape == (nlev, self.sizes[sf]) and u2.shape == (nlev, self.sizes[1])
         y = out if out is not None else torch.empty(nlev, self.sizes[sout], dtype=torch.float64, device=self.device)
         y2 = y if y.dim() == 2 else y.unsqueeze(0)
-        check(self.L.mimsem_op_apply_up(self.ctx, OPS[op], lev0, nlev, fac, dt, flags, _ptr(f2), f2.stride(0), _ptr(u2), u2.stride(0),
+        check(self.L.mimsem_op_apply_up(self.ctx, OPS[op], lev0, nlev, scale, tau, flags, _ptr(f2), f2.stride(0), _ptr(u2), u2.stride(0),
                                         _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply_up(%s)" % op)
         return y if x.dim() == 2 else y2[0]
 

@@ -552,3 +552,116 @@ int orc_project_from_quad(const orc_patch* p, int which, const double* xq, doubl
     free(BtQ);
     return 0;
 }
+
+/* ---- eul-flavour operators with upwinded TEST functions (rows B2, B4, B17) ---------------------------------
+ * which 0: Umat::assemble_up(lev, scale, tau, ui, uj)          eul/Assembly.cpp:156-279   f1 = ui, f2 = uj (local 1-forms)
+ * which 1: Uhmat::assemble_up(h2, lev, scale, dt, u1)          :477-560                   f1 = h2 (2-form), f2 = u1
+ * Element blocks [nEl][4][n1e][n1e] (UtQU UtQV VtQU VtQV) with the row tables evaluated at the departure points. */
+int orc_op_elmats_testup(const orc_patch* p, int which, int lev, double scale, double tau,
+                         const double* f1, const double* f2, double* out) {
+    int ex, ey, ei, ii, jj, mp1 = p->mp1, mp12 = p->mp12, np1 = p->np1, nn = p->n, n1e = p->n1e, iq[128];
+    double lx[16], ly[16], _ex[16], _ey[16], uil[2], ujl[2], ug[2], ul[2], hi;
+    double *Ut = (double*)malloc(sizeof(double)*n1e*mp12), *Vt = (double*)malloc(sizeof(double)*n1e*mp12);
+    double *ca = (double*)malloc(sizeof(double)*mp12), *cb = (double*)malloc(sizeof(double)*mp12), *cc = (double*)malloc(sizeof(double)*mp12);
+    double* tmp = (double*)malloc(sizeof(double)*128*mp12);
+    const double* tI = p->thickInv + (size_t)lev*p->n0q;
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        double* M = out + (size_t)(ey*p->nElsX + ex)*4*n1e*n1e;
+        ei = ey*p->nElsX + ex;
+        orc_elindsq_l(p, ex, ey, iq);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+            if (which == 0) {                                   /* :202-223 */
+                orc_interp1_l(p, ex, ey, ii%mp1, ii/mp1, f1, uil);
+                orc_interp1_l(p, ex, ey, ii%mp1, ii/mp1, f2, ujl);
+                uil[0] *= tI[iq[ii]]/det; uil[1] *= tI[iq[ii]]/det;
+                ujl[0] *= tI[iq[ii]]/det; ujl[1] *= tI[iq[ii]]/det;
+                for (jj = 0; jj < np1; jj++) {
+                    lx[jj] = orc_node_eval(nn, p->nx, p->qx[ii%mp1] + 0.5*tau*uil[0] + 0.5*tau*ujl[0], jj);
+                    ly[jj] = orc_node_eval(nn, p->nx, p->qx[ii/mp1] + 0.5*tau*uil[1] + 0.5*tau*ujl[1], jj);
+                }
+                for (jj = 0; jj < nn*mp1; jj++) {
+                    Ut[jj*mp12 + ii] = lx[jj%mp1]*p->ejxi[(ii/mp1)*nn + jj/np1];
+                    Vt[jj*mp12 + ii] = p->ejxi[(ii%mp1)*nn + jj%nn]*ly[jj/nn];
+                }
+                ca[ii] = (J00*J00 + J10*J10)*p->Q[ii]*(scale/det);
+                cb[ii] = (J00*J01 + J10*J11)*p->Q[ii]*(scale/det);
+                cc[ii] = (J01*J01 + J11*J11)*p->Q[ii]*(scale/det);
+                ca[ii] *= tI[iq[ii]]; cb[ii] *= tI[iq[ii]]; cc[ii] *= tI[iq[ii]];
+            } else {                                            /* :499-530 */
+                orc_interp2_g(p, ex, ey, ii%mp1, ii/mp1, f1, &hi);
+                orc_interp1_g(p, ex, ey, ii%mp1, ii/mp1, f2, ug);
+                ug[0] *= tI[iq[ii]]; ug[1] *= tI[iq[ii]];
+                ul[0] = (+J11*ug[0] - J01*ug[1])/det;
+                ul[1] = (-J10*ug[0] + J00*ug[1])/det;
+                for (jj = 0; jj < mp1; jj++) {
+                    lx[jj] = orc_node_eval(nn, p->nx, p->qx[ii%mp1] + tau*ul[0], jj);
+                    ly[jj] = orc_node_eval(nn, p->nx, p->qx[ii/mp1] + tau*ul[1], jj);
+                }
+                for (jj = 0; jj < nn; jj++) {
+                    _ex[jj] = orc_edge_eval(nn, p->nx, p->qx[ii%mp1] + tau*ul[0], jj);
+                    _ey[jj] = orc_edge_eval(nn, p->nx, p->qx[ii/mp1] + tau*ul[1], jj);
+                }
+                for (jj = 0; jj < nn*mp1; jj++) {
+                    Ut[jj*mp12 + ii] = lx[jj%mp1]*_ey[jj/mp1];
+                    Vt[jj*mp12 + ii] = _ex[jj%nn]*ly[jj/nn];
+                }
+                ca[ii] = hi*(J00*J00 + J10*J10)*p->Q[ii]*(scale/det);
+                cb[ii] = hi*(J00*J01 + J10*J11)*p->Q[ii]*(scale/det);
+                cc[ii] = hi*(J01*J01 + J11*J11)*p->Q[ii]*(scale/det);
+                ca[ii] *= tI[iq[ii]]; cb[ii] *= tI[iq[ii]]; cc[ii] *= tI[iq[ii]];
+            }
+        }
+        triple(p, n1e, n1e, Ut, ca, p->U, tmp, M + 0*n1e*n1e);
+        triple(p, n1e, n1e, Ut, cb, p->V, tmp, M + 1*n1e*n1e);
+        triple(p, n1e, n1e, Vt, cb, p->U, tmp, M + 2*n1e*n1e);
+        triple(p, n1e, n1e, Vt, cc, p->V, tmp, M + 3*n1e*n1e);
+    }
+    free(Ut); free(Vt); free(ca); free(cb); free(cc); free(tmp);
+    return 0;
+}
+
+/* Uvec::assemble_hu_up(lev, scale, vel, rho, fac, tau, vel2)  eul/Assembly.cpp:2281-2373 -- accumulates into vl */
+void orc_uvec_hu_up(const orc_patch* p, int lev, double scale, const double* vel, const double* rho, double fac,
+                    double tau, const double* vel2, double* vl) {
+    int ex, ey, ei, ii, jj, k, mp1 = p->mp1, mp12 = p->mp12, nn = p->n, np1 = p->np1, nj = p->n1e, ix[128], iy[128], iq[128];
+    double Qaa[128], Qab[128], Qba[128], Qbb[128], rhs[128], u[2], uh[2], r, lx[16], ly[16];
+    double *MUt = (double*)malloc(sizeof(double)*nj*mp12), *MVt = (double*)malloc(sizeof(double)*nj*mp12);
+    const double* tI = p->thickInv + (size_t)lev*p->n0q;
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        ei = ey*p->nElsX + ex;
+        orc_elindsq_l(p, ex, ey, iq);
+        orc_elinds1x_l(p, ex, ey, ix); orc_elinds1y_l(p, ex, ey, iy);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+            Qaa[ii] = (J00*J00 + J10*J10)*p->Q[ii]*(scale/det);
+            Qab[ii] = (J00*J01 + J10*J11)*p->Q[ii]*(scale/det);
+            Qbb[ii] = (J01*J01 + J11*J11)*p->Q[ii]*(scale/det);
+            Qaa[ii] *= tI[iq[ii]]; Qab[ii] *= tI[iq[ii]]; Qbb[ii] *= tI[iq[ii]];
+            Qba[ii] = Qab[ii];
+            orc_interp1_l(p, ex, ey, ii%mp1, ii/mp1, vel, u);
+            orc_interp2_g(p, ex, ey, ii%mp1, ii/mp1, rho, &r);
+            r *= tI[iq[ii]];
+            r *= fac;
+            Qaa[ii] *= (u[0]*r); Qba[ii] *= (u[0]*r); Qab[ii] *= (u[1]*r); Qbb[ii] *= (u[1]*r);
+            orc_interp1_l(p, ex, ey, ii%mp1, ii/mp1, vel2, uh);
+            uh[0] += u[0]; uh[1] += u[1];
+            uh[0] *= 0.5*tI[iq[ii]]/det; uh[1] *= 0.5*tI[iq[ii]]/det;
+            for (jj = 0; jj < np1; jj++) {
+                lx[jj] = orc_node_eval(nn, p->nx, p->qx[ii%mp1] + 0.5*tau*uh[0], jj);
+                ly[jj] = orc_node_eval(nn, p->nx, p->qx[ii/mp1] + 0.5*tau*uh[1], jj);
+            }
+            for (jj = 0; jj < nj; jj++) {
+                MUt[jj*mp12 + ii] = lx[jj%np1]*p->ejxi[(ii/mp1)*nn + jj/np1];
+                MVt[jj*mp12 + ii] = p->ejxi[(ii%mp1)*nn + jj%nn]*ly[jj/nn];
+            }
+        }
+        orc_la->axb(nj, mp12, MUt, Qaa, rhs); for (k = 0; k < nj; k++) vl[ix[k]] += rhs[k];
+        orc_la->axb(nj, mp12, MUt, Qab, rhs); for (k = 0; k < nj; k++) vl[ix[k]] += rhs[k];
+        orc_la->axb(nj, mp12, MVt, Qba, rhs); for (k = 0; k < nj; k++) vl[iy[k]] += rhs[k];
+        orc_la->axb(nj, mp12, MVt, Qbb, rhs); for (k = 0; k < nj; k++) vl[iy[k]] += rhs[k];
+    }
+    free(MUt); free(MVt);
+}

@@ -136,6 +136,13 @@ int orc_op_elmats_up(const orc_patch* p, int which, double fac, double dt, const
  * (xq interleaved [n0q][2]); y is ACCUMULATED into (local 2/0/1-form vector). */
 int orc_project_from_quad(const orc_patch* p, int which, const double* xq, double* y);
 
+/* eul operators with upwinded TEST functions: which 0 = Umat::assemble_up :156-279 (f1=ui, f2=uj), 1 = Uhmat::assemble_up
+ * :477-560 (f1=h2, f2=u1; tau = dt); out like ORC_UMAT.  orc_uvec_hu_up = Uvec::assemble_hu_up :2281-2373 (accumulates). */
+int orc_op_elmats_testup(const orc_patch* p, int which, int lev, double scale, double tau,
+                         const double* f1, const double* f2, double* out);
+void orc_uvec_hu_up(const orc_patch* p, int lev, double scale, const double* vel, const double* rho, double fac,
+                    double tau, const double* vel2, double* vl);
+
 /* matrix-free vectors, eul/Assembly.cpp */
 void orc_pvec(const orc_patch* p, int lev, double scale, double* vl);                       /* B5 Pvec  :602-632 (local part) */
 void orc_phvec(const orc_patch* p, int lev, double scale, const double* h2, double* vl);    /* B5 Phvec :654-689 */

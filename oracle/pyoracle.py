@@ -228,6 +228,23 @@ class Patch:
         rc = self.L.orc_project_from_quad(self.p, which, _dp(np.ascontiguousarray(xq)), _dp(y)); assert rc == 0
         return y
 
+    def apply_testup(self, which, x, lev, scale, tau, f1, f2, transpose=False):
+        """Umat::assemble_up / Uhmat::assemble_up then MatMult (or MatMult with MT), local vectors"""
+        em = np.zeros((self.nEl, self.elmat_size("UMAT")))
+        rc = self.L.orc_op_elmats_testup(self.p, which, lev, C.c_double(scale), C.c_double(tau), _dp(f1), _dp(f2), _dp(em))
+        assert rc == 0
+        if transpose:
+            n = self.n1e
+            b = em.reshape(self.nEl, 4, n, n)
+            em = np.ascontiguousarray(np.stack([b[:, 0].transpose(0, 2, 1), b[:, 2].transpose(0, 2, 1),
+                                                b[:, 1].transpose(0, 2, 1), b[:, 3].transpose(0, 2, 1)], axis=1)).reshape(self.nEl, -1)
+        return self.op_apply("UMAT", em, x, self.n1)
+
+    def uvec_hu_up(self, lev, scale, vel, rho, fac, tau, vel2):
+        v = np.zeros(self.n1)
+        self.L.orc_uvec_hu_up(self.p, lev, C.c_double(scale), _dp(vel), _dp(rho), C.c_double(fac), C.c_double(tau), _dp(vel2), _dp(v))
+        return v
+
     def bench_assemble_mult(self, op, x, reps, lev=0, scale=1.0, flag=0, f1=None):
         """seconds for `reps` x (assemble + MatMult) with the reference's CSR cost structure; also returns y"""
         y = np.zeros(self.out_size(op))

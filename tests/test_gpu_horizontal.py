@@ -148,3 +148,28 @@ def test_quad_grid_projections(setup, which, op):
     want = P.project_from_quad(which, xq)
     got = eng.apply(op, eng.tensor(xq), lev0=0, scale=1.0)
     assert rel_l2(got.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_eul_upwinded_test_functions(setup, which):
+    """B2 Umat::assemble_up, B4 Uhmat::assemble_up, B17 Uvec::assemble_hu_up (eul/Assembly.cpp:156-279, 477-560, 2281-2373)"""
+    eng, P, rng = setup
+    if P.n > 6:
+        pytest.skip("test-upwind kernels are built for p <= 6")
+    r = np.random.default_rng(41)
+    lev, tau = 1, 75.0
+    vscale = P.det.mean() / P.thickInv[lev].mean() * 0.3 / tau        # shift ~ 0.3 of the reference element
+    u1 = r.uniform(-1, 1, P.n1) * vscale; u2 = r.uniform(-1, 1, P.n1) * vscale
+    x = r.standard_normal(P.n1); h = r.uniform(0.5, 1.5, P.n2) * 1e6
+    t = eng.tensor
+    if which == 0:
+        want = P.apply_testup(0, x, lev, SCALE, tau, u1, u2)
+        got = eng.apply_up("UMAT_UP", t(x), t(u1), t(u2), lev0=lev, scale=SCALE, tau=tau)
+    elif which == 1:
+        want = P.apply_testup(1, x, lev, SCALE, tau, h, u1 * P.det.mean() ** 0)   # u1 is Piola-mapped inside
+        got = eng.apply_up("UHMAT_UP", t(x), t(h), t(u1), lev0=lev, scale=SCALE, tau=tau)
+    else:
+        vel = u1
+        want = P.uvec_hu_up(lev, SCALE, vel, h, 1.0 / 3.0, tau, u2)
+        got = eng.apply_up("UVEC_HU_UP", t(vel), t(h), t(u2), lev0=lev, scale=SCALE, tau=tau, alpha=1.0 / 3.0)
+    assert rel_l2(got.cpu().numpy(), want) < TOL
