@@ -1,0 +1,72 @@
+""" "Next" rows (SURVEY 8(f) N1/N2 first pieces): device CG mass solve and the weak-form grad/curl built on it,
+checked against a dense assembly of the oracle's element matrices on the whole (small) cubed sphere."""
+import numpy as np
+import pytest
+
+from tests.helpers import SCALE, z_levels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sphere(oracle):
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    pn, ne, nk = 3, 2, 2
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    topos = [Topo(cs, p, nk) for p in range(6)]
+    geoms = [Geom(t, cs, coords, nk) for t in topos]
+    rng = np.random.default_rng(3)
+    levs = z_levels(nk, geoms[0].n0)
+    for g in geoms:
+        g.set_levels(levs)
+    eng = Engine(DeviceMesh(topos, geoms, nk=nk, numbering="global"))
+    # oracle: global dense M1, M2 at every level from the per-patch element matrices
+    mats = []
+    for k in range(nk):
+        M1 = np.zeros((cs.nDofs1G, cs.nDofs1G)); M2 = np.zeros((cs.nDofs2G, cs.nDofs2G))
+        for t, g in zip(topos, geoms):
+            P = oracle.Patch(pn, pn, cs.nel, nk)
+            P.set_sphere_geometry(coords[cs.patches[t.pi].loc0]); P.set_levels(levs)
+            em = P.op_elmats("UMAT", k, SCALE, 1).reshape(P.nEl, 4, P.n1e, P.n1e)
+            gx, gy = t.all_inds1x_g(), t.all_inds1y_g()
+            for e in range(P.nEl):
+                for b, (r, c) in enumerate(((gx, gx), (gx, gy), (gy, gx), (gy, gy))):
+                    M1[np.ix_(r[e], c[e])] += em[e, b]
+            em2 = P.op_elmats("WMAT", k, SCALE, 1).reshape(P.nEl, P.n2e, P.n2e)
+            g2 = t.all_inds2_g()
+            for e in range(P.nEl):
+                M2[np.ix_(g2[e], g2[e])] += em2[e]
+        mats.append((M1, M2))
+    return cs, eng, mats, rng
+
+
+def test_device_cg_mass_solve(sphere):
+    from mimsem_amd.krylov import MassSolver
+    cs, eng, mats, rng = sphere
+    ms = MassSolver(eng, SCALE, True)
+    b = rng.standard_normal((eng.nk, cs.nDofs1G)) * 1e9
+    x, its = ms.solve(eng.tensor(b), rtol=1e-15)
+    assert its < 300
+    for k, (M1, _) in enumerate(mats):
+        ref = np.linalg.solve(M1, b[k])
+        assert np.linalg.norm(x[k].cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-10
+
+
+def test_weak_gradient_matches_dense(sphere):
+    from mimsem_amd.horizsolve import HorizSolve
+    cs, eng, mats, rng = sphere
+    hs = HorizSolve(eng)
+    phi = rng.standard_normal((eng.nk, cs.nDofs2G))
+    u = hs.grad(eng.tensor(phi)).cpu().numpy()
+    E21 = np.zeros((cs.nDofs2G, cs.nDofs1G))
+    e21 = eng.incidence("E21", eng.tensor(np.eye(cs.nDofs1G))).cpu().numpy()     # rows = unit vectors -> E21 columns
+    E21[:] = e21.T
+    for k, (M1, M2) in enumerate(mats):
+        ref = np.linalg.solve(M1, -E21.T @ (M2 @ phi[k]))
+        assert np.linalg.norm(u[k] - ref) / np.linalg.norm(ref) < 1e-9
+    # mimetic identity on the whole sphere: E21 E10 = 0
+    w = eng.incidence("E21", eng.incidence("E10", eng.tensor(rng.standard_normal((1, cs.nDofs0G)))))
+    assert float(w.abs().max()) < 1e-12
