@@ -90,7 +90,36 @@ def basis_linalg_fixture():
     np.savez_compressed(os.path.join(HERE, "basis_linalg.npz"), **out)
 
 
+def input_files_fixture(pn, ne, n_procs):
+    """the input/ directory exactly as scr/Setup.py produces it (same calls, same order), into tests/golden/"""
+    import shutil
+    from Proc2 import ParaCube
+    from Geom2 import init_geom
+    root = os.path.join(HERE, f"input_p{pn}_ne{ne}_np{n_procs}")
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, "input"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        pc = ParaCube(n_procs, pn, ne, root + "/")
+        for pi in np.arange(n_procs):
+            pc.print_nodes(pi, "nodes"); pc.print_edges(pi, 0); pc.print_edges(pi, 1); pc.print_faces(pi)
+            pc.procs[pi].writeLocalSizes()
+        with open(root + "/input/grid_res.txt", "w") as f:
+            f.write(str(pn) + "\n"); f.write(str(ne // pc.npx))
+        pc = ParaCube(n_procs, pn, ne, root + "/")
+        for pi in np.arange(n_procs):
+            pc.print_nodes(pi, "quads")
+        xg, yg, zg = init_geom(pn, ne, False, True)
+        for pi in np.arange(n_procs):
+            proc = pc.procs[pi]
+            coords = np.stack([xg[proc.loc0], yg[proc.loc0], zg[proc.loc0]], axis=1)
+            np.savetxt(root + "/input/geom_%.4u" % pi + ".txt", coords, fmt="%.18e")
+            np.savetxt(root + "/input/local_sizes_quad_%.4u" % pi + ".txt", np.array([proc.n0l], dtype=np.int32), fmt="%u")
+        with open(root + "/input/grid_res_quad.txt", "w") as f:
+            f.write(str(pn) + "\n"); f.write(str(ne // pc.npx))
+
+
 if __name__ == "__main__":
+    input_files_fixture(2, 2, 6)
     for pn, ne, npr in [(3, 2, 6), (3, 4, 24), (2, 3, 54), (4, 2, 6), (1, 2, 24)]:
         topo_fixture(pn, ne, npr)
     for pn, ne in [(3, 2), (3, 4), (4, 2), (2, 3)]:
