@@ -122,3 +122,29 @@ class Geom:
         """[nk][nEl][mp12] thickness / inverse at each element's own quad points (device layout)"""
         inds = self.all_inds0_l()
         return np.ascontiguousarray(self.thick[:, inds]), np.ascontiguousarray(self.thickInv[:, inds])
+
+
+class BoxGeom(Geom):
+    """box/ flavour (BASELINE config 5): doubly periodic planar patch with the constant diagonal Jacobian
+    J = diag(LX / (2 * elements per side)) of box/Geom.cpp:132-143; same members as the sphere Geom."""
+
+    def __init__(self, topo, quad_box, coords, nk=1, lx=1000.0):
+        self.topo, self.pi, self.nk, self.radius = topo, topo.pi, nk, None
+        self.quad_ord = quad_box.pn
+        self.nElsX = topo.nElsX
+        self.nDofsX = quad_box.D
+        qp = quad_box.patches[topo.pi]
+        self.loc0 = qp.loc0
+        self.n0, self.n0l = qp.loc0.size, qp.n0l
+        self.nDofs0G = quad_box.nDofs0G
+        self.x = np.array(coords[self.loc0], dtype=np.float64)
+        self.s = self.x[:, :2].copy()
+        self.qx = gll_points(self.quad_ord)
+        nEl, mp12 = self.nElsX ** 2, (self.quad_ord + 1) ** 2
+        j = 0.5 * lx / (topo.nElsX * quad_box.npx)
+        self.J = np.zeros((nEl, mp12, 4)); self.J[..., 0] = j; self.J[..., 3] = j
+        self.det = np.abs(self.J[..., 0] * self.J[..., 3] - self.J[..., 1] * self.J[..., 2])
+        self.topog = np.zeros(self.n0)
+        self.levs = np.zeros((nk + 1, self.n0))
+        self.thick = np.ones((nk, self.n0))
+        self.thickInv = np.ones((nk, self.n0))

@@ -216,3 +216,57 @@ def sphere_coords(pn, ne, radius=RAD_SPHERE):
 def patch_coords(mesh_q, coords, pid):
     """geom_%04u.txt content: coordinates of a patch's quad-grid nodes (scr/Setup.py:61-68)."""
     return coords[mesh_q.patches[pid].loc0]
+
+
+# ---- doubly periodic planar box (box/ flavour, BASELINE config 5) ------------------------------------------------
+class PeriodicBox:
+    """npx^2 square patches of one doubly periodic face (scr/ProcBox.py:6-245): same local layout and
+    element-contiguous edge/face numbering as the sphere, neighbours wrap around, no hanging nodes
+    (nDofs0G has no +2, box/Topo.cpp:112)."""
+
+    def __init__(self, pn, ne, n_procs=1):
+        npx = _isqrt(n_procs)
+        if npx * npx != n_procs or ne % npx:
+            raise ValueError("box patch count must be a square that divides the elements per side")
+        self.pn, self.ne, self.n_procs, self.npx = pn, ne, n_procs, npx
+        self.nel = ne // npx
+        self.D = pn * self.nel
+        self.F = pn * ne
+        self.nDofs0G = self.F * self.F
+        self.nDofs1G = 2 * self.F * self.F
+        self.nDofs2G = self.F * self.F
+        self.patches = [self._build(px, py) for py in range(npx) for px in range(npx)]
+
+    def _slot(self, gx, gy):
+        D, pn, nel, npx = self.D, self.pn, self.nel, self.npx
+        pj = (gy // D) * npx + gx // D
+        lx, ly = gx % D, gy % D
+        return pj * D * D + ((ly // pn) * nel + lx // pn) * pn * pn + (ly % pn) * pn + lx % pn
+
+    def _build(self, px, py):
+        D, F = self.D, self.F
+        p = Patch(py * self.npx + px, 0, px, py)
+        x0, y0 = px * D, py * D
+        iy, ix = np.meshgrid(np.arange(D + 1), np.arange(D + 1), indexing="ij")
+        p.loc0 = (((y0 + iy) % F) * F + (x0 + ix) % F).astype(np.int32).ravel()
+        iy, ix = np.meshgrid(np.arange(D), np.arange(D + 1), indexing="ij")
+        p.loc1x = (2 * self._slot((x0 + ix) % F, (y0 + iy) % F)).astype(np.int32).ravel()
+        iy, ix = np.meshgrid(np.arange(D + 1), np.arange(D), indexing="ij")
+        p.loc1y = (2 * self._slot((x0 + ix) % F, (y0 + iy) % F) + 1).astype(np.int32).ravel()
+        iy, ix = np.meshgrid(np.arange(D), np.arange(D), indexing="ij")
+        p.loc2 = self._slot(x0 + ix, y0 + iy).astype(np.int32).ravel()
+        p.n0l = p.n1xl = p.n1yl = p.n2l = D * D
+        return p
+
+
+def box_coords(pn, ne, lx=1000.0):
+    """planar GLL coordinates of every global node id (scr/GeomBox.py:9-74)"""
+    q = {1: np.array([-1.0, +1.0])}.get(pn)
+    if q is None:
+        q = _GLL[pn]()
+    F = pn * ne
+    dx = lx / ne
+    i = np.arange(F)
+    c = (i // pn) * dx + 0.5 * dx * (1.0 + q[i % pn])
+    gy, gx = np.meshgrid(i, i, indexing="ij")
+    return np.stack([c[gx].ravel(), c[gy].ravel(), np.zeros(F * F)], axis=1)

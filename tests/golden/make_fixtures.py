@@ -90,6 +90,22 @@ def basis_linalg_fixture():
     np.savez_compressed(os.path.join(HERE, "basis_linalg.npz"), **out)
 
 
+def box_fixture(pn, ne, n_procs, lx=1000.0):
+    from ProcBox import ParaBox
+    from GeomBox import init_geom as box_geom
+    with contextlib.redirect_stdout(io.StringIO()):
+        pc = ParaBox(n_procs, pn, ne, "/tmp/")
+        xg, yg, zg = box_geom(pn, ne, False, lx)
+    out = {}
+    for pi, pr in enumerate(pc.procs):
+        for k in ("loc0", "loc1x", "loc1y", "loc2"):
+            out[f"{k}_{pi}"] = np.asarray(getattr(pr, k), dtype=np.int32)
+        out[f"sizes_{pi}"] = np.array([pr.n0l, pr.n1xl, pr.n1yl, pr.n2l], dtype=np.int32)
+    out["coords"] = np.stack([xg, yg, zg], axis=1)
+    out["meta"] = np.array([pn, ne, n_procs], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, f"box_p{pn}_ne{ne}_np{n_procs}.npz"), **out)
+
+
 def input_files_fixture(pn, ne, n_procs):
     """the input/ directory exactly as scr/Setup.py produces it (same calls, same order), into tests/golden/"""
     import shutil
@@ -120,6 +136,8 @@ def input_files_fixture(pn, ne, n_procs):
 
 if __name__ == "__main__":
     input_files_fixture(2, 2, 6)
+    for pn, ne, npr in [(4, 4, 4), (2, 3, 9), (3, 2, 1)]:
+        box_fixture(pn, ne, npr)
     for pn, ne, npr in [(3, 2, 6), (3, 4, 24), (2, 3, 54), (4, 2, 6), (1, 2, 24)]:
         topo_fixture(pn, ne, npr)
     for pn, ne in [(3, 2), (3, 4), (4, 2), (2, 3)]:

@@ -70,3 +70,41 @@ def test_weak_gradient_matches_dense(sphere):
     # mimetic identity on the whole sphere: E21 E10 = 0
     w = eng.incidence("E21", eng.incidence("E10", eng.tensor(rng.standard_normal((1, cs.nDofs0G)))))
     assert float(w.abs().max()) < 1e-12
+
+
+def test_periodic_box_p4_global_apply(oracle):
+    """BASELINE config 5 flavour: p=4 doubly periodic box (constant Jacobian, periodic wrap in the numbering), 4 patches on
+    one GPU in global numbering; Umat / Wmat / WtQUmat applies vs a dense assembly of the oracle's element matrices"""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import BoxGeom
+    from mimsem_amd.mesh import PeriodicBox, box_coords
+    from mimsem_amd.topo import Topo
+    pn, ne, npr, nk = 4, 4, 4, 2
+    bx = PeriodicBox(pn, ne, npr); coords = box_coords(pn, ne, 1000.0)
+    topos = [Topo(bx, p, nk) for p in range(npr)]
+    geoms = [BoxGeom(t, bx, coords, nk, 1000.0) for t in topos]
+    rng = np.random.default_rng(17)
+    levs = z_levels(nk, geoms[0].n0, rng, ztop=1500.0)
+    for g in geoms:
+        g.set_levels(levs)                        # same level heights on every patch-local grid position
+    eng = Engine(DeviceMesh(topos, geoms, nk=nk, numbering="global"))
+    lev = 1
+    M1 = np.zeros((bx.nDofs1G, bx.nDofs1G)); K = np.zeros((bx.nDofs2G, bx.nDofs1G))
+    u1 = rng.standard_normal(bx.nDofs1G) * 10.0
+    for t, g in zip(topos, geoms):
+        P = oracle.Patch(pn, pn, bx.nel, nk)
+        P.set_metric(g.det, g.J); P.set_levels(levs)
+        gx, gy, g2 = t.all_inds1x_g(), t.all_inds1y_g(), t.all_inds2_g()
+        em = P.op_elmats("UMAT", lev, SCALE, 1).reshape(P.nEl, 4, P.n1e, P.n1e)
+        ul = np.zeros(P.n1); ul[t.all_inds1x_l().ravel()] = u1[gx.ravel()]; ul[t.all_inds1y_l().ravel()] = u1[gy.ravel()]
+        ek = P.op_elmats("WTQUMAT", lev, SCALE, 0, ul).reshape(P.nEl, 2, P.n2e, P.n1e)
+        for e in range(P.nEl):
+            for b, (r, c) in enumerate(((gx, gx), (gx, gy), (gy, gx), (gy, gy))):
+                M1[np.ix_(r[e], c[e])] += em[e, b]
+            K[np.ix_(g2[e], gx[e])] += ek[e, 0]; K[np.ix_(g2[e], gy[e])] += ek[e, 1]
+    x = rng.standard_normal(bx.nDofs1G)
+    xt = eng.tensor(np.stack([x, x])); ut = eng.tensor(np.stack([u1, u1]))
+    y = eng.apply("UMAT", xt, lev0=0, scale=SCALE, flags=1)[lev].cpu().numpy()
+    assert np.linalg.norm(y - M1 @ x) / np.linalg.norm(M1 @ x) < 1e-10
+    y2 = eng.apply("WTQUMAT", xt, f=ut, lev0=0, scale=SCALE)[lev].cpu().numpy()
+    assert np.linalg.norm(y2 - K @ x) / np.linalg.norm(K @ x) < 1e-10
