@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
     ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
+    ap.add_argument("--box", action="store_true", help="extra: BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
                          "working set >> the 256 MiB Infinity Cache, i.e. genuinely HBM-resident")
@@ -233,6 +234,28 @@ def main():
             torch.cuda.synchronize()
             fam[op] = units_rank * 50 / (time.perf_counter() - t1)
         out["families"] = fam
+    if a.box and rank == 0 and world == 1:
+        from mimsem_amd.geom import BoxGeom
+        from mimsem_amd.mesh import PeriodicBox, box_coords
+        bx = PeriodicBox(4, 32, 4); bc = box_coords(4, 32, 1000.0); nkb = 64
+        bt = [Topo(bx, p, nkb) for p in range(4)]; bg = [BoxGeom(t, bx, bc, nkb, 1000.0) for t in bt]
+        for g in bg:
+            g.set_levels(np.repeat(np.linspace(0.0, 1500.0, nkb + 1)[:, None], g.n0, axis=1))
+        dmb = DeviceMesh(bt, bg, nk=nkb, numbering="global"); engb = Engine(dmb, device=local_rank)
+        xb = engb.tensor(rng.standard_normal((nkb, dmb.n1))); yb = engb.zeros(nkb, dmb.n1)
+        callb, _ = engb.prepare_apply("UMAT", xb, lev0=0, scale=SCALE, flags=1, out=yb)
+        for _ in range(10):
+            callb()
+        torch.cuda.synchronize(); engb.set_profiling(4); t1 = time.perf_counter()
+        for _ in range(200):
+            callb()
+        torch.cuda.synchronize(); dtb = time.perf_counter() - t1
+        b1, b2, bn = engb.profile_read(); engb.set_profiling(0)
+        ub = dmb.nEl * nkb
+        out["box_p4"] = {"workload": "Umat apply, p=4 32x32 periodic box x 64 levels (65 536 units)", "value": ub * 200 / dtb,
+                         "k_elem_apply_us": b1 / bn * 1e3, "k_gather_sum_us": b2 / bn * 1e3, "bytes_per_unit_op": 2320,
+                         "op_GBs": ub * 2320 / ((b1 + b2) / bn * 1e-3) / 1e9}
+        del engb
     if a.column and rank == 0 and world == 1:
         out["column"] = column_extras(eng, dm, rng, torch)
     if a.cold and rank == 0 and world == 1:
