@@ -87,6 +87,9 @@ enum mimsem_op {
     MIMSEM_OP_UMAT_UP = 19,   /* Umat::assemble_up(lev,scale,tau,ui,uj)      Assembly.cpp:156-279  f=ui, u=uj (local 1-forms) 1 -> 1 */
     MIMSEM_OP_UHMAT_UP = 20,  /* Uhmat::assemble_up(h2,lev,scale,dt,u1)      :477-560              f=h2, u=u1, tau=dt        1 -> 1 */
     MIMSEM_OP_UVEC_HU_UP = 21,/* Uvec::assemble_hu_up(lev,scale,vel,rho,fac,tau,vel2) :2281-2373   x=vel, f=rho, u=vel2, alpha=fac */
+    /* Held-Suarez boundary-layer friction (mimsem_op_apply_up: f = exner at the level, u = exner at level 0 with
+     * u_stride = 0, tau = dt; both 2-forms in the horizontal layout) */
+    MIMSEM_OP_UMAT_RAY = 22,  /* Umat_ray::assemble(lev,scale,dt,exner_k,exner_s) Assembly.cpp:1876-1979    1 -> 1 */
     /* projections from the quadrature-point grid (initial conditions, Coriolis): x lives on the quad grid */
     MIMSEM_OP_WTQ = 16,      /* WtQmat::assemble  Assembly.cpp:707-751   quad scalar -> 2-form                        */
     MIMSEM_OP_PTQ = 17,      /* PtQmat::assemble  :766-808               quad scalar -> 0-form                        */
@@ -158,6 +161,11 @@ int mimsem_op_elmat_size(const mimsem_ctx* ctx, int op);
 int mimsem_op_element_matrices(mimsem_ctx* ctx, int op, int geom_lev, double scale, unsigned flags,
                                const double* f, double* out);
 
+/* Element blocks of the operators that take a second field (today: MIMSEM_OP_UMAT_RAY, f = exner_k, u = exner_s,
+ * tau = dt) -- what MatAXPY(M1->M, 1.0, M1ray->M) needs (eul/Euler_2.cpp:1448).                  */
+int mimsem_op_element_matrices_ex(mimsem_ctx* ctx, int op, int geom_lev, double scale, double tau, unsigned flags,
+                                  const double* f, const double* u, double* out);
+
 /* Pvec::assemble / Phvec::assemble (Assembly.cpp:602-689): lumped 0-form mass as a vector */
 int mimsem_pvec(mimsem_ctx* ctx, int geom_lev0, int nlev, double scale,
                 const double* h2, long long h_stride, double* y, long long y_stride);
@@ -173,7 +181,13 @@ enum mimsem_colop {
     MIMSEM_V_CONST_THETA = 4, MIMSEM_V_EOS_BLOCK = 5, MIMSEM_V_LINEAR = 6, MIMSEM_V_LINEAR_INV = 7,
     MIMSEM_V_LINEAR_RT = 8, MIMSEM_V_LINEAR_THETA = 9, MIMSEM_V_LINEAR_RHO2 = 10, MIMSEM_V_RAYLEIGH = 11,
     MIMSEM_V_LINCON = 12, MIMSEM_V_LINCON2 = 13, MIMSEM_V_CONLIN = 14, MIMSEM_V_CONLIN_W = 15,
-    MIMSEM_V_CONLIN_RHODPI = 16, MIMSEM_V_COUNT
+    MIMSEM_V_CONLIN_RHODPI = 16,
+    /* Strang / Held-Suarez rows, through the *_ex entry points (scalar parameter and/or horizontal velocity):          */
+    MIMSEM_V_LINEAR_RAYLEIGH_INV = 17, /* AssembleLinearWithRayleighInv(ex,ey,dt_fric,A) :1380-1413  param = dt_fric       */
+    MIMSEM_V_EOS_BLOCK_INV = 18,       /* Assemble_EOS_BlockInv(ex,ey,rt,theta,B)        :1049-1142  f1 = rt, f2 = theta|NULL */
+    MIMSEM_V_LINEAR_RHO2_UP = 19,      /* AssembleLinearWithRho2_up(ex,ey,rho,A,dt,uhl)  :1415-1490  f1 = rho, param = dt, uh  */
+    MIMSEM_V_LINCON2_UP = 20,          /* AssembleLinCon2_up(ex,ey,AB,dt,uhl)            :1492-1561  param = dt, uh           */
+    MIMSEM_V_COUNT
 };
 /* L2Vecs::HorizToVert (dir=0) / VertToHoriz (dir=1), eul/L2Vecs.cpp:55-101:
  * vh[k*h_stride + e*n2e + i] <-> vz[e*nkv*n2e + k*n2e + i], nkv levels (nk, nk-1 or nk+1)        */
@@ -213,6 +227,30 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
 /* the assembled block-tridiagonal L_pi itself: out [nEl][nk][3][n2e][n2e] (sub, diag, super)       */
 int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
         const double* theta, const double* rho, const double* eta, const double* pi, double* out);
+
+/* ---- Strang / Held-Suarez column rows --------------------------------------------------------- */
+/* mimsem_colop_blocks / mimsem_colop_apply with the extra arguments of the *_ex operators: param (dt_fric or dt)
+ * and uh = the horizontal velocity as local 1-forms, one row per level ([nk][uh_stride], the reference's Vec* uhl). */
+int mimsem_colop_blocks_ex(mimsem_ctx* ctx, int colop, unsigned flags, double param, const double* f1, const double* f2,
+                           const double* uh, long long uh_stride, double* out);
+int mimsem_colop_apply_ex(mimsem_ctx* ctx, int colop, unsigned flags, int transpose, double param,
+                          const double* f1, const double* f2, const double* uh, long long uh_stride,
+                          const double* x, double* y);
+/* VertSolve::diagTheta_up (eul/VertSolve.cpp:354-384) for every column: theta [nEl][(nk+1)*n2e]                */
+int mimsem_column_diag_theta_up(mimsem_ctx* ctx, double dt, const double* rho, const double* rt,
+                                const double* uh, long long uh_stride, double* theta);
+/* VertOps::AssembleTempForcing_HS (eul/VertOps.cpp:1563-1633): lat = latitude of the quadrature points
+ * [nEl][mp12] (Geom::s[elInds0_l][1]); theta on the nk+1 interfaces; out [nEl][nk*n2e]                          */
+int mimsem_column_temp_forcing_hs(mimsem_ctx* ctx, const double* lat, const double* exner, const double* theta,
+                                  const double* rho, double* out);
+/* VertSolve::solve_schur_column_3 (eul/VertSolve.cpp:504-675, RAYLEIGH friction on) for every column: the Schur
+ * complement L_rt_rt is block-PENTAdiagonal; it is assembled band by band, regrouped into 2x2 super-blocks and
+ * solved by the batched block-Thomas sweep.  theta on nk+1 interfaces, velz/F_u/d_u on nk-1, the rest on nk levels.
+ * F_* are updated in place as the reference does.  L_out (optional) [nEl][nk][5][n2e][n2e], block column = row-2+b. */
+int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt,
+        const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
+        double* F_u, double* F_rho, double* F_rt, double* F_pi,
+        double* d_u, double* d_rho, double* d_rt, double* d_pi, double* L_out);
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer

@@ -48,6 +48,7 @@ _SIGS = {
                                      c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_elmat_size": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_op_element_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_dp]),
+    "mimsem_op_element_matrices_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]),
     "mimsem_pvec": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_incidence_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
@@ -58,15 +59,21 @@ _SIGS = {
     "mimsem_column_diag_theta": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]),
     "mimsem_column_solve_schur_eta": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*12),
     "mimsem_column_helmholtz_blocks": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*5),
+    "mimsem_colop_blocks_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
+    "mimsem_colop_apply_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp, c_dp]),
+    "mimsem_column_diag_theta_up": (C.c_int, [C.c_void_p, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
+    "mimsem_column_temp_forcing_hs": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*14),
     "mimsem_halo_pack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_halo_unpack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
 }
 
 OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=7, UTMAT=8,
-           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18, UMAT_UP=19, UHMAT_UP=20, UVEC_HU_UP=21)
+           UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18, UMAT_UP=19, UHMAT_UP=20, UVEC_HU_UP=21, UMAT_RAY=22)
 COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4, EOS_BLOCK=5,
               LINEAR=6, LINEAR_INV=7, LINEAR_RT=8, LINEAR_THETA=9, LINEAR_RHO2=10, RAYLEIGH=11,
-              LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16)
+              LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16,
+              LINEAR_RAYLEIGH_INV=17, EOS_BLOCK_INV=18, LINEAR_RHO2_UP=19, LINCON2_UP=20)
 FLAG_VERT = 1
 FLAG_ACCUM = 2
 

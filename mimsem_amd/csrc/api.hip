@@ -123,7 +123,7 @@ int op_spaces(int op, int* in, int* cf, int* out) {
     case MIMSEM_OP_PHMAT_UP:  *in = 0; *cf = 2; *out = 0; return 0;
     case MIMSEM_OP_ROTMAT_UP: *in = 1; *cf = 0; *out = 1; return 0;
     case MIMSEM_OP_UMAT_UP:   *in = 1; *cf = 1; *out = 1; return 0;
-    case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP: *in = 1; *cf = 2; *out = 1; return 0;
+    case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP: case MIMSEM_OP_UMAT_RAY: *in = 1; *cf = 2; *out = 1; return 0;
     }
     return 1;
 }
@@ -364,13 +364,13 @@ int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale
 
 static bool is_up_op(int op) {
     return op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP || op == MIMSEM_OP_UMAT_UP || op == MIMSEM_OP_UHMAT_UP ||
-           op == MIMSEM_OP_UVEC_HU_UP;
+           op == MIMSEM_OP_UVEC_HU_UP || op == MIMSEM_OP_UMAT_RAY;
 }
 int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
                        const double* f, long long fs, const double* u, long long us,
                        const double* x, long long xs, double* y, long long ys, double alpha) {
     if (!is_up_op(op) || !u) return MIMSEM_ERR_ARG;
-    if (c && c->es.n > 6 && op >= MIMSEM_OP_UMAT_UP) return MIMSEM_ERR_UNSUPPORTED;    // LDS budget of the test-upwind kernels
+    if (c && c->es.n > 6 && op >= MIMSEM_OP_UMAT_UP && op <= MIMSEM_OP_UVEC_HU_UP) return MIMSEM_ERR_UNSUPPORTED;    // LDS budget of the test-upwind kernels
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, y, ys, alpha);
 }
 
@@ -419,7 +419,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         return rc;
     }
     a.fperm = nullptr; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0;
-    if (outsp == 1 && c->fused1 && op < MIMSEM_OP_UMAT_UP) {
+    if (outsp == 1 && c->fused1 && op < MIMSEM_OP_UMAT_UP && op != MIMSEM_OP_UMAT_RAY) {
         // fused path: group-local sums in LDS, complete slots written straight to y, perimeter partials to the workspace
         if ((rc = c->ensure_ye((long long)std::max(c->f_npart, 1)*nlev))) return rc;
         a.fperm = c->d_fperm; a.flid = c->d_flid; a.fslot = c->d_fslot; a.fcnt = c->d_fcnt;
@@ -447,7 +447,8 @@ int mimsem_op_elmat_size(const mimsem_ctx* c, int op) {
     if (!c) return MIMSEM_ERR_ARG;
     const ElemSizes& es = c->es;
     switch (op) {
-    case MIMSEM_OP_UMAT: case MIMSEM_OP_UHMAT: case MIMSEM_OP_UTMAT: case MIMSEM_OP_UTMAT_H: return 4*es.n1e*es.n1e;
+    case MIMSEM_OP_UMAT: case MIMSEM_OP_UHMAT: case MIMSEM_OP_UTMAT: case MIMSEM_OP_UTMAT_H: case MIMSEM_OP_UMAT_RAY:
+        return 4*es.n1e*es.n1e;
     case MIMSEM_OP_ROTMAT: return 2*es.n1e*es.n1e;
     case MIMSEM_OP_WMAT: case MIMSEM_OP_WHMAT: case MIMSEM_OP_WMATINV: case MIMSEM_OP_WHMATINV: return es.n2e*es.n2e;
     case MIMSEM_OP_PMAT: case MIMSEM_OP_PHMAT: return es.n0e*es.n0e;
@@ -456,9 +457,18 @@ int mimsem_op_elmat_size(const mimsem_ctx* c, int op) {
     return MIMSEM_ERR_ARG;
 }
 
+int mimsem_op_element_matrices_ex(mimsem_ctx* c, int op, int geom_lev, double scale, double tau, unsigned flags,
+                                  const double* f, const double* u, double* out) {
+    if (!c || !out || !f || !u) return MIMSEM_ERR_ARG;
+    if (op != MIMSEM_OP_UMAT_RAY) return MIMSEM_ERR_ARG;
+    if (geom_lev < 0 || geom_lev >= c->nk) return MIMSEM_ERR_ARG;
+    return launch_elmats(c, op, geom_lev, scale, flags, f, out, u, tau);
+}
+
 int mimsem_op_element_matrices(mimsem_ctx* c, int op, int geom_lev, double scale, unsigned flags,
                                const double* f, double* out) {
     if (!c || !out) return MIMSEM_ERR_ARG;
+    if (is_up_op(op)) return MIMSEM_ERR_ARG;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
     if (cf >= 0 && !f) return MIMSEM_ERR_ARG;

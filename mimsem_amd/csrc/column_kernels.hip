@@ -40,10 +40,12 @@ int each(mimsem_ctx* c, long long n, F f) {
 struct CG {
     int n, mp1, mp12, n2, nEl, nk;
     const double *det, *tI, *th, *E, *w;
+    double param;              // scalar argument of the operator (dt_fric of AssembleLinearWithRayleighInv)
 };
 CG make_cg(const mimsem_ctx* c) {
     CG g; g.n = c->es.n; g.mp1 = c->es.mp1; g.mp12 = c->es.mp12; g.n2 = c->es.n2e; g.nEl = c->nEl; g.nk = c->nk;
     g.det = c->d_det; g.tI = c->d_tI; g.th = c->d_th; g.E = c->d_E; g.w = c->d_w;
+    g.param = c->col_param;
     return g;
 }
 __device__ __forceinline__ double g_th(const CG& g, int e, int k, int q) { return g.th[((size_t)k*g.nEl + e)*g.mp12 + q]; }
@@ -63,12 +65,12 @@ void colop_shape(int colop, int nk, int* nr, int* nw, int* nx, int* ny) {
     *nw = 1;
     switch (colop) {
     case MIMSEM_V_CONST: case MIMSEM_V_CONST_INV: case MIMSEM_V_CONST_RHO: case MIMSEM_V_CONST_RHO_INV:
-    case MIMSEM_V_CONST_THETA: case MIMSEM_V_EOS_BLOCK: *nr = nk; *nx = nk; *ny = nk; break;
+    case MIMSEM_V_CONST_THETA: case MIMSEM_V_EOS_BLOCK: case MIMSEM_V_EOS_BLOCK_INV: *nr = nk; *nx = nk; *ny = nk; break;
     case MIMSEM_V_LINEAR: case MIMSEM_V_LINEAR_INV: case MIMSEM_V_LINEAR_RT: case MIMSEM_V_LINEAR_THETA:
-    case MIMSEM_V_RAYLEIGH: *nr = nk - 1; *nx = nk - 1; *ny = nk - 1; break;
-    case MIMSEM_V_LINEAR_RHO2: *nr = nk + 1; *nx = nk + 1; *ny = nk + 1; break;
+    case MIMSEM_V_RAYLEIGH: case MIMSEM_V_LINEAR_RAYLEIGH_INV: *nr = nk - 1; *nx = nk - 1; *ny = nk - 1; break;
+    case MIMSEM_V_LINEAR_RHO2: case MIMSEM_V_LINEAR_RHO2_UP: *nr = nk + 1; *nx = nk + 1; *ny = nk + 1; break;
     case MIMSEM_V_LINCON:  *nr = nk - 1; *nw = 2; *nx = nk; *ny = nk - 1; break;
-    case MIMSEM_V_LINCON2: *nr = nk + 1; *nw = 2; *nx = nk; *ny = nk + 1; break;
+    case MIMSEM_V_LINCON2: case MIMSEM_V_LINCON2_UP: *nr = nk + 1; *nw = 2; *nx = nk; *ny = nk + 1; break;
     default: /* CONLIN family */ *nr = nk; *nw = 2; *nx = nk - 1; *ny = nk; break;
     }
 }
@@ -96,6 +98,13 @@ __device__ double colop_coef(const CG& g, int colop, unsigned flags, int e, int 
         return q0*(0.5*g_th(g, e, r, q)) + q0*(0.5*g_th(g, e, r + 1, q));
     case MIMSEM_V_LINEAR_INV:                                    // :422-430
         return q0*(0.5*(g_th(g, e, r, q) + g_th(g, e, r + 1, q)));
+    case MIMSEM_V_LINEAR_RAYLEIGH_INV: {                         // :1391-1400 (the kk == nk-1 branch is unreachable there too)
+        double c = q0*(0.5*(g_th(g, e, r, q) + g_th(g, e, r + 1, q)));
+        if (r == nk - 1)      c *= (1.0 + 1.00*g.param);
+        else if (r == nk - 2) c *= (1.0 + 0.50*g.param);
+        else if (r == nk - 3) c *= (1.0 + 0.25*g.param);
+        return c;
+    }
     case MIMSEM_V_LINEAR_RT: {                                   // :621-662 ; flag = do_internal
         const bool internal = (flags & MIMSEM_FLAG_VERT) != 0;
         double acc = 0.0;
@@ -496,8 +505,11 @@ int flat_mm(mimsem_ctx* c, long long nb, int n, const double* A, const double* B
 }
 
 bool colop_is_inverse(int colop) {
-    return colop == MIMSEM_V_CONST_INV || colop == MIMSEM_V_CONST_RHO_INV || colop == MIMSEM_V_LINEAR_INV;
+    return colop == MIMSEM_V_CONST_INV || colop == MIMSEM_V_CONST_RHO_INV || colop == MIMSEM_V_LINEAR_INV ||
+           colop == MIMSEM_V_LINEAR_RAYLEIGH_INV;
 }
+
+int up_blocks_into(mimsem_ctx* c, int colop, const double* rho, double* M, double* tmpM);   // below (needs the velocity set in the ctx)
 
 // blocks of a column operator into M ([nEl][nr][nw][n2][n2]); cq scratch [nEl][nr][nw][mp12] (x2 for EOS)
 int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1, const double* f2,
@@ -520,6 +532,28 @@ int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1
         MIMSEM_HIP_TRY(hipMemcpyAsync(M, t2, (size_t)nb*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return MIMSEM_OK;
     }
+    if (colop == MIMSEM_V_EOS_BLOCK_INV) {    // (T B^-1 + I) B B(rt)^-1 B, inverted   VertOps.cpp:1066-1128 (f2 = theta, optional)
+        double *s0 = tmpM, *s1 = tmpM + nb*nn, *s2 = tmpM + 2*nb*nn, *s3 = tmpM + 3*nb*nn;
+        if ((rc = coef_block_pass(c, MIMSEM_V_CONST_RHO, 0, f1, nullptr, s0, nr, 1))) return rc;
+        if ((rc = mimsem_block_inverse_inplace(c, nb, n2, s0))) return rc;
+        if ((rc = coef_block_pass(c, MIMSEM_V_CONST, 0, nullptr, nullptr, s1, nr, 1))) return rc;
+        if ((rc = flat_mm(c, nb, n2, s0, s1, M))) return rc;                  // BinvB
+        if ((rc = flat_mm(c, nb, n2, s1, M, s2))) return rc;                  // B_BinvB
+        double* res = s2;
+        if (f2) {
+            MIMSEM_HIP_TRY(hipMemcpyAsync(s0, s1, (size_t)nb*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = mimsem_block_inverse_inplace(c, nb, n2, s0))) return rc;                       // B^-1
+            if ((rc = coef_block_pass(c, MIMSEM_V_CONST_THETA, 0, f2, nullptr, s3, nr, 1))) return rc;
+            if ((rc = flat_mm(c, nb, n2, s3, s0, M))) return rc;
+            if ((rc = each(c, nb*n2, [=] __device__(long long i) { M[(i/n2)*nn + (i%n2)*(n2 + 1)] += 1.0; }))) return rc;
+            if ((rc = flat_mm(c, nb, n2, M, s2, s0))) return rc;
+            res = s0;
+        }
+        MIMSEM_HIP_TRY(hipMemcpyAsync(M, res, (size_t)nb*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return mimsem_block_inverse_inplace(c, nb, n2, M);
+    }
+    if (colop == MIMSEM_V_LINEAR_RHO2_UP || colop == MIMSEM_V_LINCON2_UP)
+        return up_blocks_into(c, colop, f1, M, tmpM);
     if ((rc = coef_block_pass(c, colop, flags, f1, f2, M, nr, nw))) return rc;
     if (colop_is_inverse(colop)) return mimsem_block_inverse_inplace(c, nb, n2, M);
     return MIMSEM_OK;
@@ -539,7 +573,7 @@ int stored_apply(mimsem_ctx* c, int colop, int transpose, const double* M, const
     int nr, nw, nx, ny;
     colop_shape(colop, c->nk, &nr, &nw, &nx, &ny);
     const int n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
-    const int off = (colop == MIMSEM_V_LINCON) ? 0 : -1;
+    const int off = (colop == MIMSEM_V_LINCON) ? 0 : -1;        // LINCON2(_UP) and the CONLIN family: -1
     const int nyy = transpose ? nx : ny, nxx = transpose ? ny : nx;
     return each(c, (long long)nEl*nyy*n2, [=] __device__(long long i) {
         const int a = (int)(i%n2); long long t = i/n2;
@@ -1343,3 +1377,5 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
 }
 
 }  // extern "C"
+
+#include "column_hs.inc"

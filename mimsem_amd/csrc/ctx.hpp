@@ -68,6 +68,9 @@ struct mimsem_ctx {
     long long ye_doubles = 0;
     double* d_col = nullptr;    // column-solver workspace
     long long col_doubles = 0;
+    double col_param = 0.0;             // scalar argument of the *_ex column operators (dt_fric / dt)
+    const double* col_uh = nullptr;     // horizontal velocity [nk][n1] of the *_up column operators
+    long long col_uhs = 0;
     long long bytes = 0;
     int swz = 1;                   // MIMSEM_NOSWZ=1 disables the XCD-aware block order (tuning)
     int lch_override = 0;          // MIMSEM_LCH environment override (tuning)
@@ -108,7 +111,8 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys);
-int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out);
+int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out,
+                  const double* f2 = nullptr, double param = 0.0);
 int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys);
 int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf);
 int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);

@@ -35,7 +35,9 @@ template <int OP> struct OpTraits;
     template <> struct OpTraits<op> { static constexpr Space in = in_, cf = cf_, out = out_; \
         /* tup: test functions at departure points: 1 nodal factor via two local velocities, 2 via (x+u), 3 nodal+edge factors */ \
         static constexpr int tup = (op == MIMSEM_OP_UMAT_UP) ? 1 : (op == MIMSEM_OP_UVEC_HU_UP ? 2 : (op == MIMSEM_OP_UHMAT_UP ? 3 : 0)); \
-        static constexpr bool up = (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP) || tup != 0; }
+        static constexpr bool up = (op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP) || tup != 0; \
+        /* second coefficient field: the velocity of the upwinded operators, the surface Exner pressure of Umat_ray */ \
+        static constexpr Space cf2 = up ? S1 : (op == MIMSEM_OP_UMAT_RAY ? S2 : SN); }
 MIMSEM_TRAIT(MIMSEM_OP_UMAT,    S1, SN, S1);
 MIMSEM_TRAIT(MIMSEM_OP_WMAT,    S2, SN, S2);
 MIMSEM_TRAIT(MIMSEM_OP_UHMAT,   S1, S2, S1);
@@ -56,13 +58,26 @@ MIMSEM_TRAIT(MIMSEM_OP_UHMAT_UP,   S1, S2, S1);   // f = h2, second field u1
 MIMSEM_TRAIT(MIMSEM_OP_UVEC_HU_UP, S1, S2, S1);   // f = rho, second field vel2
 MIMSEM_TRAIT(MIMSEM_OP_PHMAT_UP,  S0, S2, S0);   // + velocity (1-form) as second field
 MIMSEM_TRAIT(MIMSEM_OP_ROTMAT_UP, S1, S0, S1);   // + velocity (1-form) as second field
+MIMSEM_TRAIT(MIMSEM_OP_UMAT_RAY,  S1, S2, S1);   // f = exner at the level, second field = exner at level 0 (both 2-forms)
 
 // ---- per-quadrature-point coefficient: the fused restatement of each assemble()'s Q?? loop --------
 // in : interpolated input (u,v for a 1-form, h for a 0/2-form in .u)
 // out: a,b = the two flux components to project (1-form out) or a = scalar to project (0/2-form out)
 struct QPoint {
     double J00, J01, J10, J11, det, Q, tI, th0, th1;
+    double tI0, param;          // Umat_ray: thickInv of level 0, dt
 };
+
+// Held-Suarez boundary-layer friction rate, compute_k_v eul/Assembly.cpp:1845-1856
+__device__ __forceinline__ double hs_k_v(double exner, double exner_s) {
+    const double p = pow(exner/1004.5, 1004.5/287.0);
+    const double ps = pow(exner_s/1004.5, 1004.5/287.0);
+    const double sigma = p/ps;
+    const double sigma_b = 0.7;
+    const double k_f = 1.1574074074074073e-05;
+    if (sigma < sigma_b) return 0.0;
+    return k_f*(sigma - sigma_b)/(1.0 - sigma_b);
+}
 
 template <int OP>
 __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigned flags,
@@ -72,9 +87,18 @@ __device__ __forceinline__ void qpoint_op(const QPoint& g, double scale, unsigne
     const double sd = scale/g.det;
     const bool vert = (flags & MIMSEM_FLAG_VERT) != 0;
     if constexpr (OP == MIMSEM_OP_UMAT || OP == MIMSEM_OP_UHMAT || OP == MIMSEM_OP_UTMAT || OP == MIMSEM_OP_UTMAT_H ||
-                  OP == MIMSEM_OP_UMAT_UP || OP == MIMSEM_OP_UHMAT_UP || OP == MIMSEM_OP_UVEC_HU_UP) {
+                  OP == MIMSEM_OP_UMAT_UP || OP == MIMSEM_OP_UHMAT_UP || OP == MIMSEM_OP_UVEC_HU_UP || OP == MIMSEM_OP_UMAT_RAY) {
         double caa, cab, cbb;
-        if constexpr (OP == MIMSEM_OP_UMAT_UP) {                    // Assembly.cpp:225-232 (thickness always applied)
+        if constexpr (OP == MIMSEM_OP_UMAT_RAY) {                    // Umat_ray::assemble Assembly.cpp:1913-1933 (fu = exner_k, fv = exner_s)
+            caa = (g.J00*g.J00 + g.J10*g.J10)*g.Q*sd;
+            cab = (g.J00*g.J01 + g.J10*g.J11)*g.Q*sd;
+            cbb = (g.J01*g.J01 + g.J11*g.J11)*g.Q*sd;
+            double ek = fu/g.det, es = fv/g.det;                     // interp2_g
+            ek *= g.tI; es *= g.tI0;
+            double k_v = hs_k_v(ek, es);
+            k_v *= g.param;
+            caa *= k_v*g.tI; cab *= k_v*g.tI; cbb *= k_v*g.tI;
+        } else if constexpr (OP == MIMSEM_OP_UMAT_UP) {                    // Assembly.cpp:225-232 (thickness always applied)
             caa = (g.J00*g.J00 + g.J10*g.J10)*g.Q*sd;
             cab = (g.J00*g.J01 + g.J10*g.J11)*g.Q*sd;
             cbb = (g.J01*g.J01 + g.J11*g.J11)*g.Q*sd;
@@ -271,7 +295,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     __shared__ double s_f[EPB][2*LPE];
     __shared__ double s_a[EPB][LPE];
     __shared__ double s_b[EPB][LPE];
-    __shared__ double s_g[T::up ? EPB : 1][2*LPE];     // velocity DoFs of the upwinded operators
+    __shared__ double s_g[T::cf2 != SN ? EPB : 1][2*LPE];     // second coefficient field (velocity of the upwinded operators)
     __shared__ double sXn[D::np1];
     constexpr int TUP = T::tup;
     __shared__ double s_lx[TUP ? EPB : 1][TUP ? D::mp12*D::np1 : 1], s_ly[TUP ? EPB : 1][TUP ? D::mp12*D::np1 : 1];
@@ -302,7 +326,9 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     // ---- level-invariant registers ----
     QPoint g;
     g.J00 = g.J01 = g.J10 = g.J11 = 0.0; g.det = 1.0; g.Q = 0.0; g.tI = 1.0; g.th0 = g.th1 = 1.0;
+    g.tI0 = 1.0; g.param = a.param;
     if (qact) {
+        if constexpr (OP == MIMSEM_OP_UMAT_RAY) g.tI0 = a.tI[(size_t)e*D::mp12 + q];
         const double* Je = a.J + (size_t)e*4*D::mp12;
         g.J00 = Je[0*D::mp12 + q]; g.J01 = Je[1*D::mp12 + q];
         g.J10 = Je[2*D::mp12 + q]; g.J11 = Je[3*D::mp12 + q];
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     dof_slots<N, T::in>(a, e, q, act, xs0, xs1);
     if constexpr (T::cf != SN) dof_slots<N, T::cf>(a, e, q, act, fs0, fs1);
     int us0 = -1, us1 = -1;
-    if constexpr (T::up) dof_slots<N, S1>(a, e, q, act, us0, us1);
+    if constexpr (T::cf2 != SN) dof_slots<N, T::cf2>(a, e, q, act, us0, us1);
     const size_t lstride = (size_t)a.nEl*D::mp12;
     const size_t gq = (size_t)e*D::mp12 + q;
     int fcnt = 0;
@@ -330,10 +356,10 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
             if (fs0 >= 0) nf0 = fv[fs0];
             if constexpr (T::cf == S1) { if (fs1 >= 0) nf1 = fv[fs1]; }
         }
-        if constexpr (T::up) {
+        if constexpr (T::cf2 != SN) {
             const double* uv = a.f2 + (size_t)lev*a.f2s;
             if (us0 >= 0) ng0 = uv[us0];
-            if (us1 >= 0) ng1 = uv[us1];
+            if constexpr (T::cf2 == S1) { if (us1 >= 0) ng1 = uv[us1]; }
         }
         if (qact) {
             const size_t gl = (size_t)(a.lev0 + lev)*lstride + gq;
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     for (int lev = lbeg; lev < lend; lev++) {
         dof_store<N, T::in>(nx0, nx1, xs0, xs1, q, s_x[el]);
         if constexpr (T::cf != SN) dof_store<N, T::cf>(nf0, nf1, fs0, fs1, q, s_f[el]);
-        if constexpr (T::up) dof_store<N, S1>(ng0, ng1, us0, us1, q, s_g[el]);
+        if constexpr (T::cf2 != SN) dof_store<N, T::cf2>(ng0, ng1, us0, us1, q, s_g[el]);
         g.tI = ntI; g.th0 = nth0; g.th1 = nth1;
         if (lev + 1 < lend) fetch(lev + 1);
         wave_lds_sync();
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
             double u, v, fu = 0.0, fv = 0.0;
             interp_point<N, T::in>(s_x[el], sE, q, qx, qy, u, v);
             if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f[el], sE, q, qx, qy, fu, fv);
+            if constexpr (OP == MIMSEM_OP_UMAT_RAY) { double dmy; interp_point<N, S2>(s_g[el], sE, q, qx, qy, fv, dmy); }
             if constexpr (TUP != 0) {
                 // test functions of this point evaluated at its departure point (rows B2 / B4 / B17)
                 double gu, gv, px, py;
@@ -554,6 +581,7 @@ struct ElmatArgs {
     const double *J, *det, *tI, *th, *E, *w, *U, *V, *W, *P;
     const int *i0, *i1x, *i1y, *i2;
     const double* f;
+    const double* f2; double param;     // Umat_ray: exner at level 0, dt
     double* out;
 };
 
@@ -564,12 +592,14 @@ __global__ __launch_bounds__(256) void k_elmats(ElmatArgs a) {
     __shared__ double sE[D::mp1*N];
     __shared__ double s_f[2*64];
     __shared__ double c0[64], c1[64], c2[64];      // per-point coefficients (aa/ab/bb or a/b)
+    __shared__ double s_g[64];
     const int e = blockIdx.x, tid = threadIdx.x, q = tid;
     const int qx = q%D::mp1, qy = q/D::mp1;
     if (tid < D::mp1*N) sE[tid] = a.E[tid];
     if constexpr (T::cf != SN) {
         ElemArgs ea{}; ea.i0 = a.i0; ea.i1x = a.i1x; ea.i1y = a.i1y; ea.i2 = a.i2;
         if (tid < 64) stage_dofs<N, T::cf>(ea, a.f, e, tid, s_f);
+        if constexpr (OP == MIMSEM_OP_UMAT_RAY) { if (tid < 64) stage_dofs<N, S2>(ea, a.f2, e, tid, s_g); }
     }
     __syncthreads();
     if (q < D::mp12) {
@@ -581,8 +611,10 @@ __global__ __launch_bounds__(256) void k_elmats(ElmatArgs a) {
         g.tI = a.tI[gl]; g.th0 = a.th[gl];
         g.th1 = (OP == MIMSEM_OP_UTMAT) ? a.th[gl + (size_t)a.nEl*D::mp12] : 1.0;
         g.Q = a.w[qx]*a.w[qy];
+        g.tI0 = a.tI[(size_t)e*D::mp12 + q]; g.param = a.param;
         double fu = 0.0, fv = 0.0;
         if constexpr (T::cf != SN) interp_point<N, T::cf>(s_f, sE, q, qx, qy, fu, fv);
+        if constexpr (OP == MIMSEM_OP_UMAT_RAY) { double dmy; interp_point<N, S2>(s_g, sE, q, qx, qy, fv, dmy); }
         // probe the coefficient functor with unit inputs to read the coefficients out
         double a10, b10, a01, b01;
         qpoint_op<OP>(g, a.scale, a.flags, 1.0, 0.0, fu, fv, a10, b10);
@@ -761,7 +793,7 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_PMAT) MIMSEM_CASE(MIMSEM_OP_PHMAT) MIMSEM_CASE(MIMSEM_OP_WTQUMAT)
         MIMSEM_CASE(MIMSEM_OP_ROTMAT) MIMSEM_CASE(MIMSEM_OP_WHMAT) MIMSEM_CASE(MIMSEM_OP_UTMAT)
         MIMSEM_CASE(MIMSEM_OP_UTMAT_H) MIMSEM_CASE(MIMSEM_OP_UTQWMAT) MIMSEM_CASE(MIMSEM_OP_WTQDUDZ)
-        MIMSEM_CASE(MIMSEM_OP_PHMAT_UP) MIMSEM_CASE(MIMSEM_OP_ROTMAT_UP)
+        MIMSEM_CASE(MIMSEM_OP_PHMAT_UP) MIMSEM_CASE(MIMSEM_OP_ROTMAT_UP) MIMSEM_CASE(MIMSEM_OP_UMAT_RAY)
         MIMSEM_CASE(MIMSEM_OP_WTQ) MIMSEM_CASE(MIMSEM_OP_PTQ) MIMSEM_CASE(MIMSEM_OP_UTQ)
         case MIMSEM_OP_UMAT_UP: case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP:
             if constexpr (N <= 6) { switch (op) { MIMSEM_CASE(MIMSEM_OP_UMAT_UP) MIMSEM_CASE(MIMSEM_OP_UHMAT_UP) MIMSEM_CASE(MIMSEM_OP_UVEC_HU_UP) } break; }
@@ -783,6 +815,7 @@ int dispatch_elmats(mimsem_ctx* c, int op, const ElmatArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_PMAT) MIMSEM_CASE(MIMSEM_OP_PHMAT) MIMSEM_CASE(MIMSEM_OP_WTQUMAT)
         MIMSEM_CASE(MIMSEM_OP_ROTMAT) MIMSEM_CASE(MIMSEM_OP_WHMAT) MIMSEM_CASE(MIMSEM_OP_UTMAT)
         MIMSEM_CASE(MIMSEM_OP_UTMAT_H) MIMSEM_CASE(MIMSEM_OP_UTQWMAT) MIMSEM_CASE(MIMSEM_OP_WTQDUDZ)
+        MIMSEM_CASE(MIMSEM_OP_UMAT_RAY)
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE
@@ -835,8 +868,10 @@ int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long 
     return MIMSEM_OK;
 }
 
-int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out) {
+int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out,
+                  const double* f2, double param) {
     ElmatArgs a;
+    a.f2 = f2; a.param = param;
     a.nEl = c->nEl; a.lev = lev; a.flags = flags; a.scale = scale;
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
     a.U = c->d_U; a.V = c->d_V; a.W = c->d_W; a.P = c->d_P;

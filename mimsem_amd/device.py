@@ -160,6 +160,18 @@ class Engine:
                                         _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply_up(%s)" % op)
         return y if x.dim() == 2 else y2[0]
 
+    def apply_ray(self, x, exner, exner_s, dt, lev0=0, scale=1.0, alpha=1.0, flags=0, out=None):
+        """Umat_ray (Held-Suarez friction): x [nlev, n1], exner [nlev, n2] (levels lev0..), exner_s [n2] = level 0."""
+        x2 = x if x.dim() == 2 else x.unsqueeze(0); f2 = exner if exner.dim() == 2 else exner.unsqueeze(0)
+        nlev = x2.shape[0]
+        assert x2.shape[1] == self.sizes[1] and f2.shape == (nlev, self.sizes[2]) and exner_s.shape == (self.sizes[2],)
+        y = out if out is not None else torch.empty(nlev, self.sizes[1], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        check(self.L.mimsem_op_apply_up(self.ctx, OPS["UMAT_RAY"], lev0, nlev, scale, dt, flags, _ptr(f2), f2.stride(0),
+                                        _ptr(exner_s), 0, _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha),
+              "mimsem_op_apply_up(UMAT_RAY)")
+        return y if x.dim() == 2 else y2[0]
+
     def prepare_apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
         """Validate once, return (call, y): `call()` re-issues the same mimsem_op_apply with pre-marshalled
         arguments (the buffers are fixed) -- the host-side fast path for time-step loops and bench.py."""
@@ -191,6 +203,13 @@ class Engine:
         out = torch.empty(self.nEl, esz, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_op_element_matrices(self.ctx, OPS[op], lev, scale, flags, _ptr(f), _ptr(out)),
               "mimsem_op_element_matrices(%s)" % op)
+        return out
+
+    def element_matrices_ray(self, exner, exner_s, dt, lev=0, scale=1.0):
+        esz = self.L.mimsem_op_elmat_size(self.ctx, OPS["UMAT_RAY"])
+        out = torch.empty(self.nEl, esz, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_op_element_matrices_ex(self.ctx, OPS["UMAT_RAY"], lev, scale, dt, 0, _ptr(exner), _ptr(exner_s), _ptr(out)),
+              "mimsem_op_element_matrices_ex(UMAT_RAY)")
         return out
 
     def pvec(self, lev0=0, nlev=1, scale=1.0, h2=None):
@@ -231,6 +250,41 @@ class Engine:
         check(self.L.mimsem_colop_apply(self.ctx, COLOPS[colop], flags, int(transpose), _ptr(f1), _ptr(f2), _ptr(x), _ptr(y)),
               "colop_apply(%s)" % colop)
         return y
+
+    def colop_blocks_ex(self, colop, param=0.0, f1=None, f2=None, uh=None, flags=0):
+        """the Strang / Held-Suarez colops: param = dt_fric or dt, uh = [nk, n1] horizontal velocity (local 1-forms)"""
+        nb = self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])
+        out = torch.empty(self.nEl, nb, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_colop_blocks_ex(self.ctx, COLOPS[colop], flags, param, _ptr(f1), _ptr(f2), _ptr(uh),
+                                            uh.stride(0) if uh is not None else 0, _ptr(out)), "colop_blocks_ex(%s)" % colop)
+        return out
+
+    def colop_apply_ex(self, colop, x, nout_slots, param=0.0, f1=None, f2=None, uh=None, flags=0, transpose=False):
+        y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_colop_apply_ex(self.ctx, COLOPS[colop], flags, int(transpose), param, _ptr(f1), _ptr(f2), _ptr(uh),
+                                           uh.stride(0) if uh is not None else 0, _ptr(x), _ptr(y)), "colop_apply_ex(%s)" % colop)
+        return y
+
+    def diag_theta_up(self, dt, rho, rt, uh):
+        th = torch.empty(self.nEl, (self.nk + 1) * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_diag_theta_up(self.ctx, dt, _ptr(rho), _ptr(rt), _ptr(uh), uh.stride(0), _ptr(th)), "diag_theta_up")
+        return th
+
+    def temp_forcing_hs(self, lat, exner, theta, rho):
+        out = torch.empty(self.nEl, self.nk * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_temp_forcing_hs(self.ctx, _ptr(lat), _ptr(exner), _ptr(theta), _ptr(rho), _ptr(out)), "temp_forcing_hs")
+        return out
+
+    def solve_schur_3(self, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi, want_L=False):
+        """solve_schur_column_3 for every column; F_* updated in place; returns d_u, d_rho, d_rt, d_pi (, L [nEl,nk,5,n2e,n2e])"""
+        N, Nm = self.nk * self.n2e, (self.nk - 1) * self.n2e
+        mk = lambda n: torch.empty(self.nEl, n, dtype=torch.float64, device=self.device)
+        d_u, d_rho, d_rt, d_pi = mk(Nm), mk(N), mk(N), mk(N)
+        L = torch.empty(self.nEl, self.nk, 5, self.n2e, self.n2e, dtype=torch.float64, device=self.device) if want_L else None
+        check(self.L.mimsem_column_solve_schur_3(self.ctx, dt, _ptr(theta), _ptr(velz), _ptr(rho), _ptr(rt), _ptr(pi),
+                                                 _ptr(F_u), _ptr(F_rho), _ptr(F_rt), _ptr(F_pi),
+                                                 _ptr(d_u), _ptr(d_rho), _ptr(d_rt), _ptr(d_pi), _ptr(L)), "solve_schur_3")
+        return (d_u, d_rho, d_rt, d_pi, L) if want_L else (d_u, d_rho, d_rt, d_pi)
 
     def column_eos(self, which, a, b=None, p0=0.0, p1=0.0):
         out = torch.empty(self.nEl, self.nk * self.n2e, dtype=torch.float64, device=self.device)

@@ -665,3 +665,50 @@ void orc_uvec_hu_up(const orc_patch* p, int lev, double scale, const double* vel
     }
     free(MUt); free(MVt);
 }
+
+/* compute_k_v  eul/Assembly.cpp:1845-1856 */
+static double hs_k_v(double exner, double exner_s) {
+    double p = pow(exner/1004.5, 1004.5/287.0);
+    double ps = pow(exner_s/1004.5, 1004.5/287.0);
+    double sigma = p/ps;
+    double sigma_b = 0.7;
+    double k_f = 1.1574074074074073e-05;
+    if (sigma < sigma_b) return 0.0;
+    return k_f*(sigma - sigma_b)/(1.0 - sigma_b);
+}
+
+/* B16 Umat_ray::assemble(lev, scale, dt, exner_k, exner_s)  eul/Assembly.cpp:1876-1979 ; out like ORC_UMAT */
+int orc_umat_ray_elmats(const orc_patch* p, int lev, double scale, double dt, const double* exner_k,
+                        const double* exner_s, double* out) {
+    int ex, ey, ei, ii, mp1 = p->mp1, mp12 = p->mp12, n1e = p->n1e, iq[128];
+    double *ca = (double*)malloc(sizeof(double)*mp12), *cb = (double*)malloc(sizeof(double)*mp12), *cc = (double*)malloc(sizeof(double)*mp12);
+    double* tmp = (double*)malloc(sizeof(double)*128*mp12);
+    double _e, _es, k_v;
+    const double* tI = p->thickInv + (size_t)lev*p->n0q;
+    const double* tI0 = p->thickInv;
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        double* M = out + (size_t)(ey*p->nElsX + ex)*4*n1e*n1e;
+        ei = ey*p->nElsX + ex;
+        orc_elindsq_l(p, ex, ey, iq);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+            ca[ii] = (J00*J00 + J10*J10)*p->Q[ii]*(scale/det);
+            cb[ii] = (J00*J01 + J10*J11)*p->Q[ii]*(scale/det);
+            cc[ii] = (J01*J01 + J11*J11)*p->Q[ii]*(scale/det);
+            orc_interp2_g(p, ex, ey, ii%mp1, ii/mp1, exner_k, &_e);
+            orc_interp2_g(p, ex, ey, ii%mp1, ii/mp1, exner_s, &_es);
+            _e *= tI[iq[ii]];
+            _es *= tI0[iq[ii]];
+            k_v = hs_k_v(_e, _es);
+            k_v *= dt;
+            ca[ii] *= k_v*tI[iq[ii]]; cb[ii] *= k_v*tI[iq[ii]]; cc[ii] *= k_v*tI[iq[ii]];
+        }
+        triple(p, n1e, n1e, p->Ut, ca, p->U, tmp, M + 0*n1e*n1e);
+        triple(p, n1e, n1e, p->Ut, cb, p->V, tmp, M + 1*n1e*n1e);
+        triple(p, n1e, n1e, p->Vt, cb, p->U, tmp, M + 2*n1e*n1e);
+        triple(p, n1e, n1e, p->Vt, cc, p->V, tmp, M + 3*n1e*n1e);
+    }
+    free(ca); free(cb); free(cc); free(tmp);
+    return 0;
+}

@@ -476,3 +476,286 @@ int orc_solve_schur_column_eta(const orc_patch* p, int ex, int ey, double dt,
     free(GV); free(L_eta); free(CM); free(DIV); free(L_pi); free(tA1); free(tA2); free(tB1);
     return err;
 }
+
+/* ==== Held-Suarez / Strang-splitting column rows (C2-C6 remainder) ========================= */
+
+/* AssembleLinearWithRayleighInv :1380-1413 (which ORC_V_LINEAR_RAYLEIGH_INV, param = dt_fric),
+ * Assemble_EOS_BlockInv :1049-1142 (ORC_V_EOS_BLOCK_INV, f1 = rt, f2 = theta or NULL),
+ * AssembleLinearWithRho2_up :1415-1490 (ORC_V_LINEAR_RHO2_UP, f1 = rho, param = dt, uh = [nk][n1] local 1-forms),
+ * AssembleLinCon2_up :1492-1561 (ORC_V_LINCON2_UP, param = dt, uh). */
+int orc_colop_dims_ex(const orc_patch* p, int colop, int* rows, int* cols) {
+    int nk = p->nk, n2 = p->n2e;
+    switch (colop) {
+    case ORC_V_LINEAR_RAYLEIGH_INV: *rows = (nk-1)*n2; *cols = (nk-1)*n2; return 0;
+    case ORC_V_EOS_BLOCK_INV: *rows = nk*n2; *cols = nk*n2; return 0;
+    case ORC_V_LINEAR_RHO2_UP: *rows = (nk+1)*n2; *cols = (nk+1)*n2; return 0;
+    case ORC_V_LINCON2_UP: *rows = (nk+1)*n2; *cols = nk*n2; return 0;
+    }
+    return orc_colop_dims(p, colop, rows, cols);
+}
+
+int orc_colop_dense_ex(const orc_patch* p, int colop, int ex, int ey, int flag, double param,
+                       const double* f1, const double* f2, const double* uh, double* out) {
+    int rows, cols, kk, ii, jj, nk = p->nk, mp1 = p->mp1, mp12 = p->mp12, n2 = p->n2e, nn = p->n, ei = ey*p->nElsX + ex;
+    int iq[128];
+    double Q0[128];
+    double *tmp, *blk, *binv, *BinvB, *B_BinvB, *Wt;
+    const double* det = p->det + (size_t)ei*mp12;
+    if (colop < ORC_V_LINEAR_RAYLEIGH_INV) return orc_colop_dense(p, colop, ex, ey, flag, f1, f2, out);
+    if (orc_colop_dims_ex(p, colop, &rows, &cols)) return 1;
+    tmp = (double*)malloc(sizeof(double)*n2*mp12); blk = (double*)malloc(sizeof(double)*n2*n2);
+    binv = (double*)malloc(sizeof(double)*n2*n2); BinvB = (double*)malloc(sizeof(double)*n2*n2);
+    B_BinvB = (double*)malloc(sizeof(double)*n2*n2); Wt = (double*)malloc(sizeof(double)*n2*mp12);
+    memset(out, 0, sizeof(double)*(size_t)rows*cols);
+    orc_elindsq_l(p, ex, ey, iq);
+
+    if (colop == ORC_V_LINEAR_RAYLEIGH_INV) {
+        for (kk = 0; kk < nk-1; kk++) {
+            for (ii = 0; ii < mp12; ii++) {
+                Q0[ii]  = p->Q[ii]*(SCALE/det[ii]);
+                Q0[ii] *= 0.5*(TH(kk+0, ii) + TH(kk+1, ii));
+                if (kk == nk-1)      Q0[ii] *= (1.0 + 1.00*param);
+                else if (kk == nk-2) Q0[ii] *= (1.0 + 0.50*param);
+                else if (kk == nk-3) Q0[ii] *= (1.0 + 0.25*param);
+            }
+            wqw(p, Q0, tmp, blk);
+            orc_la->inv(blk, binv, n2);
+            put(p, out, cols, kk, kk, binv, 1);
+        }
+    } else if (colop == ORC_V_EOS_BLOCK_INV) {
+        for (kk = 0; kk < nk; kk++) {
+            double tk, tkp1;
+            for (ii = 0; ii < mp12; ii++) {                       /* the layer-wise inverse matrix :1071-1085 */
+                Q0[ii] = p->Q[ii]*(SCALE/det[ii]);
+                Q0[ii] *= THI(kk, ii);
+                tk = w_interp(p, f1, kk, ii);
+                Q0[ii] *= tk/(TH(kk, ii)*det[ii]);
+            }
+            wqw(p, Q0, tmp, blk);
+            orc_la->inv(blk, binv, n2);
+            for (ii = 0; ii < mp12; ii++) { Q0[ii] = p->Q[ii]*(SCALE/det[ii]); Q0[ii] *= THI(kk, ii); }   /* :1088-1094 */
+            wqw(p, Q0, tmp, blk);
+            orc_la->mult(n2, n2, n2, binv, blk, BinvB);           /* :1097-1098 */
+            orc_la->mult(n2, n2, n2, blk, BinvB, B_BinvB);
+            if (f2) {                                             /* rho correction :1101-1126 */
+                orc_la->inv(blk, binv, n2);
+                for (ii = 0; ii < mp12; ii++) {
+                    Q0[ii]  = p->Q[ii]*(SCALE/det[ii]);
+                    Q0[ii] *= THI(kk, ii);
+                    tk = w_interp(p, f2, kk, ii); tkp1 = w_interp(p, f2, kk+1, ii);
+                    Q0[ii] *= 0.5*(tk + tkp1)/det[ii];
+                }
+                wqw(p, Q0, tmp, blk);
+                orc_la->mult(n2, n2, n2, blk, binv, BinvB);
+                for (ii = 0; ii < n2; ii++) BinvB[ii*n2+ii] += 1.0;
+                orc_la->mult(n2, n2, n2, BinvB, B_BinvB, blk);
+                for (ii = 0; ii < n2*n2; ii++) B_BinvB[ii] = blk[ii];
+            }
+            orc_la->inv(B_BinvB, binv, n2);                       /* :1128 */
+            put(p, out, cols, kk, kk, binv, 1);
+        }
+    } else {   /* the two *_up assemblies: test functions at x_q + dt * (local velocity) */
+        for (kk = 0; kk < nk; kk++) {
+            const double* uArray = uh + (size_t)kk*p->n1;
+            for (ii = 0; ii < mp12; ii++) {
+                const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+                double ug[2], ul[2], _ex[16], _ey[16];
+                Q0[ii] = p->Q[ii]*(SCALE/det[ii]);
+                if (colop == ORC_V_LINEAR_RHO2_UP) {
+                    double rk = w_interp(p, f1, kk, ii);
+                    Q0[ii] *= 0.5*rk/det[ii];
+                } else Q0[ii] *= 0.5;
+                orc_interp1_g(p, ex, ey, ii%mp1, ii/mp1, uArray, ug);
+                ul[0] = (+jac[3]*ug[0] - jac[1]*ug[1])/det[ii];
+                ul[1] = (-jac[2]*ug[0] + jac[0]*ug[1])/det[ii];
+                ul[0] *= THI(kk, ii);
+                ul[1] *= THI(kk, ii);
+                for (jj = 0; jj < nn; jj++) {
+                    _ex[jj] = orc_edge_eval(nn, p->nx, p->qx[ii%mp1] + param*ul[0], jj);
+                    _ey[jj] = orc_edge_eval(nn, p->nx, p->qx[ii/mp1] + param*ul[1], jj);
+                }
+                for (jj = 0; jj < n2; jj++) Wt[jj*mp12+ii] = _ex[jj%nn]*_ey[jj/nn];
+            }
+            orc_la->mult_fd(n2, mp12, mp12, Wt, Q0, tmp);
+            orc_la->mult(n2, n2, mp12, tmp, p->W, blk);
+            if (colop == ORC_V_LINEAR_RHO2_UP) {
+                put(p, out, cols, kk, kk, blk, 1);
+                put(p, out, cols, kk+1, kk+1, blk, 1);
+            } else {
+                put(p, out, cols, kk, kk, blk, 1);
+                put(p, out, cols, kk+1, kk, blk, 1);
+            }
+        }
+    }
+    free(tmp); free(blk); free(binv); free(BinvB); free(B_BinvB); free(Wt);
+    return 0;
+}
+
+/* diagTheta_up eul/VertSolve.cpp:354-384 for one column */
+int orc_diag_theta_up(const orc_patch* p, int ex, int ey, double dt, const double* rho, const double* rt,
+                      const double* uh, double* theta) {
+    int N = p->nk*p->n2e, Np = (p->nk+1)*p->n2e, err;
+    double *VAB2 = dmat(Np, N), *VA2 = dmat(Np, Np), *frt = dmat(Np, 1);
+    orc_colop_dense_ex(p, ORC_V_LINCON2_UP, ex, ey, 0, dt, NULL, NULL, uh, VAB2);
+    mv(Np, N, VAB2, rt, frt);
+    orc_colop_dense_ex(p, ORC_V_LINEAR_RHO2_UP, ex, ey, 0, dt, rho, NULL, uh, VA2);
+    err = orc_dense_solve(Np, VA2, frt, theta);
+    free(VAB2); free(VA2); free(frt);
+    return err;
+}
+
+/* compute_k_T eul/VertOps.cpp:1563-1587 */
+static double hs_k_T(double phi, double exner, double exner_s, double theta) {
+    double pr       = pow(exner/CP, CP/RD);
+    double ps       = pow(exner_s/CP, CP/RD);
+    double sigma    = pr/ps;
+    double sigma_b  = 0.7;
+    double theta_eq;
+    double k_a      = 2.8935185185185185e-07;
+    double k_s      = 2.8935185185185184e-06;
+    double k_t      = 0.0;
+    double t_eq     = 315.0 - 60.0*sin(phi)*sin(phi) - 10.0*log(pr)*cos(phi)*cos(phi);
+    t_eq *= pow(pr, RD/CP);
+    if (t_eq < 200.0) t_eq = 200.0;
+    theta_eq = t_eq*pow(1.0/pr, RD/CP);
+    if (sigma > sigma_b) {
+        k_t  = (k_s - k_a)*(sigma - sigma_b)/(1.0 - sigma_b);
+        k_t *= pow(cos(phi), 4.0);
+    }
+    k_t += k_a;
+    return k_t*(theta - theta_eq);
+}
+
+/* AssembleTempForcing_HS :1589-1633 ; theta on nk+1 interfaces */
+void orc_temp_forcing_hs(const orc_patch* p, int ex, int ey, const double* exner, const double* theta,
+                         const double* rho, double* vec) {
+    int kk, ii, jj, ll, ei = ey*p->nElsX + ex, mp12 = p->mp12, n2 = p->n2e, iq[128];
+    double _e[128], _r[128], _tb[128], _tt[128], _es[128], k_t[128];
+    const double* det = p->det + (size_t)ei*mp12;
+    orc_elindsq_l(p, ex, ey, iq);
+    memset(vec, 0, sizeof(double)*p->nk*n2);
+    for (kk = 0; kk < p->nk; kk++) {
+        for (ii = 0; ii < mp12; ii++) {
+            _e[ii] = _tb[ii] = _tt[ii] = _r[ii] = _es[ii] = 0.0;
+            for (ll = 0; ll < n2; ll++) {
+                _e[ii]  += exner[kk*n2+ll]*p->W[ii*n2+ll];
+                _tb[ii] += theta[(kk+0)*n2+ll]*p->W[ii*n2+ll];
+                _tt[ii] += theta[(kk+1)*n2+ll]*p->W[ii*n2+ll];
+                _r[ii]  += rho[kk*n2+ll]*p->W[ii*n2+ll];
+                _es[ii] += exner[ll]*p->W[ii*n2+ll];
+            }
+            _e[ii]  /= (det[ii]*TH(kk, ii));
+            _tb[ii] /= (det[ii]);
+            _tt[ii] /= (det[ii]);
+            _r[ii]  /= (det[ii]*TH(kk, ii));
+            _es[ii] /= (det[ii]*TH(0, ii));
+            k_t[ii] = hs_k_T(p->sq[2*iq[ii]+1], _e[ii], _es[ii], 0.5*(_tb[ii] + _tt[ii]));
+        }
+        for (jj = 0; jj < n2; jj++)
+            for (ii = 0; ii < mp12; ii++)
+                vec[kk*n2+jj] += p->Wt[jj*mp12+ii]*p->Q[ii]*SCALE*_r[ii]*k_t[ii];
+    }
+}
+
+/* VertSolve::solve_schur_column_3 eul/VertSolve.cpp:504-675 (RAYLEIGH defined, :32), dense restatement.
+ * F_* modified in place as the reference does; d_* outputs; Lrt_out (N x N) optional. */
+#define RAYLEIGH (4.0/120.0)
+int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
+        const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
+        double* F_u, double* F_rho, double* F_rt, double* F_pi,
+        double* d_u, double* d_rho, double* d_rt, double* d_pi, double* Lrt_out) {
+    int nk = p->nk, n2 = p->n2e, N = nk*n2, Nm = (nk-1)*n2, i, j, k, err;
+    double *M_u_inv = dmat(Nm, Nm), *M_rho_inv = dmat(N, N), *M_rt = dmat(N, N), *N_pi_inv = dmat(N, N);
+    double *VB = dmat(N, N), *VA_inv = dmat(Nm, Nm), *VB_inv = dmat(N, N), *VA = dmat(Nm, Nm), *VBA = dmat(N, Nm), *VAB = dmat(Nm, N);
+    double *V10 = dmat(N, Nm), *V01 = dmat(Nm, N);
+    double *t_mn = dmat(Nm, N), *t_mn2 = dmat(Nm, N), *t_mm = dmat(Nm, Nm), *t_nm = dmat(N, Nm), *t_nn = dmat(N, N), *t_nn2 = dmat(N, N);
+    double *G_rt = dmat(Nm, N), *G_pi = dmat(Nm, N), *D_rho = dmat(N, Nm), *D_rt = dmat(N, Nm), *N_rt = dmat(N, N);
+    double *Q_rt_rho = dmat(N, N), *QM = dmat(N, N), *GN = dmat(Nm, N), *GG = dmat(Nm, N), *DD = dmat(N, Nm), *DDM = dmat(N, Nm);
+    double *L = dmat(N, N);
+    double *tA1 = dmat(Nm, 1), *tA2 = dmat(Nm, 1), *tB1 = dmat(N, 1);
+
+    for (k = 0; k < nk; k++) for (i = 0; i < n2; i++) {
+        if (k > 0)    V10[(size_t)(k*n2+i)*Nm + (k-1)*n2 + i] = -1.0;
+        if (k < nk-1) V10[(size_t)(k*n2+i)*Nm + k*n2 + i] = +1.0;
+    }
+    for (i = 0; i < N; i++) for (j = 0; j < Nm; j++) V01[(size_t)j*N + i] = -V10[(size_t)i*Nm + j];
+
+    orc_colop_dense_ex(p, ORC_V_LINEAR_RAYLEIGH_INV, ex, ey, 0, 0.5*dt*RAYLEIGH, NULL, NULL, NULL, M_u_inv);  /* :520 */
+    orc_colop_dense(p, ORC_V_CONST, ex, ey, 0, NULL, NULL, M_rt);                 /* :524 */
+    orc_colop_dense(p, ORC_V_CONST_INV, ex, ey, 0, NULL, NULL, M_rho_inv);        /* :525 */
+    orc_colop_dense_ex(p, ORC_V_EOS_BLOCK_INV, ex, ey, 0, 0.0, pi, NULL, NULL, N_pi_inv);   /* :526 */
+    orc_colop_dense(p, ORC_V_CONST, ex, ey, 0, NULL, NULL, VB);                   /* :527 */
+    mv(N, N, VB, pi, tB1);                                                        /* :528 */
+    mv(Nm, N, V01, tB1, tA1);                                                     /* :529 */
+    orc_colop_dense(p, ORC_V_LINEAR_INV, ex, ey, 0, NULL, NULL, VA_inv);          /* :530 */
+    mv(Nm, Nm, VA_inv, tA1, tA2);                                                 /* :531 pressure gradient */
+    orc_colop_dense(p, ORC_V_CONLIN_W, ex, ey, 0, tA2, NULL, VBA);                /* :532 */
+    for (i = 0; i < N; i++) for (j = 0; j < Nm; j++) VAB[(size_t)j*N + i] = VBA[(size_t)i*Nm + j];   /* :533 */
+    orc_colop_dense(p, ORC_V_CONST_RHO_INV, ex, ey, 0, rho, NULL, VB_inv);        /* :536 */
+    mm(Nm, N, N, VAB, VB_inv, t_mn);                                              /* :537 */
+    mm(Nm, N, N, t_mn, VB, G_rt);                                                 /* :540 */
+    for (i = 0; i < Nm*N; i++) G_rt[i] *= 0.5*dt;                                 /* :541 */
+
+    mm(Nm, N, N, V01, VB, t_mn);                                                  /* :546 pc_DTV1 */
+    mm(Nm, Nm, N, VA_inv, t_mn, t_mn2);                                           /* :550 */
+    orc_colop_dense(p, ORC_V_LINEAR_THETA, ex, ey, 0, theta, NULL, VA);           /* :553 */
+    mm(Nm, Nm, N, VA, t_mn2, G_pi);                                               /* :554 */
+    for (i = 0; i < Nm*N; i++) G_pi[i] *= 0.5*dt;                                 /* :555 */
+
+    orc_colop_dense(p, ORC_V_LINEAR_RT, ex, ey, 1, rho, NULL, VA);                /* :559 */
+    mm(Nm, Nm, Nm, VA_inv, VA, t_mm);                                             /* :561 */
+    mm(N, Nm, Nm, V10, t_mm, t_nm);                                               /* :564 */
+    mm(N, N, Nm, VB, t_nm, D_rho);                                                /* :568 */
+    for (i = 0; i < N*Nm; i++) D_rho[i] *= 0.5*dt;                                /* :569 */
+
+    orc_colop_dense(p, ORC_V_CONST_RHO, ex, ey, 0, rt, NULL, t_nn);               /* :573 */
+    mm(N, N, Nm, t_nn, V10, D_rt);                                                /* :574 */
+    for (i = 0; i < N*Nm; i++) D_rt[i] *= 0.5*dt;                                 /* :575 */
+
+    orc_colop_dense(p, ORC_V_CONST_RHO_INV, ex, ey, 0, rt, NULL, VB_inv);         /* :580 */
+    mm(N, N, N, VB_inv, VB, t_nn);                                                /* :581 */
+    mm(N, N, N, VB, t_nn, N_rt);                                                  /* :584 */
+    for (i = 0; i < N*N; i++) N_rt[i] *= -1.0*RD/CV;                              /* :585 */
+
+    orc_colop_dense(p, ORC_V_CONST_THETA, ex, ey, 0, theta, NULL, t_nn);          /* :589 */
+    mm(Nm, N, N, V01, t_nn, t_mn);                                                /* :590 */
+    mm(Nm, Nm, N, VA_inv, t_mn, t_mn2);                                           /* :594 */
+    orc_colop_dense(p, ORC_V_CONLIN_W, ex, ey, 0, velz, NULL, VBA);               /* :597 */
+    mm(N, Nm, N, VBA, t_mn2, Q_rt_rho);                                           /* :598 */
+    for (i = 0; i < N*N; i++) Q_rt_rho[i] *= 0.5*dt;                              /* :599 */
+
+    mm(N, N, N, Q_rt_rho, M_rho_inv, QM);                                         /* :603 */
+    mm(Nm, N, N, G_pi, N_pi_inv, GN);                                             /* :607 */
+    mm(Nm, N, N, GN, N_rt, GG);                                                   /* :611 */
+    for (i = 0; i < Nm*N; i++) GG[i] = -1.0*GG[i] + G_rt[i];                      /* :612 MatAYPX */
+
+    mm(N, N, Nm, QM, D_rho, DD);                                                  /* :618 */
+    for (i = 0; i < N*Nm; i++) DD[i] = -1.0*DD[i] + D_rt[i];                      /* :619 */
+    mm(N, Nm, Nm, DD, M_u_inv, DDM);                                              /* :622 */
+    mm(N, Nm, N, DDM, GG, L);                                                     /* :626 */
+    for (i = 0; i < N*N; i++) L[i] = -1.0*L[i] + M_rt[i];                         /* :627 */
+    if (Lrt_out) memcpy(Lrt_out, L, sizeof(double)*(size_t)N*N);
+
+    mv(N, N, QM, F_rho, tB1);  for (i = 0; i < N; i++) F_rt[i] += -1.0*tB1[i];    /* :632-633 */
+    mv(Nm, N, GN, F_pi, tA1);  for (i = 0; i < Nm; i++) F_u[i] += -1.0*tA1[i];    /* :635-636 */
+    mv(N, Nm, DDM, F_u, tB1);  for (i = 0; i < N; i++) F_rt[i] += -1.0*tB1[i];    /* :638-639 */
+
+    for (i = 0; i < N; i++) F_rt[i] *= -1.0;                                      /* :652 */
+    err = orc_dense_solve(N, L, F_rt, d_rt);                                      /* :653 PCLU */
+
+    mv(Nm, N, GG, d_rt, tA1);                                                     /* :656 */
+    for (i = 0; i < Nm; i++) { F_u[i] += tA1[i]; F_u[i] *= -1.0; }                /* :657-658 */
+    mv(Nm, Nm, M_u_inv, F_u, d_u);                                                /* :659 */
+    mv(N, N, N_rt, d_rt, tB1);                                                    /* :661 */
+    for (i = 0; i < N; i++) { F_pi[i] += tB1[i]; F_pi[i] *= -1.0; }               /* :662-663 */
+    mv(N, N, N_pi_inv, F_pi, d_pi);                                               /* :664 */
+    mv(N, Nm, D_rho, d_u, tB1);                                                   /* :666 */
+    for (i = 0; i < N; i++) { F_rho[i] += tB1[i]; F_rho[i] *= -1.0; }             /* :667-668 */
+    mv(N, N, M_rho_inv, F_rho, d_rho);                                            /* :669 */
+
+    free(M_u_inv); free(M_rho_inv); free(M_rt); free(N_pi_inv); free(VB); free(VA_inv); free(VB_inv); free(VA);
+    free(VBA); free(VAB); free(V10); free(V01); free(t_mn); free(t_mn2); free(t_mm); free(t_nm); free(t_nn); free(t_nn2);
+    free(G_rt); free(G_pi); free(D_rho); free(D_rt); free(N_rt); free(Q_rt_rho); free(QM); free(GN); free(GG);
+    free(DD); free(DDM); free(L); free(tA1); free(tA2); free(tB1);
+    return err;
+}

@@ -143,6 +143,10 @@ int orc_op_elmats_testup(const orc_patch* p, int which, int lev, double scale, d
 void orc_uvec_hu_up(const orc_patch* p, int lev, double scale, const double* vel, const double* rho, double fac,
                     double tau, const double* vel2, double* vl);
 
+/* B16 Umat_ray::assemble(lev,scale,dt,exner_k,exner_s) :1876-1979 (Held-Suarez friction); out like ORC_UMAT */
+int orc_umat_ray_elmats(const orc_patch* p, int lev, double scale, double dt, const double* exner_k,
+                        const double* exner_s, double* out);
+
 /* matrix-free vectors, eul/Assembly.cpp */
 void orc_pvec(const orc_patch* p, int lev, double scale, double* vl);                       /* B5 Pvec  :602-632 (local part) */
 void orc_phvec(const orc_patch* p, int lev, double scale, const double* h2, double* vl);    /* B5 Phvec :654-689 */
@@ -187,6 +191,10 @@ enum orc_colop {
     ORC_V_CONLIN = 14,        /* C4 AssembleConLin          :890-928   nk x (nk-1)                      */
     ORC_V_CONLIN_W = 15,      /* C4 AssembleConLinWithW     :538-605   f1=velz[(nk-1)*n2e]              */
     ORC_V_CONLIN_RHODPI = 16, /* C4 AssembleConLinWithRhodPi:1307-1378 f1=theta(rt)[nk*n2e] f2=dpi[(nk-1)*n2e] */
+    ORC_V_LINEAR_RAYLEIGH_INV = 17, /* C3 AssembleLinearWithRayleighInv :1380-1413 param=dt_fric              */
+    ORC_V_EOS_BLOCK_INV = 18, /* C2 Assemble_EOS_BlockInv   :1049-1142 f1=rt f2=theta[(nk+1)*n2e] or NULL         */
+    ORC_V_LINEAR_RHO2_UP = 19,/* C3 AssembleLinearWithRho2_up :1415-1490 f1=rho param=dt uh=[nk][n1]             */
+    ORC_V_LINCON2_UP = 20,    /* C4 AssembleLinCon2_up      :1492-1561 param=dt uh=[nk][n1]                       */
     ORC_V_NOPS
 };
 /* dense result: out is a row-major (rows x cols) matrix of the column operator, zeroed
@@ -213,6 +221,22 @@ int orc_solve_schur_column_eta(const orc_patch* p, int ex, int ey, double dt,
         const double* theta, const double* velz, const double* rho, const double* eta, const double* pi,
         double* F_u, double* F_rho, double* F_eta, double* F_pi,
         double* d_u, double* d_rho, double* d_eta, double* d_pi, double* Lpi_out);
+
+/* Held-Suarez / Strang column rows: the colops that take a scalar parameter and/or the horizontal velocity */
+int orc_colop_dims_ex(const orc_patch* p, int colop, int* rows, int* cols);
+int orc_colop_dense_ex(const orc_patch* p, int colop, int ex, int ey, int flag, double param,
+                       const double* f1, const double* f2, const double* uh, double* out);
+/* C6 diagTheta_up eul/VertSolve.cpp:354-384 (one column); uh = [nk][n1] local horizontal 1-forms */
+int orc_diag_theta_up(const orc_patch* p, int ex, int ey, double dt, const double* rho, const double* rt,
+                      const double* uh, double* theta);
+/* AssembleTempForcing_HS eul/VertOps.cpp:1589-1633 (latitude from the patch's quad-point coordinates) */
+void orc_temp_forcing_hs(const orc_patch* p, int ex, int ey, const double* exner, const double* theta,
+                         const double* rho, double* vec);
+/* C5 solve_schur_column_3 eul/VertSolve.cpp:504-675 (dense restatement; Lrt_out optional N x N) */
+int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
+        const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
+        double* F_u, double* F_rho, double* F_rt, double* F_pi,
+        double* d_u, double* d_rho, double* d_rt, double* d_pi, double* Lrt_out);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,8 @@ OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=
            UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13)
 COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4, EOS_BLOCK=5,
               LINEAR=6, LINEAR_INV=7, LINEAR_RT=8, LINEAR_THETA=9, LINEAR_RHO2=10, RAYLEIGH=11,
-              LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16)
+              LINCON=12, LINCON2=13, CONLIN=14, CONLIN_W=15, CONLIN_RHODPI=16,
+              LINEAR_RAYLEIGH_INV=17, EOS_BLOCK_INV=18, LINEAR_RHO2_UP=19, LINCON2_UP=20)
 
 
 def gll(n):
@@ -240,6 +241,13 @@ class Patch:
                                                 b[:, 1].transpose(0, 2, 1), b[:, 3].transpose(0, 2, 1)], axis=1)).reshape(self.nEl, -1)
         return self.op_apply("UMAT", em, x, self.n1)
 
+    def umat_ray(self, x, lev, scale, dt, exner_k, exner_s):
+        """Umat_ray::assemble then MatMult on local vectors; also returns the element blocks"""
+        em = np.zeros((self.nEl, self.elmat_size("UMAT")))
+        rc = self.L.orc_umat_ray_elmats(self.p, lev, C.c_double(scale), C.c_double(dt), _dp(exner_k), _dp(exner_s), _dp(em))
+        assert rc == 0
+        return self.op_apply("UMAT", em, x, self.n1), em
+
     def uvec_hu_up(self, lev, scale, vel, rho, fac, tau, vel2):
         v = np.zeros(self.n1)
         self.L.orc_uvec_hu_up(self.p, lev, C.c_double(scale), _dp(vel), _dp(rho), C.c_double(fac), C.c_double(tau), _dp(vel2), _dp(v))
@@ -278,8 +286,36 @@ class Patch:
     # column operators -----------------------------------------------------------------------
     def colop_dims(self, colop):
         r = C.c_int(); c = C.c_int()
-        self.L.orc_colop_dims(self.p, COLOPS[colop], C.byref(r), C.byref(c))
+        self.L.orc_colop_dims_ex(self.p, COLOPS[colop], C.byref(r), C.byref(c))
         return r.value, c.value
+
+    def colop_dense_ex(self, colop, ex, ey, param=0.0, f1=None, f2=None, uh=None, flag=0):
+        r, c = self.colop_dims(colop)
+        out = np.zeros((r, c))
+        rc = self.L.orc_colop_dense_ex(self.p, COLOPS[colop], ex, ey, int(flag), C.c_double(param), _dp(f1), _dp(f2), _dp(uh), _dp(out))
+        assert rc == 0
+        return out
+
+    def diag_theta_up(self, ex, ey, dt, rho, rt, uh):
+        th = np.zeros((self.nk + 1) * self.n2e)
+        rc = self.L.orc_diag_theta_up(self.p, ex, ey, C.c_double(dt), _dp(rho), _dp(rt), _dp(uh), _dp(th)); assert rc == 0; return th
+
+    def temp_forcing_hs(self, ex, ey, exner, theta, rho):
+        o = np.zeros(self.nk * self.n2e)
+        self.L.orc_temp_forcing_hs(self.p, ex, ey, _dp(exner), _dp(theta), _dp(rho), _dp(o)); return o
+
+    def solve_schur_column_3(self, ex, ey, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi):
+        N = self.nk * self.n2e; Nm = (self.nk - 1) * self.n2e
+        F_u, F_rho, F_rt, F_pi = (np.array(a, dtype=np.float64) for a in (F_u, F_rho, F_rt, F_pi))
+        d_u = np.zeros(Nm); d_rho = np.zeros(N); d_rt = np.zeros(N); d_pi = np.zeros(N); L = np.zeros((N, N))
+        rc = self.L.orc_solve_schur_column_3(self.p, ex, ey, C.c_double(dt), _dp(theta), _dp(velz), _dp(rho), _dp(rt), _dp(pi),
+                                             _dp(F_u), _dp(F_rho), _dp(F_rt), _dp(F_pi),
+                                             _dp(d_u), _dp(d_rho), _dp(d_rt), _dp(d_pi), _dp(L))
+        assert rc == 0
+        return dict(d_u=d_u, d_rho=d_rho, d_rt=d_rt, d_pi=d_pi, L=L, F_u=F_u, F_rho=F_rho, F_rt=F_rt, F_pi=F_pi)
+
+    @property
+    def sq(self): return self.arr("sq", (self.n0q, 2))
 
     def colop_dense(self, colop, ex, ey, flag=0, f1=None, f2=None):
         r, c = self.colop_dims(colop)

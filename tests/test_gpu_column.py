@@ -35,7 +35,7 @@ def _dense_from_blocks(P, colop, blk):
     rows, cols = P.colop_dims(colop)
     M = np.zeros((rows, cols))
     nb = blk.shape[0]
-    if colop in ("LINCON", "LINCON2", "CONLIN", "CONLIN_W", "CONLIN_RHODPI"):
+    if colop in ("LINCON", "LINCON2", "LINCON2_UP", "CONLIN", "CONLIN_W", "CONLIN_RHODPI"):
         off = 0 if colop == "LINCON" else -1
         for r in range(nb // 2):
             for w in range(2):
@@ -192,3 +192,89 @@ def test_residual_compositions(setup):
         assert rel_l2(G[e].cpu().numpy(), G_ref) < 1e-9
         assert rel_l2(fw[e].cpu().numpy(), fw_ref) < 1e-9
         assert rel_l2(ftc[e].cpu().numpy(), ftc_ref) < 1e-9
+
+
+def _uh(P, r, dt):
+    """horizontal velocities [nk][n1] whose departure shift is ~0.3 of the reference element"""
+    vs = P.det.mean() / P.thickInv.mean(axis=1) * 0.3 / dt            # per level: the stretched grid's thickness varies a lot
+    return r.uniform(-1, 1, (P.nk, P.n1)) * vs[:, None]
+
+
+HSCASES = [("LINEAR_RAYLEIGH_INV", None, None, 3.7e-2, False), ("EOS_BLOCK_INV", "pi", None, 0.0, False),
+           ("EOS_BLOCK_INV", "pi", "theta", 0.0, False), ("LINEAR_RHO2_UP", "rho", None, 75.0, True), ("LINCON2_UP", None, None, 75.0, True)]
+
+
+@pytest.mark.parametrize("colop,k1,k2,param,up", HSCASES, ids=[f"{c[0]}_{c[2]}" for c in HSCASES])
+def test_hs_colops(setup, colop, k1, k2, param, up):
+    """C2-C4 remainder: AssembleLinearWithRayleighInv, Assemble_EOS_BlockInv, AssembleLinearWithRho2_up, AssembleLinCon2_up"""
+    eng, P = setup
+    if up and P.n > 7:
+        pytest.skip("edge-function scratch sized for p <= 7")
+    F = _col_fields(P)
+    r = np.random.default_rng(15)
+    f1 = F[k1] if k1 else None; f2 = F[k2] if k2 else None
+    uh = _uh(P, r, param) if up else None
+    t = lambda a: eng.tensor(a) if a is not None else None
+    blk = eng.colop_blocks_ex(colop, param=param, f1=t(f1), f2=t(f2), uh=t(uh)).cpu().numpy()
+    rows, cols = P.colop_dims(colop)
+    x = r.standard_normal((P.nEl, cols))
+    y = eng.colop_apply_ex(colop, eng.tensor(x), rows // P.n2e, param=param, f1=t(f1), f2=t(f2), uh=t(uh)).cpu().numpy()
+    for e in (0, P.nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        want = P.colop_dense_ex(colop, ex, ey, param=param, f1=None if f1 is None else f1[e], f2=None if f2 is None else f2[e], uh=uh)
+        got = _dense_from_blocks(P, colop, blk[e])
+        assert rel_l2(got, want) < 1e-9, colop
+        assert rel_l2(y[e], want @ x[e]) < 1e-9, colop
+
+
+def test_diag_theta_up_and_temp_forcing(setup):
+    """C6 diagTheta_up (eul/VertSolve.cpp:354-384) and AssembleTempForcing_HS (eul/VertOps.cpp:1563-1633)"""
+    eng, P = setup
+    F = _col_fields(P)
+    r = np.random.default_rng(21)
+    dt = 60.0
+    uh = _uh(P, r, dt)
+    t = eng.tensor
+    th = eng.diag_theta_up(dt, t(F["rho"]), t(F["rt"]), t(uh)).cpu().numpy()
+    iq = P.elinds("q")
+    lat = np.ascontiguousarray(P.sq[:, 1][iq])                        # Geom::s[elInds0_l][1]
+    # Exner pressures cp*sigma^(R/cp) as column 2-forms: value * area * thickness, so that sigma > 0.7 and < 0.7 both occur
+    area = P.det.mean() * 4.0 / P.n2e
+    sig = np.linspace(1.0, 0.3, P.nk)[None, :, None] * r.uniform(0.97, 1.0, (P.nEl, 1, P.n2e))
+    exner = (1004.5 * sig ** (287.0 / 1004.5) * area * P.thick.mean(axis=1)[None, :, None]).reshape(P.nEl, -1)
+    got = eng.temp_forcing_hs(t(lat), t(exner), t(F["theta"]), t(F["rho"])).cpu().numpy()
+    for e in (0, P.nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        assert rel_l2(th[e], P.diag_theta_up(ex, ey, dt, F["rho"][e], F["rt"][e], uh)) < 1e-9
+        assert rel_l2(got[e], P.temp_forcing_hs(ex, ey, exner[e], F["theta"][e], F["rho"][e])) < 1e-9
+
+
+def test_schur_column_3_pentadiagonal(setup):
+    """solve_schur_column_3 (eul/VertSolve.cpp:504-675): banded assembly of the block-pentadiagonal L_rt_rt, 2x2 super-block
+    Thomas solve and back substitution vs the oracle's dense restatement of the MatMatMult chain + LU"""
+    eng, P = setup
+    F = _col_fields(P)
+    r = np.random.default_rng(29)
+    nEl, nk, n2 = P.nEl, P.nk, P.n2e
+    N, Nm = nk * n2, (nk - 1) * n2
+    dt = 75.0
+    Fu, Frho, Frt, Fpi = (r.standard_normal((nEl, n)) * 1e8 for n in (Nm, N, N, N))
+    t = eng.tensor
+    dFu, dFrho, dFrt, dFpi = t(Fu), t(Frho), t(Frt), t(Fpi)
+    d_u, d_rho, d_rt, d_pi, L = eng.solve_schur_3(dt, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]),
+                                                  dFu, dFrho, dFrt, dFpi, want_L=True)
+    L = L.cpu().numpy()
+    for e in (0, nEl - 1):
+        ex, ey = e % P.nElsX, e // P.nElsX
+        ref = P.solve_schur_column_3(ex, ey, dt, F["theta"][e], F["velz"][e], F["rho"][e], F["rt"][e], F["pi"][e],
+                                     Fu[e], Frho[e], Frt[e], Fpi[e])
+        Ld = np.zeros((N, N))
+        for k in range(nk):
+            for b in range(5):
+                c = k - 2 + b
+                if 0 <= c < nk:
+                    Ld[k*n2:(k+1)*n2, c*n2:(c+1)*n2] = L[e, k, b]
+        assert rel_l2(Ld, ref["L"]) < 1e-9                      # incl. exact zeros outside the five block diagonals
+        for name, got in (("d_rt", d_rt), ("d_u", d_u), ("d_pi", d_pi), ("d_rho", d_rho),
+                          ("F_u", dFu), ("F_rho", dFrho), ("F_rt", dFrt), ("F_pi", dFpi)):
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name

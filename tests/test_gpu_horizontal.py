@@ -173,3 +173,52 @@ def test_eul_upwinded_test_functions(setup, which):
         want = P.uvec_hu_up(lev, SCALE, vel, h, 1.0 / 3.0, tau, u2)
         got = eng.apply_up("UVEC_HU_UP", t(vel), t(h), t(u2), lev0=lev, scale=SCALE, tau=tau, alpha=1.0 / 3.0)
     assert rel_l2(got.cpu().numpy(), want) < TOL
+
+
+def _exner_fields(P, r, lev):
+    """2-form DoFs whose point values (after /det * thickInv) are Exner pressures cp*sigma^(R/cp), sigma in [0.5,1] per element"""
+    n = P.n
+    dx = np.diff(P.arr("nx", (n + 1,)))
+    cell = np.outer(dx, dx).reshape(-1)                                       # integral of 1 over each face of the reference element
+    i2 = P.elinds("n2")
+    iq = P.elinds("q")
+    out = []
+    for (k, lo, hi) in ((lev, 0.5, 1.0), (0, 0.98, 1.02)):
+        f = np.zeros(P.n2)
+        for e in range(P.nEl):
+            sig = r.uniform(lo, hi)
+            val = 1004.5 * sig ** (287.0 / 1004.5)
+            scale_e = P.det[e].mean() / P.thickInv[k][iq[e]].mean()
+            f[i2[e]] = val * cell * scale_e * (1.0 + 1e-3 * r.standard_normal(n * n))
+        out.append(f)
+    return out
+
+
+def test_umat_ray_held_suarez_friction(setup):
+    """B16 Umat_ray::assemble (eul/Assembly.cpp:1876-1979): apply, element blocks, level batching"""
+    eng, P, rng = setup
+    r = np.random.default_rng(97)
+    lev, dt = 2, 120.0
+    ek, es = _exner_fields(P, r, lev)
+    x = r.standard_normal(P.n1)
+    want, em = P.umat_ray(x, lev, SCALE, dt, ek, es)
+    assert np.abs(em).max() > 0                       # sigma > 0.7 somewhere (and the k_v = 0 branch elsewhere)
+    t = eng.tensor
+    got = eng.apply_ray(t(x), t(ek), t(es), dt, lev0=lev, scale=SCALE)
+    assert rel_l2(got.cpu().numpy(), want) < TOL
+    gm = eng.element_matrices_ray(t(ek), t(es), dt, lev=lev, scale=SCALE)
+    assert rel_l2(gm.cpu().numpy(), em) < TOL
+    # M1 + M1ray as the reference forms it with MatAXPY (eul/Euler_2.cpp:1448): accumulate into the Umat apply
+    import torch
+    base = eng.apply("UMAT", t(x), lev0=lev, scale=SCALE, flags=1)
+    both = base.clone()
+    from mimsem_amd._lib import FLAG_ACCUM
+    eng.apply_ray(t(x), t(ek), t(es), dt, lev0=lev, scale=SCALE, flags=FLAG_ACCUM, out=both)
+    assert rel_l2(both.cpu().numpy(), base.cpu().numpy() + want) < TOL
+    # all levels in one call
+    eks = [_exner_fields(P, r, k)[0] for k in range(3)]
+    xs = r.standard_normal((3, P.n1))
+    got3 = eng.apply_ray(t(xs), t(np.stack(eks)), t(es), dt, lev0=0, scale=SCALE).cpu().numpy()
+    for k in range(3):
+        wk, _ = P.umat_ray(xs[k], k, SCALE, dt, eks[k], es)
+        assert rel_l2(got3[k], wk) < TOL
