@@ -247,7 +247,10 @@ int mimsem_column_temp_forcing_hs(mimsem_ctx* ctx, const double* lat, const doub
  * complement L_rt_rt is block-PENTAdiagonal; it is assembled band by band, regrouped into 2x2 super-blocks and
  * solved by the batched block-Thomas sweep.  theta on nk+1 interfaces, velz/F_u/d_u on nk-1, the rest on nk levels.
  * F_* are updated in place as the reference does.  L_out (optional) [nEl][nk][5][n2e][n2e], block column = row-2+b. */
-int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt,
+#define MIMSEM_SCHUR3_NO_RAYLEIGH 1u   /* M_u_inv = AssembleLinearInv (box/VertSolve.cpp:30: RAYLEIGH undefined)          */
+#define MIMSEM_SCHUR3_BOX_Q       2u   /* Q_rt_rho keeps VBA(pressure gradient): the box twin never re-assembles VBA(velz) */
+#define MIMSEM_SCHUR3_BOX (MIMSEM_SCHUR3_NO_RAYLEIGH | MIMSEM_SCHUR3_BOX_Q)   /* box/VertSolve.cpp:879-1058 (config 5)  */
+int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt, unsigned flags,
         const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
         double* F_u, double* F_rho, double* F_rt, double* F_pi,
         double* d_u, double* d_rho, double* d_rt, double* d_pi, double* L_out);

@@ -275,13 +275,14 @@ class Engine:
         check(self.L.mimsem_column_temp_forcing_hs(self.ctx, _ptr(lat), _ptr(exner), _ptr(theta), _ptr(rho), _ptr(out)), "temp_forcing_hs")
         return out
 
-    def solve_schur_3(self, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi, want_L=False):
-        """solve_schur_column_3 for every column; F_* updated in place; returns d_u, d_rho, d_rt, d_pi (, L [nEl,nk,5,n2e,n2e])"""
+    def solve_schur_3(self, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi, want_L=False, flags=0):
+        """solve_schur_column_3 for every column; F_* updated in place; returns d_u, d_rho, d_rt, d_pi (, L [nEl,nk,5,n2e,n2e]);
+        flags = 3 reproduces the box twin (box/VertSolve.cpp:879-1058)"""
         N, Nm = self.nk * self.n2e, (self.nk - 1) * self.n2e
         mk = lambda n: torch.empty(self.nEl, n, dtype=torch.float64, device=self.device)
         d_u, d_rho, d_rt, d_pi = mk(Nm), mk(N), mk(N), mk(N)
         L = torch.empty(self.nEl, self.nk, 5, self.n2e, self.n2e, dtype=torch.float64, device=self.device) if want_L else None
-        check(self.L.mimsem_column_solve_schur_3(self.ctx, dt, _ptr(theta), _ptr(velz), _ptr(rho), _ptr(rt), _ptr(pi),
+        check(self.L.mimsem_column_solve_schur_3(self.ctx, dt, flags, _ptr(theta), _ptr(velz), _ptr(rho), _ptr(rt), _ptr(pi),
                                                  _ptr(F_u), _ptr(F_rho), _ptr(F_rt), _ptr(F_pi),
                                                  _ptr(d_u), _ptr(d_rho), _ptr(d_rt), _ptr(d_pi), _ptr(L)), "solve_schur_3")
         return (d_u, d_rho, d_rt, d_pi, L) if want_L else (d_u, d_rho, d_rt, d_pi)

@@ -60,3 +60,70 @@ class MassSolver:
     def solve(self, b, lev0=0, rtol=1e-14, maxit=300):
         nlev = b.shape[0]
         return pcg(lambda v: self.apply(v, lev0), b, minv=self.minv[lev0:lev0 + nlev], rtol=rtol, maxit=maxit)
+
+
+def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30, maxit=1000, dot=None):
+    """Restarted, left-preconditioned GMRES for ONE (nonsymmetric) system on device tensors of any shape -- the stand-in for
+    the reference's KSPGMRES solves on the packed [u,h] operator A and on the upwinded M0h (src/SWEqn_Picard.cpp:600-606, :348-353).
+    As in PETSc's default the PRECONDITIONED residual is monitored.  Arnoldi by classical Gram-Schmidt with one
+    re-orthogonalisation pass (two GEMVs on the device); the (restart+1) x restart Hessenberg matrix lives on the host:
+    one host synchronisation per iteration.  dot(U, w): inner products of the rows of U [k, n] with w [n] -> [k]
+    (multi-GPU callers pass an ownership-weighted, all-reduced version).  Returns (x, iterations, relative residual)."""
+    shape = b.shape
+    bf = b.reshape(-1)
+    n = bf.numel()
+    A = (lambda v: apply_A(v.view(shape)).reshape(-1))
+    M = (lambda v: v) if precond is None else (lambda v: precond(v.view(shape)).reshape(-1))
+    if dot is None:
+        dot = lambda U, w: U @ w
+    nrm = lambda v: float(torch.sqrt(dot(v.view(1, -1), v))[0])
+    x = torch.zeros_like(bf) if x0 is None else x0.reshape(-1).clone()
+    pb = M(bf)
+    bnorm = nrm(pb)
+    if bnorm == 0.0:
+        return x.view(shape), 0, 0.0
+    tol = max(rtol * bnorm, atol)
+    V = torch.empty(restart + 1, n, dtype=bf.dtype, device=bf.device)
+    its, res = 0, bnorm
+    while its < maxit:
+        r = pb.clone() if (its == 0 and x0 is None) else M(bf - A(x))
+        beta = nrm(r)
+        res = beta
+        if beta <= tol:
+            break
+        V[0] = r / beta
+        H = [[0.0] * restart for _ in range(restart + 1)]
+        cs, sn, g = [0.0] * restart, [0.0] * restart, [0.0] * (restart + 1)
+        g[0] = beta
+        k = 0
+        for j in range(restart):
+            w = M(A(V[j]))
+            h = dot(V[:j + 1], w)
+            w = w - h @ V[:j + 1]
+            h2 = dot(V[:j + 1], w)                      # re-orthogonalisation
+            w = w - h2 @ V[:j + 1]
+            hn = torch.sqrt(dot(w.view(1, -1), w))
+            col = torch.cat([h + h2, hn]).tolist()      # the host synchronisation of this iteration
+            for i in range(j + 2):
+                H[i][j] = col[i]
+            for i in range(j):                          # previous Givens rotations
+                t = cs[i] * H[i][j] + sn[i] * H[i + 1][j]
+                H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j]
+                H[i][j] = t
+            d = (H[j][j] ** 2 + H[j + 1][j] ** 2) ** 0.5
+            cs[j], sn[j] = (1.0, 0.0) if d == 0.0 else (H[j][j] / d, H[j + 1][j] / d)
+            H[j][j] = d; H[j + 1][j] = 0.0
+            g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j]
+            its += 1; k = j + 1
+            res = abs(g[j + 1])
+            if res <= tol or its >= maxit or col[j + 1] == 0.0:
+                break
+            V[j + 1] = w / col[j + 1]
+        y = [0.0] * k                                   # back substitution on the host
+        for i in range(k - 1, -1, -1):
+            s = g[i] - sum(H[i][l] * y[l] for l in range(i + 1, k))
+            y[i] = s / H[i][i]
+        x = x + torch.tensor(y, dtype=bf.dtype, device=bf.device) @ V[:k]
+        if res <= tol:
+            break
+    return x.view(shape), its, res / bnorm

@@ -1,0 +1,188 @@
+"""Rotating shallow water: one Picard/Rosenbrock time step on the device -- the host-side mirror of the reference's
+SWEqn (src/SWEqn_Picard.cpp), SURVEY 8(f) row N3.  Every matrix of the reference (M0, M1, M2, M1h, M0h, K, R, R_up, the
+packed [u,h] operator A) is applied matrix-free through the C-ABI engine; the KSP solves are device Krylov iterations.
+
+src/ flavour: no SCALE, no layer thickness (the engine runs with nk = 1 and unit thickness), signed Jacobian determinant.
+Single GPU, global numbering: the reference's local (`*l`) and global vectors coincide, so its VecScatters are identities."""
+import math
+
+import torch
+
+from .krylov import gmres, pcg
+
+RAD_EARTH = 6371220.0          # src/SWEqn_Picard.cpp:22-23
+RAD_SPHERE = 6371220.0
+H_MEAN = 1.0e+4                # :27
+ROS_ALPHA = 0.5                # :29
+UP_TAU = 0.5                   # :30
+
+
+class SWEqn:
+    def __init__(self, eng, quad_coords, krylov_rtol=1e-14):
+        """eng: Engine over the whole sphere (numbering="global", nk=1, unit thickness); quad_coords: [nq, 3] xyz of the
+        quadrature-point grid in the engine's quad-grid numbering (Geom::x)."""
+        assert eng.nk == 1
+        self.eng, self.rtol = eng, krylov_rtol
+        self.grav = 9.80616 * (RAD_SPHERE / RAD_EARTH)          # :52
+        self.omega = 7.292e-5                                    # :53
+        self.step = 0
+        self.n1, self.n2 = eng.sizes[1], eng.sizes[2]
+        xq = torch.as_tensor(quad_coords, dtype=torch.float64, device=eng.device)
+        self.lat = torch.asin(xq[:, 2] / RAD_SPHERE)
+        self.m0 = eng.pvec(0, 1, 1.0)                            # M0 is diagonal (collocated 0-forms): Pmat as a vector
+        self.m1_minv = self._m1_jacobi()
+        self.coriolis()
+        self.A_dt = None
+        self.its = {}
+
+    # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
+    def M1(self, u): return self.eng.apply("UMAT", u)
+    def M2(self, h): return self.eng.apply("WMAT", h)
+    def M1h(self, h, u, out=None, alpha=1.0, accum=False):
+        return self.eng.apply("UHMAT", u, f=h, alpha=alpha, flags=2 if accum else 0, out=out)
+    def K(self, ul, u): return self.eng.apply("WTQUMAT", u, f=ul)
+    def R(self, q, u): return self.eng.apply("ROTMAT", u, f=q)
+    def R_up(self, q, ul, dt, u): return self.eng.apply_up("ROTMAT_UP", u, q, ul, fac=UP_TAU, dt=dt)
+    def E(self, name, x): return self.eng.incidence(name, x)
+
+    def _m1_jacobi(self):
+        eng = self.eng
+        n1e = eng.n1e
+        ix = torch.as_tensor(eng.mesh.inds1x, device=eng.device).long().reshape(-1)
+        iy = torch.as_tensor(eng.mesh.inds1y, device=eng.device).long().reshape(-1)
+        em = eng.element_matrices("UMAT").view(eng.nEl, 4, n1e, n1e)
+        d = eng.zeros(1, eng.sizes[1])
+        d[0].index_add_(0, ix, torch.diagonal(em[:, 0], dim1=1, dim2=2).reshape(-1))
+        d[0].index_add_(0, iy, torch.diagonal(em[:, 3], dim1=1, dim2=2).reshape(-1))
+        return 1.0 / d
+
+    def solve_M1(self, b, key="M1"):
+        """KSPSolve(ksp, b, x) on M1 (:84-92): SPD => preconditioned CG reaches the same solution"""
+        x, its = pcg(self.M1, b, minv=self.m1_minv, rtol=self.rtol, maxit=1000, check_every=5)
+        self.its[key] = its
+        return x
+
+    # ---- diagnostics ------------------------------------------------------------------------------------------
+    def coriolis(self):
+        """:186-233: f = 2 Omega sin(lat) at the quadrature points, projected onto the 0-forms"""
+        fq = (2.0 * self.omega * torch.sin(self.lat)).unsqueeze(0)
+        self.fg = self.eng.apply("PTQ", fq) / self.m0
+
+    def curl(self, u):
+        """:236-250: w = M0^-1 E01 M1 u"""
+        return self.E("E01", self.M1(u)) / self.m0
+
+    def diagnose_F(self, ui, uj, hi, hj):
+        """:253-284: F = M1^-1 (1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj)"""
+        hu = self.M1h(hi, ui, alpha=1.0 / 3.0)
+        self.M1h(hi, uj, out=hu, alpha=1.0 / 6.0, accum=True)
+        self.M1h(hj, ui, out=hu, alpha=1.0 / 6.0, accum=True)
+        self.M1h(hj, uj, out=hu, alpha=1.0 / 3.0, accum=True)
+        return self.solve_M1(hu, "F")
+
+    def diagnose_Phi(self, ui, uj, hi, hj):
+        """:289-320 (integral form): 1/3 K(ui) ui + 1/3 K(ui) uj + 1/3 K(uj) uj + g/2 M2 (hi + hj)"""
+        Phi = (1.0 / 3.0) * self.K(ui, ui)
+        Phi += (1.0 / 3.0) * self.K(ui, uj)
+        Phi += (1.0 / 3.0) * self.K(uj, uj)
+        Phi += (self.grav / 2.0) * self.M2(hi)
+        Phi += (self.grav / 2.0) * self.M2(hj)
+        return Phi
+
+    def diagnose_q(self, dt, u, h):
+        """:322-341: M0h q = M0 f + E01 M1 u ; M0h upwinded (Phmat::assemble_up) when dt > 1e-6"""
+        rhs = self.m0 * self.fg + self.E("E01", self.M1(u))
+        m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
+        if dt > 1.0e-6:
+            A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
+            q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000)
+            self.its["q"] = its
+            return q
+        return rhs / m0h
+
+    # ---- the packed [u,h] system ---------------------------------------------------------------------------------
+    def pack(self, u, h): return torch.cat([u, h], dim=1)
+    def unpack(self, x): return x[:, :self.n1].contiguous(), x[:, self.n1:].contiguous()
+
+    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None):
+        """:402-607"""
+        F = self.diagnose_F(ui, uj, hi, hj)
+        Phi = self.diagnose_Phi(ui, uj, hi, hj)
+        if bot is not None:
+            Phi = Phi + self.grav * self.M2(bot)
+        fu = self.E("E12", Phi)
+        if q_exact:
+            um, hm = 0.5 * ui + 0.5 * uj, 0.5 * hi + 0.5 * hj
+            q = self.diagnose_q(0.0, um, hm)
+            fu = fu + self.R(q, F)
+        else:
+            qi = self.diagnose_q(dt, ui, hi)
+            qj = self.diagnose_q(dt, uj, hj)
+            fu = fu + 0.5 * self.R_up(qi, ui, dt, F)
+            fu = fu + 0.5 * self.R_up(qj, uj, dt, F)
+        fh = self.M2(self.E("E21", F))                            # continuity term
+        mu = self.M1(uj) - self.M1(ui)
+        mh = self.M2(hj) - self.M2(hi)
+        return self.pack(mu + dt * fu, mh + dt * fh)
+
+    def apply_A(self, x, dt):
+        """:609-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]]"""
+        u, h = self.unpack(x)
+        a = ROS_ALPHA * dt
+        yu = self.M1(u) + a * self.R(self.fg, u) + (a * self.grav) * self.E("E12", self.M2(h))
+        yh = (a * H_MEAN) * self.M2(self.E("E21", u)) + self.M2(h)
+        return self.pack(yu, yh)
+
+    def precond_A(self, r):
+        """block diagonal: Jacobi on M1, the exact element-wise inverse on M2 (WmatInv)"""
+        u, h = self.unpack(r)
+        return self.pack(u * self.m1_minv, self.eng.apply("WMATINV", h))
+
+    def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
+        """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
+        ui, hi = un.clone(), hn.clone()
+        uj, hj = un.clone(), hn.clone()
+        x = self.pack(uj, hj)
+        it, hist = 0, []
+        while True:
+            f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot)
+            dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
+                                 restart=restart, maxit=1000)
+            self.its["A"] = its
+            x = x + dx
+            uj, hj = self.unpack(x)
+            norm_x, norm_dx = float(torch.linalg.vector_norm(x)), float(torch.linalg.vector_norm(dx))
+            norm = norm_dx / norm_x
+            hist.append(norm)
+            if verbose:
+                print("iteration: %d\t|x|: %.6e\t|dx|: %.6e\t|dx|/|x|: %.6e  (gmres %d)" % (it, norm_x, norm_dx, norm, its))
+            it += 1
+            if not (norm > 1.0e-14 and it < nits):
+                break
+        self.step += 1
+        self.history = hist
+        return uj, hj
+
+    # ---- initial conditions (init1 :880-932, init2 :934-975) ---------------------------------------------------------
+    def init1(self, uq):
+        """uq: [nq, 2] zonal/meridional velocity at the quadrature-grid points -> 1-form u = M1^-1 UtQ uq"""
+        b = self.eng.apply("UTQ", uq.reshape(1, -1).contiguous())
+        return self.solve_M1(b, "init1")
+
+    def init2(self, hq):
+        """hq: [nq] -> 2-form h = M2^-1 WtQ hq (M2 is element-block diagonal: exact inverse)"""
+        return self.eng.apply("WMATINV", self.eng.apply("WTQ", hq.reshape(1, -1).contiguous()))
+
+
+def williamson2(xq, alpha=0.25 * math.pi):
+    """src/Williamson2.cpp:20-61 evaluated at points xq [n,3]: (u, v), h.  NB the SWEqn Coriolis term is un-rotated unless
+    W2_ALPHA is defined in SWEqn_Picard.cpp (it is commented out there, :24) -- callers pass alpha=0 for a steady state."""
+    U0, H0 = 38.61068276698372, 2998.1154702758267
+    OMEGA, GRAV = 7.292e-5, 9.80616
+    theta = torch.asin(xq[:, 2] / RAD_SPHERE)
+    lam = torch.atan2(xq[:, 1], xq[:, 0])
+    u = U0 * (torch.cos(theta) * math.cos(alpha) + torch.cos(lam) * torch.sin(theta) * math.sin(alpha))
+    v = -U0 * torch.sin(lam) * math.sin(alpha)
+    b = -torch.cos(lam) * torch.cos(theta) * math.sin(alpha) + torch.sin(theta) * math.cos(alpha)
+    h = H0 - (RAD_SPHERE * OMEGA * U0 + 0.5 * U0 * U0) * b * b / GRAV
+    return torch.stack([u, v], dim=1), h

@@ -658,9 +658,10 @@ void orc_temp_forcing_hs(const orc_patch* p, int ex, int ey, const double* exner
 }
 
 /* VertSolve::solve_schur_column_3 eul/VertSolve.cpp:504-675 (RAYLEIGH defined, :32), dense restatement.
+ * flags: 1 = RAYLEIGH undefined, 2 = VBA(velz) not re-assembled -- together the box twin box/VertSolve.cpp:879-1058.
  * F_* modified in place as the reference does; d_* outputs; Lrt_out (N x N) optional. */
 #define RAYLEIGH (4.0/120.0)
-int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
+int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt, int flags,
         const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
         double* F_u, double* F_rho, double* F_rt, double* F_pi,
         double* d_u, double* d_rho, double* d_rt, double* d_pi, double* Lrt_out) {
@@ -680,7 +681,8 @@ int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
     }
     for (i = 0; i < N; i++) for (j = 0; j < Nm; j++) V01[(size_t)j*N + i] = -V10[(size_t)i*Nm + j];
 
-    orc_colop_dense_ex(p, ORC_V_LINEAR_RAYLEIGH_INV, ex, ey, 0, 0.5*dt*RAYLEIGH, NULL, NULL, NULL, M_u_inv);  /* :520 */
+    if (flags & 1) orc_colop_dense(p, ORC_V_LINEAR_INV, ex, ey, 0, NULL, NULL, M_u_inv);                      /* :522 (box: RAYLEIGH undefined) */
+    else orc_colop_dense_ex(p, ORC_V_LINEAR_RAYLEIGH_INV, ex, ey, 0, 0.5*dt*RAYLEIGH, NULL, NULL, NULL, M_u_inv);  /* :520 */
     orc_colop_dense(p, ORC_V_CONST, ex, ey, 0, NULL, NULL, M_rt);                 /* :524 */
     orc_colop_dense(p, ORC_V_CONST_INV, ex, ey, 0, NULL, NULL, M_rho_inv);        /* :525 */
     orc_colop_dense_ex(p, ORC_V_EOS_BLOCK_INV, ex, ey, 0, 0.0, pi, NULL, NULL, N_pi_inv);   /* :526 */
@@ -720,7 +722,7 @@ int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
     orc_colop_dense(p, ORC_V_CONST_THETA, ex, ey, 0, theta, NULL, t_nn);          /* :589 */
     mm(Nm, N, N, V01, t_nn, t_mn);                                                /* :590 */
     mm(Nm, Nm, N, VA_inv, t_mn, t_mn2);                                           /* :594 */
-    orc_colop_dense(p, ORC_V_CONLIN_W, ex, ey, 0, velz, NULL, VBA);               /* :597 */
+    if (!(flags & 2)) orc_colop_dense(p, ORC_V_CONLIN_W, ex, ey, 0, velz, NULL, VBA);   /* :597 ; absent in box/VertSolve.cpp:978-981 */
     mm(N, Nm, N, VBA, t_mn2, Q_rt_rho);                                           /* :598 */
     for (i = 0; i < N*N; i++) Q_rt_rho[i] *= 0.5*dt;                              /* :599 */
 

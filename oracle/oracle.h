@@ -233,7 +233,7 @@ int orc_diag_theta_up(const orc_patch* p, int ex, int ey, double dt, const doubl
 void orc_temp_forcing_hs(const orc_patch* p, int ex, int ey, const double* exner, const double* theta,
                          const double* rho, double* vec);
 /* C5 solve_schur_column_3 eul/VertSolve.cpp:504-675 (dense restatement; Lrt_out optional N x N) */
-int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt,
+int orc_solve_schur_column_3(const orc_patch* p, int ex, int ey, double dt, int flags /* 1|2 = box twin */,
         const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
         double* F_u, double* F_rho, double* F_rt, double* F_pi,
         double* d_u, double* d_rho, double* d_rt, double* d_pi, double* Lrt_out);

@@ -304,11 +304,11 @@ class Patch:
         o = np.zeros(self.nk * self.n2e)
         self.L.orc_temp_forcing_hs(self.p, ex, ey, _dp(exner), _dp(theta), _dp(rho), _dp(o)); return o
 
-    def solve_schur_column_3(self, ex, ey, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi):
+    def solve_schur_column_3(self, ex, ey, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi, flags=0):
         N = self.nk * self.n2e; Nm = (self.nk - 1) * self.n2e
         F_u, F_rho, F_rt, F_pi = (np.array(a, dtype=np.float64) for a in (F_u, F_rho, F_rt, F_pi))
         d_u = np.zeros(Nm); d_rho = np.zeros(N); d_rt = np.zeros(N); d_pi = np.zeros(N); L = np.zeros((N, N))
-        rc = self.L.orc_solve_schur_column_3(self.p, ex, ey, C.c_double(dt), _dp(theta), _dp(velz), _dp(rho), _dp(rt), _dp(pi),
+        rc = self.L.orc_solve_schur_column_3(self.p, ex, ey, C.c_double(dt), int(flags), _dp(theta), _dp(velz), _dp(rho), _dp(rt), _dp(pi),
                                              _dp(F_u), _dp(F_rho), _dp(F_rt), _dp(F_pi),
                                              _dp(d_u), _dp(d_rho), _dp(d_rt), _dp(d_pi), _dp(L))
         assert rc == 0

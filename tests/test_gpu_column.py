@@ -249,7 +249,8 @@ def test_diag_theta_up_and_temp_forcing(setup):
         assert rel_l2(got[e], P.temp_forcing_hs(ex, ey, exner[e], F["theta"][e], F["rho"][e])) < 1e-9
 
 
-def test_schur_column_3_pentadiagonal(setup):
+@pytest.mark.parametrize("flags", [0, 3], ids=["eul", "box"])
+def test_schur_column_3_pentadiagonal(setup, flags):
     """solve_schur_column_3 (eul/VertSolve.cpp:504-675): banded assembly of the block-pentadiagonal L_rt_rt, 2x2 super-block
     Thomas solve and back substitution vs the oracle's dense restatement of the MatMatMult chain + LU"""
     eng, P = setup
@@ -262,12 +263,12 @@ def test_schur_column_3_pentadiagonal(setup):
     t = eng.tensor
     dFu, dFrho, dFrt, dFpi = t(Fu), t(Frho), t(Frt), t(Fpi)
     d_u, d_rho, d_rt, d_pi, L = eng.solve_schur_3(dt, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]),
-                                                  dFu, dFrho, dFrt, dFpi, want_L=True)
+                                                  dFu, dFrho, dFrt, dFpi, want_L=True, flags=flags)
     L = L.cpu().numpy()
     for e in (0, nEl - 1):
         ex, ey = e % P.nElsX, e // P.nElsX
         ref = P.solve_schur_column_3(ex, ey, dt, F["theta"][e], F["velz"][e], F["rho"][e], F["rt"][e], F["pi"][e],
-                                     Fu[e], Frho[e], Frt[e], Fpi[e])
+                                     Fu[e], Frho[e], Frt[e], Fpi[e], flags=flags)
         Ld = np.zeros((N, N))
         for k in range(nk):
             for b in range(5):
