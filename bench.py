@@ -102,6 +102,43 @@ def column_extras(eng, dm, rng, torch):
     return res
 
 
+def sw_extras(local_rank, torch):
+    """SW time steps/s (the second half of BASELINE's metric): SWEqn::solve as the reference drivers call it, on the
+    config 2 (16x16x6, Williamson-2: q from the mean state, iterate to 1e-14) and config 3 (24x24x6, Galewsky: 2 Picard
+    iterations, upwinded potential vorticity) grids, Williamson-2 initial state, everything resident on the device."""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.sweqn import SWEqn, williamson2
+    from mimsem_amd.topo import Topo
+    res = {}
+    for name, ne, dt, nits, q_exact, nsteps in (("config2_w2_16x16x6", 16, 600.0, 99, True, 3), ("config3_galewsky_24x24x6", 24, 360.0, 2, False, 5)):
+        cs = CubedSphere(PN, ne, 6); coords = sphere_coords(PN, ne)
+        topos = [Topo(cs, p, 1) for p in range(6)]
+        geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+        for g in geoms:
+            g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+        dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+        eng = Engine(dm, device=local_rank)
+        xq = np.zeros((dm.nq, 3))
+        for g in geoms:
+            xq[g.loc0] = coords[g.loc0]
+        S = SWEqn(eng, xq[dm.gidq])
+        uq, hq = williamson2(torch.as_tensor(xq[dm.gidq], device=eng.device), alpha=0.0)
+        u, h = S.init1(uq), S.init2(hq)
+        u, h = S.solve(u, h, dt, nits=nits, q_exact=q_exact)            # warm-up step
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        picard = 0
+        for _ in range(nsteps):
+            u, h = S.solve(u, h, dt, nits=nits, q_exact=q_exact)
+            picard += len(S.history)
+        torch.cuda.synchronize(); el = time.perf_counter() - t1
+        res[name] = {"steps_per_s": nsteps / el, "ms_per_step": 1e3 * el / nsteps, "dt": dt, "picard_iterations_per_step": picard / nsteps,
+                     "krylov_iterations_last": dict(S.its), "elements": dm.nEl, "dofs": dm.n1 + dm.n2}
+        del S, eng
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +148,7 @@ def main():
     ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
     ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
     ap.add_argument("--box", action="store_true", help="extra: BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
+    ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
                          "working set >> the 256 MiB Infinity Cache, i.e. genuinely HBM-resident")
@@ -258,6 +296,8 @@ def main():
         del engb
     if a.column and rank == 0 and world == 1:
         out["column"] = column_extras(eng, dm, rng, torch)
+    if a.sw and rank == 0 and world == 1:
+        out["sw"] = sw_extras(local_rank, torch)
     if a.cold and rank == 0 and world == 1:
         R = a.cold
         dmc = replicate(dm, R)

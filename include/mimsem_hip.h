@@ -100,6 +100,8 @@ enum mimsem_op {
 #define MIMSEM_FLAG_VERT   1u
 /* y += result instead of y = result (Uvec::assemble_hu(..., zero_and_scatter=false, ...), :2198-2279) */
 #define MIMSEM_FLAG_ACCUM  2u
+/* apply the transpose (mimsem_elem_blocks_apply: blocks are read column-major, the coalesced direction) */
+#define MIMSEM_FLAG_TRANSPOSE 4u
 
 /* ---- context ------------------------------------------------------------------------------- */
 int  mimsem_abi_version(void);
@@ -165,6 +167,14 @@ int mimsem_op_element_matrices(mimsem_ctx* ctx, int op, int geom_lev, double sca
  * tau = dt) -- what MatAXPY(M1->M, 1.0, M1ray->M) needs (eul/Euler_2.cpp:1448).                  */
 int mimsem_op_element_matrices_ex(mimsem_ctx* ctx, int op, int geom_lev, double scale, double tau, unsigned flags,
                                   const double* f, const double* u, double* out);
+
+/* MatMult of caller-assembled element blocks: y_lev (+)= alpha * sum_e P_e^T B_e P_e x_lev, the blocks being what the
+ * reference hands to MatSetValues(M, n, inds, n, inds, blk, ADD_VALUES) (eul/Assembly.cpp:128-131).  form 0/1/2 selects the
+ * DoF lists (1-forms: x-edges then y-edges, block size 2*n1e).  blocks: device [nEl][nd][nd] row-major per level
+ * (blocks_level_stride doubles apart; 0 = the same blocks on every level).  Used for element-block (PCBJACOBI-per-element,
+ * eul/HorizSolve.cpp:77-96) preconditioners and for operators a caller modified entry-wise (MatAXPY).  flags: ACCUM, TRANSPOSE. */
+int mimsem_elem_blocks_apply(mimsem_ctx* ctx, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
+                             const double* x, long long x_stride, double* y, long long y_stride, double alpha);
 
 /* Pvec::assemble / Phvec::assemble (Assembly.cpp:602-689): lumped 0-form mass as a vector */
 int mimsem_pvec(mimsem_ctx* ctx, int geom_lev0, int nlev, double scale,
@@ -254,6 +264,12 @@ int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt, unsigned flags,
         const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
         double* F_u, double* F_rho, double* F_rt, double* F_pi,
         double* d_u, double* d_rho, double* d_rt, double* d_pi, double* L_out);
+
+/* ---- dense building blocks of the device Krylov solvers (the KSPGMRES solves, eul/HorizSolve.cpp:77-96, src/SWEqn_Picard.cpp:600-606)
+ * V: Krylov basis stored row-wise [k][ldv] (ldv >= n).  mdot: h[i] = <V_i, w>, i < k (one pass over V, deterministic two-stage
+ * reduction).  maxpy: w += alpha * sum_i h[i] V_i.  Together: one classical Gram-Schmidt pass.                                   */
+int mimsem_krylov_mdot(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* w, double* h);
+int mimsem_krylov_maxpy(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* h, double alpha, double* w);
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer

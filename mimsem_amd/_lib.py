@@ -46,6 +46,7 @@ _SIGS = {
                                   c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_apply_up": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
                                      c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
+    "mimsem_elem_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_elmat_size": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_op_element_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_dp]),
     "mimsem_op_element_matrices_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]),
@@ -64,6 +65,8 @@ _SIGS = {
     "mimsem_column_diag_theta_up": (C.c_int, [C.c_void_p, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
     "mimsem_column_temp_forcing_hs": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double, C.c_uint] + [c_dp]*14),
+    "mimsem_krylov_mdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp]),
+    "mimsem_krylov_maxpy": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, C.c_double, c_dp]),
     "mimsem_halo_pack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_halo_unpack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
 }
@@ -76,6 +79,7 @@ COLOPS = dict(CONST=0, CONST_INV=1, CONST_RHO=2, CONST_RHO_INV=3, CONST_THETA=4,
               LINEAR_RAYLEIGH_INV=17, EOS_BLOCK_INV=18, LINEAR_RHO2_UP=19, LINCON2_UP=20)
 FLAG_VERT = 1
 FLAG_ACCUM = 2
+FLAG_TRANSPOSE = 4
 
 _lib = None
 

@@ -137,6 +137,13 @@ int mimsem_ctx::ensure_ye(long long doubles) {
     ye_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
 }
+int mimsem_ctx::ensure_kry(long long doubles) {
+    if (doubles <= kry_doubles) return MIMSEM_OK;
+    if (d_kry) { MIMSEM_HIP_TRY(hipFree(d_kry)); bytes -= kry_doubles*8; d_kry = nullptr; kry_doubles = 0; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_kry, (size_t)doubles*sizeof(double)));
+    kry_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
 int mimsem_ctx::ensure_col(long long doubles) {
     if (doubles <= col_doubles) return MIMSEM_OK;
     if (d_col) { MIMSEM_HIP_TRY(hipFree(d_col)); bytes -= col_doubles*8; d_col = nullptr; col_doubles = 0; }
@@ -299,7 +306,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col};
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -482,6 +489,13 @@ int mimsem_op_element_matrices(mimsem_ctx* c, int op, int geom_lev, double scale
         return mimsem_block_inverse_inplace(c, c->nEl, c->es.n2e, out);
     }
     return launch_elmats(c, op, geom_lev, scale, flags, f, out);
+}
+
+int mimsem_elem_blocks_apply(mimsem_ctx* c, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
+                             const double* x, long long xs, double* y, long long ys, double alpha) {
+    if (!c || !blocks || !x || !y || form < 0 || form > 2 || nlev < 0) return MIMSEM_ERR_ARG;
+    return launch_blocks_apply(c, form, nlev, (flags & MIMSEM_FLAG_TRANSPOSE) ? 1 : 0, blocks, blocks_level_stride,
+                               x, xs, y, ys, alpha, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0);
 }
 
 int mimsem_incidence_apply(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys) {

@@ -85,6 +85,9 @@ struct mimsem_ctx {
 
     int ensure_ye(long long doubles);
     int ensure_col(long long doubles);
+    double* d_kry = nullptr;            // partial sums of the Krylov multi-dot
+    long long kry_doubles = 0;
+    int ensure_kry(long long doubles);
 };
 
 // kernels (elem_kernels.hip / column_kernels.hip) ---------------------------------------------------
@@ -111,6 +114,8 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys);
+int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,
+                        const double* x, long long xs, double* y, long long ys, double alpha, int accum);
 int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out,
                   const double* f2 = nullptr, double param = 0.0);
 int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys);

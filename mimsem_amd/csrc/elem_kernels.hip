@@ -773,6 +773,47 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const int* __restrict__ idx
     if (mode) *o += buf[t]; else *o = buf[t];
 }
 
+// ---- apply caller-supplied dense element blocks: ye[e] = B_e x_e (or B_e^T x_e) -------------------------------
+// The MatMult of an operator the caller assembled per element (MatSetValues blocks) -- and the element-block
+// preconditioners of the KSP solves (PCBJACOBI with one block per element, eul/HorizSolve.cpp:77-96).
+// A workgroup takes `epb` elements: x_e is gathered into LDS, thread (element, row) forms its dot product.
+// transposed: the row index runs fastest in memory (reads of B coalesce across the threads of an element).
+__global__ __launch_bounds__(256) void k_blocks_apply(int nEl, int nlev, int nd, int epb, int transposed,
+        const int* __restrict__ idxA, const int* __restrict__ idxB, int nA,      // slots of the element DoFs: first nA from idxA, rest from idxB
+        const double* __restrict__ B, long long bstride_lev,
+        const double* __restrict__ x, long long xs, double* __restrict__ out, long long os, double alpha,
+        int direct, int accum) {
+    extern __shared__ double sx[];               // [epb][nd]
+    const int tid = threadIdx.x;
+    const long long base = (long long)blockIdx.x*epb;
+    for (int t = tid; t < epb*nd; t += 256) {
+        const long long eg = base + t/nd; const int r = t%nd;
+        double v = 0.0;
+        if (eg < (long long)nEl*nlev) {
+            const int e = (int)(eg%nEl), lev = (int)(eg/nEl);
+            const int slot = (r < nA) ? (idxA ? idxA[(size_t)e*nA + r] : e*nA + r) : idxB[(size_t)e*(nd - nA) + (r - nA)];
+            v = x[(size_t)lev*xs + slot];
+        }
+        sx[t] = v;
+    }
+    __syncthreads();
+    for (int t = tid; t < epb*nd; t += 256) {
+        const long long eg = base + t/nd; const int r = t%nd, le = t/nd;
+        if (eg >= (long long)nEl*nlev) continue;
+        const int e = (int)(eg%nEl), lev = (int)(eg/nEl);
+        const double* Be = B + (size_t)lev*bstride_lev + (size_t)e*nd*nd;
+        const double* xe = sx + le*nd;
+        double s = 0.0;
+        if (transposed) { for (int c = 0; c < nd; c++) s += Be[(size_t)c*nd + r]*xe[c]; }
+        else            { for (int c = 0; c < nd; c++) s += Be[(size_t)r*nd + c]*xe[c]; }
+        if (direct) {                           // 2-forms: never shared, written straight into y
+            const int slot = idxA ? idxA[(size_t)e*nA + r] : e*nA + r;
+            double* o = out + (size_t)lev*os + slot;
+            if (accum) *o += alpha*s; else *o = alpha*s;
+        } else out[(size_t)lev*os + (size_t)e*nd + r] = alpha*s;
+    }
+}
+
 template <int N>
 int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     using D = Dims<N>;
@@ -839,6 +880,33 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     case 7: return dispatch_apply<7>(c, op, a);
     default: return MIMSEM_ERR_UNSUPPORTED;
     }
+}
+
+int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,
+                        const double* x, long long xs, double* y, long long ys, double alpha, int accum) {
+    const ElemSizes& es = c->es;
+    const int nd = form == 1 ? 2*es.n1e : (form == 0 ? es.n0e : es.n2e);
+    const long long total = (long long)c->nEl*nlev;
+    if (total == 0) return MIMSEM_OK;
+    const int epb = std::max(1, 256/nd);
+    const unsigned grid = (unsigned)((total + epb - 1)/epb);
+    const size_t lds = (size_t)epb*nd*sizeof(double);
+    const int* ia = form == 1 ? c->d_i1x : (form == 0 ? c->d_i0 : c->d_i2);
+    const int* ib = form == 1 ? c->d_i1y : nullptr;
+    const int nA = form == 1 ? es.n1e : nd;
+    if (form == 2) {
+        hipLaunchKernelGGL(k_blocks_apply, dim3(grid), dim3(256), lds, c->stream, c->nEl, nlev, nd, epb, transposed, ia, ib, nA,
+                           B, bstride_lev, x, xs, y, ys, alpha, 1, accum);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
+    const long long per = (long long)c->nEl*nd;
+    int rc = c->ensure_ye(per*nlev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_blocks_apply, dim3(grid), dim3(256), lds, c->stream, c->nEl, nlev, nd, epb, transposed, ia, ib, nA,
+                       B, bstride_lev, x, xs, c->d_ye, per, alpha, 0, 0);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return launch_gather_sum(c, form, nlev, c->d_ye, per, accum, y, ys);
 }
 
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys) {

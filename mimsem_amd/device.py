@@ -101,7 +101,24 @@ class Engine:
             pass
 
     def use_stream(self, stream):
+        self._stream = stream
         check(self.L.mimsem_ctx_set_stream(self.ctx, C.c_void_p(stream.cuda_stream)), "set_stream")
+
+    def on_current_stream(self):
+        """context manager: launch the engine's kernels on torch's CURRENT stream (hipGraph capture, side streams), then
+        go back to the stream the engine used before"""
+        eng = self
+
+        class _Bind:
+            def __enter__(self_b):
+                self_b.prev = getattr(eng, "_stream", None)
+                eng.use_stream(torch.cuda.current_stream(eng.device))
+
+            def __exit__(self_b, *exc):
+                if self_b.prev is not None:
+                    eng.use_stream(self_b.prev)
+                return False
+        return _Bind()
 
     def sync(self):
         check(self.L.mimsem_ctx_sync(self.ctx), "sync")
@@ -212,6 +229,22 @@ class Engine:
               "mimsem_op_element_matrices_ex(UMAT_RAY)")
         return out
 
+    def blocks_apply(self, form, blocks, x, transpose=False, alpha=1.0, accum=False, out=None):
+        """y = alpha * sum_e P_e^T B_e P_e x with caller-supplied element blocks [nEl, nd, nd] (same on every level) or
+        [nlev, nEl, nd, nd]; form 0/1/2 (1-forms: nd = 2*n1e, x-edges then y-edges)."""
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        nlev = x2.shape[0]
+        nd = {0: self.n0e, 1: 2 * self.n1e, 2: self.n2e}[form]
+        assert blocks.shape[-3:] == (self.nEl, nd, nd) and x2.shape[1] == self.sizes[form]
+        bstride = blocks.stride(0) if blocks.dim() == 4 else 0
+        assert blocks.dim() == 3 or blocks.shape[0] == nlev
+        y = out if out is not None else torch.empty(nlev, self.sizes[form], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        flags = (4 if transpose else 0) | (2 if accum else 0)
+        check(self.L.mimsem_elem_blocks_apply(self.ctx, form, nlev, flags, _ptr(blocks), bstride, _ptr(x2), x2.stride(0),
+                                              _ptr(y2), y2.stride(0), alpha), "mimsem_elem_blocks_apply")
+        return y if x.dim() == 2 else y2[0]
+
     def pvec(self, lev0=0, nlev=1, scale=1.0, h2=None):
         y = torch.empty(nlev, self.sizes[0], dtype=torch.float64, device=self.device)
         check(self.L.mimsem_pvec(self.ctx, lev0, nlev, scale, _ptr(h2), h2.stride(0) if h2 is not None else 0,
@@ -312,6 +345,20 @@ class Engine:
                                                    _ptr(F_u), _ptr(F_rho), _ptr(F_eta), _ptr(F_pi),
                                                    _ptr(d_u), _ptr(d_rho), _ptr(d_eta), _ptr(d_pi)), "solve_schur_eta")
         return d_u, d_rho, d_eta, d_pi
+
+    # ---- Krylov building blocks ----------------------------------------------------------------
+    def mdot(self, V, w, k=None, out=None):
+        """h[i] = <V[i], w> for i < k; V: [m, n] contiguous rows"""
+        k = V.shape[0] if k is None else k
+        h = out if out is not None else torch.empty(k, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_krylov_mdot(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(w), _ptr(h)), "krylov_mdot")
+        return h
+
+    def maxpy(self, V, h, w, alpha=1.0, k=None):
+        """w += alpha * sum_{i<k} h[i] V[i]  (in place)"""
+        k = V.shape[0] if k is None else k
+        check(self.L.mimsem_krylov_maxpy(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(h), alpha, _ptr(w)), "krylov_maxpy")
+        return w
 
     # ---- halo pack / unpack ---------------------------------------------------------------------
     def halo_pack(self, idx, v):

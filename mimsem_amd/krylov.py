@@ -8,10 +8,13 @@ on the device: no host synchronisation inside the iteration).  Mat-vecs are the 
 import torch
 
 
-def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, allreduce=None):
+def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, allreduce=None, precond=None):
     """Solve A x = b for a batch of systems (rows of b).  apply_A(x)->A x on [nlev, n] tensors.
-    minv: elementwise preconditioner (Jacobi) of the same shape.  allreduce(t): sums per-level scalars over ranks
-    (multi-GPU: each rank holds ghost copies, the caller's dot weights handle ownership)."""
+    minv: elementwise preconditioner (Jacobi) of the same shape, or precond(r)->z (symmetric positive definite).
+    allreduce(t): sums per-level scalars over ranks (multi-GPU: each rank holds ghost copies, the caller's dot
+    weights handle ownership)."""
+    if precond is not None:
+        return _pcg_general(apply_A, b, precond, x0, rtol, maxit, check_every, allreduce)
     x = torch.zeros_like(b) if x0 is None else x0.clone()
     r = b - apply_A(x) if x0 is not None else b.clone()
     z = r * minv if minv is not None else r
@@ -34,6 +37,30 @@ def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, a
         if its % check_every == 0:                    # the only host synchronisation
             if bool((torch.sqrt(dot(r, r)) / bnorm).max() < rtol):
                 break
+    return x, its
+
+
+def _pcg_general(apply_A, b, precond, x0, rtol, maxit, check_every, allreduce):
+    x = torch.zeros_like(b) if x0 is None else x0.clone()
+    r = b - apply_A(x) if x0 is not None else b.clone()
+    z = precond(r)
+    p = z.clone()
+    dot = (lambda u, v: (u * v).sum(dim=1)) if allreduce is None else (lambda u, v: allreduce((u * v).sum(dim=1)))
+    rz = dot(r, z)
+    bnorm = torch.sqrt(dot(b, b)).clamp_min(1e-300)
+    its = 0
+    for it in range(maxit):
+        Ap = apply_A(p)
+        alpha = rz / dot(p, Ap).clamp_min(1e-300)
+        x += alpha[:, None] * p
+        r -= alpha[:, None] * Ap
+        its = it + 1
+        if its % check_every == 0 and bool((torch.sqrt(dot(r, r)) / bnorm).max() < rtol):
+            break
+        z = precond(r)
+        rz_new = dot(r, z)
+        p = z + (rz_new / rz.clamp_min(1e-300))[:, None] * p
+        rz = rz_new
     return x, its
 
 
@@ -62,7 +89,7 @@ class MassSolver:
         return pcg(lambda v: self.apply(v, lev0), b, minv=self.minv[lev0:lev0 + nlev], rtol=rtol, maxit=maxit)
 
 
-def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30, maxit=1000, dot=None):
+def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30, maxit=1000, dot=None, eng=None):
     """Restarted, left-preconditioned GMRES for ONE (nonsymmetric) system on device tensors of any shape -- the stand-in for
     the reference's KSPGMRES solves on the packed [u,h] operator A and on the upwinded M0h (src/SWEqn_Picard.cpp:600-606, :348-353).
     As in PETSc's default the PRECONDITIONED residual is monitored.  Arnoldi by classical Gram-Schmidt with one
@@ -98,10 +125,15 @@ def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30,
         k = 0
         for j in range(restart):
             w = M(A(V[j]))
-            h = dot(V[:j + 1], w)
-            w = w - h @ V[:j + 1]
-            h2 = dot(V[:j + 1], w)                      # re-orthogonalisation
-            w = w - h2 @ V[:j + 1]
+            if eng is not None:                         # the engine's one-pass multi-dot / multi-axpy kernels
+                w = w.contiguous() if not w.is_contiguous() else w
+                h = eng.mdot(V, w, k=j + 1); eng.maxpy(V, h, w, alpha=-1.0, k=j + 1)
+                h2 = eng.mdot(V, w, k=j + 1); eng.maxpy(V, h2, w, alpha=-1.0, k=j + 1)
+            else:
+                h = dot(V[:j + 1], w)
+                w = w - h @ V[:j + 1]
+                h2 = dot(V[:j + 1], w)                  # re-orthogonalisation
+                w = w - h2 @ V[:j + 1]
             hn = torch.sqrt(dot(w.view(1, -1), w))
             col = torch.cat([h + h2, hn]).tolist()      # the host synchronisation of this iteration
             for i in range(j + 2):
@@ -127,3 +159,111 @@ def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30,
         if res <= tol:
             break
     return x.view(shape), its, res / bnorm
+
+
+class GraphedGMRES:
+    """The same restarted, left-preconditioned GMRES with the whole Arnoldi step j -- operator, preconditioner, two
+    classical Gram-Schmidt passes against the j+1 basis vectors (the engine's mdot/maxpy kernels), normalisation, the copy
+    of the new Hessenberg column to pinned host memory -- captured in a hipGraph (one per j, captured lazily, reused by
+    every later solve with the same operator) and replayed: the inner loop is launch-bound (~20 small kernels per
+    iteration on 1e5 unknowns), so one graph launch + one stream synchronisation per iteration replaces them.
+
+    body(v) -> M^-1 A v must be capturable: fixed shapes, no host synchronisation, every kernel on the current stream
+    (`eng.on_current_stream()` rebinds the engine's HIP stream for the capture)."""
+
+    def __init__(self, eng, n, body, restart=30, dtype=torch.float64):
+        self.eng, self.n, self.m, self.body = eng, n, restart, body
+        dev = eng.device
+        self.V = torch.zeros(restart + 1, n, dtype=dtype, device=dev)
+        self.h = torch.zeros(restart + 1, dtype=dtype, device=dev)
+        self.h2 = torch.zeros(restart + 1, dtype=dtype, device=dev)
+        self.col = torch.zeros(restart + 2, dtype=dtype, device=dev)
+        self.col_host = torch.zeros(restart + 2, dtype=dtype).pin_memory()
+        self.graphs = [None] * restart
+        self.pool = None
+
+    def _step(self, j):
+        eng, V, k = self.eng, self.V, j + 1
+        w = self.body(V[j:j + 1]).reshape(-1)
+        if not w.is_contiguous():
+            w = w.contiguous()
+        eng.mdot(V, w, k=k, out=self.h); eng.maxpy(V, self.h, w, alpha=-1.0, k=k)
+        eng.mdot(V, w, k=k, out=self.h2); eng.maxpy(V, self.h2, w, alpha=-1.0, k=k)      # re-orthogonalisation
+        hn2 = self.col[self.m + 1:self.m + 2]
+        eng.mdot(w.view(1, -1), w, k=1, out=hn2)
+        hn2.sqrt_()
+        torch.div(w, hn2, out=V[j + 1])
+        torch.add(self.h[:k], self.h2[:k], out=self.col[:k])
+        self.col_host.copy_(self.col, non_blocking=True)
+
+    def _graph(self, j):
+        if self.graphs[j] is None:
+            dev = self.eng.device
+            keep = self.V[j + 1].clone()
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s), self.eng.on_current_stream():
+                self._step(j)                           # warm-up: engine / allocator workspaces get their final size here
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool), self.eng.on_current_stream():
+                self._step(j)
+            if self.pool is None:
+                self.pool = g.pool()
+            torch.cuda.synchronize(dev)
+            self.V[j + 1].copy_(keep)
+            self.graphs[j] = g
+        return self.graphs[j]
+
+    def solve(self, apply_A, b, precond, x0=None, rtol=1e-14, atol=1e-50, maxit=1000):
+        """apply_A / precond are used for the (un-graphed) residual at each restart; the graphed steps do the iterations"""
+        shape = b.shape
+        bf = b.reshape(-1)
+        m = self.m
+        dev = self.eng.device
+        x = torch.zeros_like(bf) if x0 is None else x0.reshape(-1).clone()
+        pb = precond(b).reshape(-1)
+        bnorm = float(torch.linalg.vector_norm(pb))
+        if bnorm == 0.0:
+            return x.view(shape), 0, 0.0
+        tol = max(rtol * bnorm, atol)
+        its, res = 0, bnorm
+        while its < maxit:
+            r = pb.clone() if (its == 0 and x0 is None) else precond(b - apply_A(x.view(shape))).reshape(-1)
+            beta = float(torch.linalg.vector_norm(r))
+            res = beta
+            if beta <= tol:
+                break
+            self.V[0] = r / beta
+            H = [[0.0] * m for _ in range(m + 1)]
+            cs, sn, g = [0.0] * m, [0.0] * m, [0.0] * (m + 1)
+            g[0] = beta
+            k = 0
+            for j in range(m):
+                self._graph(j).replay()
+                torch.cuda.current_stream(dev).synchronize()
+                col = self.col_host.tolist()
+                for i in range(j + 1):
+                    H[i][j] = col[i]
+                H[j + 1][j] = col[m + 1]
+                for i in range(j):
+                    t = cs[i] * H[i][j] + sn[i] * H[i + 1][j]
+                    H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j]
+                    H[i][j] = t
+                d = (H[j][j] ** 2 + H[j + 1][j] ** 2) ** 0.5
+                cs[j], sn[j] = (1.0, 0.0) if d == 0.0 else (H[j][j] / d, H[j + 1][j] / d)
+                H[j][j] = d; H[j + 1][j] = 0.0
+                g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j]
+                its += 1; k = j + 1
+                res = abs(g[j + 1])
+                if res <= tol or its >= maxit or col[m + 1] == 0.0:
+                    break
+            y = [0.0] * k
+            for i in range(k - 1, -1, -1):
+                sacc = g[i] - sum(H[i][l] * y[l] for l in range(i + 1, k))
+                y[i] = sacc / H[i][i]
+            self.eng.maxpy(self.V, torch.tensor(y, dtype=bf.dtype, device=bf.device), x, alpha=1.0, k=k)
+            if res <= tol:
+                break
+        return x.view(shape), its, res / bnorm

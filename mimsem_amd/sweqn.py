@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .krylov import gmres, pcg
+from .krylov import GraphedGMRES, gmres, pcg
 
 RAD_EARTH = 6371220.0          # src/SWEqn_Picard.cpp:22-23
 RAD_SPHERE = 6371220.0
@@ -18,7 +18,7 @@ UP_TAU = 0.5                   # :30
 
 
 class SWEqn:
-    def __init__(self, eng, quad_coords, krylov_rtol=1e-14):
+    def __init__(self, eng, quad_coords, krylov_rtol=1e-14, use_graphs=True):
         """eng: Engine over the whole sphere (numbering="global", nk=1, unit thickness); quad_coords: [nq, 3] xyz of the
         quadrature-point grid in the engine's quad-grid numbering (Geom::x)."""
         assert eng.nk == 1
@@ -30,10 +30,13 @@ class SWEqn:
         xq = torch.as_tensor(quad_coords, dtype=torch.float64, device=eng.device)
         self.lat = torch.asin(xq[:, 2] / RAD_SPHERE)
         self.m0 = eng.pvec(0, 1, 1.0)                            # M0 is diagonal (collocated 0-forms): Pmat as a vector
-        self.m1_minv = self._m1_jacobi()
+        self.m1_pre = self._m1_element_blocks()
+        self.m2_inv = eng.element_matrices("WMATINV").view(eng.nEl, eng.n2e, eng.n2e)            # M2 is element-block diagonal: its exact inverse, built once
         self.coriolis()
         self.A_dt = None
         self.its = {}
+        self.graphs = use_graphs
+        self._gA = None
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
     def M1(self, u): return self.eng.apply("UMAT", u)
@@ -45,20 +48,26 @@ class SWEqn:
     def R_up(self, q, ul, dt, u): return self.eng.apply_up("ROTMAT_UP", u, q, ul, fac=UP_TAU, dt=dt)
     def E(self, name, x): return self.eng.incidence(name, x)
 
-    def _m1_jacobi(self):
+    def _m1_element_blocks(self):
+        """element-block preconditioner of M1 (the reference: PCBJACOBI with one block per element, :88-90):
+        P^-1 = sum_e R_e^T D_e (M1_e)^-1 D_e R_e, D_e = 1/(number of elements sharing the edge) -- cond(P^-1 M1) ~ 1.2"""
         eng = self.eng
         n1e = eng.n1e
-        ix = torch.as_tensor(eng.mesh.inds1x, device=eng.device).long().reshape(-1)
-        iy = torch.as_tensor(eng.mesh.inds1y, device=eng.device).long().reshape(-1)
-        em = eng.element_matrices("UMAT").view(eng.nEl, 4, n1e, n1e)
-        d = eng.zeros(1, eng.sizes[1])
-        d[0].index_add_(0, ix, torch.diagonal(em[:, 0], dim1=1, dim2=2).reshape(-1))
-        d[0].index_add_(0, iy, torch.diagonal(em[:, 3], dim1=1, dim2=2).reshape(-1))
-        return 1.0 / d
+        em = eng.element_matrices("UMAT").view(eng.nEl, 2, 2, n1e, n1e)
+        B = em.permute(0, 1, 3, 2, 4).reshape(eng.nEl, 2 * n1e, 2 * n1e)        # [[UtQU, UtQV], [VtQU, VtQV]]
+        idx = torch.cat([torch.as_tensor(eng.mesh.inds1x, device=eng.device), torch.as_tensor(eng.mesh.inds1y, device=eng.device)], dim=1).long()
+        mult = torch.zeros(eng.sizes[1], dtype=torch.float64, device=eng.device)
+        mult.index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
+        d = 1.0 / mult[idx]                                                      # [nEl, 2 n1e]
+        Binv = torch.linalg.inv(B)
+        return (d[:, :, None] * Binv * d[:, None, :]).contiguous()
+
+    def precond_M1(self, r, out=None):
+        return self.eng.blocks_apply(1, self.m1_pre, r, transpose=True, out=out)        # symmetric blocks: the coalesced read order
 
     def solve_M1(self, b, key="M1"):
         """KSPSolve(ksp, b, x) on M1 (:84-92): SPD => preconditioned CG reaches the same solution"""
-        x, its = pcg(self.M1, b, minv=self.m1_minv, rtol=self.rtol, maxit=1000, check_every=5)
+        x, its = pcg(self.M1, b, precond=self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
         self.its[key] = its
         return x
 
@@ -95,7 +104,7 @@ class SWEqn:
         m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
         if dt > 1.0e-6:
             A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
-            q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000)
+            q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000, eng=self.eng)
             self.its["q"] = its
             return q
         return rhs / m0h
@@ -127,16 +136,27 @@ class SWEqn:
 
     def apply_A(self, x, dt):
         """:609-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]]"""
-        u, h = self.unpack(x)
+        eng, n1 = self.eng, self.n1
+        u, h = x[:, :n1], x[:, n1:]                                # views of the packed vector (one row => contiguous)
         a = ROS_ALPHA * dt
-        yu = self.M1(u) + a * self.R(self.fg, u) + (a * self.grav) * self.E("E12", self.M2(h))
-        yh = (a * H_MEAN) * self.M2(self.E("E21", u)) + self.M2(h)
-        return self.pack(yu, yh)
+        y = torch.empty_like(x)
+        yu, yh = y[:, :n1], y[:, n1:]
+        eng.apply("UMAT", u, out=yu)
+        eng.apply("ROTMAT", u, f=self.fg, alpha=a, flags=2, out=yu)                       # += a R(f) u
+        yu += (a * self.grav) * eng.incidence("E12", eng.apply("WMAT", h))
+        w = eng.incidence("E21", u)
+        w *= a * H_MEAN
+        w += h
+        eng.apply("WMAT", w, out=yh)                                                      # M2 (a H E21 u + h)
+        return y
 
     def precond_A(self, r):
-        """block diagonal: Jacobi on M1, the exact element-wise inverse on M2 (WmatInv)"""
-        u, h = self.unpack(r)
-        return self.pack(u * self.m1_minv, self.eng.apply("WMATINV", h))
+        """block diagonal: the element-block preconditioner on M1, the exact element-wise inverse on M2 (WmatInv)"""
+        n1 = self.n1
+        y = torch.empty_like(r)
+        self.precond_M1(r[:, :n1], out=y[:, :n1])
+        self.eng.blocks_apply(2, self.m2_inv, r[:, n1:], out=y[:, n1:])
+        return y
 
     def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
         """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
@@ -146,8 +166,14 @@ class SWEqn:
         it, hist = 0, []
         while True:
             f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot)
-            dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
-                                 restart=restart, maxit=1000)
+            if self.graphs:
+                if self._gA is None or self._gA[0] != (dt, restart):       # the operator is fixed for a given dt: capture once
+                    self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2,
+                                                            lambda v: self.precond_A(self.apply_A(v, dt)), restart=restart))
+                dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, self.precond_A, rtol=self.rtol, maxit=1000)
+            else:
+                dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
+                                     restart=restart, maxit=1000, eng=self.eng)
             self.its["A"] = its
             x = x + dx
             uj, hj = self.unpack(x)
@@ -171,7 +197,7 @@ class SWEqn:
 
     def init2(self, hq):
         """hq: [nq] -> 2-form h = M2^-1 WtQ hq (M2 is element-block diagonal: exact inverse)"""
-        return self.eng.apply("WMATINV", self.eng.apply("WTQ", hq.reshape(1, -1).contiguous()))
+        return self.eng.blocks_apply(2, self.m2_inv, self.eng.apply("WTQ", hq.reshape(1, -1).contiguous()))
 
 
 def williamson2(xq, alpha=0.25 * math.pi):

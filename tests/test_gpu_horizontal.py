@@ -222,3 +222,34 @@ def test_umat_ray_held_suarez_friction(setup):
     for k in range(3):
         wk, _ = P.umat_ray(xs[k], k, SCALE, dt, eks[k], es)
         assert rel_l2(got3[k], wk) < TOL
+
+
+def test_element_blocks_apply(setup):
+    """mimsem_elem_blocks_apply: MatMult with caller-supplied element blocks (the reference's MatSetValues blocks), all forms"""
+    eng, P, rng = setup
+    import torch
+    r = np.random.default_rng(63)
+    n1e = P.n1e
+    x = r.standard_normal((2, P.n1))
+    em = eng.element_matrices("UMAT", lev=1, scale=SCALE, flags=1).view(P.nEl, 2, 2, n1e, n1e)
+    B = em.permute(0, 1, 3, 2, 4).reshape(P.nEl, 2 * n1e, 2 * n1e).contiguous()
+    want = eng.apply("UMAT", eng.tensor(x), lev0=1, scale=SCALE, flags=1)            # level 1 geometry on both rows
+    want1 = eng.apply("UMAT", eng.tensor(x[1]), lev0=1, scale=SCALE, flags=1)
+    got = eng.blocks_apply(1, B, eng.tensor(x))
+    assert rel_l2(got[1].cpu().numpy(), want1.cpu().numpy()) < TOL
+    idx = {0: P.elinds("n0"), 2: P.elinds("n2"), 1: np.concatenate([P.elinds("n1x"), P.elinds("n1y")], axis=1)}
+    for form, nd, nv in ((0, P.n0e, P.n0), (1, 2 * n1e, P.n1), (2, P.n2e, P.n2)):
+        Bl = r.standard_normal((2, P.nEl, nd, nd))                                   # different blocks per level, nonsymmetric
+        xv = r.standard_normal((2, nv))
+        for tr in (False, True):
+            ref = np.zeros((2, nv))
+            for lev in range(2):
+                for e in range(P.nEl):
+                    Be = Bl[lev, e].T if tr else Bl[lev, e]
+                    ref[lev, idx[form][e]] += Be @ xv[lev, idx[form][e]]
+            got = eng.blocks_apply(form, eng.tensor(Bl), eng.tensor(xv), transpose=tr, alpha=0.5).cpu().numpy()
+            assert rel_l2(got, 0.5 * ref) < 1e-12, (form, tr)
+    y0 = eng.tensor(r.standard_normal((2, P.n2))); keep = y0.clone()
+    B2 = eng.tensor(r.standard_normal((P.nEl, P.n2e, P.n2e))); x2 = eng.tensor(r.standard_normal((2, P.n2)))
+    eng.blocks_apply(2, B2, x2, accum=True, out=y0)
+    assert rel_l2((y0 - keep).cpu().numpy(), eng.blocks_apply(2, B2, x2).cpu().numpy()) < 1e-12

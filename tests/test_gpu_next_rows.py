@@ -108,3 +108,19 @@ def test_periodic_box_p4_global_apply(oracle):
     assert np.linalg.norm(y - M1 @ x) / np.linalg.norm(M1 @ x) < 1e-10
     y2 = eng.apply("WTQUMAT", xt, f=ut, lev0=0, scale=SCALE)[lev].cpu().numpy()
     assert np.linalg.norm(y2 - K @ x) / np.linalg.norm(K @ x) < 1e-10
+
+
+def test_krylov_mdot_maxpy(sphere):
+    """the Gram-Schmidt building blocks of the device GMRES: h = V w and w += alpha V^T h, bitwise reproducible"""
+    import torch
+    cs, eng, mats, rng = sphere
+    n, m = 93312, 31
+    V = eng.tensor(rng.standard_normal((m, n))); w = eng.tensor(rng.standard_normal(n))
+    for k in (1, 7, m):
+        h = eng.mdot(V, w, k=k)
+        ref = (V[:k].double() @ w)
+        assert float((h - ref).abs().max() / ref.abs().max()) < 1e-13
+        assert torch.equal(h, eng.mdot(V, w, k=k))
+        w2 = w.clone(); eng.maxpy(V, h, w2, alpha=-0.5, k=k)
+        ref2 = w - 0.5 * (h @ V[:k])
+        assert float((w2 - ref2).abs().max()) < 1e-10 * float(ref2.abs().max())

@@ -77,3 +77,8 @@ def test_sw_time_step(sw, q_exact, nits, dt):
     assert np.allclose(S.history, O.history, rtol=1e-4, atol=1e-13)          # the Picard iteration takes the same path
     # the update itself (not just the state) agrees: the step moved the fields by ~1e-3, compare the increments
     assert rel_l2(ud[0].cpu().numpy() - u0, ur - u0) < 1e-6
+    # the hipGraph-captured Arnoldi step and the eager GMRES give the same step
+    from mimsem_amd.sweqn import SWEqn
+    S2 = SWEqn(eng, O.xq[eng.mesh.gidq], use_graphs=False)
+    ue, he = S2.solve(_t(eng, u0), _t(eng, h0), dt, nits=nits, q_exact=q_exact)
+    assert rel_l2(ue[0].cpu().numpy(), ud[0].cpu().numpy()) < 1e-11 and rel_l2(he[0].cpu().numpy(), hd[0].cpu().numpy()) < 1e-11
