@@ -246,6 +246,9 @@ int mimsem_colop_blocks_ex(mimsem_ctx* ctx, int colop, unsigned flags, double pa
 int mimsem_colop_apply_ex(mimsem_ctx* ctx, int colop, unsigned flags, int transpose, double param,
                           const double* f1, const double* f2, const double* uh, long long uh_stride,
                           const double* x, double* y);
+/* C1 VertOps::vertOps (eul/VertOps.cpp:134-182): MatMult with V10 (which 0: [nEl][(nk-1)*n2e] -> [nEl][nk*n2e]),
+ * V01 = -V10^T (which 1: nk -> nk-1 slots) or V10_full (which 2: nk+1 -> nk slots); pure +-1 stencils, bit-exact */
+int mimsem_column_incidence(mimsem_ctx* ctx, int which, const double* x, double* y);
 /* VertSolve::diagTheta_up (eul/VertSolve.cpp:354-384) for every column: theta [nEl][(nk+1)*n2e]                */
 int mimsem_column_diag_theta_up(mimsem_ctx* ctx, double dt, const double* rho, const double* rt,
                                 const double* uh, long long uh_stride, double* theta);

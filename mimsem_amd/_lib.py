@@ -62,6 +62,7 @@ _SIGS = {
     "mimsem_column_helmholtz_blocks": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*5),
     "mimsem_colop_blocks_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
     "mimsem_colop_apply_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp, c_dp]),
+    "mimsem_column_incidence": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp]),
     "mimsem_column_diag_theta_up": (C.c_int, [C.c_void_p, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
     "mimsem_column_temp_forcing_hs": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double, C.c_uint] + [c_dp]*14),

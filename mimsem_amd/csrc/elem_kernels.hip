@@ -435,6 +435,19 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
 #pragma unroll
                     for (int i = 0; i < N; i++) { cx -= dxs[i]; cy -= dys[i]; s_ex[el][q*N + i] = cx; s_ey[el][q*N + i] = cy; }
                 }
+                if constexpr (TUP == 1 || TUP == 3) {
+                    if (a.flags & MIMSEM_FLAG_TRANSPOSE) {
+                        // MT = M^T (MatTranspose, Assembly.cpp:261, :559): the TRIAL side carries the departure-point basis --
+                        // x is interpolated with this point's own upwinded tables, the projection below is the standard one
+                        u = 0.0; v = 0.0;
+                        for (int i = 0; i < D::n1e; i++) {
+                            const double ty = (TUP == 3) ? s_ey[el][q*N + i/D::np1] : sE[qy*N + i/D::np1];
+                            const double sx = (TUP == 3) ? s_ex[el][q*N + i%N] : sE[qx*N + i%N];
+                            u += s_x[el][i]*(s_lx[el][q*D::np1 + i%D::np1]*ty);
+                            v += s_x[el][D::n1e + i]*(sx*s_ly[el][q*D::np1 + i/N]);
+                        }
+                    }
+                }
             } else if constexpr (T::up) {
                 // departure point of this quadrature point: x_q - tau * (velocity in element coordinates)
                 double gu, gv;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
                     double yx = 0.0, yy = 0.0;
                     const int ixx = q%D::np1, iyx = q/D::np1;     // x-normal edge: node in x, edge fn in y
                     const int ixy = q%N,      iyy = q/N;          // y-normal edge: edge fn in x, node in y
-                    if constexpr (TUP == 0) {
+                    if (TUP == 0 || (a.flags & MIMSEM_FLAG_TRANSPOSE)) {
 #pragma unroll
                         for (int k = 0; k < D::mp1; k++) {
                             yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];

@@ -298,6 +298,14 @@ class Engine:
                                            uh.stride(0) if uh is not None else 0, _ptr(x), _ptr(y)), "colop_apply_ex(%s)" % colop)
         return y
 
+    def column_incidence(self, which, x):
+        """'V10' | 'V01' | 'V10_full' applied to every column (VertOps::vertOps)"""
+        w = dict(V10=0, V01=1, V10_full=2)[which]
+        ny = self.nk - 1 if w == 1 else self.nk
+        y = torch.empty(self.nEl, ny * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_incidence(self.ctx, w, _ptr(x), _ptr(y)), "column_incidence")
+        return y
+
     def diag_theta_up(self, dt, rho, rt, uh):
         th = torch.empty(self.nEl, (self.nk + 1) * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_diag_theta_up(self.ctx, dt, _ptr(rho), _ptr(rt), _ptr(uh), uh.stride(0), _ptr(th)), "diag_theta_up")

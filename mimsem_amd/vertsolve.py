@@ -20,18 +20,11 @@ class VertSolve:
 
     def V10(self, x):
         """MatMult(vo->V10, x, y): (nk x (nk-1)) -I/+I vertical divergence (eul/VertOps.cpp:134-163)"""
-        n, nk = self.n2e, self.nk
-        xv = x.view(x.shape[0], nk - 1, n)
-        y = torch.zeros(x.shape[0], nk, n, dtype=x.dtype, device=x.device)
-        y[:, :-1] += xv
-        y[:, 1:] -= xv
-        return y.view(x.shape[0], nk * n)
+        return self.eng.column_incidence("V10", x.contiguous())
 
     def V01(self, x):
         """MatMult(vo->V01, x, y): V01 = -V10^T, vertical gradient across interfaces"""
-        n, nk = self.n2e, self.nk
-        xv = x.view(x.shape[0], nk, n)
-        return (xv[:, 1:] - xv[:, :-1]).reshape(x.shape[0], (nk - 1) * n)
+        return self.eng.column_incidence("V01", x.contiguous())
 
     def diagnose_F_z(self, velz1, velz2, rho1, rho2):
         """eul/VertSolve.cpp:237-260"""

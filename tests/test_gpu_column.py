@@ -279,3 +279,20 @@ def test_schur_column_3_pentadiagonal(setup, flags):
         for name, got in (("d_rt", d_rt), ("d_u", d_u), ("d_pi", d_pi), ("d_rho", d_rho),
                           ("F_u", dFu), ("F_rho", dFrho), ("F_rt", dFrt), ("F_pi", dFpi)):
             assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name
+
+
+def test_vertical_incidence(setup):
+    """C1 VertOps::vertOps (eul/VertOps.cpp:134-182): V10, V01 = -V10^T, V10_full as bit-exact +-1 stencils"""
+    eng, P = setup
+    nk, n2, nEl = P.nk, P.n2e, P.nEl
+    V10 = np.zeros((nk * n2, (nk - 1) * n2)); V10f = np.zeros((nk * n2, (nk + 1) * n2))
+    for k in range(nk):
+        for i in range(n2):
+            if k > 0: V10[k*n2+i, (k-1)*n2+i] = -1.0
+            if k < nk - 1: V10[k*n2+i, k*n2+i] = +1.0
+            V10f[k*n2+i, k*n2+i] = -1.0; V10f[k*n2+i, (k+1)*n2+i] = +1.0
+    r = np.random.default_rng(2)
+    xm, xk, xp = (r.integers(-50, 50, (nEl, m * n2)).astype(np.float64) for m in (nk - 1, nk, nk + 1))
+    assert np.array_equal(eng.column_incidence("V10", eng.tensor(xm)).cpu().numpy(), xm @ V10.T)
+    assert np.array_equal(eng.column_incidence("V01", eng.tensor(xk)).cpu().numpy(), xk @ (-V10))
+    assert np.array_equal(eng.column_incidence("V10_full", eng.tensor(xp)).cpu().numpy(), xp @ V10f.T)

@@ -173,6 +173,11 @@ def test_eul_upwinded_test_functions(setup, which):
         want = P.uvec_hu_up(lev, SCALE, vel, h, 1.0 / 3.0, tau, u2)
         got = eng.apply_up("UVEC_HU_UP", t(vel), t(h), t(u2), lev0=lev, scale=SCALE, tau=tau, alpha=1.0 / 3.0)
     assert rel_l2(got.cpu().numpy(), want) < TOL
+    if which < 2:      # MT = MatTranspose(M) (Assembly.cpp:261, :559): the transposed apply of the same operator
+        wantT = P.apply_testup(which, x, lev, SCALE, tau, u1 if which == 0 else h, u2 if which == 0 else u1, transpose=True)
+        gotT = (eng.apply_up("UMAT_UP", t(x), t(u1), t(u2), lev0=lev, scale=SCALE, tau=tau, flags=4) if which == 0 else
+                eng.apply_up("UHMAT_UP", t(x), t(h), t(u1), lev0=lev, scale=SCALE, tau=tau, flags=4))
+        assert rel_l2(gotT.cpu().numpy(), wantT) < TOL
 
 
 def _exner_fields(P, r, lev):
