@@ -278,6 +278,13 @@ int mimsem_krylov_maxpy(mimsem_ctx* ctx, int k, long long n, const double* V, lo
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer
  * (torch.distributed / ncclSend-ncclRecv) on the buffers these calls fill.
  * idx: device int32 list of vector slots; buf: device [nlev][count].                              */
+/* The same for ALL neighbour ranks in one launch: idx = concatenated slot lists, segment s = [seg_off[s], seg_off[s+1])
+ * (host array, nseg+1 entries); buf is segment-major [segment][level][slot], i.e. one contiguous message per neighbour
+ * (alltoallv layout).  mode 0 = pack (v -> buf), 1 = unpack/INSERT, 2 = unpack/ADD; only segments [seg_begin, seg_end) are
+ * touched (callers split an ADD into ranges without repeated target slots to keep the sums ordered).                      */
+#define MIMSEM_HALO_MAX_SEGMENTS 64
+int mimsem_halo_segments(mimsem_ctx* ctx, const int* idx, int nseg, const int* seg_off, int seg_begin, int seg_end,
+                         int nlev, int mode, double* buf, double* v, long long v_stride);
 int mimsem_halo_pack(mimsem_ctx* ctx, const int* idx, int count, int nlev,
                      const double* v, long long v_stride, double* buf);
 /* mode 0 = INSERT_VALUES (SCATTER_FORWARD ghost fill), 1 = ADD_VALUES (SCATTER_REVERSE reduce)     */

@@ -68,6 +68,7 @@ _SIGS = {
     "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double, C.c_uint] + [c_dp]*14),
     "mimsem_krylov_mdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp]),
     "mimsem_krylov_maxpy": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, C.c_double, c_dp]),
+    "mimsem_halo_segments": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
     "mimsem_halo_pack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_halo_unpack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
 }

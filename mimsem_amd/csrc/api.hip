@@ -513,4 +513,14 @@ int mimsem_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int m
     return launch_halo_unpack(c, idx, count, nlev, mode, buf, v, vs);
 }
 
+// all neighbours in one launch; buf is segment-major [segment][level][slot]
+int mimsem_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int seg_begin, int seg_end, int nlev, int mode,
+                         double* buf, double* v, long long vs) {
+    if (!c || !idx || !seg_off || !buf || !v || nseg < 0 || nseg > MIMSEM_HALO_MAX_SEGMENTS || nlev < 0 || mode < 0 || mode > 2)
+        return MIMSEM_ERR_ARG;
+    if (seg_begin < 0 || seg_end < seg_begin || seg_end > nseg) return MIMSEM_ERR_ARG;
+    for (int i = 0; i < nseg; i++) if (seg_off[i + 1] < seg_off[i]) return MIMSEM_ERR_ARG;
+    return launch_halo_segments(c, idx, nseg, seg_off, seg_begin, seg_end, nlev, mode, buf, v, vs);
+}
+
 }  // extern "C"

@@ -827,6 +827,24 @@ __global__ __launch_bounds__(256) void k_blocks_apply(int nEl, int nlev, int nd,
     }
 }
 
+// all neighbours of a rank in ONE launch: the list idx[] is the concatenation of the per-neighbour slot lists
+// (segment s = [off[s], off[s+1])); buf is laid out segment-major, [segment][level][slot] -- each neighbour's message is
+// one contiguous range, ready for a single alltoallv / grouped send-recv.
+struct HaloSegs { int nseg; int off[MIMSEM_HALO_MAX_SEGMENTS + 1]; };
+__global__ __launch_bounds__(256) void k_halo_segments(HaloSegs sg, int s_begin, int s_end, int nlev, int mode /* 0 pack, 1 insert, 2 add */,
+        const int* __restrict__ idx, double* __restrict__ buf, double* __restrict__ v, long long vs) {
+    const int g0 = sg.off[s_begin], total = sg.off[s_end] - g0;
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= (long long)total*nlev) return;
+    const int gi = g0 + (int)(t%total), lev = (int)(t/total);
+    int s = s_begin;
+    while (gi >= sg.off[s + 1]) s++;
+    const int cnt = sg.off[s + 1] - sg.off[s];
+    double* b = buf + (size_t)sg.off[s]*nlev + (size_t)lev*cnt + (gi - sg.off[s]);
+    double* o = v + (size_t)lev*vs + idx[gi];
+    if (mode == 0) *b = *o; else if (mode == 1) *o = *b; else *o += *b;
+}
+
 template <int N>
 int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     using D = Dims<N>;
@@ -1005,6 +1023,16 @@ int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long l
     return MIMSEM_OK;
 }
 
+int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,
+                         double* buf, double* v, long long vs) {
+    HaloSegs sg; sg.nseg = nseg;
+    for (int i = 0; i <= nseg; i++) sg.off[i] = seg_off[i];
+    const long long total = (long long)(seg_off[s_end] - seg_off[s_begin])*nlev;
+    if (total == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_halo_segments, dim3((unsigned)((total + 255)/256)), dim3(256), 0, c->stream, sg, s_begin, s_end, nlev, mode, idx, buf, v, vs);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
 int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     const long long total = (long long)count*nlev;
     if (total == 0) return MIMSEM_OK;

@@ -369,6 +369,12 @@ class Engine:
         return w
 
     # ---- halo pack / unpack ---------------------------------------------------------------------
+    def halo_segments(self, idx, seg_off, s_begin, s_end, mode, buf, v):
+        """all neighbours in one launch (mimsem_halo_segments): mode 0 pack, 1 insert, 2 add; seg_off: host int32 array"""
+        v2 = v if v.dim() == 2 else v.unsqueeze(0)
+        check(self.L.mimsem_halo_segments(self.ctx, _ptr(idx), len(seg_off) - 1, seg_off.ctypes.data, s_begin, s_end,
+                                          v2.shape[0], mode, _ptr(buf), _ptr(v2), v2.stride(0)), "halo_segments")
+
     def halo_pack(self, idx, v):
         v2 = v if v.dim() == 2 else v.unsqueeze(0)
         buf = torch.empty(v2.shape[0], idx.numel(), dtype=torch.float64, device=self.device)

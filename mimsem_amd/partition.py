@@ -91,51 +91,94 @@ def build_plans(sphere, world, rank, gid0, gid1):
 
 class HaloExchanger:
     """REVERSE/ADD (partial sums at ghost slots -> owner adds) and FORWARD/INSERT (owner -> ghosts).
-    `engine` supplies device pack/unpack; with engine=None plain torch indexing is used (CPU/gloo tests)."""
+
+    One message per neighbour rank carrying every level; the messages of all neighbours live in ONE send and ONE receive
+    buffer (segment-major [rank][level][slot]) that are packed / unpacked by a single kernel launch and travel in a single
+    `all_to_all_single` (RCCL: one grouped send/recv launch).  Buffers are cached per level count.  `engine` supplies the
+    device pack/unpack (mimsem_halo_segments); with engine=None plain torch indexing does the same (CPU/gloo tests).
+    An ADD whose target slots repeat between neighbours (cube-corner nodes) is unpacked in rank-ordered ranges without
+    repeats, so the sums are formed in a fixed order."""
 
     def __init__(self, plan, engine=None, device=None):
         self.plan, self.engine = plan, engine
         self.device = device if device is not None else (engine.device if engine is not None else torch.device("cpu"))
-        to = lambda a: torch.as_tensor(a, dtype=torch.int32, device=self.device)
-        self.ghost = {r: to(s) for r, s in plan.ghost_slots.items()}
-        self.mirror = {r: to(s) for r, s in plan.mirror_slots.items()}
+        self.world = plan.world
+        self.sides = {"ghost": self._side(plan.ghost_slots), "mirror": self._side(plan.mirror_slots)}
+        self._bufs = {}
 
-    def _pack(self, idx, v):
+    def _side(self, slots_by_rank):
+        ranks = sorted(slots_by_rank)
+        counts = np.zeros(self.world, dtype=np.int64)
+        for r in ranks:
+            counts[r] = len(slots_by_rank[r])
+        off = np.zeros(len(ranks) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(slots_by_rank[r]) for r in ranks])
+        cat = np.concatenate([slots_by_rank[r] for r in ranks]).astype(np.int32) if ranks else np.zeros(0, dtype=np.int32)
+        # ranges of neighbours whose slot sets are pairwise disjoint (greedy, rank order)
+        ranges, seen, start = [], set(), 0
+        for i, r in enumerate(ranks):
+            sl = set(int(x) for x in slots_by_rank[r])
+            if seen & sl:
+                ranges.append((start, i)); start, seen = i, set()
+            seen |= sl
+        if ranks:
+            ranges.append((start, len(ranks)))
+        return dict(ranks=ranks, counts=counts, off=off, ranges=ranges,
+                    idx=torch.as_tensor(cat, dtype=torch.int32, device=self.device),
+                    idx_long=torch.as_tensor(cat, dtype=torch.long, device=self.device))
+
+    def _buffers(self, key, nlev, dtype):
+        k = (key, nlev, dtype)
+        if k not in self._bufs:
+            total = int(self.sides[key]["off"][-1])
+            self._bufs[k] = torch.zeros(max(total * nlev, 1), dtype=dtype, device=self.device)
+        return self._bufs[k]
+
+    def _move(self, side, mode, buf, v2, s_begin=None, s_end=None):
+        """mode 0: v -> buf (pack); 1: buf -> v (insert); 2: v += buf"""
+        nseg = len(side["ranks"])
+        s_begin = 0 if s_begin is None else s_begin
+        s_end = nseg if s_end is None else s_end
+        if nseg == 0 or s_begin == s_end:
+            return
+        nlev = v2.shape[0]
         if self.engine is not None:
-            return self.engine.halo_pack(idx, v)
-        return v[:, idx.long()].contiguous()
+            self.engine.halo_segments(side["idx"], side["off"], s_begin, s_end, mode, buf, v2)
+            return
+        off = side["off"]
+        for s in range(s_begin, s_end):
+            a, b = int(off[s]), int(off[s + 1])
+            seg = buf[a * nlev:b * nlev].view(nlev, b - a)
+            ix = side["idx_long"][a:b]
+            if mode == 0:
+                seg.copy_(v2[:, ix])
+            elif mode == 1:
+                v2[:, ix] = seg
+            else:
+                v2[:, ix] += seg
 
-    def _unpack(self, idx, buf, v, add):
-        if self.engine is not None:
-            self.engine.halo_unpack(idx, buf, v, add)
-        elif add:
-            v[:, idx.long()] += buf
-        else:
-            v[:, idx.long()] = buf
-
-    def _exchange(self, v, send, recv, add):
+    def _exchange(self, v, send_key, recv_key, add):
         v2 = v if v.dim() == 2 else v.unsqueeze(0)
-        ops, bufs = [], {}
-        for r, idx in recv.items():
-            bufs[r] = torch.empty(v2.shape[0], idx.numel(), dtype=v2.dtype, device=v2.device)
-            ops.append(dist.P2POp(dist.irecv, bufs[r], r))
-        outs = []
-        for r, idx in send.items():
-            b = self._pack(idx, v2); outs.append(b)
-            ops.append(dist.P2POp(dist.isend, b, r))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for r in sorted(recv):                      # fixed order => reproducible sums
-            self._unpack(recv[r], bufs[r], v2, add)
+        nlev = v2.shape[0]
+        snd, rcv = self.sides[send_key], self.sides[recv_key]
+        sbuf, rbuf = self._buffers(send_key, nlev, v2.dtype), self._buffers(recv_key, nlev, v2.dtype)
+        self._move(snd, 0, sbuf, v2)
+        ns, nr = int(snd["off"][-1]) * nlev, int(rcv["off"][-1]) * nlev
+        dist.all_to_all_single(rbuf[:nr], sbuf[:ns], output_split_sizes=(rcv["counts"] * nlev).tolist(),
+                               input_split_sizes=(snd["counts"] * nlev).tolist())
+        if add:
+            for (a, b) in rcv["ranges"]:                 # fixed order => reproducible sums
+                self._move(rcv, 2, rbuf, v2, a, b)
+        else:
+            self._move(rcv, 1, rbuf, v2)
 
     def reverse_add(self, v):
         """VecScatter(gtol, vl, vg, ADD_VALUES, SCATTER_REVERSE): owners accumulate the ghosts' partial sums"""
-        self._exchange(v, send=self.ghost, recv=self.mirror, add=True)
+        self._exchange(v, "ghost", "mirror", add=True)
 
     def forward_insert(self, v):
         """VecScatter(gtol, vg, vl, INSERT_VALUES, SCATTER_FORWARD): ghosts receive the owners' values"""
-        self._exchange(v, send=self.mirror, recv=self.ghost, add=False)
+        self._exchange(v, "mirror", "ghost", add=False)
 
 
 def rank_mesh(sphere, geoms_or_none, world, rank, nk, coords=None):

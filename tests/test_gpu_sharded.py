@@ -108,3 +108,58 @@ def test_plan_consistency_for_benchmark_grid():
                     assert (send is None) == (recv is None)
                     if send is not None:
                         assert np.array_equal(ga[send], gb[recv])      # same global ids, same order
+
+
+def _emulated_exchange(exs, vs, send_key, recv_key, add):
+    """what HaloExchanger._exchange does, with the all_to_all_single replaced by in-process copies between the virtual ranks"""
+    nlev = vs[0].shape[0]
+    sb = [ex._buffers(send_key, nlev, torch.float64) for ex in exs]
+    rb = [ex._buffers(recv_key, nlev, torch.float64) for ex in exs]
+    for ex, v, b in zip(exs, vs, sb):
+        ex._move(ex.sides[send_key], 0, b, v)
+    for src, ex in enumerate(exs):
+        snd = ex.sides[send_key]
+        for i, dst in enumerate(snd["ranks"]):
+            rcv = exs[dst].sides[recv_key]
+            j = rcv["ranks"].index(src)
+            a, b = int(snd["off"][i]) * nlev, int(snd["off"][i + 1]) * nlev
+            c, d = int(rcv["off"][j]) * nlev, int(rcv["off"][j + 1]) * nlev
+            assert b - a == d - c
+            rb[dst][c:d].copy_(sb[src][a:b])
+    for ex, v, b in zip(exs, vs, rb):
+        rcv = ex.sides[recv_key]
+        if add:
+            for (a, c) in rcv["ranges"]:
+                ex._move(rcv, 2, b, v, a, c)
+        else:
+            ex._move(rcv, 1, b, v)
+
+
+@gpu
+@pytest.mark.parametrize("world,form", [(2, 1), (4, 0), (8, 1), (8, 0)])
+def test_fused_halo_segments_match_global(world, form):
+    """the one-launch segment pack/unpack (mimsem_halo_segments) + the alltoallv buffer layout of HaloExchanger, 0- and 1-forms
+    (cube-corner nodes are ghosts of several ranks: the ADD is split into rank-ordered ranges)"""
+    from mimsem_amd.partition import HaloExchanger
+    nk = 3
+    cs, single = _build(1, nk)
+    dm1, eng1, _ = single[0]
+    rng = np.random.default_rng(11)
+    if form == 1:
+        xg = rng.standard_normal((nk, cs.nDofs1G))
+        want = eng1.apply("UMAT", eng1.tensor(xg), lev0=0, scale=SCALE, flags=1).cpu().numpy()
+    else:
+        xg = rng.standard_normal((nk, cs.nDofs0G))
+        want = eng1.apply("PMAT", eng1.tensor(xg), lev0=0, scale=SCALE).cpu().numpy()
+    cs, ranks = _build(world, nk)
+    exs, ys, gids = [], [], []
+    for dm, eng, plans in ranks:
+        gid = dm.gid1 if form == 1 else dm.gid0
+        x = eng.tensor(xg[:, gid])
+        ys.append(eng.apply("UMAT" if form == 1 else "PMAT", x, lev0=0, scale=SCALE, flags=1 if form == 1 else 0))
+        exs.append(HaloExchanger(plans[form], engine=eng)); gids.append(gid)
+    assert form == 1 or any(len(ex.sides["mirror"]["ranges"]) > 1 for ex in exs) or world < 8
+    _emulated_exchange(exs, ys, "ghost", "mirror", add=True)
+    _emulated_exchange(exs, ys, "mirror", "ghost", add=False)
+    for y, gid in zip(ys, gids):
+        assert np.linalg.norm(y.cpu().numpy() - want[:, gid]) / np.linalg.norm(want) < 1e-12
