@@ -54,3 +54,52 @@ def read_input(dirname, pi):
     out["geom"] = np.loadtxt(os.path.join(d, "geom_%.4u.txt" % pi), dtype=np.float64, ndmin=2)
     out["n0l_quad"] = int(li("local_sizes_quad_%.4u.txt" % pi)[0])
     return out
+
+
+# ---- PETSc binary Vec files (the reference's checkpoints: VecView / VecLoad through PetscViewerBinaryOpen) ------------------
+# Third-party format (PETSc is not part of /root/reference; version unpinned there, src/Makefile:14-15 mentions 3.12.2 / 3.17.4).
+# Published layout of a Vec in a PETSc binary file, unchanged across those versions, default (32-bit index) build:
+#     int32  VEC_FILE_CLASSID = 1211214      (big-endian)
+#     int32  n                               (big-endian, global length)
+#     n x float64                            (big-endian), entries in global PETSc ordering
+# Call sites mirrored: eul/UMJS14.cpp:238-267 (LoadVecs / LoadVecsVert: "output/<field>_<lev %.3u>_<step %.4u>.vec"),
+# src/Williamson2.cpp:104-113 ("output/pressure_%.4u.vec", "output/velocity_%.4u.vec"), Geom::write0/1/2.
+VEC_FILE_CLASSID = 1211214
+
+
+def vec_filename(fieldname, step, lev=None, outdir="output"):
+    """the reference's naming: eul flavour has a level field (%.3u), src flavour has none"""
+    if lev is None:
+        return os.path.join(outdir, "%s_%.4u.vec" % (fieldname, step))
+    return os.path.join(outdir, "%s_%.3u_%.4u.vec" % (fieldname, lev, step))
+
+
+def write_vec(path, a):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    with open(path, "wb") as f:
+        f.write(np.array([VEC_FILE_CLASSID, a.size], dtype=">i4").tobytes())
+        f.write(a.astype(">f8").tobytes())
+
+
+def read_vec(path):
+    with open(path, "rb") as f:
+        head = np.frombuffer(f.read(8), dtype=">i4")
+        if head.size != 2 or int(head[0]) != VEC_FILE_CLASSID:
+            raise ValueError("%s: not a PETSc binary Vec (classid %s)" % (path, head[:1]))
+        n = int(head[1])
+        data = np.frombuffer(f.read(8 * n), dtype=">f8")
+        if data.size != n:
+            raise ValueError("%s: truncated (%d of %d entries)" % (path, data.size, n))
+    return data.astype(np.float64)
+
+
+def save_levels(fieldname, step, fields, outdir="output"):
+    """one file per level, like the reference's dump loops (eul/Euler_2.cpp: geom->write2(vec, fieldname, step, lev))"""
+    os.makedirs(outdir, exist_ok=True)
+    for k, v in enumerate(fields):
+        write_vec(vec_filename(fieldname, step, k, outdir), v)
+
+
+def load_levels(fieldname, step, nk, outdir="output"):
+    """LoadVecs (eul/UMJS14.cpp:238-249)"""
+    return np.stack([read_vec(vec_filename(fieldname, step, k, outdir)) for k in range(nk)])
