@@ -124,3 +124,58 @@ def test_krylov_mdot_maxpy(sphere):
         w2 = w.clone(); eng.maxpy(V, h, w2, alpha=-0.5, k=k)
         ref2 = w - 0.5 * (h @ V[:k])
         assert float((w2 - ref2).abs().max()) < 1e-10 * float(ref2.abs().max())
+
+
+def test_horizsolve_right_hand_sides(oracle):
+    """N2: HorizSolve::advection_rhs_ec / momentum_rhs_ec (eul/HorizSolve.cpp:380-417, 637-786) for all levels at once vs
+    the dense restatement oracle/horiz_oracle.py (per-level dense matrices, LU for the KSP solves)"""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.horizsolve import HorizSolve
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from oracle import horiz_oracle as ho
+    pn, ne, nk = 3, 2, 3
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    topos = [Topo(cs, p, nk) for p in range(6)]
+    geoms = [Geom(t, cs, coords, nk) for t in topos]
+    levs = z_levels(nk, geoms[0].n0)
+    for g in geoms:
+        g.set_levels(levs)
+    dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+    eng = Engine(dm)
+    gd = ho.GlobalDense(cs, topos, geoms, coords, levs)
+    H = ho.HorizOracle(gd)
+    hs = HorizSolve(eng, quad_coords=gd.xq[dm.gidq])
+    assert abs(hs.del2 - H.del2) < 1e-6 * abs(H.del2)
+    assert np.linalg.norm(hs.fg.cpu().numpy() - H.fg) / np.linalg.norm(H.fg) < 1e-10
+    r = np.random.default_rng(31)
+    # physically scaled fields: 2-form dofs ~ value * area * thickness, 1-form dofs ~ value * edge length * thickness
+    area = np.mean([P.det.mean() for P in gd.P]) * 4.0 / (pn * pn); dz = np.mean([P.thick.mean() for P in gd.P]); ln = np.sqrt(area)
+    N1, N2 = gd.N1, gd.N2
+    u1 = r.standard_normal((nk, N1)) * 20.0 * ln * dz; u2 = u1 * (1 + 0.05 * r.standard_normal((nk, N1)))
+    h1 = r.uniform(0.8, 1.2, (nk, N2)) * area * dz; h2 = h1 * (1 + 0.01 * r.standard_normal((nk, N2)))
+    th = r.uniform(290, 310, (nk, N2)) * area * dz; Pi = r.uniform(900, 1000, (nk, N2)) * area * dz
+    velz = r.standard_normal((nk - 1, N2)) * area; velz2 = velz * (1 + 0.05 * r.standard_normal(velz.shape))
+    dudz = r.standard_normal((nk - 1, N1)) * 1e-3 * ln; dudz2 = dudz * 1.1
+    t = eng.tensor
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    dF, dG, Fk, Gk = H.advection_rhs_ec(u1, u2, h1, h2, th)
+    gF, gG, gFk, gGk = hs.advection_rhs_ec(t(u1), t(u2), t(h1), t(h2), t(th))
+    assert rel(gFk.cpu().numpy(), Fk) < 1e-10 and rel(gGk.cpu().numpy(), Gk) < 1e-10
+    assert rel(gF.cpu().numpy(), dF) < 1e-9 and rel(gG.cpu().numpy(), dG) < 1e-9
+    for lev in range(nk):
+        assert rel(hs.diagnose_Phi(t(u1), t(u2), t(velz), t(velz2))[lev].cpu().numpy(), H.diagnose_Phi(lev, u1[lev], u2[lev], velz, velz2)) < 1e-10
+        assert rel(hs.diagnose_q(t(h1), t(u1))[lev].cpu().numpy(), H.diagnose_q(lev, h1[lev], u1[lev])) < 1e-10
+    for kwargs in (dict(), dict(use_F=True)):
+        Fx = Fk if kwargs.get("use_F") else None
+        Fz = (velz * 0.7) if kwargs.get("use_F") else None
+        got = hs.momentum_rhs_ec(t(th), t(dudz), t(dudz2), t(velz), t(velz2), t(Pi), t(u1), t(u2), t(h1), t(h2),
+                                 Fx=None if Fx is None else t(Fx), Fz=None if Fz is None else t(Fz), Fk=t(Fk)).cpu().numpy()
+        k2i = 0.0
+        for lev in range(nk):
+            want, k = H.momentum_rhs_ec(lev, th[lev], dudz, dudz2, velz, velz2, Pi[lev], u1[lev], u2[lev], h1[lev], h2[lev],
+                                        Fx=None if Fx is None else Fx[lev], Fz=Fz, Fk=Fk[lev])
+            k2i += k
+            assert rel(got[lev], want) < 1e-8, (lev, kwargs)
+        assert abs(hs.k2i - k2i) < 1e-8 * abs(k2i)
