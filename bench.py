@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
     ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
     ap.add_argument("--box", action="store_true", help="extra: BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
+    ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
@@ -296,6 +297,38 @@ def main():
         del engb
     if a.column and rank == 0 and world == 1:
         out["column"] = column_extras(eng, dm, rng, torch)
+    if a.horiz and rank == 0 and world == 1:
+        from mimsem_amd.horizsolve import HorizSolve
+        xqg = np.zeros((dm.nq, 3))
+        for g in geoms:
+            xqg[g.loc0] = coords[g.loc0]
+        hs = HorizSolve(eng, quad_coords=xqg[dm.gidq])
+        area = float(dm.det.mean()) * 4.0 / (PN * PN); dz = float(dm.thick.mean()); ln = area ** 0.5
+        u1 = eng.tensor(rng.standard_normal((NK, dm.n1)) * 20.0 * ln * dz); u2 = u1 * 1.01
+        h1 = eng.tensor(rng.uniform(0.8, 1.2, (NK, dm.n2)) * area * dz); h2 = h1 * 1.001
+        th = eng.tensor(rng.uniform(290, 310, (NK, dm.n2)) * area * dz); Pi = eng.tensor(rng.uniform(900, 1000, (NK, dm.n2)) * area * dz)
+        vz = eng.tensor(rng.standard_normal((NK - 1, dm.n2)) * area); dudz = eng.tensor(rng.standard_normal((NK - 1, dm.n1)) * 1e-3 * ln)
+
+        def rhs():
+            dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
+            return hs.momentum_rhs_ec(th, dudz, dudz, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk)
+        ref = rhs(); torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(5):
+            rhs()
+        torch.cuda.synchronize(); el = (time.perf_counter() - t1) / 5
+        its = hs.last_its
+        hs.m1.fixed_its = 14                            # fixed-length PCG: the whole evaluation becomes one hipGraph
+        graph, gout = eng.capture(rhs)
+        graph.replay(); torch.cuda.synchronize()
+        err = float(torch.linalg.vector_norm(gout - ref) / torch.linalg.vector_norm(ref))
+        t1 = time.perf_counter()
+        for _ in range(20):
+            graph.replay()
+        torch.cuda.synchronize(); elg = (time.perf_counter() - t1) / 20
+        hs.m1.fixed_its = 0
+        out["horiz_rhs"] = {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels per evaluation",
+                            "ms_per_evaluation_eager": 1e3 * el, "ms_per_evaluation_hipgraph": 1e3 * elg, "evaluations_per_s": 1.0 / elg,
+                            "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
     if a.sw and rank == 0 and world == 1:
         out["sw"] = sw_extras(local_rank, torch)
     if a.cold and rank == 0 and world == 1:

@@ -172,8 +172,12 @@ int mimsem_op_element_matrices_ex(mimsem_ctx* ctx, int op, int geom_lev, double 
  * reference hands to MatSetValues(M, n, inds, n, inds, blk, ADD_VALUES) (eul/Assembly.cpp:128-131).  form 0/1/2 selects the
  * DoF lists (1-forms: x-edges then y-edges, block size 2*n1e).  blocks: device [nEl][nd][nd] row-major per level
  * (blocks_level_stride doubles apart; 0 = the same blocks on every level).  Used for element-block (PCBJACOBI-per-element,
- * eul/HorizSolve.cpp:77-96) preconditioners and for operators a caller modified entry-wise (MatAXPY).  flags: ACCUM, TRANSPOSE. */
+ * eul/HorizSolve.cpp:77-96) preconditioners and for operators a caller modified entry-wise (MatAXPY).  flags: ACCUM, TRANSPOSE.
+ * With blocks_level_stride = 0 the blocks stay in LDS while the kernel sweeps the levels, and elem_scale (nullable,
+ * [nlev][elem_scale_stride >= nEl]) multiplies element e's result at level lev: B_e(lev) = elem_scale[lev][e] * B_e -- e.g. the
+ * inverse 1-form mass blocks of all levels from ONE thickness-free inverse per element and 1/thickInv per (level, element). */
 int mimsem_elem_blocks_apply(mimsem_ctx* ctx, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
+                             const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long x_stride, double* y, long long y_stride, double alpha);
 
 /* Pvec::assemble / Phvec::assemble (Assembly.cpp:602-689): lumped 0-form mass as a vector */
@@ -273,6 +277,15 @@ int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt, unsigned flags,
  * reduction).  maxpy: w += alpha * sum_i h[i] V_i.  Together: one classical Gram-Schmidt pass.                                   */
 int mimsem_krylov_mdot(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* w, double* h);
 int mimsem_krylov_maxpy(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* h, double alpha, double* w);
+/* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in
+ * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
+ * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */
+int mimsem_krylov_rowdot(mimsem_ctx* ctx, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out);
+int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
+                            const double* p, long long ldp, const double* Ap, long long ldap,
+                            double* x, long long ldx, double* r, long long ldr);
+int mimsem_krylov_cg_direction(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
+                               const double* z, long long ldz, double* p, long long ldp);
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer

@@ -46,7 +46,7 @@ _SIGS = {
                                   c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_apply_up": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
                                      c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
-    "mimsem_elem_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
+    "mimsem_elem_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double]),
     "mimsem_op_elmat_size": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_op_element_matrices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_dp]),
     "mimsem_op_element_matrices_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]),
@@ -68,6 +68,9 @@ _SIGS = {
     "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double, C.c_uint] + [c_dp]*14),
     "mimsem_krylov_mdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp]),
     "mimsem_krylov_maxpy": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, C.c_double, c_dp]),
+    "mimsem_krylov_rowdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp]),
+    "mimsem_krylov_cg_update": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_dp, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_krylov_cg_direction": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_halo_segments": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
     "mimsem_halo_pack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_halo_unpack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),

@@ -493,10 +493,11 @@ int mimsem_op_element_matrices(mimsem_ctx* c, int op, int geom_lev, double scale
 }
 
 int mimsem_elem_blocks_apply(mimsem_ctx* c, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
+                             const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long xs, double* y, long long ys, double alpha) {
     if (!c || !blocks || !x || !y || form < 0 || form > 2 || nlev < 0) return MIMSEM_ERR_ARG;
     return launch_blocks_apply(c, form, nlev, (flags & MIMSEM_FLAG_TRANSPOSE) ? 1 : 0, blocks, blocks_level_stride,
-                               x, xs, y, ys, alpha, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0);
+                               x, xs, y, ys, alpha, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, elem_scale, elem_scale_stride);
 }
 
 int mimsem_incidence_apply(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys) {

@@ -115,7 +115,8 @@ int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys);
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,
-                        const double* x, long long xs, double* y, long long ys, double alpha, int accum);
+                        const double* x, long long xs, double* y, long long ys, double alpha, int accum,
+                        const double* escale = nullptr, long long escale_stride = 0);
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,
                          double* buf, double* v, long long vs);
 int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out,

@@ -845,6 +845,93 @@ __global__ __launch_bounds__(256) void k_halo_segments(HaloSegs sg, int s_begin,
     if (mode == 0) *b = *o; else if (mode == 1) *o = *b; else *o += *b;
 }
 
+// Level-independent blocks (one per element, optionally scaled by escale[lev][e]): a workgroup keeps the blocks of its
+// `epb` elements in LDS and sweeps the levels -- the blocks are read from memory once, not once per level.
+__global__ __launch_bounds__(256) void k_blocks_apply_levels(int nEl, int nlev, int lch, int nd, int epb, int transposed,
+        const int* __restrict__ idxA, const int* __restrict__ idxB, int nA,
+        const double* __restrict__ B, const double* __restrict__ escale, long long escale_stride,
+        const double* __restrict__ x, long long xs, double* __restrict__ out, long long os, double alpha,
+        int direct, int accum) {
+    extern __shared__ double sm[];
+    double* sB = sm;                             // [epb][nd*nd], stored so that the row index runs fastest
+    double* sx = sm + (size_t)epb*nd*nd;         // [2][epb*nd]: double-buffered by level parity => one barrier per level
+    const int tid = threadIdx.x, nn = nd*nd;
+    const int e0 = blockIdx.x*epb, ne = min(epb, nEl - e0);
+    const int l0 = blockIdx.y*lch, l1 = min(nlev, l0 + lch);
+    for (int t = tid; t < ne*nn; t += 256) {
+        const int le = t/nn, ij = t%nn;
+        const double v = B[(size_t)(e0 + le)*nn + ij];
+        const int r = transposed ? ij%nd : ij/nd, c = transposed ? ij/nd : ij%nd;     // element (r,c) of the matrix applied
+        sB[(size_t)le*nn + c*nd + r] = v;
+    }
+    const int le = tid/nd, r = tid%nd;           // one thread per (element, row); epb*nd <= 256
+    const bool act = tid < ne*nd;
+    int slot = 0;
+    if (act) { const int e = e0 + le; slot = (r < nA) ? (idxA ? idxA[(size_t)e*nA + r] : e*nA + r) : idxB[(size_t)e*(nd - nA) + (r - nA)]; }
+    double xv = (act && l0 < l1) ? x[(size_t)l0*xs + slot] : 0.0;
+    for (int lev = l0; lev < l1; lev++) {
+        double* sxl = sx + (size_t)(lev & 1)*epb*nd;
+        if (act) sxl[tid] = xv;
+        __syncthreads();                         // also publishes sB on the first trip
+        if (act) {
+            if (lev + 1 < l1) xv = x[(size_t)(lev + 1)*xs + slot];      // prefetch the next level
+            const int e = e0 + le;
+            const double* Be = sB + (size_t)le*nn + r;
+            const double* xe = sxl + le*nd;
+            double s = 0.0;
+            for (int c = 0; c < nd; c++) s += Be[c*nd]*xe[c];
+            if (escale) s *= escale[(size_t)lev*escale_stride + e];
+            if (direct) { double* o = out + (size_t)lev*os + slot; if (accum) *o += alpha*s; else *o = alpha*s; }
+            else out[(size_t)lev*os + (size_t)e*nd + r] = alpha*s;
+        }
+    }
+}
+
+// Register-resident variant for block sizes up to 64: one lane per row holds its row of the block in registers for the
+// whole level sweep; the lanes of an element share a wavefront, so the per-level hand-off of x_e through LDS needs only
+// wave-level ordering (the design of k_elem_apply).  Work item = (element, chunk of lch levels).
+template <int ND>
+__global__ __launch_bounds__(256) void k_blocks_apply_reg(int nEl, int nlev, int lch, int transposed,
+        const int* __restrict__ idxA, const int* __restrict__ idxB, int nA,
+        const double* __restrict__ B, const double* __restrict__ escale, long long escale_stride,
+        const double* __restrict__ x, long long xs, double* __restrict__ out, long long os, double alpha,
+        int direct, int accum) {
+    constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    __shared__ double s_x[2][EPB][LPE];
+    const int tid = threadIdx.x, el = tid/LPE, r = tid%LPE;
+    const int nchunk = (nlev + lch - 1)/lch;
+    const long long item = (long long)blockIdx.x*EPB + el;
+    const bool eact = item < (long long)nEl*nchunk;
+    const int e = eact ? (int)(item%nEl) : 0;
+    const int l0 = eact ? (int)(item/nEl)*lch : 0, l1 = eact ? min(nlev, l0 + lch) : 0;
+    const bool act = eact && r < ND;
+    double b[ND];
+#pragma unroll
+    for (int c = 0; c < ND; c++) b[c] = 0.0;
+    int slot = 0;
+    if (act) {
+        const double* Be = B + (size_t)e*ND*ND;
+#pragma unroll
+        for (int c = 0; c < ND; c++) b[c] = transposed ? Be[c*ND + r] : Be[r*ND + c];
+        slot = (r < nA) ? (idxA ? idxA[(size_t)e*nA + r] : e*nA + r) : idxB[(size_t)e*(ND - nA) + (r - nA)];
+    }
+    double xv = (act && l0 < l1) ? x[(size_t)l0*xs + slot] : 0.0;
+    for (int lev = l0; lev < l1; lev++) {
+        double* sx = s_x[lev & 1][el];
+        if (act) sx[r] = xv;
+        wave_lds_sync();
+        if (act) {
+            if (lev + 1 < l1) xv = x[(size_t)(lev + 1)*xs + slot];
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < ND; c++) s += b[c]*sx[c];
+            if (escale) s *= escale[(size_t)lev*escale_stride + e];
+            if (direct) { double* o = out + (size_t)lev*os + slot; if (accum) *o += alpha*s; else *o = alpha*s; }
+            else out[(size_t)lev*os + (size_t)e*ND + r] = alpha*s;
+        }
+    }
+}
+
 template <int N>
 int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     using D = Dims<N>;
@@ -914,11 +1001,75 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
 }
 
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,
-                        const double* x, long long xs, double* y, long long ys, double alpha, int accum) {
+                        const double* x, long long xs, double* y, long long ys, double alpha, int accum,
+                        const double* escale, long long escale_stride) {
     const ElemSizes& es = c->es;
     const int nd = form == 1 ? 2*es.n1e : (form == 0 ? es.n0e : es.n2e);
     const long long total = (long long)c->nEl*nlev;
     if (total == 0) return MIMSEM_OK;
+    if (escale && bstride_lev != 0) return MIMSEM_ERR_ARG;
+    if (bstride_lev == 0 && nd <= 64 && !getenv("MIMSEM_BLOCKS_LDS")) {
+        // register-resident rows, wave-level synchronisation
+        const int* ia = form == 1 ? c->d_i1x : (form == 0 ? c->d_i0 : c->d_i2);
+        const int* ib = form == 1 ? c->d_i1y : nullptr;
+        const int nA = form == 1 ? es.n1e : nd;
+        double* out = y; long long os = ys; int direct = 1;
+        if (form != 2) {
+            const long long per = (long long)c->nEl*nd;
+            int rc = c->ensure_ye(per*nlev);
+            if (rc) return rc;
+            out = c->d_ye; os = per; direct = 0;
+        }
+        const int lpe = nd <= 16 ? 16 : (nd <= 32 ? 32 : 64), epb = 256/lpe;
+        int lch = (int)(((long long)((c->nEl + epb - 1)/epb)*nlev)/(256*6));         // ~6 workgroups per CU, as k_elem_apply
+        lch = std::max(1, std::min(lch, 8)); lch = std::min(lch, std::max(nlev, 1));
+        const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
+        const unsigned grid = (unsigned)((items + epb - 1)/epb);
+#define MIMSEM_BR(ND) case ND: hipLaunchKernelGGL((k_blocks_apply_reg<ND>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, lch, transposed, \
+                ia, ib, nA, B, escale, escale_stride, x, xs, out, os, alpha, direct, direct ? accum : 0); break;
+        bool done = true;
+        switch (nd) {
+            MIMSEM_BR(1) MIMSEM_BR(4) MIMSEM_BR(9) MIMSEM_BR(12) MIMSEM_BR(16) MIMSEM_BR(24) MIMSEM_BR(25) MIMSEM_BR(36)
+            MIMSEM_BR(40) MIMSEM_BR(49) MIMSEM_BR(60) MIMSEM_BR(64)
+        default: done = false;
+        }
+#undef MIMSEM_BR
+        if (done) {
+            MIMSEM_HIP_TRY(hipGetLastError());
+            if (form != 2) return launch_gather_sum(c, form, nlev, c->d_ye, os, accum, y, ys);
+            return MIMSEM_OK;
+        }
+    }
+    if (bstride_lev == 0 && nd <= 256 && (size_t)nd*(nd + 1)*sizeof(double) <= 150*1024) {
+        // blocks shared by all levels: keep them in LDS and sweep the levels inside the kernel
+        int epb = std::max(1, std::min(256/nd, (int)((60*1024)/((size_t)nd*(nd + 2)*sizeof(double)))));
+        if ((size_t)nd*(nd + 2)*sizeof(double) > 60*1024) epb = 1;
+        const unsigned gx = (unsigned)((c->nEl + epb - 1)/epb);
+        // enough workgroups to fill 256 CUs several times over: split the level sweep when there are few element groups
+        int nchunk = (int)std::min<long long>(nlev, std::max<long long>(1, (2048 + gx - 1)/gx));
+        const int lch = (nlev + nchunk - 1)/nchunk;
+        nchunk = (nlev + lch - 1)/lch;
+        const dim3 grid(gx, (unsigned)nchunk);
+        const size_t lds = (size_t)epb*nd*(nd + 2)*sizeof(double);
+        if (lds > 64*1024)
+            MIMSEM_HIP_TRY(hipFuncSetAttribute((const void*)k_blocks_apply_levels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int* ia = form == 1 ? c->d_i1x : (form == 0 ? c->d_i0 : c->d_i2);
+        const int* ib = form == 1 ? c->d_i1y : nullptr;
+        const int nA = form == 1 ? es.n1e : nd;
+        double* out = y; long long os = ys; int direct = 1;
+        if (form != 2) {
+            const long long per = (long long)c->nEl*nd;
+            int rc = c->ensure_ye(per*nlev);
+            if (rc) return rc;
+            out = c->d_ye; os = per; direct = 0;
+        }
+        hipLaunchKernelGGL(k_blocks_apply_levels, grid, dim3(256), lds, c->stream, c->nEl, nlev, lch, nd, epb, transposed, ia, ib, nA,
+                           B, escale, escale_stride, x, xs, out, os, alpha, direct, direct ? accum : 0);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        if (form != 2) return launch_gather_sum(c, form, nlev, c->d_ye, os, accum, y, ys);
+        return MIMSEM_OK;
+    }
+    if (escale) return MIMSEM_ERR_UNSUPPORTED;
     const int epb = std::max(1, 256/nd);
     const unsigned grid = (unsigned)((total + epb - 1)/epb);
     const size_t lds = (size_t)epb*nd*sizeof(double);

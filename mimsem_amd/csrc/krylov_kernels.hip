@@ -55,9 +55,86 @@ __global__ __launch_bounds__(256) void k_maxpy(int k, long long n, const double*
     w[t] += alpha*s;
 }
 
+// ---- batched (one system per row / level) CG vector kernels: per-row scalars stay in device memory -----------------
+constexpr int RD_BLOCKS = 32;       // partial sums per row
+__global__ __launch_bounds__(256) void k_rowdot_partial(long long n, long long chunk, const double* __restrict__ A, long long lda,
+                                                        const double* __restrict__ B, long long ldb, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.y;
+    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
+    const double* a = A + (size_t)row*lda; const double* b = B + (size_t)row*ldb;
+    double s = 0.0;
+    for (long long t = lo + tid; t < hi; t += 256) s += a[t]*b[t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) part[(size_t)row*gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double s = (lane < nb) ? part[(size_t)row*nb + lane] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[row] = s;
+}
+// x += alpha p ; r -= alpha Ap with alpha_row = num[row]/den[row]
+__global__ __launch_bounds__(256) void k_cg_update(long long n, const double* __restrict__ num, const double* __restrict__ den,
+        const double* __restrict__ p, long long ldp, const double* __restrict__ Ap, long long ldap,
+        double* __restrict__ x, long long ldx, double* __restrict__ r, long long ldr) {
+    const int row = blockIdx.y;
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= n) return;
+    const double d = den[row];
+    const double alpha = num[row]/(fabs(d) < 1e-300 ? 1e-300 : d);
+    x[(size_t)row*ldx + t] += alpha*p[(size_t)row*ldp + t];
+    r[(size_t)row*ldr + t] -= alpha*Ap[(size_t)row*ldap + t];
+}
+// p = z + beta p with beta_row = num[row]/den[row]
+__global__ __launch_bounds__(256) void k_cg_direction(long long n, const double* __restrict__ num, const double* __restrict__ den,
+        const double* __restrict__ z, long long ldz, double* __restrict__ p, long long ldp) {
+    const int row = blockIdx.y;
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= n) return;
+    const double d = den[row];
+    const double beta = num[row]/(fabs(d) < 1e-300 ? 1e-300 : d);
+    p[(size_t)row*ldp + t] = z[(size_t)row*ldz + t] + beta*p[(size_t)row*ldp + t];
+}
+
 }  // namespace
 
 extern "C" {
+
+int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out) {
+    if (!c || !A || !B || !out || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;
+    if (nrows == 0) return MIMSEM_OK;
+    const int nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+    const long long chunk = (n + nb - 1)/nb;
+    int rc = c->ensure_kry((long long)nb*nrows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rowdot_partial, dim3(nb, nrows), dim3(256), 0, c->stream, n, chunk, A, lda, B, ldb, c->d_kry);
+    hipLaunchKernelGGL(k_rowdot_final, dim3(nrows), dim3(64), 0, c->stream, nb, c->d_kry, out);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int mimsem_krylov_cg_update(mimsem_ctx* c, int nrows, long long n, const double* num, const double* den,
+                            const double* p, long long ldp, const double* Ap, long long ldap,
+                            double* x, long long ldx, double* r, long long ldr) {
+    if (!c || !num || !den || !p || !Ap || !x || !r || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_cg_update, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, num, den, p, ldp, Ap, ldap, x, ldx, r, ldr);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int mimsem_krylov_cg_direction(mimsem_ctx* c, int nrows, long long n, const double* num, const double* den,
+                               const double* z, long long ldz, double* p, long long ldp) {
+    if (!c || !num || !den || !z || !p || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_cg_direction, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, num, den, z, ldz, p, ldp);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 
 int mimsem_krylov_mdot(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, const double* w, double* h) {
     if (!c || !V || !w || !h || k < 0 || n < 0 || ldv < n) return MIMSEM_ERR_ARG;

@@ -120,6 +120,23 @@ class Engine:
                 return False
         return _Bind()
 
+    def capture(self, fn):
+        """Capture fn() -- engine calls and torch ops on fixed buffers, no host synchronisation -- in a hipGraph.  Returns
+        (graph, outputs): graph.replay() re-runs the whole launch sequence with one submission; outputs are the static
+        tensors fn returned (overwritten by every replay)."""
+        dev = self.device
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s), self.on_current_stream():
+            fn()                                        # warm-up: workspaces reach their final size outside the capture
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), self.on_current_stream():
+            out = fn()
+        torch.cuda.synchronize(dev)
+        return g, out
+
     def sync(self):
         check(self.L.mimsem_ctx_sync(self.ctx), "sync")
 
@@ -229,9 +246,9 @@ class Engine:
               "mimsem_op_element_matrices_ex(UMAT_RAY)")
         return out
 
-    def blocks_apply(self, form, blocks, x, transpose=False, alpha=1.0, accum=False, out=None):
-        """y = alpha * sum_e P_e^T B_e P_e x with caller-supplied element blocks [nEl, nd, nd] (same on every level) or
-        [nlev, nEl, nd, nd]; form 0/1/2 (1-forms: nd = 2*n1e, x-edges then y-edges)."""
+    def blocks_apply(self, form, blocks, x, transpose=False, alpha=1.0, accum=False, out=None, elem_scale=None):
+        """y = alpha * sum_e P_e^T B_e P_e x with caller-supplied element blocks [nEl, nd, nd] (same on every level, optionally
+        times elem_scale[lev, e]) or [nlev, nEl, nd, nd]; form 0/1/2 (1-forms: nd = 2*n1e, x-edges then y-edges)."""
         x2 = x if x.dim() == 2 else x.unsqueeze(0)
         nlev = x2.shape[0]
         nd = {0: self.n0e, 1: 2 * self.n1e, 2: self.n2e}[form]
@@ -241,7 +258,10 @@ class Engine:
         y = out if out is not None else torch.empty(nlev, self.sizes[form], dtype=torch.float64, device=self.device)
         y2 = y if y.dim() == 2 else y.unsqueeze(0)
         flags = (4 if transpose else 0) | (2 if accum else 0)
-        check(self.L.mimsem_elem_blocks_apply(self.ctx, form, nlev, flags, _ptr(blocks), bstride, _ptr(x2), x2.stride(0),
+        if elem_scale is not None:
+            assert blocks.dim() == 3 and elem_scale.shape == (nlev, self.nEl)
+        check(self.L.mimsem_elem_blocks_apply(self.ctx, form, nlev, flags, _ptr(blocks), bstride, _ptr(elem_scale),
+                                              elem_scale.stride(0) if elem_scale is not None else 0, _ptr(x2), x2.stride(0),
                                               _ptr(y2), y2.stride(0), alpha), "mimsem_elem_blocks_apply")
         return y if x.dim() == 2 else y2[0]
 
@@ -367,6 +387,22 @@ class Engine:
         k = V.shape[0] if k is None else k
         check(self.L.mimsem_krylov_maxpy(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(h), alpha, _ptr(w)), "krylov_maxpy")
         return w
+
+    def rowdot(self, A, B, out=None):
+        """out[i] = <A[i], B[i]> for [nrows, n] tensors (rows contiguous)"""
+        out = out if out is not None else torch.empty(A.shape[0], dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_krylov_rowdot(self.ctx, A.shape[0], A.shape[1], _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out)), "rowdot")
+        return out
+
+    def cg_update(self, num, den, p, Ap, x, r):
+        """x += (num/den) p ; r -= (num/den) Ap  row-wise, in place"""
+        check(self.L.mimsem_krylov_cg_update(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(p), p.stride(0),
+                                             _ptr(Ap), Ap.stride(0), _ptr(x), x.stride(0), _ptr(r), r.stride(0)), "cg_update")
+
+    def cg_direction(self, num, den, z, p):
+        """p = z + (num/den) p  row-wise, in place"""
+        check(self.L.mimsem_krylov_cg_direction(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(z), z.stride(0),
+                                                _ptr(p), p.stride(0)), "cg_direction")
 
     # ---- halo pack / unpack ---------------------------------------------------------------------
     def halo_segments(self, idx, seg_off, s_begin, s_end, mode, buf, v):

@@ -28,9 +28,14 @@ class HorizSolve:
         self.m1 = MassSolver(eng, SCALE, True)
         self.m0 = eng.pvec(0, eng.nk, SCALE)                  # M0 is diagonal for the collocated 0-forms (Pvec)
         self.fg = None
-        self.k2i = 0.0
+        self.k2i_dev = None
         if quad_coords is not None:
             self.coriolis(quad_coords)
+
+    @property
+    def k2i(self):
+        """horizontal kinetic-to-internal energy exchange of the last momentum_rhs_ec (:697-701)"""
+        return 0.0 if self.k2i_dev is None else float(self.k2i_dev)
 
     # ---- operators --------------------------------------------------------------------------------------------------
     def _ap(self, op, x, f=None, flags=0, alpha=1.0, out=None):
@@ -129,7 +134,7 @@ class HorizSolve:
         dp = eng.incidence("E12", self._ap("WHMAT", theta, f=Pi, flags=VERT))
         fu += 0.5 * dp
         if Fk is not None:
-            self.k2i = float((Fk * dp).sum()) / SCALE
+            self.k2i_dev = (Fk * dp).sum() / SCALE       # stays on the device (no host sync: the call is hipGraph-capturable)
         # second vorticity term: interface i feeds levels i and i+1 (:704-746)
         dz = 0.5 * dudz1 + 0.5 * dudz2
         if dwdx1 is not None:

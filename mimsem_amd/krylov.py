@@ -40,26 +40,78 @@ def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, a
     return x, its
 
 
+def pcg_engine(eng, apply_A, b, precond, rtol=1e-14, maxit=300, check_every=2, fixed_its=0):
+    """PCG for a batch of SPD systems (rows of b) on the engine's fused vector kernels: rowdot (two-stage deterministic reduction),
+    cg_update (x += a p, r -= a Ap) and cg_direction (p = z + b p) read their per-row scalars from device memory -- an
+    iteration is operator + preconditioner + 6 small launches, no host synchronisation (fixed_its > 0: none at all, so the
+    whole solve is hipGraph-capturable; otherwise a convergence test every `check_every` iterations)."""
+    x = torch.zeros_like(b)
+    r = b.clone()
+    z = precond(r)
+    p = z.clone()
+    rz = eng.rowdot(r, z)
+    rz_new = torch.empty_like(rz); pAp = torch.empty_like(rz); rr = torch.empty_like(rz)
+    bnorm2 = None if fixed_its else eng.rowdot(b, b).clamp_min(1e-300)
+    its = 0
+    for it in range(fixed_its if fixed_its else maxit):
+        Ap = apply_A(p)
+        eng.rowdot(p, Ap, out=pAp)
+        eng.cg_update(rz, pAp, p, Ap, x, r)
+        its = it + 1
+        if not fixed_its and its % check_every == 0:
+            eng.rowdot(r, r, out=rr)
+            if bool((rr / bnorm2).max() < rtol * rtol):
+                break
+        z = precond(r)
+        eng.rowdot(r, z, out=rz_new)
+        eng.cg_direction(rz_new, rz, z, p)
+        rz, rz_new = rz_new, rz
+    return x, its
+
+
+def pcg_fixed(apply_A, b, precond, iterations):
+    """PCG with a FIXED iteration count and no host synchronisation: capturable in a hipGraph.  For the element-block
+    preconditioned mass systems (condition ~1.2, error contraction ~0.05 per iteration) 14 iterations reach round-off."""
+    x = torch.zeros_like(b)
+    r = b.clone()
+    z = precond(r)
+    p = z.clone()
+    dot = lambda u, v: torch.linalg.vecdot(u, v, dim=1)
+    rz = dot(r, z)
+    tiny = 1e-300
+    for _ in range(iterations):
+        Ap = apply_A(p)
+        alpha = rz / dot(p, Ap).clamp_min(tiny)
+        torch.addcmul(x, alpha[:, None], p, out=x)
+        torch.addcmul(r, alpha[:, None], Ap, value=-1.0, out=r)
+        z = precond(r)
+        rz_new = dot(r, z)
+        p = torch.addcmul(z, (rz_new / rz.clamp_min(tiny))[:, None], p)
+        rz = rz_new
+    return x
+
+
 def _pcg_general(apply_A, b, precond, x0, rtol, maxit, check_every, allreduce):
     x = torch.zeros_like(b) if x0 is None else x0.clone()
     r = b - apply_A(x) if x0 is not None else b.clone()
     z = precond(r)
     p = z.clone()
-    dot = (lambda u, v: (u * v).sum(dim=1)) if allreduce is None else (lambda u, v: allreduce((u * v).sum(dim=1)))
+    vd = lambda u, v: torch.linalg.vecdot(u, v, dim=1)
+    dot = vd if allreduce is None else (lambda u, v: allreduce(vd(u, v)))
     rz = dot(r, z)
     bnorm = torch.sqrt(dot(b, b)).clamp_min(1e-300)
     its = 0
     for it in range(maxit):
         Ap = apply_A(p)
         alpha = rz / dot(p, Ap).clamp_min(1e-300)
-        x += alpha[:, None] * p
-        r -= alpha[:, None] * Ap
+        torch.addcmul(x, alpha[:, None], p, out=x)
+        torch.addcmul(r, alpha[:, None], Ap, value=-1.0, out=r)
         its = it + 1
         if its % check_every == 0 and bool((torch.sqrt(dot(r, r)) / bnorm).max() < rtol):
             break
         z = precond(r)
         rz_new = dot(r, z)
-        p = z + (rz_new / rz.clamp_min(1e-300))[:, None] * p
+        p = torch.addcmul(z, (rz_new / rz.clamp_min(1e-300))[:, None], p)
         rz = rz_new
     return x, its
 
@@ -77,6 +129,7 @@ class MassSolver:
         ix = torch.as_tensor(dm.inds1x, device=eng.device).long()
         iy = torch.as_tensor(dm.inds1y, device=eng.device).long()
         self.kind = precond
+        self.fixed_its = 0          # > 0: run exactly that many PCG iterations (hipGraph capture)
         if precond == "jacobi":
             diag = eng.zeros(eng.nk, dm.n1)
             for k in range(eng.nk):
@@ -89,23 +142,30 @@ class MassSolver:
             mult = torch.zeros(dm.n1, dtype=torch.float64, device=eng.device)
             mult.index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
             d = 1.0 / mult[idx]
-            blocks = torch.empty(eng.nk, eng.nEl, 2 * n1e, 2 * n1e, dtype=torch.float64, device=eng.device)
-            for k in range(eng.nk):
-                em = eng.element_matrices("UMAT", lev=k, scale=scale, flags=self.flags).view(eng.nEl, 2, 2, n1e, n1e)
-                B = em.permute(0, 1, 3, 2, 4).reshape(eng.nEl, 2 * n1e, 2 * n1e)
-                blocks[k] = d[:, :, None] * torch.linalg.inv(B) * d[:, None, :]
-            self.blocks = blocks
+            # M1_e(k) = U^T diag(c_q thickInv_k(q)) U ~ tau_{k,e} * U^T diag(c_q) U with tau = the element's mean thickInv (exact when
+            # the layer thickness is horizontally uniform over the element): ONE thickness-free inverse per element, resident in
+            # LDS while the kernel sweeps the levels, times 1/tau per (level, element)
+            em = eng.element_matrices("UMAT", lev=0, scale=scale, flags=0).view(eng.nEl, 2, 2, n1e, n1e)
+            B = em.permute(0, 1, 3, 2, 4).reshape(eng.nEl, 2 * n1e, 2 * n1e)
+            self.blocks = (d[:, :, None] * torch.linalg.inv(B) * d[:, None, :]).contiguous()
+            tau = torch.as_tensor(dm.thickInv, device=eng.device).mean(dim=2) if vert_scale else \
+                torch.ones(eng.nk, eng.nEl, dtype=torch.float64, device=eng.device)
+            self.escale = (1.0 / tau).contiguous()
+
+    def precond(self, r, lev0=0):
+        return self.eng.blocks_apply(1, self.blocks, r, transpose=True, elem_scale=self.escale[lev0:lev0 + r.shape[0]])
 
     def apply(self, x, lev0=0):
         return self.eng.apply("UMAT", x, lev0=lev0, scale=self.scale, flags=self.flags)
 
     def solve(self, b, lev0=0, rtol=1e-14, maxit=300):
         nlev = b.shape[0]
+        if self.kind != "jacobi":
+            return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
+                              fixed_its=self.fixed_its)
         if self.kind == "jacobi":
             return pcg(lambda v: self.apply(v, lev0), b, minv=self.minv[lev0:lev0 + nlev], rtol=rtol, maxit=maxit)
-        blk = self.blocks[lev0:lev0 + nlev]
-        return pcg(lambda v: self.apply(v, lev0), b, precond=lambda r: self.eng.blocks_apply(1, blk, r, transpose=True),
-                   rtol=rtol, maxit=maxit, check_every=2)
+        return pcg(lambda v: self.apply(v, lev0), b, precond=lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit, check_every=2)
 
 
 def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30, maxit=1000, dot=None, eng=None):

@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .krylov import GraphedGMRES, gmres, pcg
+from .krylov import GraphedGMRES, gmres, pcg_engine
 
 RAD_EARTH = 6371220.0          # src/SWEqn_Picard.cpp:22-23
 RAD_SPHERE = 6371220.0
@@ -67,7 +67,7 @@ class SWEqn:
 
     def solve_M1(self, b, key="M1"):
         """KSPSolve(ksp, b, x) on M1 (:84-92): SPD => preconditioned CG reaches the same solution"""
-        x, its = pcg(self.M1, b, precond=self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
+        x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
         self.its[key] = its
         return x
 

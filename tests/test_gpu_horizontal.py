@@ -258,3 +258,22 @@ def test_element_blocks_apply(setup):
     B2 = eng.tensor(r.standard_normal((P.nEl, P.n2e, P.n2e))); x2 = eng.tensor(r.standard_normal((2, P.n2)))
     eng.blocks_apply(2, B2, x2, accum=True, out=y0)
     assert rel_l2((y0 - keep).cpu().numpy(), eng.blocks_apply(2, B2, x2).cpu().numpy()) < 1e-12
+
+
+def test_element_blocks_apply_level_sweep(setup):
+    """level-independent blocks kept in LDS across the level sweep, with the per-(level, element) scale"""
+    eng, P, rng = setup
+    r = np.random.default_rng(64)
+    idx = {0: P.elinds("n0"), 2: P.elinds("n2"), 1: np.concatenate([P.elinds("n1x"), P.elinds("n1y")], axis=1)}
+    for form, nd, nv in ((0, P.n0e, P.n0), (1, 2 * P.n1e, P.n1), (2, P.n2e, P.n2)):
+        B = r.standard_normal((P.nEl, nd, nd)); xv = r.standard_normal((3, nv)); sc = r.uniform(0.5, 2.0, (3, P.nEl))
+        for tr in (False, True):
+            for scale in (None, sc):
+                ref = np.zeros((3, nv))
+                for lev in range(3):
+                    for e in range(P.nEl):
+                        Be = (B[e].T if tr else B[e]) * (1.0 if scale is None else scale[lev, e])
+                        ref[lev, idx[form][e]] += Be @ xv[lev, idx[form][e]]
+                got = eng.blocks_apply(form, eng.tensor(B), eng.tensor(xv), transpose=tr,
+                                       elem_scale=None if scale is None else eng.tensor(scale)).cpu().numpy()
+                assert rel_l2(got, ref) < 1e-12, (form, tr, scale is not None)

@@ -179,3 +179,22 @@ def test_horizsolve_right_hand_sides(oracle):
             k2i += k
             assert rel(got[lev], want) < 1e-8, (lev, kwargs)
         assert abs(hs.k2i - k2i) < 1e-8 * abs(k2i)
+
+
+def test_krylov_batched_cg_kernels(sphere):
+    """rowdot / cg_update / cg_direction: per-row scalars read from device memory, bitwise reproducible reductions"""
+    import torch
+    cs, eng, mats, rng = sphere
+    nr, n = 5, 62208
+    A, B = eng.tensor(rng.standard_normal((nr, n))), eng.tensor(rng.standard_normal((nr, n)))
+    d = eng.rowdot(A, B)
+    ref = (A * B).sum(dim=1)
+    assert float(((d - ref) / ref.abs().max()).abs().max()) < 1e-13 and torch.equal(d, eng.rowdot(A, B))
+    num, den = eng.tensor(rng.uniform(1, 2, nr)), eng.tensor(rng.uniform(1, 2, nr))
+    x, r = A.clone(), B.clone(); p, Ap = eng.tensor(rng.standard_normal((nr, n))), eng.tensor(rng.standard_normal((nr, n)))
+    eng.cg_update(num, den, p, Ap, x, r)
+    al = (num / den)[:, None]
+    assert torch.allclose(x, A + al * p, rtol=1e-14, atol=0) and torch.allclose(r, B - al * Ap, rtol=1e-13, atol=1e-13)
+    z = eng.tensor(rng.standard_normal((nr, n))); p2 = p.clone()
+    eng.cg_direction(num, den, z, p2)
+    assert torch.allclose(p2, z + al * p, rtol=1e-14, atol=1e-14)
