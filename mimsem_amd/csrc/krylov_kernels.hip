@@ -12,36 +12,6 @@
 
 namespace {
 
-constexpr int MD_BLOCKS = 256;      // partial sums per row
-
-// stage 1: block b owns the contiguous chunk [b*chunk, (b+1)*chunk) of every row; part[b][i] = sum over the chunk
-__global__ __launch_bounds__(256) void k_mdot_partial(int k, long long n, long long chunk, const double* __restrict__ V, long long ldv,
-                                                      const double* __restrict__ w, double* __restrict__ part) {
-    __shared__ double red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
-    for (int i = 0; i < k; i++) {
-        const double* v = V + (size_t)i*ldv;
-        double s = 0.0;
-        for (long long t = lo + tid; t < hi; t += 256) s += v[t]*w[t];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        if (tid == 0) part[(size_t)blockIdx.x*k + i] = (red[0] + red[1]) + (red[2] + red[3]);
-        __syncthreads();
-    }
-}
-// stage 2: h[i] = sum_b part[b][i], pairwise in a fixed order
-__global__ __launch_bounds__(256) void k_mdot_final(int k, int nb, const double* __restrict__ part, double* __restrict__ h) {
-    __shared__ double red[256];
-    const int i = blockIdx.x, tid = threadIdx.x;
-    double s = 0.0;
-    for (int b = tid; b < nb; b += 256) s += part[(size_t)b*k + i];
-    red[tid] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
-    if (tid == 0) h[i] = red[0];
-}
 // w[t] += alpha * sum_i h[i] V[i][t]
 __global__ __launch_bounds__(256) void k_maxpy(int k, long long n, const double* __restrict__ V, long long ldv,
                                                const double* __restrict__ h, double alpha, double* __restrict__ w) {
@@ -136,17 +106,12 @@ int mimsem_krylov_cg_direction(mimsem_ctx* c, int nrows, long long n, const doub
 }
 
 
+int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out);
+
+// h = V w: the k dot products are k rows of a row-dot with a broadcast second operand (ldb = 0): grid = chunks x rows
 int mimsem_krylov_mdot(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, const double* w, double* h) {
     if (!c || !V || !w || !h || k < 0 || n < 0 || ldv < n) return MIMSEM_ERR_ARG;
-    if (k == 0) return MIMSEM_OK;
-    const int nb = (int)std::min<long long>(MD_BLOCKS, (n + 255)/256);
-    const long long chunk = (n + nb - 1)/nb;
-    int rc = c->ensure_kry((long long)nb*k);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_mdot_partial, dim3(nb), dim3(256), 0, c->stream, k, n, chunk, V, ldv, w, c->d_kry);
-    hipLaunchKernelGGL(k_mdot_final, dim3(k), dim3(256), 0, c->stream, k, nb, c->d_kry, h);
-    MIMSEM_HIP_TRY(hipGetLastError());
-    return MIMSEM_OK;
+    return mimsem_krylov_rowdot(c, k, n, V, ldv, w, 0, h);
 }
 
 int mimsem_krylov_maxpy(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, const double* h, double alpha, double* w) {
