@@ -1,0 +1,155 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (the dense oracle cannot run there):
+config 4 grid (p=3, 24x24x6 sphere x 30 levels, 103 680 element-level units, 3 456 columns) and config 3 (SW step on 24x24x6).
+Known answers: sphere area, exact mimetic identities; algebraic properties: linearity, symmetry / skew-symmetry, inverse
+round trips, residual of the block-tridiagonal solve, discrete mass conservation of the shallow-water step."""
+import numpy as np
+import pytest
+
+from tests.helpers import SCALE, z_levels
+
+pytestmark = pytest.mark.gpu
+PN, NE, NK, NPATCH = 3, 24, 30, 24
+RAD = 6371220.0
+
+
+@pytest.fixture(scope="module")
+def full():
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(PN, NE, NPATCH); coords = sphere_coords(PN, NE)
+    topos = [Topo(cs, p, NK) for p in range(NPATCH)]
+    geoms = [Geom(t, cs, coords, NK) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(NK, g.n0))
+    dm = DeviceMesh(topos, geoms, nk=NK, numbering="global")
+    eng = Engine(dm)
+    assert dm.nEl * NK == 103680
+    return cs, dm, eng, np.random.default_rng(77)
+
+
+def _dot(a, b):
+    return float((a * b).sum())
+
+
+def test_known_answers_sphere_area_and_identities(full):
+    import torch
+    cs, dm, eng, rng = full
+    # 0-form mass applied to 1 and summed = SCALE * area * thickInv  (levels are horizontally uniform here)
+    ones0 = eng.tensor(np.ones((NK, dm.n0)))
+    tot = eng.apply("PMAT", ones0, lev0=0, scale=SCALE).sum(dim=1).cpu().numpy()
+    tI = dm.thickInv[:, 0, 0]
+    area = tot / (SCALE * tI)
+    assert np.all(np.abs(area / (4.0 * np.pi * RAD * RAD) - 1.0) < 1e-8), area / (4.0 * np.pi * RAD * RAD)
+    # E21 E10 = 0 and the adjoint pair: exact integer stencils
+    x0 = eng.tensor(rng.integers(-100, 100, (2, dm.n0)).astype(np.float64))
+    assert float(eng.incidence("E21", eng.incidence("E10", x0)).abs().max()) == 0.0
+    x1 = eng.tensor(rng.integers(-100, 100, (2, dm.n1)).astype(np.float64))
+    x2 = eng.tensor(rng.integers(-100, 100, (2, dm.n2)).astype(np.float64))
+    assert _dot(eng.incidence("E21", x1), x2) == -_dot(x1, eng.incidence("E12", x2))        # E12 = -E21^T
+    assert _dot(eng.incidence("E10", x0), x1) == -_dot(x0, eng.incidence("E01", x1))        # E01 = -E10^T
+
+
+def test_linearity_symmetry_skewness(full):
+    import torch
+    cs, dm, eng, rng = full
+    t = eng.tensor
+    x, y = t(rng.standard_normal((NK, dm.n1))), t(rng.standard_normal((NK, dm.n1)))
+    h = t(rng.uniform(1, 2, (NK, dm.n2)) * 1e6); q = t(rng.standard_normal((NK, dm.n0)) * 1e-4)
+    x2, y2 = t(rng.standard_normal((NK, dm.n2))), t(rng.standard_normal((NK, dm.n2)))
+    for op, f, fl, a, b in (("UMAT", None, 1, x, y), ("UHMAT", h, 1, x, y), ("WMAT", None, 1, x2, y2), ("WHMAT", h, 1, x2, y2)):
+        A = lambda v: eng.apply(op, v, f=f, lev0=0, scale=SCALE, flags=fl)
+        Aa, Ab = A(a), A(b)
+        lin = A(2.0 * a - 3.0 * b) - (2.0 * Aa - 3.0 * Ab)
+        assert float(lin.abs().max()) < 1e-12 * float(Aa.abs().max()), op
+        assert abs(_dot(b, Aa) - _dot(a, Ab)) < 1e-12 * abs(_dot(a, Aa)), op                   # symmetric
+        assert _dot(a, Aa) > 0, op                                                              # positive definite
+    Rx = eng.apply("ROTMAT", x, f=q, lev0=0, scale=SCALE)
+    assert abs(_dot(x, Rx)) < 1e-12 * float(torch.linalg.vector_norm(x) * torch.linalg.vector_norm(Rx))     # skew: <x, R x> = 0
+    assert abs(_dot(y, Rx) + _dot(x, eng.apply("ROTMAT", y, f=q, lev0=0, scale=SCALE))) < 1e-11 * abs(_dot(y, Rx))
+    # UtQWmat is the transpose of WtQdUdz_mat (same coefficient, rows and columns swapped)
+    u = t(rng.standard_normal((NK, dm.n1)))
+    assert abs(_dot(x, eng.apply("UTQWMAT", x2, f=u, lev0=0, scale=SCALE)) - _dot(x2, eng.apply("WTQDUDZ", x, f=u, lev0=0, scale=SCALE))) \
+        < 1e-12 * abs(_dot(x, eng.apply("UTQWMAT", x2, f=u, lev0=0, scale=SCALE)))
+
+
+def test_batching_reproducibility_and_inverse_roundtrips(full):
+    import torch
+    cs, dm, eng, rng = full
+    t = eng.tensor
+    x = t(rng.standard_normal((NK, dm.n1)))
+    y = eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1)
+    assert torch.equal(y, eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1))                    # bitwise run-to-run
+    for k in (0, 13, NK - 1):
+        assert torch.equal(y[k], eng.apply("UMAT", x[k], lev0=k, scale=SCALE, flags=1))         # level batch == single level
+    x2 = t(rng.standard_normal((NK, dm.n2))); h = t(rng.uniform(1, 2, (NK, dm.n2)) * 1e6)
+    back = eng.apply("WMATINV", eng.apply("WMAT", x2, lev0=0, scale=SCALE, flags=1), lev0=0, scale=SCALE)
+    assert float((back - x2).abs().max()) < 1e-10
+    back = eng.apply("WHMATINV", eng.apply("WHMAT", x2, f=h, lev0=0, scale=SCALE, flags=1), f=h, lev0=0, scale=SCALE)
+    assert float((back - x2).abs().max()) < 1e-9
+    vz = eng.l2_horiz_to_vert(x2)
+    assert torch.equal(eng.l2_vert_to_horiz(vz, NK), x2)
+    # device CG on all 30 levels at once: M1 (M1^-1 b) = b
+    from mimsem_amd.krylov import MassSolver
+    ms = MassSolver(eng, SCALE, True)
+    b = eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1)
+    sol, its = ms.solve(b, rtol=1e-14)
+    assert its <= 20 and float((sol - x).abs().max()) < 1e-10 * float(x.abs().max()) * 10
+
+
+def test_column_solve_satisfies_its_block_tridiagonal_system(full):
+    """3 456 columns x 30 levels: the block-Thomas solution d_pi satisfies L_pi d_pi = rhs (L_pi from mimsem_column_helmholtz_blocks)"""
+    import torch
+    cs, dm, eng, rng = full
+    n2, nEl = eng.n2e, dm.nEl
+    area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+    theta, rho, eta, pi = lev(NK, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 5, 6), lev(NK, 700, 1000)
+    F = [eng.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (NK - 1, NK, NK, NK)]
+    dt = 75.0
+    L = eng.helmholtz_blocks(dt, theta, rho, eta, pi).view(nEl, NK, 3, n2, n2)
+    d_u, d_rho, d_eta, d_pi = eng.solve_schur_eta(dt, theta, rho, eta, pi, *F)
+    rhs = F[3].view(nEl, NK, n2)                        # F_pi after the in-place update = the right-hand side of the Helmholtz solve
+    d = d_pi.view(nEl, NK, n2)
+    Ld = torch.einsum("ekij,ekj->eki", L[:, :, 1], d)
+    Ld[:, 1:] += torch.einsum("ekij,ekj->eki", L[:, 1:, 0], d[:, :-1])
+    Ld[:, :-1] += torch.einsum("ekij,ekj->eki", L[:, :-1, 2], d[:, 1:])
+    res = torch.linalg.vector_norm(Ld - rhs, dim=(1, 2)) / torch.linalg.vector_norm(rhs, dim=(1, 2))
+    assert float(res.max()) < 1e-9, float(res.max())
+    assert all(bool(torch.isfinite(v).all()) for v in (d_u, d_rho, d_eta, d_pi))
+
+
+def test_shallow_water_step_conserves_mass_exactly():
+    """config 3 (24x24x6, Galewsky-style step): h DoFs are face integrals and the continuity row is M2 (dh + dt E21 F) = 0, so the
+    total mass sum(h) is conserved to round-off by every Picard iteration; the vorticity integral sum(M0 w) vanishes on the sphere"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.sweqn import SWEqn, williamson2
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(PN, NE, 6); coords = sphere_coords(PN, NE)
+    topos = [Topo(cs, p, 1) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+    for g in geoms:
+        g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+    dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+    eng = Engine(dm)
+    xq = np.zeros((dm.nq, 3))
+    for g in geoms:
+        xq[g.loc0] = coords[g.loc0]
+    S = SWEqn(eng, xq[dm.gidq])
+    uq, hq = williamson2(torch.as_tensor(xq[dm.gidq], device=eng.device), alpha=0.0)
+    u0, h0 = S.init1(uq), S.init2(hq)
+    m0 = float(h0.sum())
+    U0, H0 = 38.61068276698372, 2998.1154702758267            # known answer: integral of h over the sphere (mean of sin^2 = 1/3)
+    mean_h = H0 - (RAD * 7.292e-5 * U0 + 0.5 * U0 * U0) / (3.0 * 9.80616)
+    assert abs(m0 / (mean_h * 4 * np.pi * RAD * RAD) - 1.0) < 1e-6
+    u1, h1 = S.solve(u0, h0, 360.0, nits=2, q_exact=False)
+    assert abs(float(h1.sum()) - m0) < 1e-12 * abs(m0)
+    w = S.curl(u1)
+    assert abs(float((S.m0 * w).sum())) < 1e-9 * float((S.m0 * w.abs()).sum())
+    # Williamson-2 is a steady state: one step moves the fields by the (small) truncation error only
+    assert float(torch.linalg.vector_norm(u1 - u0) / torch.linalg.vector_norm(u0)) < 2e-4
+    assert float(torch.linalg.vector_norm(h1 - h0) / torch.linalg.vector_norm(h0)) < 2e-5
