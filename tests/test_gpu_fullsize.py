@@ -153,3 +153,45 @@ def test_shallow_water_step_conserves_mass_exactly():
     # Williamson-2 is a steady state: one step moves the fields by the (small) truncation error only
     assert float(torch.linalg.vector_norm(u1 - u0) / torch.linalg.vector_norm(u0)) < 2e-4
     assert float(torch.linalg.vector_norm(h1 - h0) / torch.linalg.vector_norm(h0)) < 2e-5
+
+
+def test_config5_periodic_box_p4_full_size():
+    """config 5 grid: p=4, 32x32 elements, 64 levels, doubly periodic box (1024 columns of 16x16 blocks): area known answer,
+    symmetry, batched-level equality, and the residual of the column Schur solve"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import BoxGeom
+    from mimsem_amd.mesh import PeriodicBox, box_coords
+    from mimsem_amd.topo import Topo
+    pn, ne, npr, nk, lx = 4, 32, 4, 64, 1000.0
+    bx = PeriodicBox(pn, ne, npr); bc = box_coords(pn, ne, lx)
+    topos = [Topo(bx, p, nk) for p in range(npr)]
+    geoms = [BoxGeom(t, bx, bc, nk, lx) for t in topos]
+    for g in geoms:
+        g.set_levels(np.repeat(np.linspace(0.0, 1500.0, nk + 1)[:, None], g.n0, axis=1))
+    dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+    eng = Engine(dm)
+    assert dm.nEl * nk == 65536
+    rng = np.random.default_rng(55)
+    t = eng.tensor
+    tot = eng.apply("PMAT", t(np.ones((nk, dm.n0))), lev0=0, scale=SCALE).sum(dim=1).cpu().numpy()
+    area = tot / (SCALE * dm.thickInv[:, 0, 0])
+    assert np.all(np.abs(area / (lx * lx) - 1.0) < 1e-12)                         # periodic box: the quadrature is exact
+    x, y = t(rng.standard_normal((nk, dm.n1))), t(rng.standard_normal((nk, dm.n1)))
+    Mx, My = eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1), eng.apply("UMAT", y, lev0=0, scale=SCALE, flags=1)
+    assert abs(_dot(y, Mx) - _dot(x, My)) < 1e-12 * abs(_dot(x, Mx))
+    assert torch.equal(Mx[17], eng.apply("UMAT", x[17], lev0=17, scale=SCALE, flags=1))
+    n2, nEl = eng.n2e, dm.nEl
+    a2 = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    lev = lambda nl, lo, hi: t(rng.uniform(lo, hi, (nEl, nl * n2)) * a2 * dz)
+    theta, rho, eta, pi = lev(nk, 295, 305), lev(nk, 0.9, 1.1), lev(nk, 5.6, 5.8), lev(nk, 900, 1000)
+    F = [t(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (nk - 1, nk, nk, nk)]
+    dt = 0.5
+    L = eng.helmholtz_blocks(dt, theta, rho, eta, pi).view(nEl, nk, 3, n2, n2)
+    d_u, d_rho, d_eta, d_pi = eng.solve_schur_eta(dt, theta, rho, eta, pi, *F)
+    rhs, d = F[3].view(nEl, nk, n2), d_pi.view(nEl, nk, n2)
+    Ld = torch.einsum("ekij,ekj->eki", L[:, :, 1], d)
+    Ld[:, 1:] += torch.einsum("ekij,ekj->eki", L[:, 1:, 0], d[:, :-1])
+    Ld[:, :-1] += torch.einsum("ekij,ekj->eki", L[:, :-1, 2], d[:, 1:])
+    res = torch.linalg.vector_norm(Ld - rhs, dim=(1, 2)) / torch.linalg.vector_norm(rhs, dim=(1, 2))
+    assert float(res.max()) < 1e-9, float(res.max())
