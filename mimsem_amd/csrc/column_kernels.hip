@@ -929,7 +929,8 @@ __device__ __forceinline__ void wsync() {
 }
 template <int N2>
 __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* __restrict__ L, const double* __restrict__ f,
-                                                          double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws) {
+                                                          double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws,
+                                                          double* __restrict__ Dinv /* optional [nEl][nk][nn]: kept for re-solves */) {
     constexpr int nn = N2*N2, EPL = (nn + 63)/64;           // entries per lane
     __shared__ double D[nn], Di[nn], Gp[nn], S[nn], U[nn], v[N2], yp[N2], dn[N2];
     const int lane = threadIdx.x, e = blockIdx.x;
@@ -1013,6 +1014,7 @@ __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* 
                     for (int m = 0; m < N2; m++) s += Di[i*N2 + m]*U[m*N2 + j];
                 }
                 G[(size_t)k*nn + t] = s; Gp[t] = s;
+                if (Dinv) Dinv[((size_t)e*nk + k)*nn + t] = Di[t];
             }
         }
         if (lane < N2) {
@@ -1040,11 +1042,59 @@ __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* 
     }
 }
 
-int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws) {
+// re-solve with the factors of a previous sweep (Dinv_k = D'_k^-1, G_k = D'_k^-1 sup_k): forward y_k = Dinv_k (f_k - sub_k y_{k-1}),
+// backward d_k = y_k - G_k d_{k+1}.  One thread per (column, row), the column's recurrences run in LDS (columns do not interact).
+template <int N2>
+__global__ __launch_bounds__(64) void k_block_thomas_resolve(int nEl, int nk, const double* __restrict__ L, const double* __restrict__ Dinv,
+        const double* __restrict__ G, const double* __restrict__ f, double* __restrict__ d) {
+    constexpr int nn = N2*N2, CPW = 64/N2;               // columns per wave
+    __shared__ double yl[CPW][2][N2], t[CPW][N2];
+    const int lane = threadIdx.x, lc = lane/N2, a = lane%N2;
+    const int e = blockIdx.x*CPW + lc;
+    const bool act = lc < CPW && e < nEl;
+    extern __shared__ double ybuf[];                      // [CPW][nk][N2]  forward results
+    double* yv = ybuf + (size_t)lc*nk*N2;
+    for (int k = 0; k < nk; k++) {
+        if (act) {
+            const double* sub = L + (((size_t)e*nk + k)*3 + 0)*nn;
+            double s = f[((size_t)e*nk + k)*N2 + a];
+            if (k > 0) {
+#pragma unroll
+                for (int m = 0; m < N2; m++) s -= sub[a*N2 + m]*yv[(size_t)(k - 1)*N2 + m];
+            }
+            t[lc][a] = s;
+        }
+        wsync();
+        if (act) {
+            const double* Di = Dinv + ((size_t)e*nk + k)*nn;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += Di[a*N2 + m]*t[lc][m];
+            yv[(size_t)k*N2 + a] = s;
+        }
+        wsync();
+    }
+    for (int k = nk - 1; k >= 0; k--) {
+        double s = 0.0;
+        if (act) {
+            s = yv[(size_t)k*N2 + a];
+            if (k < nk - 1) {
+                const double* Gk = G + ((size_t)e*nk + k)*nn;
+#pragma unroll
+                for (int m = 0; m < N2; m++) s -= Gk[a*N2 + m]*yl[lc][(k + 1) & 1][m];
+            }
+            d[((size_t)e*nk + k)*N2 + a] = s;
+            yl[lc][k & 1][a] = s;
+        }
+        wsync();
+    }
+}
+
+int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* Dinv = nullptr) {
     const int n2 = c->es.n2e, nn = n2*n2;
     if (!getenv("MIMSEM_THOMAS_WG")) {
         switch (n2) {
-#define MIMSEM_TW(N) case N: hipLaunchKernelGGL((k_block_thomas_wave<N>), dim3(c->nEl), dim3(64), 0, c->stream, c->nk, L, f, d, Gws, yws); \
+#define MIMSEM_TW(N) case N: hipLaunchKernelGGL((k_block_thomas_wave<N>), dim3(c->nEl), dim3(64), 0, c->stream, c->nk, L, f, d, Gws, yws, Dinv); \
                      MIMSEM_HIP_TRY(hipGetLastError()); return MIMSEM_OK;
         MIMSEM_TW(1) MIMSEM_TW(4) MIMSEM_TW(9) MIMSEM_TW(16)
 #undef MIMSEM_TW
@@ -1076,13 +1126,27 @@ int block_tridiag_residual(mimsem_ctx* c, int nk, int n2, const double* L, const
 // L d = f with ONE step of iterative refinement: the block-Thomas sweep pivots only inside the running diagonal block, so on
 // columns whose running diagonal blocks are poorly conditioned its backward error grows (1e-6 on the worst of 3 456 random
 // columns, cond ~ 2e7, where LU with row pivoting over the whole band gives 1e-12); d += solve(f - L d) restores it.
-int block_thomas_refined(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* r, double* dd) {
+int block_thomas_refined(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* r, double* dd,
+                         double* Dinv /* [nEl][nk][nn] scratch or null */) {
     int rc;
-    if ((rc = block_thomas(c, L, f, d, Gws, yws))) return rc;
+    const int n2 = c->es.n2e, nk = c->nk, nEl = c->nEl;
+    const bool wave = !getenv("MIMSEM_THOMAS_WG") && (n2 == 1 || n2 == 4 || n2 == 9 || n2 == 16);
+    const bool keep = Dinv && wave && (size_t)(64/n2)*nk*n2*sizeof(double) <= 48*1024;
+    if ((rc = block_thomas(c, L, f, d, Gws, yws, keep ? Dinv : nullptr))) return rc;
     if (getenv("MIMSEM_NO_REFINE")) return MIMSEM_OK;
-    if ((rc = block_tridiag_residual(c, c->nk, c->es.n2e, L, f, d, r))) return rc;
-    if ((rc = block_thomas(c, L, r, dd, Gws, yws))) return rc;
-    return each(c, (long long)c->nEl*c->nk*c->es.n2e, [=] __device__(long long i) { d[i] += dd[i]; });
+    if ((rc = block_tridiag_residual(c, nk, n2, L, f, d, r))) return rc;
+    if (keep) {                      // substitution only, with the factors of the first sweep
+        const int cpw = 64/n2;
+        const size_t lds = (size_t)cpw*nk*n2*sizeof(double);
+        const unsigned grid = (unsigned)((nEl + cpw - 1)/cpw);
+        switch (n2) {
+#define MIMSEM_TR(N) case N: hipLaunchKernelGGL((k_block_thomas_resolve<N>), dim3(grid), dim3(64), lds, c->stream, nEl, nk, L, Dinv, Gws, r, dd); break;
+        MIMSEM_TR(1) MIMSEM_TR(4) MIMSEM_TR(9) MIMSEM_TR(16)
+#undef MIMSEM_TR
+        }
+        MIMSEM_HIP_TRY(hipGetLastError());
+    } else if ((rc = block_thomas(c, L, r, dd, Gws, yws))) return rc;
+    return each(c, (long long)nEl*nk*n2, [=] __device__(long long i) { d[i] += dd[i]; });
 }
 
 // one workgroup per (column, level): the two DIV blocks of the row, the four G_pi blocks they meet and N_pi are
@@ -1343,7 +1407,7 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
         }))) return rc;
     }
     // Helmholtz solve                                                                     (:783-789)
-    if ((rc = block_thomas_refined(c, S.L.p, F_pi, d_pi, S.G.p, S.tB, S.tA, S.tC))) return rc;     // tA: free scratch by now
+    if ((rc = block_thomas_refined(c, S.L.p, F_pi, d_pi, S.G.p, S.tB, S.tA, S.tC, S.Npi.p))) return rc;     // tA, Npi: free scratch by now
     // back substitution                                                                   (:792-815)
     {
         const double *Gl = S.Gl.p, *Gu = S.Gu.p, *rl = S.rlump;
