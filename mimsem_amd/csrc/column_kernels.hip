@@ -513,7 +513,7 @@ int up_blocks_into(mimsem_ctx* c, int colop, const double* rho, double* M, doubl
 
 // blocks of a column operator into M ([nEl][nr][nw][n2][n2]); cq scratch [nEl][nr][nw][mp12] (x2 for EOS)
 int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1, const double* f2,
-                      double* M, double* cq, double* tmpM) {
+                      double* M, double* cq, double* tmpM, const double* Bconst = nullptr /* CONST blocks if the caller has them */) {
     int nr, nw, nx, ny;
     colop_shape(colop, c->nk, &nr, &nw, &nx, &ny);
     const long long nb = (long long)c->nEl*nr*nw;
@@ -523,7 +523,8 @@ int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1
         if ((rc = coef_block_pass(c, MIMSEM_V_CONST_RHO, 0, f1, nullptr, tmpM, nr, 1))) return rc;   // B(rt)
         if ((rc = mimsem_block_inverse_inplace(c, nb, n2, tmpM))) return rc;
         double* Bm = tmpM + nb*nn;
-        if ((rc = coef_block_pass(c, MIMSEM_V_CONST, 0, nullptr, nullptr, Bm, nr, 1))) return rc;     // B
+        if (Bconst) Bm = const_cast<double*>(Bconst);
+        else if ((rc = coef_block_pass(c, MIMSEM_V_CONST, 0, nullptr, nullptr, Bm, nr, 1))) return rc;     // B
         const double* Binv = tmpM;
         double* t1 = M;                                                        // Binv.B lands in the output, then B.(Binv.B)
         if ((rc = flat_mm(c, nb, n2, Binv, Bm, t1))) return rc;
@@ -1208,7 +1209,8 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
 
     // VB, VB_inv, VA_inv   (VertSolve.cpp:690-692)
     if ((rc = colop_blocks_into(c, MIMSEM_V_CONST, 0, nullptr, nullptr, S.B.p, cq, tmpM))) return rc;
-    if ((rc = colop_blocks_into(c, MIMSEM_V_CONST_INV, 0, nullptr, nullptr, S.Binv.p, cq, tmpM))) return rc;
+    MIMSEM_HIP_TRY(hipMemcpyAsync(S.Binv.p, S.B.p, (size_t)nEl*nk*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = mimsem_block_inverse_inplace(c, (long long)nEl*nk, n2, S.Binv.p))) return rc;      // AssembleConstInv == Inv(AssembleConst block)
     if ((rc = colop_blocks_into(c, MIMSEM_V_LINEAR_INV, 0, nullptr, nullptr, S.Ainv.p, cq, tmpM))) return rc;
     // grad: g_i = Ainv_i (B_{i+1} f_{i+1} - B_i f_i)       (:694-695, :700, :729)
     auto grad = [&](const double* fld, double* out) -> int {
@@ -1232,8 +1234,8 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
     if ((rc = grad(eta, S.geta))) return rc;
     if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_W, 0, S.geta, nullptr, C2.p, cq, tmpM))) return rc;
     // EOS blocks                                                     (:736, :739)
-    if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, pi, nullptr, S.Npi.p, cq, tmpM))) return rc;
-    if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, rho, nullptr, S.Nrho.p, cq, tmpM))) return rc;
+    if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, pi, nullptr, S.Npi.p, cq, tmpM, S.B.p))) return rc;
+    if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, rho, nullptr, S.Nrho.p, cq, tmpM, S.B.p))) return rc;
     return MIMSEM_OK;
 }
 
