@@ -269,6 +269,31 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         if (rc) return fail(rc);
         if ((rc = upload(&c->d_g0, plan.data(), plan.size(), c))) return fail(rc);
     }
+    // direct-write tables: a DoF with a single contributing element needs no scatter-add at all
+    {
+        auto build = [&](int nslots, const std::vector<const int*>& maps, int counts, std::vector<std::vector<int>>& dir, std::vector<int>& shared) {
+            std::vector<int> cnt(nslots, 0);
+            for (const int* m : maps) for (size_t i = 0; i < (size_t)d->nEl*counts; i++) cnt[m[i]]++;
+            dir.assign(maps.size(), std::vector<int>((size_t)d->nEl*counts));
+            for (size_t k = 0; k < maps.size(); k++)
+                for (size_t i = 0; i < (size_t)d->nEl*counts; i++) dir[k][i] = (cnt[maps[k][i]] == 1) ? maps[k][i] : -1;
+            shared.clear();
+            for (int sl = 0; sl < nslots; sl++) if (cnt[sl] != 1) shared.push_back(sl);     // incl. untouched slots (written as 0)
+        };
+        std::vector<std::vector<int>> dir; std::vector<int> sh;
+        build(d->n1, {d->inds1x, d->inds1y}, es.n1e, dir, sh);
+        if ((rc = upload(&c->d_d1x, dir[0].data(), dir[0].size(), c))) return fail(rc);
+        if ((rc = upload(&c->d_d1y, dir[1].data(), dir[1].size(), c))) return fail(rc);
+        if ((rc = upload(&c->d_sh1, sh.data(), sh.size(), c))) return fail(rc);
+        c->nsh1 = (int)sh.size();
+        build(d->n0, {d->inds0}, es.n0e, dir, sh);
+        if ((rc = upload(&c->d_d0, dir[0].data(), dir[0].size(), c))) return fail(rc);
+        if ((rc = upload(&c->d_sh0, sh.data(), sh.size(), c))) return fail(rc);
+        c->nsh0 = (int)sh.size();
+        // measured SLOWER on MI355X (pass 1 14.9 -> 17.4 us: the single-contributor stores are scattered, the ye stores coalesce;
+        // pass 2 over the shared-slot list 7.4 -> 8.2 us), profiles/r01_direct_interior_ab.txt: opt-in only
+        c->direct = getenv("MIMSEM_DIRECT") != nullptr;
+    }
     // Fused single-barrier scatter-add (group-local sums in LDS + perimeter pass): measured SLOWER than the two-pass
     // form on MI355X in round 1 (profiles/r01_fused_scatter_ab.txt), so it is opt-in (MIMSEM_FUSE=1) for further tuning.
     if (getenv("MIMSEM_FUSE")) {
@@ -306,7 +331,8 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry};
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
+                    c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -427,6 +453,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         return rc;
     }
     a.fperm = nullptr; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0;
+    a.d0 = a.d1x = a.d1y = nullptr; a.y = nullptr; a.ys = 0;
     if (outsp == 1 && c->fused1 && op < MIMSEM_OP_UMAT_UP && op != MIMSEM_OP_UMAT_RAY) {
         // fused path: group-local sums in LDS, complete slots written straight to y, perimeter partials to the workspace
         if ((rc = c->ensure_ye((long long)std::max(c->f_npart, 1)*nlev))) return rc;
@@ -443,8 +470,9 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     if ((rc = c->ensure_ye(per*nlev))) return rc;
     a.out = c->d_ye; a.os = per;
     a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+    if (c->direct) { a.d0 = c->d_d0; a.d1x = c->d_d1x; a.d1y = c->d_d1y; a.y = y; a.ys = ys; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0; }
     rc = launch_elem_apply(c, op, a);
-    if (!rc) rc = launch_gather_sum(c, outsp, nlev, c->d_ye, per, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, y, ys);
+    if (!rc) rc = launch_gather_sum(c, outsp, nlev, c->d_ye, per, (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0, y, ys, c->direct);
     c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
     return rc;
 }

@@ -66,6 +66,9 @@ struct mimsem_ctx {
     // workspace
     double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
     long long ye_doubles = 0;
+    int *d_d0 = nullptr, *d_d1x = nullptr, *d_d1y = nullptr;   // direct-write slots (single-contributor DoFs), see ElemArgs
+    int *d_sh0 = nullptr, *d_sh1 = nullptr; int nsh0 = 0, nsh1 = 0;   // slots with >= 2 contributors: the only ones pass 2 visits
+    bool direct = false;
     double* d_col = nullptr;    // column-solver workspace
     long long col_doubles = 0;
     double col_param = 0.0;             // scalar argument of the *_ex column operators (dt_fric / dt)
@@ -108,12 +111,14 @@ struct ElemArgs {
     // fused 1-form scatter-add
     const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
     double* y; long long ys; int accum;
+    // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)
+    const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
 };
 
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
-                      double* y, long long ys);
+                      double* y, long long ys, bool shared_only = false);
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,
                         const double* x, long long xs, double* y, long long ys, double alpha, int accum,
                         const double* escale = nullptr, long long escale_stride = 0);

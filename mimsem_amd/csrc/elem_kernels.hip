@@ -342,6 +342,12 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     if constexpr (T::cf2 != SN) dof_slots<N, T::cf2>(a, e, q, act, us0, us1);
     const size_t lstride = (size_t)a.nEl*D::mp12;
     const size_t gq = (size_t)e*D::mp12 + q;
+    // direct path: this lane's output DoFs that no other element touches go straight to y
+    int ds0 = -1, ds1 = -1;
+    if constexpr (!FUSED) {
+        if constexpr (T::out == S1) { if (a.d1x && act && q < D::n1e) { ds0 = a.d1x[e*D::n1e + q]; ds1 = a.d1y[e*D::n1e + q]; } }
+        if constexpr (T::out == S0) { if (a.d0 && qact) ds0 = a.d0[e*D::n0e + q]; }
+    }
     int fcnt = 0;
     if constexpr (FUSED) fcnt = a.fcnt[grp];
 
@@ -482,7 +488,10 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
 
         if constexpr (T::out == S0) {
             // collocated 0-form projection is the identity: P^T diag(c) P = diag(c)
-            if (qact) a.out[(size_t)lev*a.os + (size_t)e*D::n0e + q] = a.alpha*ra;
+            if (qact) {
+                if (ds0 >= 0) { double* o = a.y + (size_t)lev*a.ys + ds0; if (a.accum) *o += a.alpha*ra; else *o = a.alpha*ra; }
+                else a.out[(size_t)lev*a.os + (size_t)e*D::n0e + q] = a.alpha*ra;
+            }
             wave_lds_sync();
         } else {
             s_a[el][q] = ra; s_b[el][q] = rb;
@@ -509,8 +518,10 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
                     }
                     if constexpr (!FUSED) {
                         double* o = a.out + (size_t)lev*a.os + (size_t)e*2*D::n1e;
-                        o[q] = a.alpha*yx;
-                        o[D::n1e + q] = a.alpha*yy;
+                        if (ds0 >= 0) { double* t = a.y + (size_t)lev*a.ys + ds0; if (a.accum) *t += a.alpha*yx; else *t = a.alpha*yx; }
+                        else o[q] = a.alpha*yx;
+                        if (ds1 >= 0) { double* t = a.y + (size_t)lev*a.ys + ds1; if (a.accum) *t += a.alpha*yy; else *t = a.alpha*yy; }
+                        else o[D::n1e + q] = a.alpha*yy;
                     } else {                 // park the element-local results in LDS (conflict-free, no branching)
                         double* st = s_acc[lev & 1] + el*2*D::n1e;
                         st[q] = a.alpha*yx; st[D::n1e + q] = a.alpha*yy;
@@ -553,10 +564,12 @@ constexpr int GS_LC = 4;
 template <int K>
 __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ ye, long long ye_stride,
                                                     const int* __restrict__ plan, int nslots, int nlev,
-                                                    int accum, double* __restrict__ y, long long ys) {
-    const int s = xcd_swizzle(blockIdx.x, gridDim.x, accum >> 8)*256 + threadIdx.x;
+                                                    int accum, double* __restrict__ y, long long ys,
+                                                    const int* __restrict__ slots /* null: every slot; else the shared ones */) {
+    int s = xcd_swizzle(blockIdx.x, gridDim.x, accum >> 8)*256 + threadIdx.x;
     accum &= 1;
     if (s >= nslots) return;
+    if (slots) s = slots[s];
     int j[K];
 #pragma unroll
     for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
@@ -1102,14 +1115,15 @@ int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps
 }
 
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
-                      double* y, long long ys) {
-    const int nslots = form == 1 ? c->n1 : c->n0;
+                      double* y, long long ys, bool shared_only) {
+    const int* slots = shared_only ? (form == 1 ? c->d_sh1 : c->d_sh0) : nullptr;
+    const int nslots = shared_only ? (form == 1 ? c->nsh1 : c->nsh0) : (form == 1 ? c->n1 : c->n0);
     if (nslots == 0 || nlev == 0) return MIMSEM_OK;
     const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
     hipEvent_t s0 = c->ev_k2[0], s1 = c->ev_k2[1];
 #define MIMSEM_GS(K, PLAN) \
-    if (s0) hipExtLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, s0, s1, 0, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys); \
-    else hipLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys)
+    if (s0) hipExtLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, s0, s1, 0, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots); \
+    else hipLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots)
     if (form == 1) { MIMSEM_GS(2, c->d_g1); }
     else if (c->G0 == 4) { MIMSEM_GS(4, c->d_g0); }
     else { MIMSEM_GS(8, c->d_g0); }
