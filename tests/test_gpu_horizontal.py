@@ -277,3 +277,29 @@ def test_element_blocks_apply_level_sweep(setup):
                 got = eng.blocks_apply(form, eng.tensor(B), eng.tensor(xv), transpose=tr,
                                        elem_scale=None if scale is None else eng.tensor(scale)).cpu().numpy()
                 assert rel_l2(got, ref) < 1e-12, (form, tr, scale is not None)
+
+
+@pytest.mark.parametrize("env", ["MIMSEM_DIRECT", "MIMSEM_FUSE"])
+def test_opt_in_scatter_variants_agree_with_default(setup, env, monkeypatch):
+    """the two alternative scatter-add organisations kept behind environment switches (direct single-contributor writes;
+    LDS group sums + perimeter pass) produce the default two-pass result"""
+    import torch
+    from mimsem_amd.device import Engine
+    eng, P, rng = setup
+    monkeypatch.setenv(env, "1")
+    alt = Engine(eng.mesh)                                  # the switches are read at context creation
+    monkeypatch.delenv(env)
+    r = np.random.default_rng(8)
+    x1 = r.standard_normal((3, P.n1)); x0 = r.standard_normal((3, P.n0)); h = r.uniform(0.5, 1.5, (3, P.n2)) * 1e6
+    for op, x, f, fl in (("UMAT", x1, None, 1), ("UHMAT", x1, h, 1), ("PMAT", x0, None, 0)):
+        a = eng.apply(op, eng.tensor(x), f=None if f is None else eng.tensor(f), lev0=0, scale=SCALE, flags=fl)
+        b = alt.apply(op, alt.tensor(x), f=None if f is None else alt.tensor(f), lev0=0, scale=SCALE, flags=fl)
+        if env == "MIMSEM_DIRECT":
+            assert torch.equal(a, b), op                    # same arithmetic, different store path
+        else:
+            assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-13, op
+    base = eng.tensor(r.standard_normal((3, P.n1)))
+    ya, yb = base.clone(), base.clone()
+    eng.apply("UMAT", eng.tensor(x1), lev0=0, scale=SCALE, flags=3, alpha=0.25, out=ya)      # accumulate
+    alt.apply("UMAT", alt.tensor(x1), lev0=0, scale=SCALE, flags=3, alpha=0.25, out=yb)
+    assert rel_l2(yb.cpu().numpy(), ya.cpu().numpy()) < 1e-13
