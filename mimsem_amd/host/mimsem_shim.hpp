@@ -68,7 +68,7 @@ class Mesh {
 public:
     Mesh(const Topo* t, const Geom* g, int device = 0) : topo(t), geom(g) {
         const int n = t->elOrd, np1 = n + 1, mp12 = (g->quad_n + 1)*(g->quad_n + 1), nEl = t->nElsX*t->nElsX;
-        std::vector<int> i0((size_t)nEl*np1*np1), ix((size_t)nEl*np1*n), iy((size_t)nEl*np1*n), iq(mp12);
+        std::vector<int> i0((size_t)nEl*np1*np1), ix((size_t)nEl*np1*n), iy((size_t)nEl*np1*n), iq(mp12), iqa((size_t)nEl*mp12);
         std::vector<double> th((size_t)g->nk*nEl*mp12, 1.0), ti((size_t)g->nk*nEl*mp12, 1.0);
         const size_t n0q = (size_t)(g->nDofsX + 1)*(g->nDofsX + 1);
         for (int ey = 0; ey < t->nElsX; ey++) for (int ex = 0; ex < t->nElsX; ex++) {
@@ -77,6 +77,7 @@ public:
             t->elInds1x_l(ex, ey, &ix[(size_t)e*np1*n]);
             t->elInds1y_l(ex, ey, &iy[(size_t)e*np1*n]);
             g->elInds0_l(t->nElsX, ex, ey, iq.data());
+            for (int q = 0; q < mp12; q++) iqa[(size_t)e*mp12 + q] = iq[q];
             if (!g->thick.empty())
                 for (int k = 0; k < g->nk; k++) for (int q = 0; q < mp12; q++) {
                     th[((size_t)k*nEl + e)*mp12 + q] = g->thick[(size_t)k*n0q + iq[q]];
@@ -87,6 +88,8 @@ public:
         d.elOrd = n; d.quadOrd = g->quad_n; d.nEl = nEl; d.nk = g->nk; d.n0 = t->n0; d.n1 = t->n1; d.n2 = t->n2;
         d.inds0 = i0.data(); d.inds1x = ix.data(); d.inds1y = iy.data(); d.inds2 = nullptr;
         d.det = g->det.data(); d.J = g->J.data(); d.thick = th.data(); d.thickInv = ti.data();
+        d.indsq = iqa.data(); d.nq = (int)n0q;
+        nEl_ = nEl; n2e = n*n;
         check(mimsem_ctx_create(&d, device, &ctx), "mimsem_ctx_create");
     }
     ~Mesh() { mimsem_ctx_destroy(ctx); }
@@ -99,7 +102,13 @@ public:
         return (double*)p;
     }
     void to_host(double* host, const double* dev, size_t n) { check(mimsem_memcpy_d2h(ctx, host, dev, (long long)(n*sizeof(double))), "d2h"); }
+    double* device_alloc(size_t n) {
+        void* p = nullptr;
+        check(mimsem_malloc(&p, (long long)(n*sizeof(double))), "mimsem_malloc");
+        return (double*)p;
+    }
     const Topo* topo; const Geom* geom; mimsem_ctx* ctx = nullptr;
+    int nEl_ = 0, n2e = 0;
 };
 
 // common part of every operator class: remembers what assemble() was given, mult() issues the fused launch
@@ -184,6 +193,140 @@ struct Uvec {
         check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_ROTMAT, lev, 1, scale, 0, vort, 0, vel, 0, vl, 0, 1.0), "Uvec::assemble_wxu");
     }
     Mesh* mesh;
+};
+
+// Umat_ray (eul/Assembly.h; Assembly.cpp:1858-1979): Held-Suarez friction, same assemble() argument order
+struct Umat_ray {
+    Umat_ray(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
+    void assemble(int lev_, double scale_, double dt_, const double* exner_k_, const double* exner_s_) {
+        lev = lev_; scale = scale_; dt = dt_; exner_k = exner_k_; exner_s = exner_s_;
+    }
+    void mult(const double* x, double* y, bool add = false) const {       // add: MatAXPY(M1->M, 1.0, M1ray->M) then MatMult
+        check(mimsem_op_apply_up(mesh->ctx, MIMSEM_OP_UMAT_RAY, lev, 1, scale, dt, add ? MIMSEM_FLAG_ACCUM : 0u,
+                                 exner_k, 0, exner_s, 0, x, 0, y, 0, 1.0), "Umat_ray");
+    }
+    void element_matrices(double* out) const {
+        check(mimsem_op_element_matrices_ex(mesh->ctx, MIMSEM_OP_UMAT_RAY, lev, scale, dt, 0, exner_k, exner_s, out), "Umat_ray blocks");
+    }
+    Mesh* mesh; int lev = 0; double scale = 1.0, dt = 0.0; const double *exner_k = nullptr, *exner_s = nullptr;
+};
+
+// Pvec / Phvec (Assembly.cpp:585-689): lumped 0-form mass as a vector
+struct Pvec {
+    Pvec(Mesh* m, LagrangeNode*) : mesh(m) {}
+    void assemble(int lev, double scale, double* vl) { check(mimsem_pvec(mesh->ctx, lev, 1, scale, nullptr, 0, vl, 0), "Pvec"); }
+    Mesh* mesh;
+};
+struct Phvec {
+    Phvec(Mesh* m, LagrangeNode*) : mesh(m) {}
+    void assemble(const double* h2, int lev, double scale, double* vl) { check(mimsem_pvec(mesh->ctx, lev, 1, scale, h2, 0, vl, 0), "Phvec"); }
+    Mesh* mesh;
+};
+
+// projections from the quadrature-point grid (Assembly.cpp:691-902); x indexed like Geom's quad grid
+struct WtQmat { WtQmat(Mesh* m, LagrangeEdge*) : mesh(m) {}
+    void mult(const double* xq, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_WTQ, 0, 1, 1.0, 0, nullptr, 0, xq, 0, y, 0, 1.0), "WtQmat"); } Mesh* mesh; };
+struct PtQmat { PtQmat(Mesh* m, LagrangeNode*) : mesh(m) {}
+    void mult(const double* xq, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_PTQ, 0, 1, 1.0, 0, nullptr, 0, xq, 0, y, 0, 1.0), "PtQmat"); } Mesh* mesh; };
+struct UtQmat { UtQmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
+    void mult(const double* xq2, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UTQ, 0, 1, 1.0, 0, nullptr, 0, xq2, 0, y, 0, 1.0), "UtQmat"); } Mesh* mesh; };
+
+// E10mat / E21mat (Assembly.cpp:1102-1220): public members E10, E01 / E21, E12 become mult functions
+struct E10mat { E10mat(Mesh* m) : mesh(m) {}
+    void mult_E10(const double* x0, double* y1) const { check(mimsem_incidence_apply(mesh->ctx, 0, 1, x0, 0, y1, 0), "E10"); }
+    void mult_E01(const double* x1, double* y0) const { check(mimsem_incidence_apply(mesh->ctx, 3, 1, x1, 0, y0, 0), "E01"); }
+    Mesh* mesh; };
+struct E21mat { E21mat(Mesh* m) : mesh(m) {}
+    void mult_E21(const double* x1, double* y2) const { check(mimsem_incidence_apply(mesh->ctx, 1, 1, x1, 0, y2, 0), "E21"); }
+    void mult_E12(const double* x2, double* y1) const { check(mimsem_incidence_apply(mesh->ctx, 2, 1, x2, 0, y1, 0), "E12"); }
+    Mesh* mesh; };
+
+// L2Vecs (eul/L2Vecs.h:1-25): vh[k] = level k's horizontal 2-form vector, vz[e] = column e's vertical vector.
+// Device storage: vh [nk][n2] contiguous, vz [nEl][nk*n2e] contiguous (the per-element Vecs of the reference, concatenated).
+struct L2Vecs {
+    L2Vecs(int nk_, Mesh* m) : nk(nk_), mesh(m) {
+        n2 = m->topo->n2; nEl = m->nEl_; n2e = m->n2e;
+        vh = m->device_alloc((size_t)nk*n2); vz = m->device_alloc((size_t)nEl*nk*n2e);
+    }
+    ~L2Vecs() { mimsem_free(vh); mimsem_free(vz); }
+    L2Vecs(const L2Vecs&) = delete;
+    L2Vecs& operator=(const L2Vecs&) = delete;
+    void HorizToVert() { check(mimsem_l2_transpose(mesh->ctx, 0, nk, vh, n2, vz), "HorizToVert"); }      // L2Vecs.cpp:55-76
+    void VertToHoriz() { check(mimsem_l2_transpose(mesh->ctx, 1, nk, vh, n2, vz), "VertToHoriz"); }      // :78-101
+    double* level(int k) { return vh + (size_t)k*n2; }                    // vh[k]
+    double* column(int e) { return vz + (size_t)e*nk*n2e; }               // vz[e]
+    void CopyFromHoriz(const double* host) { check(mimsem_memcpy_h2d(mesh->ctx, vh, host, (long long)((size_t)nk*n2*sizeof(double))), "h2d"); }
+    void CopyFromVert(const double* host) { check(mimsem_memcpy_h2d(mesh->ctx, vz, host, (long long)((size_t)nEl*nk*n2e*sizeof(double))), "h2d"); }
+    int nk, n2 = 0, nEl = 0, n2e = 0; Mesh* mesh; double *vh = nullptr, *vz = nullptr;
+};
+
+// VertOps (eul/VertOps.h:3-72).  The reference assembles ONE column's matrix into VA/VB/... and the caller loops over the
+// columns (`for(ii...) { vo->AssembleX(ex, ey, ..., vo->VB); MatMult(vo->VB, a, b); }`); here Assemble* records the operator for
+// ALL columns (fields are the concatenated vz arrays) and mult() is that loop's body for every column in one launch.
+struct VertOps {
+    explicit VertOps(Mesh* m) : mesh(m) {}
+    void AssembleConst()                                  { set(MIMSEM_V_CONST); }
+    void AssembleConstInv()                               { set(MIMSEM_V_CONST_INV); }
+    void AssembleConstWithRho(const double* rho)          { set(MIMSEM_V_CONST_RHO, rho); }
+    void AssembleConstWithRhoInv(const double* rho)       { set(MIMSEM_V_CONST_RHO_INV, rho); }
+    void AssembleConstWithTheta(const double* theta)      { set(MIMSEM_V_CONST_THETA, theta); }
+    void Assemble_EOS_Block(const double* rt)             { set(MIMSEM_V_EOS_BLOCK, rt); }
+    void Assemble_EOS_BlockInv(const double* rt, const double* theta) { set(MIMSEM_V_EOS_BLOCK_INV, rt, theta); }
+    void AssembleLinear()                                 { set(MIMSEM_V_LINEAR); }
+    void AssembleLinearInv()                              { set(MIMSEM_V_LINEAR_INV); }
+    void AssembleLinearWithRT(const double* rt, bool do_internal) { set(MIMSEM_V_LINEAR_RT, rt, nullptr, do_internal ? MIMSEM_FLAG_VERT : 0u); }
+    void AssembleLinearWithTheta(const double* theta)     { set(MIMSEM_V_LINEAR_THETA, theta); }
+    void AssembleLinearWithRho2(const double* rho)        { set(MIMSEM_V_LINEAR_RHO2, rho); }
+    void AssembleLinearWithRayleighInv(double dt_fric)    { set(MIMSEM_V_LINEAR_RAYLEIGH_INV); param = dt_fric; }
+    void AssembleRayleigh()                               { set(MIMSEM_V_RAYLEIGH); }
+    void AssembleLinCon()                                 { set(MIMSEM_V_LINCON); }
+    void AssembleLinCon2()                                { set(MIMSEM_V_LINCON2); }
+    void AssembleConLin()                                 { set(MIMSEM_V_CONLIN); }
+    void AssembleConLinWithW(const double* velz)          { set(MIMSEM_V_CONLIN_W, velz); }
+    void AssembleConLinWithRhodPi(const double* theta, const double* dpi) { set(MIMSEM_V_CONLIN_RHODPI, theta, dpi); }
+    void AssembleLinearWithRho2_up(const double* rho, double dt, const double* uhl, long long uhl_stride) {
+        set(MIMSEM_V_LINEAR_RHO2_UP, rho); param = dt; uh = uhl; uhs = uhl_stride; }
+    void AssembleLinCon2_up(double dt, const double* uhl, long long uhl_stride) { set(MIMSEM_V_LINCON2_UP); param = dt; uh = uhl; uhs = uhl_stride; }
+    // MatMult(VX, x, y) / MatMultTranspose for every column
+    void mult(const double* x, double* y, bool transpose = false) const {
+        check(mimsem_colop_apply_ex(mesh->ctx, colop, flags, transpose ? 1 : 0, param, f1, f2, uh, uhs, x, y), "VertOps::mult");
+    }
+    int nblocks() const { return mimsem_colop_nblocks(mesh->ctx, colop); }
+    void blocks(double* out) const { check(mimsem_colop_blocks_ex(mesh->ctx, colop, flags, param, f1, f2, uh, uhs, out), "VertOps::blocks"); }
+    // vectors (VertOps.cpp:732-787, 987-1047, 1204-1305)
+    void Assemble_EOS_Residual(const double* rt, const double* exner, double* out) { check(mimsem_column_eos(mesh->ctx, 0, rt, exner, 0, 0, out), "EOS_Residual"); }
+    void Assemble_EOS_RHS(const double* rt, double* out, double factor, double exponent) { check(mimsem_column_eos(mesh->ctx, 1, rt, nullptr, factor, exponent, out), "EOS_RHS"); }
+    void AssembleConstWithLogThetaPlusEta(const double* theta, const double* eta, double* out) { check(mimsem_column_eos(mesh->ctx, 2, theta, eta, 0, 0, out), "LogThetaPlusEta"); }
+    void AssembleConstWithRhoExpEta(const double* rho, const double* eta, double* out) { check(mimsem_column_eos(mesh->ctx, 3, rho, eta, 0, 0, out), "RhoExpEta"); }
+    void AssembleTempForcing_HS(const double* lat, const double* exner, const double* theta, const double* rho, double* out) {
+        check(mimsem_column_temp_forcing_hs(mesh->ctx, lat, exner, theta, rho, out), "TempForcing_HS"); }
+    // V10 / V01 / V10_full (VertOps.cpp:134-182)
+    void mult_V10(const double* x, double* y) const { check(mimsem_column_incidence(mesh->ctx, 0, x, y), "V10"); }
+    void mult_V01(const double* x, double* y) const { check(mimsem_column_incidence(mesh->ctx, 1, x, y), "V01"); }
+    void mult_V10_full(const double* x, double* y) const { check(mimsem_column_incidence(mesh->ctx, 2, x, y), "V10_full"); }
+    Mesh* mesh;
+private:
+    void set(int op, const double* a = nullptr, const double* b = nullptr, unsigned fl = 0) { colop = op; f1 = a; f2 = b; flags = fl; param = 0.0; uh = nullptr; uhs = 0; }
+    int colop = MIMSEM_V_CONST; unsigned flags = 0; double param = 0.0; const double *f1 = nullptr, *f2 = nullptr, *uh = nullptr; long long uhs = 0;
+};
+
+// VertSolve (eul/VertSolve.h): the column solves, every column at once (the reference loops over ex, ey)
+struct VertSolve {
+    VertSolve(Mesh* m, double dt_) : mesh(m), dt(dt_) {}
+    void solve_schur_column_eta(const double* theta, const double* /*velz: unused by the reference*/, const double* rho, const double* eta, const double* pi,
+                                double* F_u, double* F_rho, double* F_eta, double* F_pi, double* d_u, double* d_rho, double* d_eta, double* d_pi) {
+        check(mimsem_column_solve_schur_eta(mesh->ctx, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi, d_u, d_rho, d_eta, d_pi), "solve_schur_column_eta");
+    }
+    void solve_schur_column_3(const double* theta, const double* velz, const double* rho, const double* rt, const double* pi,
+                              double* F_u, double* F_rho, double* F_rt, double* F_pi, double* d_u, double* d_rho, double* d_rt, double* d_pi, bool box_twin = false) {
+        check(mimsem_column_solve_schur_3(mesh->ctx, dt, box_twin ? MIMSEM_SCHUR3_BOX : 0u, theta, velz, rho, rt, pi,
+                                          F_u, F_rho, F_rt, F_pi, d_u, d_rho, d_rt, d_pi, nullptr), "solve_schur_column_3");
+    }
+    void diagTheta2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 1, rho, rt, theta), "diagTheta2"); }
+    void diagTheta_L2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 0, rho, rt, theta), "diagTheta_L2"); }
+    void diagTheta_up(const double* rho, const double* rt, double* theta, const double* ul, long long ul_stride) {
+        check(mimsem_column_diag_theta_up(mesh->ctx, dt, rho, rt, ul, ul_stride, theta), "diagTheta_up"); }
+    Mesh* mesh; double dt;
 };
 
 }  // namespace mimsem_host

@@ -1,6 +1,7 @@
 // tests/cpp/test_shim.cpp -- C++ caller of the drop-in boundary, written like a reference call site
 // (eul/HorizSolve.cpp:216-221:  M1->assemble(lev, SCALE, true); MatMult(M1->M, u, Mu);) and checked against the
 // CPU oracle (oracle/oracle.h, test infrastructure).  Built and run by tests/test_gpu_cpp_shim.py on the GPU box.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -67,6 +68,89 @@ int main() {
     orc_op_apply(P, ORC_UHMAT, em.data(), u.data(), want.data());
     compare("Uhmat");
 
+    // ---- incidence, Pvec, projections -------------------------------------------------------------------
+    {
+        std::vector<double> x0(P->n0), y1(P->n1), w1(P->n1, 0.0), y2(P->n2), w2(P->n2, 0.0), pv(P->n0), wp(P->n0, 0.0);
+        for (auto& v : x0) v = S(rng);
+        double *d_x0 = mesh.to_device(x0.data(), x0.size()), *d_y1 = mesh.device_alloc(P->n1), *d_y2 = mesh.device_alloc(P->n2), *d_p = mesh.device_alloc(P->n0);
+        E10mat NtoE(&mesh); E21mat EtoF(&mesh);
+        NtoE.mult_E10(d_x0, d_y1); mesh.to_host(y1.data(), d_y1, y1.size()); orc_e10_apply(P, x0.data(), w1.data());
+        EtoF.mult_E21(d_u, d_y2);  mesh.to_host(y2.data(), d_y2, y2.size()); orc_e21_apply(P, u.data(), w2.data());
+        bool same = true;
+        for (size_t i = 0; i < y1.size(); i++) same = same && y1[i] == w1[i];
+        for (size_t i = 0; i < y2.size(); i++) same = same && y2[i] == w2[i];
+        std::printf("%-8s %s\n", "E10/E21", same ? "bit-exact" : "MISMATCH"); if (!same) fails++;
+        Pvec m0(&mesh, &node); m0.assemble(1, SCALE, d_p); mesh.to_host(pv.data(), d_p, pv.size()); orc_pvec(P, 1, SCALE, wp.data());
+        double num = 0, den = 0; for (size_t i = 0; i < pv.size(); i++) { num += (pv[i] - wp[i])*(pv[i] - wp[i]); den += wp[i]*wp[i]; }
+        std::printf("%-8s rel L2 = %.3e\n", "Pvec", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
+        std::vector<double> xq(P->n0q), pq(P->n0), wq(P->n0, 0.0);
+        for (auto& v : xq) v = S(rng);
+        double* d_xq = mesh.to_device(xq.data(), xq.size());
+        PtQmat PtQ(&mesh, &node); PtQ.mult(d_xq, d_p); mesh.to_host(pq.data(), d_p, pq.size()); orc_project_from_quad(P, 1, xq.data(), wq.data());
+        num = den = 0; for (size_t i = 0; i < pq.size(); i++) { num += (pq[i] - wq[i])*(pq[i] - wq[i]); den += wq[i]*wq[i]; }
+        std::printf("%-8s rel L2 = %.3e\n", "PtQmat", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
+        mimsem_free(d_x0); mimsem_free(d_y1); mimsem_free(d_y2); mimsem_free(d_p); mimsem_free(d_xq);
+    }
+    // ---- L2Vecs, VertOps, VertSolve: the column path as eul/VertSolve.cpp drives it ---------------------------
+    {
+        const int n2e = P->n2e, N = nk*n2e;
+        L2Vecs rho(nk, &mesh);
+        std::vector<double> vh((size_t)nk*P->n2), vz((size_t)nEl*N), wz((size_t)nEl*N);
+        for (auto& v : vh) v = U(rng)*1e9;
+        rho.CopyFromHoriz(vh.data()); rho.HorizToVert();
+        mesh.to_host(vz.data(), rho.vz, vz.size()); orc_horiz_to_vert(P, vh.data(), wz.data());
+        bool same = true; for (size_t i = 0; i < vz.size(); i++) same = same && vz[i] == wz[i];
+        std::printf("%-8s %s\n", "L2Vecs", same ? "bit-exact" : "MISMATCH"); if (!same) fails++;
+
+        // vo->AssembleConstWithRho(ex, ey, rho, vo->VB); MatMult(vo->VB, a, b);   (every column at once)
+        VertOps vo(&mesh);
+        std::vector<double> a((size_t)nEl*N), b((size_t)nEl*N), dense((size_t)N*N);
+        for (auto& v : a) v = S(rng);
+        double *d_a = mesh.to_device(a.data(), a.size()), *d_b = mesh.device_alloc(a.size());
+        vo.AssembleConstWithRho(rho.vz); vo.mult(d_a, d_b); mesh.to_host(b.data(), d_b, b.size());
+        double worst = 0.0;
+        for (int e : {0, nEl - 1}) {
+            orc_colop_dense(P, ORC_V_CONST_RHO, e%nels, e/nels, 0, &vz[(size_t)e*N], nullptr, dense.data());
+            double num = 0, den = 0;
+            for (int i = 0; i < N; i++) { double s = 0; for (int j = 0; j < N; j++) s += dense[(size_t)i*N + j]*a[(size_t)e*N + j];
+                                          num += (b[(size_t)e*N + i] - s)*(b[(size_t)e*N + i] - s); den += s*s; }
+            worst = std::max(worst, std::sqrt(num/den));
+        }
+        std::printf("%-8s rel L2 = %.3e\n", "VertOps", worst); if (!(worst < 1e-10)) fails++;
+        mimsem_free(d_a); mimsem_free(d_b);
+
+        // solve_schur_column_eta(ex, ey, theta, velz, rho, eta, pi, F_u, F_rho, F_eta, F_pi, d_u, d_rho, d_eta, d_pi)  eul/VertSolve.cpp:1868
+        double area = 0.0, dz = 0.0;
+        for (double v : det) area += v; area = area/det.size()*4.0/n2e;
+        for (size_t i = 0; i < (size_t)nk*P->n0q; i++) dz += P->thick[i]; dz /= (double)nk*P->n0q;
+        const int Nm = (nk - 1)*n2e;
+        auto field = [&](int slots, double lo, double hi) { std::vector<double> f((size_t)nEl*slots*n2e); for (auto& v : f) v = (lo + (hi - lo)*(U(rng) - 0.5))*area*dz; return f; };
+        std::vector<double> th = field(nk, 280, 320), rh = field(nk, 0.5, 1.2), et = field(nk, 5, 6), pi = field(nk, 700, 1000);
+        std::vector<double> Fu((size_t)nEl*Nm), Fr((size_t)nEl*N), Fe((size_t)nEl*N), Fp((size_t)nEl*N);
+        for (auto* F : {&Fu, &Fr, &Fe, &Fp}) for (auto& v : *F) v = S(rng)*1e8;
+        std::vector<double*> dv;
+        for (auto* f : {&th, &rh, &et, &pi, &Fu, &Fr, &Fe, &Fp}) dv.push_back(mesh.to_device(f->data(), f->size()));
+        double *d_du = mesh.device_alloc((size_t)nEl*Nm), *d_dr = mesh.device_alloc((size_t)nEl*N), *d_de = mesh.device_alloc((size_t)nEl*N), *d_dp = mesh.device_alloc((size_t)nEl*N);
+        VertSolve vert(&mesh, 75.0);
+        vert.solve_schur_column_eta(dv[0], nullptr, dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], d_du, d_dr, d_de, d_dp);
+        std::vector<double> gp((size_t)nEl*N), gu((size_t)nEl*Nm);
+        mesh.to_host(gp.data(), d_dp, gp.size()); mesh.to_host(gu.data(), d_du, gu.size());
+        worst = 0.0;
+        for (int e : {0, nEl - 1}) {
+            std::vector<double> velz(Nm, 0.0), wu(Nm), wr(N), we(N), wp(N);
+            std::vector<double> fu(Fu.begin() + (size_t)e*Nm, Fu.begin() + (size_t)(e + 1)*Nm), fr(Fr.begin() + (size_t)e*N, Fr.begin() + (size_t)(e + 1)*N),
+                                fe(Fe.begin() + (size_t)e*N, Fe.begin() + (size_t)(e + 1)*N), fp(Fp.begin() + (size_t)e*N, Fp.begin() + (size_t)(e + 1)*N);
+            orc_solve_schur_column_eta(P, e%nels, e/nels, 75.0, &th[(size_t)e*N], velz.data(), &rh[(size_t)e*N], &et[(size_t)e*N], &pi[(size_t)e*N],
+                                       fu.data(), fr.data(), fe.data(), fp.data(), wu.data(), wr.data(), we.data(), wp.data(), nullptr);
+            double num = 0, den = 0;
+            for (int i = 0; i < N; i++) { num += (gp[(size_t)e*N + i] - wp[i])*(gp[(size_t)e*N + i] - wp[i]); den += wp[i]*wp[i]; }
+            for (int i = 0; i < Nm; i++) { num += (gu[(size_t)e*Nm + i] - wu[i])*(gu[(size_t)e*Nm + i] - wu[i]); den += wu[i]*wu[i]; }
+            worst = std::max(worst, std::sqrt(num/den));
+        }
+        std::printf("%-8s rel L2 = %.3e\n", "Schur", worst); if (!(worst < 1e-8)) fails++;
+        for (double* q : dv) mimsem_free(q);
+        mimsem_free(d_du); mimsem_free(d_dr); mimsem_free(d_de); mimsem_free(d_dp);
+    }
     mimsem_free(d_u); mimsem_free(d_h); mimsem_free(d_y);
     orc_patch_destroy(P);
     std::printf(fails ? "FAILED\n" : "OK\n");
