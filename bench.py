@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
     ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
     ap.add_argument("--box", action="store_true", help="extra: BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
+    ap.add_argument("--pcie", action="store_true", help="extra: the same step with the input copied host->device and the result device->host "
+                                                        "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
     ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
@@ -297,6 +299,24 @@ def main():
         del engb
     if a.column and rank == 0 and world == 1:
         out["column"] = column_extras(eng, dm, rng, torch)
+    if a.pcie and rank == 0 and world == 1:
+        import ctypes as C
+        xh = np.ascontiguousarray(rng.standard_normal((NK, dm.n1))); yh = np.empty_like(xh)
+        nbytes = xh.nbytes
+
+        def step_pcie():
+            eng.L.mimsem_memcpy_h2d(eng.ctx, C.c_void_p(x.data_ptr()), C.c_void_p(xh.ctypes.data), nbytes)
+            apply_b1()
+            eng.L.mimsem_memcpy_d2h(eng.ctx, C.c_void_p(yh.ctypes.data), C.c_void_p(y.data_ptr()), nbytes)
+        for _ in range(3):
+            step_pcie()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(20):
+            step_pcie()
+        torch.cuda.synchronize(); elp = (time.perf_counter() - t1) / 20
+        out["pcie_inclusive"] = {"value": units_rank / elp, "ms_per_step": 1e3 * elp, "bytes_each_way": nbytes,
+                                 "GBs_each_way": nbytes / elp / 1e9 * 2 / 2,
+                                 "note": "pageable host memory, synchronous hipMemcpy through mimsem_memcpy_h2d/_d2h; never the headline value"}
     if a.horiz and rank == 0 and world == 1:
         from mimsem_amd.horizsolve import HorizSolve
         xqg = np.zeros((dm.nq, 3))
