@@ -105,6 +105,7 @@ class HaloExchanger:
         self.world = plan.world
         self.sides = {"ghost": self._side(plan.ghost_slots), "mirror": self._side(plan.mirror_slots)}
         self._bufs = {}
+        self._plans = {}
 
     def _side(self, slots_by_rank):
         ranks = sorted(slots_by_rank)
@@ -161,11 +162,16 @@ class HaloExchanger:
         v2 = v if v.dim() == 2 else v.unsqueeze(0)
         nlev = v2.shape[0]
         snd, rcv = self.sides[send_key], self.sides[recv_key]
-        sbuf, rbuf = self._buffers(send_key, nlev, v2.dtype), self._buffers(recv_key, nlev, v2.dtype)
+        key = (send_key, recv_key, nlev, v2.dtype)
+        plan = self._plans.get(key)
+        if plan is None:                          # buffers, views and split lists are fixed per (direction, level count): build once
+            sbuf, rbuf = self._buffers(send_key, nlev, v2.dtype), self._buffers(recv_key, nlev, v2.dtype)
+            ns, nr = int(snd["off"][-1]) * nlev, int(rcv["off"][-1]) * nlev
+            plan = (sbuf, rbuf, sbuf[:ns], rbuf[:nr], (rcv["counts"] * nlev).tolist(), (snd["counts"] * nlev).tolist())
+            self._plans[key] = plan
+        sbuf, rbuf, sview, rview, out_splits, in_splits = plan
         self._move(snd, 0, sbuf, v2)
-        ns, nr = int(snd["off"][-1]) * nlev, int(rcv["off"][-1]) * nlev
-        dist.all_to_all_single(rbuf[:nr], sbuf[:ns], output_split_sizes=(rcv["counts"] * nlev).tolist(),
-                               input_split_sizes=(snd["counts"] * nlev).tolist())
+        dist.all_to_all_single(rview, sview, output_split_sizes=out_splits, input_split_sizes=in_splits)
         if add:
             for (a, b) in rcv["ranges"]:                 # fixed order => reproducible sums
                 self._move(rcv, 2, rbuf, v2, a, b)
