@@ -165,12 +165,20 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # rehearsal of the N > 1 control flow on a one-GPU box: every rank on device 0, gloo transport staged through the host
+    # (RCCL refuses two ranks on one device).  Never used by the driver; numbers from such a run mean nothing.
+    rehearsal = os.environ.get("MIMSEM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("MIMSEM_BENCH_FORCE_DIST") == "1"     # FORCE: rehearse the RCCL set-up on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from mimsem_amd.device import DeviceMesh, Engine
     from mimsem_amd.geom import Geom
@@ -221,7 +229,7 @@ def main():
     ms1, ms2, nl = eng.profile_read()
     eng.set_profiling(0)
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 

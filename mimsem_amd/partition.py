@@ -106,6 +106,7 @@ class HaloExchanger:
         self.sides = {"ghost": self._side(plan.ghost_slots), "mirror": self._side(plan.mirror_slots)}
         self._bufs = {}
         self._plans = {}
+        self._stage_host = None
 
     def _side(self, slots_by_rank):
         ranks = sorted(slots_by_rank)
@@ -171,7 +172,14 @@ class HaloExchanger:
             self._plans[key] = plan
         sbuf, rbuf, sview, rview, out_splits, in_splits = plan
         self._move(snd, 0, sbuf, v2)
-        dist.all_to_all_single(rview, sview, output_split_sizes=out_splits, input_split_sizes=in_splits)
+        if self._stage_host is None:
+            self._stage_host = sview.is_cuda and dist.get_backend() == "gloo"
+        if self._stage_host:                      # gloo moves host memory only: rehearsals of the device path on CPU transport
+            rh = torch.empty(rview.shape, dtype=rview.dtype)
+            dist.all_to_all_single(rh, sview.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+            rview.copy_(rh)
+        else:
+            dist.all_to_all_single(rview, sview, output_split_sizes=out_splits, input_split_sizes=in_splits)
         if add:
             for (a, b) in rcv["ranges"]:                 # fixed order => reproducible sums
                 self._move(rcv, 2, rbuf, v2, a, b)

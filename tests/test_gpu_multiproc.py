@@ -1,0 +1,97 @@
+"""The sharded operator path of bench.py --gpus N as REAL processes (one per rank, all on the one GPU of the test box):
+each rank owns its patches, applies the operator with its own device context and reduces the halo through HaloExchanger's
+device pack/unpack kernels; the transport is gloo (staged through host memory) because RCCL refuses two ranks on one device.
+The reduced result must equal the single-context global apply on every rank's slots."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mimsem_amd.device import DeviceMesh, Engine
+        from mimsem_amd.geom import Geom
+        from mimsem_amd.mesh import CubedSphere, sphere_coords
+        from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
+        from mimsem_amd.topo import Topo
+        from tests.helpers import SCALE, z_levels
+        pn, ne, npatch, nk = 3, 4, 24, 3
+        cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+        rng = np.random.default_rng(123)                                  # the same global field on every rank
+        xg = rng.standard_normal((nk, cs.nDofs1G)); x0g = rng.standard_normal((nk, cs.nDofs0G))
+
+        def build(pids):
+            topos = [Topo(cs, p, nk) for p in pids]
+            geoms = [Geom(t, cs, coords, nk) for t in topos]
+            for g in geoms:
+                g.set_levels(z_levels(nk, g.n0))
+            dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+            return dm, Engine(dm)
+        dm, eng = build(patches_of_rank(npatch, world, rank))
+        plans = build_plans(cs, world, rank, dm.gid0, dm.gid1)
+        ok = True
+        for form, op, xglob, gid in ((1, "UMAT", xg, dm.gid1), (0, "PMAT", x0g, dm.gid0)):
+            y = eng.apply(op, eng.tensor(xglob[:, gid]), lev0=0, scale=SCALE, flags=1 if form == 1 else 0)
+            halo = HaloExchanger(plans[form], engine=eng)
+            halo.reverse_add(y)                    # owners hold the sums
+            halo.forward_insert(y)                 # ghosts too
+            halo.reverse_add(y.clone())            # second use of the cached buffers
+            if rank == 0:
+                dm1, eng1 = build(list(range(npatch)))
+                want = eng1.apply(op, eng1.tensor(xglob), lev0=0, scale=SCALE, flags=1 if form == 1 else 0).cpu().numpy()
+                t = torch.as_tensor(want)
+            else:
+                t = torch.empty(nk, cs.nDofs1G if form == 1 else cs.nDofs0G, dtype=torch.float64)
+            dist.broadcast(t, 0)
+            want = t.numpy()
+            err = np.linalg.norm(y.cpu().numpy() - want[:, gid]) / np.linalg.norm(want)
+            ok = ok and bool(err < 1e-12)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_apply_and_halo_as_processes(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), except that both ranks
+    sit on the one GPU of the test box and the transport is gloo (MIMSEM_BENCH_REHEARSAL=1): exercises sharding, halo plans,
+    the barrier / max-over-ranks timing and the JSON line of the N > 1 path"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIMSEM_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["patches_per_gpu"] == 12 and d["config"]["units_per_step"] == 103680
