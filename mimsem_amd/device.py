@@ -404,6 +404,20 @@ class Engine:
         check(self.L.mimsem_krylov_cg_direction(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(z), z.stride(0),
                                                 _ptr(p), p.stride(0)), "cg_direction")
 
+    def norm(self, x):
+        """2-norm of a whole (single-rank) vector; DistEngine overrides with the ownership-weighted, all-reduced version"""
+        return float(torch.linalg.vector_norm(x))
+
+    def complete(self, form, y):
+        """single rank: results are already complete (DistEngine reduces the halo here)"""
+        return y
+
+    def space(self, key):
+        """context manager naming the vector space of the inner products inside (0, 1, 2 or "uh" = packed [1-form, 2-form]);
+        a no-op on one rank, the ownership weights on a DistEngine"""
+        import contextlib
+        return contextlib.nullcontext()
+
     # ---- halo pack / unpack ---------------------------------------------------------------------
     def halo_segments(self, idx, seg_off, s_begin, s_end, mode, buf, v):
         """all neighbours in one launch (mimsem_halo_segments): mode 0 pack, 1 insert, 2 add; seg_off: host int32 array"""

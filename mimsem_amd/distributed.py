@@ -1,0 +1,130 @@
+"""One rank's view of a sharded mesh: an Engine over the rank's patches plus the halo exchangers, exposing the same calls as
+Engine but with COMPLETE results -- every 0/1-form output is reduced over the halo (owners add the ghosts' partial sums) and
+sent back to the ghosts, so all copies of a shared DoF agree on all ranks (what the reference gets from MatMult on MPIAIJ
+matrices followed by VecScatter gtol FORWARD).  Inner products count every global DoF once (ownership weights) and are summed
+over the ranks.  SURVEY 8(e); used by the sharded SW step (SWEqn over a DistEngine) and testable on one GPU with several
+processes (gloo transport staged through the host, tests/test_gpu_multiproc.py).
+
+Cost model: one exchange pair per operator application -- on the BASELINE problem sizes this is latency bound and slower than
+one GPU; the class exists for correctness at scale, not for speed on 1e5 unknowns."""
+import torch
+import torch.distributed as dist
+
+from .device import Engine
+from .partition import HaloExchanger, build_plans
+
+
+class DistEngine:
+    def __init__(self, eng, sphere, world, rank):
+        self.eng, self.world, self.rank = eng, world, rank
+        dm = eng.mesh
+        plans = build_plans(sphere, world, rank, dm.gid0, dm.gid1)
+        self.halo = {0: HaloExchanger(plans[0], engine=eng), 1: HaloExchanger(plans[1], engine=eng)}
+        f = lambda m: torch.as_tensor(m, dtype=torch.float64, device=eng.device)
+        self.own = {0: f(plans[0].owned), 1: f(plans[1].owned), 2: torch.ones(dm.n2, dtype=torch.float64, device=eng.device)}
+        self._spaces = {0: self.own[0], 1: self.own[1], 2: self.own[2], "uh": torch.cat([self.own[1], self.own[2]])}
+        self._cur = None
+        self._host = None
+
+    def __getattr__(self, name):                 # sizes, nk, nEl, n1e, mesh, tensor, zeros, element_matrices, cg_update, ... are local
+        return getattr(self.eng, name)
+
+    # ---- completion ---------------------------------------------------------------------------------------------------------
+    def complete(self, form, y):
+        if form in (0, 1):
+            self.halo[form].reverse_add(y)
+            self.halo[form].forward_insert(y)
+        return y
+
+    def allreduce(self, t):
+        if self.world == 1:
+            return t
+        if self._host is None:
+            self._host = dist.get_backend() == "gloo"
+        if self._host and t.is_cuda:
+            h = t.cpu(); dist.all_reduce(h); t.copy_(h)
+        else:
+            dist.all_reduce(t)
+        return t
+
+    def space(self, key):
+        """the vector space of the inner products inside the `with` block: 0, 1, 2 or "uh" (packed [1-form, 2-form])"""
+        outer = self
+
+        class _Space:
+            def __enter__(self_s):
+                self_s.prev = outer._cur; outer._cur = outer._spaces[key]
+
+            def __exit__(self_s, *exc):
+                outer._cur = self_s.prev
+                return False
+        return _Space()
+
+    def _weight(self, n):
+        if self._cur is None or self._cur.numel() != n:
+            raise RuntimeError("DistEngine inner product outside a matching `with eng.space(...)` block (vector length %d)" % n)
+        return self._cur
+
+    # ---- operators with complete results ----------------------------------------------------------------------------------------
+    def _finish(self, form, tmp, out, accum):
+        self.complete(form, tmp)
+        if out is None:
+            return tmp
+        o = out if out.dim() == 2 else out.unsqueeze(0)
+        if accum:
+            o += tmp
+        else:
+            o.copy_(tmp)
+        return out
+
+    def apply(self, op, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
+        form = Engine._SPACES[op][2]
+        if form == 2:
+            return self.eng.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags, alpha=alpha, out=out)
+        tmp = self.eng.apply(op, x if x.dim() == 2 else x.unsqueeze(0), f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha)
+        r = self._finish(form, tmp, out, bool(flags & 2))
+        return r if (out is not None or x.dim() == 2) else r[0]
+
+    def apply_up(self, op, x, f, u, fac=None, dt=None, lev0=0, alpha=1.0, flags=0, out=None, scale=1.0, tau=None):
+        form = Engine._SPACES[op][2]
+        tmp = self.eng.apply_up(op, x if x.dim() == 2 else x.unsqueeze(0), f, u, fac=fac, dt=dt, lev0=lev0, alpha=alpha, flags=flags & ~2,
+                                scale=scale, tau=tau)
+        r = self._finish(form, tmp, out, bool(flags & 2))
+        return r if (out is not None or x.dim() == 2) else r[0]
+
+    def incidence(self, which, x):
+        y = self.eng.incidence(which, x if x.dim() == 2 else x.unsqueeze(0))
+        form = {"E10": 1, "E12": 1, "E01": 0, "E21": 2}[which]
+        self.complete(form, y)
+        return y if x.dim() == 2 else y[0]
+
+    def pvec(self, lev0=0, nlev=1, scale=1.0, h2=None):
+        return self.complete(0, self.eng.pvec(lev0, nlev, scale, h2=h2))
+
+    def blocks_apply(self, form, blocks, x, transpose=False, alpha=1.0, accum=False, out=None, elem_scale=None):
+        if form == 2:
+            return self.eng.blocks_apply(form, blocks, x, transpose=transpose, alpha=alpha, accum=accum, out=out, elem_scale=elem_scale)
+        tmp = self.eng.blocks_apply(form, blocks, x if x.dim() == 2 else x.unsqueeze(0), transpose=transpose, alpha=alpha, elem_scale=elem_scale)
+        r = self._finish(form, tmp, out, accum)
+        return r if (out is not None or x.dim() == 2) else r[0]
+
+    # ---- inner products over the GLOBAL vector: every DoF counted once, summed over the ranks ----------------------------------
+    def rowdot(self, A, B, out=None):
+        w = self._weight(A.shape[1])
+        r = self.eng.rowdot(A * w, B, out=out)
+        return self.allreduce(r)
+
+    def mdot(self, V, w, k=None, out=None):
+        h = self.eng.mdot(V, (w * self._weight(w.numel())).contiguous(), k=k, out=out)
+        return self.allreduce(h)
+
+    def norm(self, x):
+        x2 = x.reshape(1, -1)
+        return float(torch.sqrt(self.rowdot(x2, x2))[0])
+
+    def gather_owned(self, form, v, gids, n_global):
+        """global vector (on every rank) from the owned entries of each rank's local vector -- tests / output only"""
+        g = torch.zeros(v.shape[0], n_global, dtype=v.dtype, device=v.device)
+        idx = torch.as_tensor(gids, device=v.device).long()
+        g[:, idx] = v * self.own[form]
+        return self.allreduce(g)

@@ -180,8 +180,8 @@ def gmres(apply_A, b, precond=None, x0=None, rtol=1e-14, atol=1e-50, restart=30,
     n = bf.numel()
     A = (lambda v: apply_A(v.view(shape)).reshape(-1))
     M = (lambda v: v) if precond is None else (lambda v: precond(v.view(shape)).reshape(-1))
-    if dot is None:
-        dot = lambda U, w: U @ w
+    if dot is None:                                     # with an engine: its multi-dot (a DistEngine weights and all-reduces it)
+        dot = (lambda U, w: U @ w) if eng is None else (lambda U, w: eng.mdot(U.contiguous(), w.contiguous(), k=U.shape[0]))
     nrm = lambda v: float(torch.sqrt(dot(v.view(1, -1), v))[0])
     x = torch.zeros_like(bf) if x0 is None else x0.reshape(-1).clone()
     pb = M(bf)

@@ -35,7 +35,7 @@ class SWEqn:
         self.coriolis()
         self.A_dt = None
         self.its = {}
-        self.graphs = use_graphs
+        self.graphs = use_graphs and not hasattr(eng, "halo")       # the hipGraph Arnoldi step is single-rank (no collectives inside)
         self._gA = None
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
@@ -56,8 +56,9 @@ class SWEqn:
         em = eng.element_matrices("UMAT").view(eng.nEl, 2, 2, n1e, n1e)
         B = em.permute(0, 1, 3, 2, 4).reshape(eng.nEl, 2 * n1e, 2 * n1e)        # [[UtQU, UtQV], [VtQU, VtQV]]
         idx = torch.cat([torch.as_tensor(eng.mesh.inds1x, device=eng.device), torch.as_tensor(eng.mesh.inds1y, device=eng.device)], dim=1).long()
-        mult = torch.zeros(eng.sizes[1], dtype=torch.float64, device=eng.device)
-        mult.index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
+        mult = torch.zeros(1, eng.sizes[1], dtype=torch.float64, device=eng.device)
+        mult[0].index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
+        mult = eng.complete(1, mult)[0]                                          # sharded: count the sharers on other ranks too
         d = 1.0 / mult[idx]                                                      # [nEl, 2 n1e]
         Binv = torch.linalg.inv(B)
         return (d[:, :, None] * Binv * d[:, None, :]).contiguous()
@@ -67,7 +68,8 @@ class SWEqn:
 
     def solve_M1(self, b, key="M1"):
         """KSPSolve(ksp, b, x) on M1 (:84-92): SPD => preconditioned CG reaches the same solution"""
-        x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
+        with self.eng.space(1):
+            x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
         self.its[key] = its
         return x
 
@@ -83,10 +85,12 @@ class SWEqn:
 
     def diagnose_F(self, ui, uj, hi, hj):
         """:253-284: F = M1^-1 (1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj)"""
-        hu = self.M1h(hi, ui, alpha=1.0 / 3.0)
-        self.M1h(hi, uj, out=hu, alpha=1.0 / 6.0, accum=True)
-        self.M1h(hj, ui, out=hu, alpha=1.0 / 6.0, accum=True)
-        self.M1h(hj, uj, out=hu, alpha=1.0 / 3.0, accum=True)
+        loc = getattr(self.eng, "eng", self.eng)                   # local partial sums, one halo reduction
+        hu = loc.apply("UHMAT", ui, f=hi, alpha=1.0 / 3.0)
+        loc.apply("UHMAT", uj, f=hi, alpha=1.0 / 6.0, flags=2, out=hu)
+        loc.apply("UHMAT", ui, f=hj, alpha=1.0 / 6.0, flags=2, out=hu)
+        loc.apply("UHMAT", uj, f=hj, alpha=1.0 / 3.0, flags=2, out=hu)
+        self.eng.complete(1, hu)
         return self.solve_M1(hu, "F")
 
     def diagnose_Phi(self, ui, uj, hi, hj):
@@ -104,7 +108,8 @@ class SWEqn:
         m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
         if dt > 1.0e-6:
             A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
-            q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000, eng=self.eng)
+            with self.eng.space(0):
+                q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000, eng=self.eng)
             self.its["q"] = its
             return q
         return rhs / m0h
@@ -137,13 +142,15 @@ class SWEqn:
     def apply_A(self, x, dt):
         """:609-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]]"""
         eng, n1 = self.eng, self.n1
+        loc = getattr(eng, "eng", eng)                             # sharded: add the LOCAL partial sums first, reduce the halo once
         u, h = x[:, :n1], x[:, n1:]                                # views of the packed vector (one row => contiguous)
         a = ROS_ALPHA * dt
         y = torch.empty_like(x)
         yu, yh = y[:, :n1], y[:, n1:]
-        eng.apply("UMAT", u, out=yu)
-        eng.apply("ROTMAT", u, f=self.fg, alpha=a, flags=2, out=yu)                       # += a R(f) u
-        yu += (a * self.grav) * eng.incidence("E12", eng.apply("WMAT", h))
+        loc.apply("UMAT", u, out=yu)
+        loc.apply("ROTMAT", u, f=self.fg, alpha=a, flags=2, out=yu)                       # += a R(f) u
+        yu += (a * self.grav) * loc.incidence("E12", loc.apply("WMAT", h))
+        eng.complete(1, yu)
         w = eng.incidence("E21", u)
         w *= a * H_MEAN
         w += h
@@ -172,12 +179,14 @@ class SWEqn:
                                                             lambda v: self.precond_A(self.apply_A(v, dt)), restart=restart))
                 dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, self.precond_A, rtol=self.rtol, maxit=1000)
             else:
-                dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
-                                     restart=restart, maxit=1000, eng=self.eng)
+                with self.eng.space("uh"):
+                    dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
+                                         restart=restart, maxit=1000, eng=self.eng)
             self.its["A"] = its
             x = x + dx
             uj, hj = self.unpack(x)
-            norm_x, norm_dx = float(torch.linalg.vector_norm(x)), float(torch.linalg.vector_norm(dx))
+            with self.eng.space("uh"):
+                norm_x, norm_dx = self.eng.norm(x), self.eng.norm(dx)
             norm = norm_dx / norm_x
             hist.append(norm)
             if verbose:

@@ -95,3 +95,75 @@ def test_bench_multi_rank_control_flow_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["patches_per_gpu"] == 12 and d["config"]["units_per_step"] == 103680
+
+
+def _sw_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mimsem_amd.device import DeviceMesh, Engine
+        from mimsem_amd.distributed import DistEngine
+        from mimsem_amd.geom import Geom
+        from mimsem_amd.mesh import CubedSphere, sphere_coords
+        from mimsem_amd.partition import patches_of_rank
+        from mimsem_amd.sweqn import SWEqn, williamson2
+        from mimsem_amd.topo import Topo
+        pn, ne, npatch = 3, 4, 6
+        cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+
+        def build(pids):
+            topos = [Topo(cs, p, 1) for p in pids]
+            geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+            for g in geoms:
+                g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+            dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+            xq = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
+            for g in geoms:
+                xq[g.loc0] = coords[g.loc0]
+            return dm, Engine(dm), xq[dm.gidq]
+        dm, eng, xq = build(patches_of_rank(npatch, world, rank))
+        deng = DistEngine(eng, cs, world, rank)
+        S = SWEqn(deng, xq)
+        uq, hq = williamson2(torch.as_tensor(xq, device=eng.device), alpha=0.0)
+        lam = torch.atan2(torch.as_tensor(xq[:, 1]), torch.as_tensor(xq[:, 0])).to(eng.device)
+        uq = uq + torch.stack([3.0 * torch.sin(2 * lam), 2.0 * torch.cos(lam)], dim=1)            # perturbed: every term active
+        u0, h0 = S.init1(uq), S.init2(hq)
+        u1, h1 = S.solve(u0, h0, 360.0, nits=2, q_exact=False)
+        ug = deng.gather_owned(1, u1, dm.gid1, cs.nDofs1G).cpu().numpy()
+        hg = deng.gather_owned(2, h1, dm.gid2, cs.nDofs2G).cpu().numpy()
+        ok = True
+        if rank == 0:                                # the same step on ONE context holding the whole sphere
+            dm1, eng1, xq1 = build(list(range(npatch)))
+            S1 = SWEqn(eng1, xq1, use_graphs=False)
+            uq1, hq1 = williamson2(torch.as_tensor(xq1, device=eng1.device), alpha=0.0)
+            lam1 = torch.atan2(torch.as_tensor(xq1[:, 1]), torch.as_tensor(xq1[:, 0])).to(eng1.device)
+            uq1 = uq1 + torch.stack([3.0 * torch.sin(2 * lam1), 2.0 * torch.cos(lam1)], dim=1)
+            a0, b0 = S1.init1(uq1), S1.init2(hq1)
+            a1, b1 = S1.solve(a0, b0, 360.0, nits=2, q_exact=False)
+            eu = np.linalg.norm(ug - a1.cpu().numpy()) / np.linalg.norm(a1.cpu().numpy())
+            eh = np.linalg.norm(hg - b1.cpu().numpy()) / np.linalg.norm(b1.cpu().numpy())
+            du = np.linalg.norm((a1 - a0).cpu().numpy())
+            ok = bool(eu < 1e-10 and eh < 1e-11 and du > 0 and np.allclose(S.history, S1.history, rtol=1e-6))
+            if not ok:
+                print("sharded SW step mismatch", eu, eh, S.history, S1.history, flush=True)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_shallow_water_step_as_processes(world):
+    """N3 on several ranks: SWEqn over a DistEngine (halo-completed operators, ownership-weighted all-reduced inner products)
+    takes the same Picard step as the single-context run"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sw_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
