@@ -379,6 +379,30 @@ def main():
                        "k_elem_apply_GBs": uc * BYTES_K1_B1 / (c1 / cn * 1e-3) / 1e9,
                        "op_GBs": uc * BYTES_OP_B1 / ((c1 + c2) / cn * 1e-3) / 1e9}
         del engc
+    if a.sw and world > 1:
+        # the SW step on the ranks' shards (config 3: 24x24x6 sphere over N GPUs, halo over xGMI); latency-bound at this size
+        from mimsem_amd.distributed import DistEngine
+        from mimsem_amd.sweqn import SWEqn, williamson2
+        t1s = [Topo(cs, p, 1) for p in pids]
+        g1s = [Geom(t, cs, coords, 1, signed_det=True) for t in t1s]
+        for g in g1s:
+            g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+        dms = DeviceMesh(t1s, g1s, nk=1, numbering="global")
+        engs = Engine(dms, device=local_rank)
+        xqs = np.zeros((int(max(g.loc0.max() for g in g1s)) + 1, 3))
+        for g in g1s:
+            xqs[g.loc0] = coords[g.loc0]
+        S = SWEqn(DistEngine(engs, cs, world, rank), xqs[dms.gidq])
+        uq, hq = williamson2(torch.as_tensor(xqs[dms.gidq], device=engs.device), alpha=0.0)
+        us, hs_ = S.init1(uq), S.init2(hq)
+        us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
+        fence(); t1 = time.perf_counter()
+        for _ in range(3):
+            us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
+        fence(); els = (time.perf_counter() - t1) / 3
+        if rank == 0:
+            out["sw_sharded"] = {"workload": "SWEqn::solve, Galewsky-style (2 Picard iterations), 24x24x6 sphere sharded over the ranks",
+                                 "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "krylov_iterations_last": dict(S.its)}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
