@@ -412,6 +412,10 @@ class Engine:
         """single rank: results are already complete (DistEngine reduces the halo here)"""
         return y
 
+    def wsum(self, form, t):
+        """sum over the GLOBAL vector of one form (every DoF once); DistEngine weights by ownership and all-reduces"""
+        return t.sum()
+
     def space(self, key):
         """context manager naming the vector space of the inner products inside (0, 1, 2 or "uh" = packed [1-form, 2-form]);
         a no-op on one rank, the ownership weights on a DistEngine"""

@@ -118,6 +118,9 @@ class DistEngine:
         h = self.eng.mdot(V, (w * self._weight(w.numel())).contiguous(), k=k, out=out)
         return self.allreduce(h)
 
+    def wsum(self, form, t):
+        return self.allreduce((t * self.own[form]).sum().reshape(1))[0]
+
     def norm(self, x):
         x2 = x.reshape(1, -1)
         return float(torch.sqrt(self.rowdot(x2, x2))[0])

@@ -21,8 +21,9 @@ VERT, ACCUM = 1, 2
 class HorizSolve:
     def __init__(self, eng, del2=None, quad_coords=None, do_visc=True):
         self.eng, self.nk, self.do_visc = eng, eng.nk, do_visc
-        if del2 is None:                                        # viscosity() :112-120
-            dx = math.sqrt(4.0 * math.pi * RAD_EARTH * RAD_EARTH / eng.sizes[0])
+        if del2 is None:                                        # viscosity() :112-120, with the GLOBAL node count nDofs0G
+            n0g = float(eng.wsum(0, torch.ones(eng.sizes[0], dtype=torch.float64, device=eng.device)))
+            dx = math.sqrt(4.0 * math.pi * RAD_EARTH * RAD_EARTH / n0g)
             del2 = -math.sqrt(0.072 * dx ** 3.2)
         self.del2 = del2
         self.m1 = MassSolver(eng, SCALE, True)
@@ -134,7 +135,7 @@ class HorizSolve:
         dp = eng.incidence("E12", self._ap("WHMAT", theta, f=Pi, flags=VERT))
         fu += 0.5 * dp
         if Fk is not None:
-            self.k2i_dev = (Fk * dp).sum() / SCALE       # stays on the device (no host sync: the call is hipGraph-capturable)
+            self.k2i_dev = self.eng.wsum(1, Fk * dp) / SCALE       # stays on the device (no host sync: the call is hipGraph-capturable)
         # second vorticity term: interface i feeds levels i and i+1 (:704-746)
         dz = 0.5 * dudz1 + 0.5 * dudz2
         if dwdx1 is not None:

@@ -139,8 +139,9 @@ class MassSolver:
             self.minv = 1.0 / diag
         else:
             idx = torch.cat([ix, iy], dim=1)
-            mult = torch.zeros(dm.n1, dtype=torch.float64, device=eng.device)
-            mult.index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
+            mult = torch.zeros(1, dm.n1, dtype=torch.float64, device=eng.device)
+            mult[0].index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
+            mult = eng.complete(1, mult)[0]                  # sharded: sharers on other ranks count too
             d = 1.0 / mult[idx]
             # M1_e(k) = U^T diag(c_q thickInv_k(q)) U ~ tau_{k,e} * U^T diag(c_q) U with tau = the element's mean thickInv (exact when
             # the layer thickness is horizontally uniform over the element): ONE thickness-free inverse per element, resident in
@@ -161,8 +162,9 @@ class MassSolver:
     def solve(self, b, lev0=0, rtol=1e-14, maxit=300):
         nlev = b.shape[0]
         if self.kind != "jacobi":
-            return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
-                              fixed_its=self.fixed_its)
+            with self.eng.space(1):
+                return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
+                                  fixed_its=self.fixed_its)
         if self.kind == "jacobi":
             return pcg(lambda v: self.apply(v, lev0), b, minv=self.minv[lev0:lev0 + nlev], rtol=rtol, maxit=maxit)
         return pcg(lambda v: self.apply(v, lev0), b, precond=lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit, check_every=2)

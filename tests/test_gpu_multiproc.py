@@ -167,3 +167,80 @@ def test_sharded_shallow_water_step_as_processes(world):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def _hs_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mimsem_amd.device import DeviceMesh, Engine
+        from mimsem_amd.distributed import DistEngine
+        from mimsem_amd.geom import Geom
+        from mimsem_amd.horizsolve import HorizSolve
+        from mimsem_amd.mesh import CubedSphere, sphere_coords
+        from mimsem_amd.partition import patches_of_rank
+        from mimsem_amd.topo import Topo
+        from tests.helpers import z_levels
+        pn, ne, npatch, nk = 3, 2, 6, 3
+        cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+
+        def build(pids):
+            topos = [Topo(cs, p, nk) for p in pids]
+            geoms = [Geom(t, cs, coords, nk) for t in topos]
+            for g in geoms:
+                g.set_levels(z_levels(nk, g.n0))
+            dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+            xq = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
+            for g in geoms:
+                xq[g.loc0] = coords[g.loc0]
+            return dm, Engine(dm), xq[dm.gidq]
+        r = np.random.default_rng(31)                          # identical global fields on every rank
+        N1, N2 = cs.nDofs1G, cs.nDofs2G
+        dm, eng, xq = build(patches_of_rank(npatch, world, rank))
+        area = float(dm.det.mean()) * 4.0 / (pn * pn); dz = float(dm.thick.mean()); ln = area ** 0.5
+        G = dict(u1=r.standard_normal((nk, N1)) * 20.0 * ln * dz, h1=r.uniform(0.8, 1.2, (nk, N2)) * area * dz,
+                 th=r.uniform(290, 310, (nk, N2)) * area * dz, Pi=r.uniform(900, 1000, (nk, N2)) * area * dz,
+                 vz=r.standard_normal((nk - 1, N2)) * area, dudz=r.standard_normal((nk - 1, N1)) * 1e-3 * ln)
+        G["u2"] = G["u1"] * 1.03; G["h2"] = G["h1"] * 1.01
+
+        def run(e, d, xq_):
+            hs = HorizSolve(e, quad_coords=xq_)
+            t = lambda key, gid: e.tensor(G[key][:, gid])
+            u1, u2, dud = t("u1", d.gid1), t("u2", d.gid1), t("dudz", d.gid1)
+            h1, h2, th, Pi, vz = (t(k, d.gid2) for k in ("h1", "h2", "th", "Pi", "vz"))
+            dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
+            fu = hs.momentum_rhs_ec(th, dud, dud, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk)
+            return fu, dG, hs.k2i
+        deng = DistEngine(eng, cs, world, rank)
+        fu, dG, k2i = run(deng, dm, xq)
+        fug = deng.gather_owned(1, fu, dm.gid1, N1).cpu().numpy()
+        dGg = deng.gather_owned(2, dG, dm.gid2, N2).cpu().numpy()
+        ok = True
+        if rank == 0:
+            dm1, eng1, xq1 = build(list(range(npatch)))
+            f1, g1, k1 = run(eng1, dm1, xq1)
+            e1 = np.linalg.norm(fug - f1.cpu().numpy()) / np.linalg.norm(f1.cpu().numpy())
+            e2 = np.linalg.norm(dGg - g1.cpu().numpy()) / np.linalg.norm(g1.cpu().numpy())
+            ok = bool(e1 < 1e-9 and e2 < 1e-9 and abs(k2i - k1) < 1e-9 * abs(k1))
+            if not ok:
+                print("sharded HorizSolve mismatch", e1, e2, k2i, k1, flush=True)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_horizsolve_rhs_as_processes():
+    """N2 on two ranks: HorizSolve (advection_rhs_ec + momentum_rhs_ec with viscosity) over a DistEngine equals the one-context result"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
