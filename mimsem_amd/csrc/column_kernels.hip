@@ -4,11 +4,11 @@
 // Every reference VertOps::Assemble* builds, for ONE column, nk small blocks  W^T diag(c_q) W  and drops
 // them on the (bi)diagonal of a MATSEQAIJ; VertSolve then chains MatMatMult/PCLU on those matrices.
 // Here the block structure is kept explicit for ALL columns at once:
-//   coefficient pass  c[e][slot][q]   (one thread per quadrature point, fields interpolated with the
-//                                       collocated edge table -- no dense W table reads)
-//   block pass        M[e][slot]      = W^T diag(c) W  (one thread per entry, 16/25-term sums)
+//   coefficient + block pass (k_coef_block): c[slot][q] evaluated into LDS (one thread per quadrature point, fields interpolated
+//                     with the collocated edge table), M[e][slot] = W^T diag(c) W by sum factorisation (W is a tensor product)
 //   batched Gauss-Jordan (LinAlg.cpp:186-269 pivoting rules) for the *Inv operators
-//   block (bi)diagonal mat-vec / mat-mat kernels, and a block-Thomas sweep for the Helmholtz solve.
+//   block (bi)diagonal mat-vec / mat-mat kernels, and a block-Thomas sweep (+ one refinement step) for the Helmholtz solve.
+// column_hs.inc (included at the end) adds the Strang / Held-Suarez rows on a block-banded algebra.
 // The Schur complement of solve_schur_column_eta is assembled ANALYTICALLY from these factors: every
 // factor is block-diagonal or block-bidiagonal, so L_pi is block-tridiagonal -- no
 // sparse mat-mat products, no symbolic phases, no per-column PETSc objects.
