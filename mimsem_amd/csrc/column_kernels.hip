@@ -1207,10 +1207,239 @@ __global__ __launch_bounds__(256) void k_helmholtz_rows(int n2, int nk, double g
     }
 }
 
+// ---- fused assembly of the Schur factors: one WAVE per (column, level) resp. (column, interface) ----------------------------
+// All intermediate blocks of a task live in LDS; only what later stages need is written.  Wave-cooperative block algebra on
+// N2 x N2 blocks (N2 = 4, 9, 16): sum-factorised W^T diag(c) W, Gauss-Jordan inverse with partial pivoting, products.
+template <int N2>
+struct WaveBlocks {
+    static constexpr int nn = N2*N2, EPL = (nn + 63)/64;
+    // M = W^T diag(c) W by sum factorisation (W[q][j] = E[qx][jx] E[qy][jy]); lanes (iy, jy)
+    __device__ static void assemble(double* M, const double* cq, const double* sE, const double* sEE, int n, int mp1, int lane) {
+        if (lane < N2) {
+            const int iy = lane/n, jy = lane%n;
+            double t1[8];
+            for (int qx = 0; qx < mp1; qx++) {
+                double s = 0.0;
+                for (int qy = 0; qy < mp1; qy++) s += (sE[qy*n + iy]*cq[qy*mp1 + qx])*sE[qy*n + jy];
+                t1[qx] = s;
+            }
+            for (int ix = 0; ix < n; ix++)
+                for (int jx = 0; jx < n; jx++) {
+                    double s = 0.0;
+                    for (int qx = 0; qx < mp1; qx++) s += sEE[qx*N2 + ix*n + jx]*t1[qx];
+                    M[(iy*n + ix)*N2 + jy*n + jx] = s;
+                }
+        }
+        wsync();
+    }
+    // C = alpha * A . B   (C must not alias A or B)
+    __device__ static void mul(double* C, const double* A, const double* B, double alpha, int lane) {
+#pragma unroll
+        for (int r = 0; r < EPL; r++) {
+            const int t = lane + 64*r;
+            if (t < nn) {
+                const int i = t/N2, j = t%N2;
+                double s = 0.0;
+#pragma unroll
+                for (int m = 0; m < N2; m++) s += A[i*N2 + m]*B[m*N2 + j];
+                C[t] = alpha*s;
+            }
+        }
+        wsync();
+    }
+    // Di = D^-1 by Gauss-Jordan with partial pivoting; D is destroyed
+    __device__ static void inverse(double* D, double* Di, int lane) {
+#pragma unroll
+        for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) Di[t] = (t/N2 == t%N2) ? 1.0 : 0.0; }
+        wsync();
+        for (int col = 0; col < N2; col++) {
+            int p = col; double big = fabs(D[col*N2 + col]);
+            for (int r = col + 1; r < N2; r++) { const double a = fabs(D[r*N2 + col]); if (a > big) { big = a; p = r; } }
+            if (p != col) {
+                double t0[EPL], t1[EPL];
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {
+                    const int t = lane + 64*r;
+                    if (t < 2*N2) { double* M = (t < N2) ? D : Di; const int j = t%N2; t0[r] = M[col*N2 + j]; t1[r] = M[p*N2 + j]; }
+                }
+                wsync();
+#pragma unroll
+                for (int r = 0; r < EPL; r++) {
+                    const int t = lane + 64*r;
+                    if (t < 2*N2) { double* M = (t < N2) ? D : Di; const int j = t%N2; M[col*N2 + j] = t1[r]; M[p*N2 + j] = t0[r]; }
+                }
+                wsync();
+            }
+            const double pinv = 1.0/D[col*N2 + col];
+            double nd[EPL], ni[EPL];
+#pragma unroll
+            for (int r = 0; r < EPL; r++) {
+                const int t = lane + 64*r;
+                if (t < nn) {
+                    const int i = t/N2, j = t%N2;
+                    const double dcj = D[col*N2 + j]*pinv, icj = Di[col*N2 + j]*pinv;
+                    if (i == col) { nd[r] = dcj; ni[r] = icj; }
+                    else { const double u = D[i*N2 + col]; nd[r] = D[t] - u*dcj; ni[r] = Di[t] - u*icj; }
+                }
+            }
+            wsync();
+#pragma unroll
+            for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) { D[t] = nd[r]; Di[t] = ni[r]; } }
+            wsync();
+        }
+    }
+    __device__ static void load(double* dst, const double* src, int lane) {
+#pragma unroll
+        for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) dst[t] = src[t]; }
+        wsync();
+    }
+    __device__ static void store(double* dst, const double* src, int lane) {     // LDS -> global, no sync needed after (LDS is only read)
+#pragma unroll
+        for (int r = 0; r < EPL; r++) { const int t = lane + 64*r; if (t < nn) dst[t] = src[t]; }
+    }
+};
+
+struct FusedArgs {
+    CG g; double hdt;
+    const double *theta, *rho, *eta, *pi;
+    double *B, *Binv, *Npi, *Nrho;                 // level outputs   [nEl][nk][nn]
+    double *Ainv, *X, *Gl, *Gu, *gpi, *geta;       // interface outputs [nEl][nk-1][nn] / [nEl][nk-1][n2]
+};
+
+// level k of column e: B = VB, Binv = VB^-1, N_pi = B B(pi)^-1 B, N_rho = B B(rho)^-1 B     (VertSolve.cpp:690-692, :736-739)
+template <int N2>
+__global__ __launch_bounds__(256) void k_schur_levels(FusedArgs a) {
+    using WBk = WaveBlocks<N2>;
+    constexpr int nn = N2*N2, WPB = 4;
+    extern __shared__ double sm[];
+    const CG& g = a.g;
+    const int n = g.n, mp1 = g.mp1, mp12 = g.mp12, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    double* sE = sm; double* sEE = sE + mp1*n; double* sw = sEE + mp1*N2;
+    double* base = sw + 8 + (size_t)wv*(3*mp12 + 5*nn);
+    double *cq = base, *Bk = cq + 3*mp12, *P = Bk + nn, *Pi_ = P + nn, *t1 = Pi_ + nn, *t2 = t1 + nn;
+    for (int t = tid; t < mp1*n; t += 256) sE[t] = g.E[t];
+    if (tid < mp1) sw[tid] = g.w[tid];
+    for (int t = tid; t < mp1*N2; t += 256) { const int qx = t/N2, ij = t%N2; sEE[t] = g.E[qx*n + ij/n]*g.E[qx*n + ij%n]; }
+    __syncthreads();
+    const long long task = (long long)blockIdx.x*WPB + wv;
+    if (task >= (long long)g.nEl*g.nk) return;             // whole waves leave together; no block-level barrier below
+    const int k = (int)(task%g.nk), e = (int)(task/g.nk);
+    CG gl = g; gl.E = sE; gl.w = sw;
+    if (lane < mp12) {
+        cq[lane]          = colop_coef(gl, MIMSEM_V_CONST, 0, e, k, 0, lane, nullptr, nullptr);
+        cq[mp12 + lane]   = colop_coef(gl, MIMSEM_V_CONST_RHO, 0, e, k, 0, lane, a.pi, nullptr);
+        cq[2*mp12 + lane] = colop_coef(gl, MIMSEM_V_CONST_RHO, 0, e, k, 0, lane, a.rho, nullptr);
+    }
+    wsync();
+    const size_t off = ((size_t)e*g.nk + k)*nn;
+    WBk::assemble(Bk, cq, sE, sEE, n, mp1, lane);
+    WBk::store(a.B + off, Bk, lane);
+    WBk::load(t1, Bk, lane);
+    WBk::inverse(t1, t2, lane);
+    WBk::store(a.Binv + off, t2, lane);
+    for (int which = 0; which < 2; which++) {
+        wsync();
+        WBk::assemble(P, cq + (1 + which)*mp12, sE, sEE, n, mp1, lane);
+        WBk::inverse(P, Pi_, lane);
+        WBk::mul(t1, Pi_, Bk, 1.0, lane);                  // B(rt)^-1 B
+        WBk::mul(t2, Bk, t1, 1.0, lane);                   // B (B(rt)^-1 B)
+        WBk::store((which ? a.Nrho : a.Npi) + off, t2, lane);
+    }
+}
+
+// interface i of column e: A^-1 = VA_inv, X = A^-1 VA(rho), G_pi row (Gl, Gu), grad pi, grad eta   (:691-731)
+template <int N2>
+__global__ __launch_bounds__(256) void k_schur_interfaces(FusedArgs a) {
+    using WBk = WaveBlocks<N2>;
+    constexpr int nn = N2*N2, WPB = 4;
+    extern __shared__ double sm[];
+    const CG& g = a.g;
+    const int n = g.n, mp1 = g.mp1, mp12 = g.mp12, nk = g.nk, nm = nk - 1, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    double* sE = sm; double* sEE = sE + mp1*n; double* sw = sEE + mp1*N2;
+    double* base = sw + 8 + (size_t)wv*(3*mp12 + 7*nn + 2*N2);
+    double *cq = base, *A = cq + 3*mp12, *Ai = A + nn, *T = Ai + nn, *Rr = T + nn, *B0 = Rr + nn, *B1 = B0 + nn, *t1 = B1 + nn, *v = t1 + nn;
+    for (int t = tid; t < mp1*n; t += 256) sE[t] = g.E[t];
+    if (tid < mp1) sw[tid] = g.w[tid];
+    for (int t = tid; t < mp1*N2; t += 256) { const int qx = t/N2, ij = t%N2; sEE[t] = g.E[qx*n + ij/n]*g.E[qx*n + ij%n]; }
+    __syncthreads();
+    const long long task = (long long)blockIdx.x*WPB + wv;
+    if (task >= (long long)g.nEl*nm) return;
+    const int i = (int)(task%nm), e = (int)(task/nm);
+    CG gl = g; gl.E = sE; gl.w = sw;
+    if (lane < mp12) {
+        cq[lane]          = colop_coef(gl, MIMSEM_V_LINEAR_INV, 0, e, i, 0, lane, nullptr, nullptr);
+        cq[mp12 + lane]   = colop_coef(gl, MIMSEM_V_LINEAR_RT, MIMSEM_FLAG_VERT, e, i, 0, lane, a.theta, nullptr);
+        cq[2*mp12 + lane] = colop_coef(gl, MIMSEM_V_LINEAR_RT, MIMSEM_FLAG_VERT, e, i, 0, lane, a.rho, nullptr);
+    }
+    wsync();
+    const size_t off = ((size_t)e*nm + i)*nn;
+    WBk::assemble(A, cq, sE, sEE, n, mp1, lane);
+    WBk::inverse(A, Ai, lane);
+    WBk::store(a.Ainv + off, Ai, lane);
+    WBk::assemble(T, cq + mp12, sE, sEE, n, mp1, lane);
+    WBk::assemble(Rr, cq + 2*mp12, sE, sEE, n, mp1, lane);
+    WBk::mul(t1, Ai, Rr, 1.0, lane);                       // X = VA_inv VA(rho)
+    WBk::store(a.X + off, t1, lane);
+    WBk::load(B0, a.B + ((size_t)e*nk + i)*nn, lane);
+    WBk::load(B1, a.B + ((size_t)e*nk + i + 1)*nn, lane);
+    // grad f = A^-1 (B_{i+1} f_{i+1} - B_i f_i)  for f = pi, eta
+    for (int which = 0; which < 2; which++) {
+        const double* f = which ? a.eta : a.pi;
+        if (lane < N2) {
+            const double* f0 = f + ((size_t)e*nk + i)*N2; const double* f1 = f0 + N2;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += B1[lane*N2 + m]*f1[m];
+            double s0 = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s0 += B0[lane*N2 + m]*f0[m];
+            v[lane] = s - s0;
+        }
+        wsync();
+        if (lane < N2) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += Ai[lane*N2 + m]*v[m];
+            (which ? a.geta : a.gpi)[((size_t)e*nm + i)*N2 + lane] = s;
+        }
+        wsync();
+    }
+    WBk::mul(t1, Ai, B0, 1.0, lane);                       // A^-1 B_i
+    WBk::mul(Rr, T, t1, -a.hdt, lane);                     // G(i,i)   = -h T A^-1 B_i        (Rr is free now)
+    WBk::store(a.Gl + off, Rr, lane);
+    wsync();
+    WBk::mul(t1, Ai, B1, 1.0, lane);                       // A^-1 B_{i+1}
+    WBk::mul(Rr, T, t1, +a.hdt, lane);                     // G(i,i+1) = +h T A^-1 B_{i+1}
+    WBk::store(a.Gu + off, Rr, lane);
+}
+
+template <int N2>
+int launch_schur_fused(mimsem_ctx* c, const FusedArgs& a) {
+    const CG& g = a.g;
+    const int nn = N2*N2;
+    const size_t common = (size_t)(g.mp1*g.n + g.mp1*N2 + 8);
+    {
+        const size_t lds = (common + 4*(size_t)(3*g.mp12 + 5*nn))*sizeof(double);
+        const long long tasks = (long long)g.nEl*g.nk;
+        if (lds > 64*1024) MIMSEM_HIP_TRY(hipFuncSetAttribute((const void*)k_schur_levels<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_schur_levels<N2>), dim3((unsigned)((tasks + 3)/4)), dim3(256), lds, c->stream, a);
+        MIMSEM_HIP_TRY(hipGetLastError());
+    }
+    {
+        const size_t lds = (common + 4*(size_t)(3*g.mp12 + 7*nn + 2*N2))*sizeof(double);
+        const long long tasks = (long long)g.nEl*(g.nk - 1);
+        if (lds > 64*1024) MIMSEM_HIP_TRY(hipFuncSetAttribute((const void*)k_schur_interfaces<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_schur_interfaces<N2>), dim3((unsigned)((tasks + 3)/4)), dim3(256), lds, c->stream, a);
+        MIMSEM_HIP_TRY(hipGetLastError());
+    }
+    return MIMSEM_OK;
+}
+
 struct Schur {
     // block arrays (all [nEl][ns][nn])
     BA B, Binv, Ainv, T, Rr, X, Npi, Nrho, R2, C2, DIVl, DIVu, Gl, Gu, M1, L, G, AB0, AB1;
     double *gpi, *geta, *rlump, *tA, *tB, *tC;
+    bool fused = false;            // G_pi (Gl, Gu) already built by k_schur_interfaces
 };
 
 // assemble every factor of the Helmholtz operator; see the derivation in DESIGN.md ("C5")
@@ -1235,6 +1464,20 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
     S.tC = w.take((long long)nEl*nk*n2);
     if (w.used > w.cap) return MIMSEM_ERR_STATE;
 
+    if ((n2 == 4 || n2 == 9 || n2 == 16) && getenv("MIMSEM_SCHUR_FUSED")) {
+        // fused path: one wave per (column, level) / (column, interface), intermediates in LDS.  Measured SLOWER than the
+        // pipeline of wide kernels below (2 x 0.70 ms for what costs 1.0 ms there: three wave-cooperative Gauss-Jordan sweeps
+        // per task are latency-bound, the thread-per-block register inverse is not) -- profiles/r01_schur_fused_ab.txt; opt-in.
+        FusedArgs fa;
+        fa.g = make_cg(c); fa.hdt = 0.5*dt; fa.theta = theta; fa.rho = rho; fa.eta = eta; fa.pi = pi;
+        fa.B = S.B.p; fa.Binv = S.Binv.p; fa.Npi = S.Npi.p; fa.Nrho = S.Nrho.p;
+        fa.Ainv = S.Ainv.p; fa.X = S.X.p; fa.Gl = S.Gl.p; fa.Gu = S.Gu.p; fa.gpi = S.gpi; fa.geta = S.geta;
+        if ((rc = (n2 == 4 ? launch_schur_fused<4>(c, fa) : (n2 == 9 ? launch_schur_fused<9>(c, fa) : launch_schur_fused<16>(c, fa))))) return rc;
+        if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_RHODPI, 0, theta, S.gpi, R2.p, cq, tmpM))) return rc;       // :701
+        if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_W, 0, S.geta, nullptr, C2.p, cq, tmpM))) return rc;         // :730
+        S.fused = true;
+        return MIMSEM_OK;
+    }
     // VB, VB_inv, VA_inv   (VertSolve.cpp:690-692)
     if ((rc = colop_blocks_into(c, MIMSEM_V_CONST, 0, nullptr, nullptr, S.B.p, cq, tmpM))) return rc;
     MIMSEM_HIP_TRY(hipMemcpyAsync(S.Binv.p, S.B.p, (size_t)nEl*nk*nn*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1359,7 +1602,7 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
         }))) return rc;
     }
     // G_pi (Nm x N), row i: Gl_i = (i,i) = -0.5dt T_i Ainv_i B_i ; Gu_i = (i,i+1) = +0.5dt T_i Ainv_i B_{i+1}  (:710-711)
-    {
+    if (!S.fused) {
         if ((rc = bmm(c, nm, S.AB0, S.Ainv, 0, S.B, 0, 1.0, 0))) return rc;            // Ainv_i B_i
         if ((rc = bmm(c, nm, S.AB1, S.Ainv, 0, S.B, 1, 1.0, 0))) return rc;            // Ainv_i B_{i+1}
         if ((rc = bmm(c, nm, S.Gl, S.T, 0, S.AB0, 0, -hdt, 0))) return rc;

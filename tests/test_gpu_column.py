@@ -296,3 +296,24 @@ def test_vertical_incidence(setup):
     assert np.array_equal(eng.column_incidence("V10", eng.tensor(xm)).cpu().numpy(), xm @ V10.T)
     assert np.array_equal(eng.column_incidence("V01", eng.tensor(xk)).cpu().numpy(), xk @ (-V10))
     assert np.array_equal(eng.column_incidence("V10_full", eng.tensor(xp)).cpu().numpy(), xp @ V10f.T)
+
+
+def test_fused_schur_assembly_matches_default(setup, monkeypatch):
+    """the opt-in fused assembly of the Schur factors (one wave per (column, level) / (column, interface)) gives the default result"""
+    eng, P = setup
+    if P.n2e not in (4, 9, 16):
+        pytest.skip("fused kernels are built for 2x2, 3x3, 4x4 blocks")
+    F = _col_fields(P)
+    r = np.random.default_rng(9)
+    nEl, N, Nm = P.nEl, P.nk * P.n2e, (P.nk - 1) * P.n2e
+    Fs = [r.standard_normal((nEl, n)) * 1e8 for n in (Nm, N, N, N)]
+    t = eng.tensor
+    args = (75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]))
+    base = eng.solve_schur_eta(*args, *[t(f) for f in Fs])
+    L0 = eng.helmholtz_blocks(*args)
+    monkeypatch.setenv("MIMSEM_SCHUR_FUSED", "1")
+    alt = eng.solve_schur_eta(*args, *[t(f) for f in Fs])
+    L1 = eng.helmholtz_blocks(*args)
+    assert rel_l2(L1.cpu().numpy(), L0.cpu().numpy()) < 1e-9
+    for a, b in zip(alt, base):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8
