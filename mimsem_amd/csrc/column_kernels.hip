@@ -1435,6 +1435,158 @@ int launch_schur_fused(mimsem_ctx* c, const FusedArgs& a) {
     return MIMSEM_OK;
 }
 
+// ---- thread-per-block fused EOS block: N = B . B(f)^-1 . B with everything but B in registers (Assemble_EOS_Block :1162-1196).
+// One THREAD per (column, level): the coefficient row, the sum-factorised W^T diag(c) W, its unpivoted Gauss-Jordan inverse
+// (the design of k_block_inverse_reg) and the two products run without any inter-lane traffic; B is read from the stored CONST
+// blocks.  Blocks whose natural-order pivots are too small are flagged and redone by the generic path.
+// ---- thread-per-block register kernels (p = 3 specialisations of the Schur factors) ------------------------------------------
+// One THREAD per block/task: coefficient rows, sum-factorised W^T diag(c) W, unpivoted Gauss-Jordan (the design of
+// k_block_inverse_reg) and the small products run without any inter-lane traffic.  A block whose natural-order pivots are too
+// small is redone with partial pivoting on separate arrays in private memory, so the fast path keeps everything in registers.
+template <int N>
+__device__ __forceinline__ void reg_assemble(const double (&E)[(N + 1)*N], const double (&c)[(N + 1)*(N + 1)], double (&P)[N*N*N*N]) {
+    constexpr int N2 = N*N, MP1 = N + 1;
+#pragma unroll
+    for (int iy = 0; iy < N; iy++)
+#pragma unroll
+        for (int jy = 0; jy < N; jy++) {
+            double t1[MP1];
+#pragma unroll
+            for (int qx = 0; qx < MP1; qx++) {
+                double s = 0.0;
+#pragma unroll
+                for (int qy = 0; qy < MP1; qy++) s += (E[qy*N + iy]*c[qy*MP1 + qx])*E[qy*N + jy];
+                t1[qx] = s;
+            }
+#pragma unroll
+            for (int ix = 0; ix < N; ix++)
+#pragma unroll
+                for (int jx = 0; jx < N; jx++) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int qx = 0; qx < MP1; qx++) s += (E[qx*N + ix]*E[qx*N + jx])*t1[qx];
+                    P[(iy*N + ix)*N2 + jy*N + jx] = s;
+                }
+        }
+}
+// in place; returns false when a natural-order pivot is too small (caller falls back)
+template <int N2>
+__device__ __forceinline__ bool reg_inverse(double (&P)[N2*N2]) {
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < N2; i++) dmax = fmax(dmax, fabs(P[i*N2 + i]));
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < N2; p++) {
+        const double piv = P[p*N2 + p];
+        if (!(fabs(piv) >= 1.0e-8*dmax) || !(fabs(piv) >= 1.0e-12)) ok = false;
+        const double pinv = 1.0/piv;
+        P[p*N2 + p] = 1.0;
+#pragma unroll
+        for (int cc = 0; cc < N2; cc++) P[p*N2 + cc] *= pinv;
+#pragma unroll
+        for (int r = 0; r < N2; r++) {
+            if (r == p) continue;
+            const double d = P[r*N2 + p];
+            P[r*N2 + p] = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < N2; cc++) P[r*N2 + cc] -= P[p*N2 + cc]*d;
+        }
+    }
+    return ok;
+}
+// A (private memory, dynamic indexing) -> its inverse in I, partial pivoting
+template <int N2>
+__device__ __noinline__ void private_inverse(double* A, double* I) {
+    for (int t = 0; t < N2*N2; t++) I[t] = (t/N2 == t%N2) ? 1.0 : 0.0;
+    for (int col = 0; col < N2; col++) {
+        int pr = col; double big = fabs(A[col*N2 + col]);
+        for (int r = col + 1; r < N2; r++) if (fabs(A[r*N2 + col]) > big) { big = fabs(A[r*N2 + col]); pr = r; }
+        if (pr != col) for (int j = 0; j < N2; j++) {
+            double t = A[col*N2 + j]; A[col*N2 + j] = A[pr*N2 + j]; A[pr*N2 + j] = t;
+            t = I[col*N2 + j]; I[col*N2 + j] = I[pr*N2 + j]; I[pr*N2 + j] = t;
+        }
+        const double pinv = 1.0/A[col*N2 + col];
+        for (int j = 0; j < N2; j++) { A[col*N2 + j] *= pinv; I[col*N2 + j] *= pinv; }
+        for (int r = 0; r < N2; r++) {
+            if (r == col) continue;
+            const double d = A[r*N2 + col];
+            for (int j = 0; j < N2; j++) { A[r*N2 + j] -= d*A[col*N2 + j]; I[r*N2 + j] -= d*I[col*N2 + j]; }
+        }
+    }
+}
+// field f (slot k of nkv) interpolated to the quadrature points of element e: the rk/tb loops of VertOps.cpp
+template <int N>
+__device__ __forceinline__ void reg_interp(const double (&E)[(N + 1)*N], const double* __restrict__ f, int nkv, int e, int k, double (&v)[(N + 1)*(N + 1)]) {
+    constexpr int N2 = N*N, MP1 = N + 1;
+    const double* fe = f + ((size_t)e*nkv + k)*N2;
+    double fv[N2];
+#pragma unroll
+    for (int j = 0; j < N2; j++) fv[j] = fe[j];
+#pragma unroll
+    for (int q = 0; q < MP1*MP1; q++) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < N2; j++) r += fv[j]*(E[(q%MP1)*N + j%N]*E[(q/MP1)*N + j/N]);
+        v[q] = r;
+    }
+}
+
+// N = B . B(f)^-1 . B   (Assemble_EOS_Block :1162-1196), B read from the stored CONST blocks
+template <int N>
+__global__ __launch_bounds__(64) void k_eos_block_thread(CG g, const double* __restrict__ f, const double* __restrict__ Bc,
+                                                         double* __restrict__ out) {
+    constexpr int N2 = N*N, MP1 = N + 1, MP12 = MP1*MP1;
+    const long long b = (long long)blockIdx.x*64 + threadIdx.x;
+    if (b >= (long long)g.nEl*g.nk) return;
+    const int k = (int)(b%g.nk), e = (int)(b/g.nk);
+    double E[MP1*N];
+#pragma unroll
+    for (int t = 0; t < MP1*N; t++) E[t] = g.E[t];
+    double c[MP12], rk[MP12];
+    reg_interp<N>(E, f, g.nk, e, k, rk);
+#pragma unroll
+    for (int q = 0; q < MP12; q++) {           // coefficient of CONST_RHO (VertOps.cpp:508-521)
+        const double det = g.det[(size_t)e*MP12 + q];
+        const size_t gl = ((size_t)k*g.nEl + e)*MP12 + q;
+        const double cc = (g.w[q%MP1]*g.w[q/MP1])*(VSCALE/det)*g.tI[gl];
+        c[q] = cc*(rk[q]/(g.th[gl]*det));
+    }
+    double P[N2*N2];
+    reg_assemble<N>(E, c, P);
+    if (!reg_inverse<N2>(P)) {                 // rare: a coefficient field that is not positive
+        double A[N2*N2], I[N2*N2];
+        reg_assemble<N>(E, c, A);
+        private_inverse<N2>(A, I);
+#pragma unroll
+        for (int t = 0; t < N2*N2; t++) P[t] = I[t];
+    }
+    // N = B (Pinv B), one column at a time: v = Pinv B[:,j], N[:,j] = B v
+    double B[N2*N2];
+    const double* Bb = Bc + (size_t)b*N2*N2;
+#pragma unroll
+    for (int t = 0; t < N2*N2; t++) B[t] = Bb[t];
+    double* o = out + (size_t)b*N2*N2;
+#pragma unroll
+    for (int j = 0; j < N2; j++) {
+        double v[N2];
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += P[i*N2 + m]*B[m*N2 + j];
+            v[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < N2; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += B[i*N2 + m]*v[m];
+            o[i*N2 + j] = s;
+        }
+    }
+}
+
 struct Schur {
     // block arrays (all [nEl][ns][nn])
     BA B, Binv, Ainv, T, Rr, X, Npi, Nrho, R2, C2, DIVl, DIVu, Gl, Gu, M1, L, G, AB0, AB1;
@@ -1505,6 +1657,16 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
     if ((rc = grad(eta, S.geta))) return rc;
     if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_W, 0, S.geta, nullptr, C2.p, cq, tmpM))) return rc;
     // EOS blocks                                                     (:736, :739)
+    if (c->es.n == 3 && !getenv("MIMSEM_EOS_WIDE")) {
+        // p = 3: thread-per-block register kernel for N = B B(f)^-1 B (93 us per call vs 210 us for coef + inverse + 2 products + copy);
+        // the same treatment of the interface factors (A^-1, X, G_pi) needs two blocks live per thread, spills, and measured no gain
+        const CG g = make_cg(c);
+        const unsigned grid = (unsigned)(((long long)nEl*nk + 63)/64);
+        hipLaunchKernelGGL((k_eos_block_thread<3>), dim3(grid), dim3(64), 0, c->stream, g, pi, S.B.p, S.Npi.p);
+        hipLaunchKernelGGL((k_eos_block_thread<3>), dim3(grid), dim3(64), 0, c->stream, g, rho, S.B.p, S.Nrho.p);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, pi, nullptr, S.Npi.p, cq, tmpM, S.B.p))) return rc;
     if ((rc = colop_blocks_into(c, MIMSEM_V_EOS_BLOCK, 0, rho, nullptr, S.Nrho.p, cq, tmpM, S.B.p))) return rc;
     return MIMSEM_OK;
