@@ -1,0 +1,74 @@
+"""Error behaviour of the C ABI: every entry point returns a negative MIMSEM_ERR_* code (never crashes, never launches) on
+null / out-of-range arguments, unsupported orders and wrong entry points; mimsem_strerror names them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import SCALE, make_patch
+
+pytestmark = pytest.mark.gpu
+ERR_ARG, ERR_UNSUPPORTED = -1, -2
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    from mimsem_amd.device import DeviceMesh, Engine
+    cs, topo, geom, P, rng = make_patch(oracle, 3, 2, 6, 0, nk=4, seed=5)
+    dm = DeviceMesh([topo], [geom], nk=4, numbering="local")
+    return Engine(dm), dm, P
+
+
+def test_argument_errors(small):
+    from mimsem_amd._lib import COLOPS, OPS, MimsemError
+    eng, dm, P = small
+    L, ctx = eng.L, eng.ctx
+    x = eng.tensor(np.ones((4, dm.n1))); y = eng.zeros(4, dm.n1); h = eng.tensor(np.ones((4, dm.n2)))
+    px, py, ph = x.data_ptr(), y.data_ptr(), h.data_ptr()
+    ap = lambda op, lev0, nlev, f, xx, yy: L.mimsem_op_apply(ctx, op, lev0, nlev, SCALE, 0, f, dm.n2, xx, dm.n1, yy, dm.n1, 1.0)
+    assert ap(OPS["UMAT"], 0, 4, None, px, py) == 0
+    assert ap(999, 0, 1, None, px, py) == ERR_ARG                       # unknown operator
+    assert ap(OPS["UMAT"], 0, 5, None, px, py) == ERR_ARG               # levels beyond nk
+    assert ap(OPS["UMAT"], -1, 1, None, px, py) == ERR_ARG
+    assert ap(OPS["UMAT"], 0, 1, None, None, py) == ERR_ARG             # null input
+    assert ap(OPS["UHMAT"], 0, 1, None, px, py) == ERR_ARG              # coefficient field missing
+    assert ap(OPS["UTMAT"], 0, 4, None, px, py) == ERR_ARG              # needs thick[lev+1]
+    assert ap(OPS["UMAT_UP"], 0, 1, px, px, py) == ERR_ARG              # wrong entry point: needs mimsem_op_apply_up
+    assert L.mimsem_op_apply_up(ctx, OPS["UMAT"], 0, 1, SCALE, 1.0, 0, px, dm.n1, px, dm.n1, px, dm.n1, py, dm.n1, 1.0) == ERR_ARG
+    assert L.mimsem_op_apply_up(ctx, OPS["UMAT_UP"], 0, 1, SCALE, 1.0, 4, px, dm.n1, None, dm.n1, px, dm.n1, py, dm.n1, 1.0) == ERR_ARG
+    assert L.mimsem_op_apply(None, OPS["UMAT"], 0, 1, SCALE, 0, None, 0, px, dm.n1, py, dm.n1, 1.0) == ERR_ARG      # null context
+    assert L.mimsem_op_elmat_size(ctx, 999) == ERR_ARG
+    assert L.mimsem_incidence_apply(ctx, 7, 1, px, dm.n1, py, dm.n1) == ERR_ARG
+    assert L.mimsem_colop_nblocks(ctx, 999) == ERR_ARG
+    assert L.mimsem_colop_blocks(ctx, COLOPS["CONST_RHO"], 0, None, None, None) == ERR_ARG
+    assert L.mimsem_colop_blocks_ex(ctx, COLOPS["LINCON2_UP"], 0, 1.0, None, None, None, 0, py) == ERR_ARG         # velocity missing
+    assert L.mimsem_column_diag_theta(ctx, 5, ph, ph, ph) == ERR_ARG
+    assert L.mimsem_column_incidence(ctx, 3, ph, ph) == ERR_ARG
+    assert L.mimsem_elem_blocks_apply(ctx, 4, 1, 0, px, 0, None, 0, px, dm.n1, py, dm.n1, 1.0) == ERR_ARG
+    assert L.mimsem_halo_segments(ctx, px, 65, px, 0, 1, 1, 0, px, py, dm.n1) == ERR_ARG                            # too many segments
+    for code in (-1, -2, -3, -4, -5):
+        assert len(L.mimsem_strerror(code)) > 5
+    with pytest.raises(AssertionError):                                  # vector lengths are checked by the host layer
+        eng.incidence("E10", x)
+    with pytest.raises(AssertionError):
+        eng.apply("UHMAT", x, f=h[:, :5].contiguous())
+    with pytest.raises(MimsemError):
+        eng.apply("UTMAT", x, lev0=0, scale=SCALE)                        # needs thick[lev+1]: the ABI's error code surfaces as an exception
+    # nothing above poisoned the context
+    assert float(eng.apply("UMAT", x, lev0=0, scale=SCALE).abs().sum()) > 0
+
+
+def test_unsupported_configurations(small):
+    from mimsem_amd._lib import MeshDesc
+    eng, dm, P = small
+    d = dm.desc()
+    ctx = C.c_void_p()
+    d.quadOrd = d.elOrd + 1                                                # quadrature order != element order
+    assert eng.L.mimsem_ctx_create(C.byref(d), 0, C.byref(ctx)) == ERR_UNSUPPORTED
+    d.quadOrd = d.elOrd = 8                                                # no GLL table beyond 7 (eul/Basis.cpp:31-89)
+    assert eng.L.mimsem_ctx_create(C.byref(d), 0, C.byref(ctx)) == ERR_UNSUPPORTED
+    d = dm.desc(); d.nEl = -1
+    assert eng.L.mimsem_ctx_create(C.byref(d), 0, C.byref(ctx)) == ERR_ARG
+    assert eng.L.mimsem_ctx_create(None, 0, C.byref(ctx)) == ERR_ARG
+    # the p = 7 limit of the test-upwinded operators and of the pentadiagonal Schur solve is reported, not crashed on
+    assert not ctx.value
