@@ -32,8 +32,7 @@ class DistEngine:
     # ---- completion ---------------------------------------------------------------------------------------------------------
     def complete(self, form, y):
         if form in (0, 1):
-            self.halo[form].reverse_add(y)
-            self.halo[form].forward_insert(y)
+            self.halo[form].sum_all(y)             # edges: one symmetric exchange; nodes shared by > 2 ranks: owner sums, then scatters
         return y
 
     def allreduce(self, t):

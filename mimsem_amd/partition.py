@@ -72,6 +72,7 @@ def build_plans(sphere, world, rank, gid0, gid1):
     plans = []
     for form, gids, owner in ((0, gid0, own0), (1, gid1, own1)):
         plan = HaloPlan(gids, owner, world, rank, n_patches)
+        plan.form = form
         per = n_patches // world
         for r in range(world):
             if r == rank:
@@ -104,6 +105,19 @@ class HaloExchanger:
         self.device = device if device is not None else (engine.device if engine is not None else torch.device("cpu"))
         self.world = plan.world
         self.sides = {"ghost": self._side(plan.ghost_slots), "mirror": self._side(plan.mirror_slots)}
+        # every slot this rank shares with rank r (its ghosts owned by r and its own slots that r holds as ghosts), ordered by
+        # global id on both sides: the lists of the symmetric exchange sum_all()
+        pair = {}
+        for r in sorted(set(plan.ghost_slots) | set(plan.mirror_slots)):
+            sl = np.concatenate([plan.ghost_slots.get(r, np.zeros(0, np.int32)), plan.mirror_slots.get(r, np.zeros(0, np.int32))])
+            pair[r] = np.sort(sl).astype(np.int32)          # local slots are numbered in gid order, so this is the gid order too
+        self.sides["pair"] = self._side(pair)
+        allp = np.concatenate(list(pair.values())) if pair else np.zeros(0, np.int32)
+        # the one-exchange form needs every shared slot to have exactly one partner rank ON EVERY RANK (the ranks must agree on
+        # which collective they run): guaranteed for edges (an edge borders at most two patches), not for nodes
+        self.pairwise = getattr(plan, "form", None) == 1
+        if self.pairwise:
+            assert np.unique(allp).size == allp.size
         self._bufs = {}
         self._plans = {}
         self._stage_host = None
@@ -129,8 +143,8 @@ class HaloExchanger:
                     idx=torch.as_tensor(cat, dtype=torch.int32, device=self.device),
                     idx_long=torch.as_tensor(cat, dtype=torch.long, device=self.device))
 
-    def _buffers(self, key, nlev, dtype):
-        k = (key, nlev, dtype)
+    def _buffers(self, key, nlev, dtype, role="send"):
+        k = (key, nlev, dtype, role)               # send and receive sides never share storage (sum_all uses one list for both)
         if k not in self._bufs:
             total = int(self.sides[key]["off"][-1])
             self._bufs[k] = torch.zeros(max(total * nlev, 1), dtype=dtype, device=self.device)
@@ -166,7 +180,7 @@ class HaloExchanger:
         key = (send_key, recv_key, nlev, v2.dtype)
         plan = self._plans.get(key)
         if plan is None:                          # buffers, views and split lists are fixed per (direction, level count): build once
-            sbuf, rbuf = self._buffers(send_key, nlev, v2.dtype), self._buffers(recv_key, nlev, v2.dtype)
+            sbuf, rbuf = self._buffers(send_key, nlev, v2.dtype, "send"), self._buffers(recv_key, nlev, v2.dtype, "recv")
             ns, nr = int(snd["off"][-1]) * nlev, int(rcv["off"][-1]) * nlev
             plan = (sbuf, rbuf, sbuf[:ns], rbuf[:nr], (rcv["counts"] * nlev).tolist(), (snd["counts"] * nlev).tolist())
             self._plans[key] = plan
@@ -185,6 +199,16 @@ class HaloExchanger:
                 self._move(rcv, 2, rbuf, v2, a, b)
         else:
             self._move(rcv, 1, rbuf, v2)
+
+    def sum_all(self, v):
+        """every copy of a shared slot := the sum of all its partial values, in ONE exchange: each rank sends its partial sums to
+        the other sharer and adds what it receives (a + b on one side, b + a on the other: bitwise identical).  Needs every shared
+        slot to have exactly one partner rank -- true for 1-forms (an edge borders at most two patches); otherwise falls back
+        to reverse_add + forward_insert."""
+        if not self.pairwise:
+            self.reverse_add(v); self.forward_insert(v)
+            return
+        self._exchange(v, "pair", "pair", add=True)
 
     def reverse_add(self, v):
         """VecScatter(gtol, vl, vg, ADD_VALUES, SCATTER_REVERSE): owners accumulate the ghosts' partial sums"""

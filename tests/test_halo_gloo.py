@@ -38,8 +38,11 @@ def _worker(rank, world, port, form, q):
             s = torch.as_tensor(np.searchsorted(touched, g)).long()
             v[0].index_add_(0, s, torch.as_tensor((t.pi + 1.0) * (g + 1.0)))
             v[1].index_add_(0, s, torch.as_tensor((t.pi + 2.0) * (g + 1.0)))
+        v2 = v.clone()
         ex.reverse_add(v)
         ex.forward_insert(v)
+        ex.sum_all(v2)                                  # the one-exchange form (edges) / its two-step fallback (nodes)
+        assert torch.equal(v, v2) and ex.pairwise == (form == 1)
         # expected: the all-patch sum at every slot I hold
         want = np.zeros((2, nG))
         for p in range(6):
