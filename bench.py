@@ -140,13 +140,16 @@ def sw_extras(local_rank, torch):
         uq, hq = williamson2(torch.as_tensor(xq[dm.gidq], device=eng.device), alpha=0.0)
         u, h = S.init1(uq), S.init2(hq)
         u, h = S.solve(u, h, dt, nits=nits, q_exact=q_exact)            # warm-up step
+        c0 = S.conservation(u, h)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         picard = 0
         for _ in range(nsteps):
             u, h = S.solve(u, h, dt, nits=nits, q_exact=q_exact)
             picard += len(S.history)
         torch.cuda.synchronize(); el = time.perf_counter() - t1
+        c1 = S.conservation(u, h)
         res[name] = {"steps_per_s": nsteps / el, "ms_per_step": 1e3 * el / nsteps, "dt": dt, "picard_iterations_per_step": picard / nsteps,
+                     "relative_drift_over_timed_steps": {k: (c1[k] - c0[k]) / abs(c0[k]) for k in ("mass", "energy", "enstrophy")},
                      "krylov_iterations_last": dict(S.its), "elements": dm.nEl, "dofs": dm.n1 + dm.n2}
         del S, eng
     return res

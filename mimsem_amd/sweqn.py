@@ -198,6 +198,30 @@ class SWEqn:
         self.history = hist
         return uj, hj
 
+    # ---- conservation diagnostics (int0 :1202-1238, int2 :1240-1274, intE :1276-1323, writeConservation :1325-1359) ------------
+    def conservation(self, u, h, bot=None):
+        """mass = int2(h) = sum_q w det h_q;  vorticity = int0(curl u);  energy = 1/2 sum_q w det (g (h+b)^2 + h |u|^2);
+        enstrophy = q^T M0h(h) q with q = diagnose_q(0, u, h).  The quadrature sums are written as the bilinear forms they are:
+        int2(h) = 1^T (W^T diag(w)) h, energy = g/2 (h+b)^T M2 (h+b) + 1/2 u^T M1h(h) u (M2 = W^T diag(w/det) W, interp2_g = W h/det)."""
+        eng = self.eng
+        hb = h if bot is None else h + bot
+        with eng.space(2):
+            mass = float(eng.wsum(2, self._int2_weights() * h))
+            pot = 0.5 * self.grav * float(eng.wsum(2, hb * self.M2(hb)))
+        kin = 0.5 * float(eng.wsum(1, u * self.M1h(h, u)))
+        w = self.curl(u)
+        vort = float(eng.wsum(0, self.m0 * w))
+        q = self.diagnose_q(0.0, u, h)
+        enst = float(eng.wsum(0, q * (eng.pvec(0, 1, 1.0, h2=h) * q)))
+        return dict(mass=mass, vorticity=vort, energy=pot + kin, enstrophy=enst)
+
+    def _int2_weights(self):
+        """sum_q w_q W[q][j] per 2-form DoF (= 1 up to round-off: the edge functions integrate to one and GLL is exact for them)"""
+        if getattr(self, "_w2", None) is None:
+            ones_q = torch.ones(1, self.eng.sizes["q"], dtype=torch.float64, device=self.eng.device)
+            self._w2 = self.eng.apply("WTQ", ones_q)              # WtQmat applied to 1: W^T diag(w) 1
+        return self._w2
+
     # ---- initial conditions (init1 :880-932, init2 :934-975) ---------------------------------------------------------
     def init1(self, uq):
         """uq: [nq, 2] zonal/meridional velocity at the quadrature-grid points -> 1-form u = M1^-1 UtQ uq"""

@@ -189,6 +189,14 @@ class Patch:
                 out[ey * self.nElsX + ex] = tmp
         return out
 
+    def interp(self, kind, ex, ey, px, py, vec):
+        """Geom::interp0 / interp1_l / interp2_l / interp1_g / interp2_g at one quadrature point (eul/Geom.cpp:328-417)"""
+        fn = {"0": self.L.orc_interp0, "1l": self.L.orc_interp1_l, "2l": self.L.orc_interp2_l,
+              "1g": self.L.orc_interp1_g, "2g": self.L.orc_interp2_g}[kind]
+        val = np.zeros(2)
+        fn(self.p, ex, ey, px, py, _dp(vec), _dp(val))
+        return val
+
     # horizontal operators -----------------------------------------------------------------
     def elmat_size(self, op):
         return self.L.orc_op_elmat_size(self.p, OPS[op])

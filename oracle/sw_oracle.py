@@ -239,6 +239,31 @@ class SWOracle:
         self.history = hist
         return uj, hj
 
+    def conservation(self, u, h, bot=None):
+        """int2 / int0 / intE / enstrophy of writeConservation (:1202-1359), element by element and point by point as the reference
+        does (interp at every quadrature point, sum w det f)"""
+        mass = vort = ener = 0.0
+        w0 = self.curl(u)
+        for t, P in zip(self.topos, self.P):
+            ul, hl, wl = self._local1(t, u), self._local2(t, h), self._local0(t, w0)
+            bl = None if bot is None else self._local2(t, bot)
+            Q = P.arr("Q", (P.mp12,))
+            for e in range(P.nEl):
+                ex, ey = e % P.nElsX, e // P.nElsX
+                for ii in range(P.mp12):
+                    det = P.det[e, ii]
+                    px, py = ii % P.mp1, ii // P.mp1
+                    hq = P.interp("2g", ex, ey, px, py, hl)[0]
+                    bq = 0.0 if bl is None else P.interp("2g", ex, ey, px, py, bl)[0]
+                    uq = P.interp("1g", ex, ey, px, py, ul)
+                    wq = P.interp("0", ex, ey, px, py, wl)[0]
+                    mass += det * Q[ii] * hq
+                    vort += det * Q[ii] * wq
+                    ener += det * Q[ii] * 0.5 * (self.grav * (hq + bq) * (hq + bq) + hq * (uq[0] * uq[0] + uq[1] * uq[1]))
+        q = self.diagnose_q(0.0, u, h)
+        enst = float(q @ (self.M0h(h) @ q))
+        return dict(mass=mass, vorticity=vort, energy=ener, enstrophy=enst)
+
     def init1(self, uq):
         return np.linalg.solve(self.M1, self.project(2, uq))             # :880-932
 

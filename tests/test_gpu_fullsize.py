@@ -150,6 +150,10 @@ def test_shallow_water_step_conserves_mass_exactly():
     assert abs(float(h1.sum()) - m0) < 1e-12 * abs(m0)
     w = S.curl(u1)
     assert abs(float((S.m0 * w).sum())) < 1e-9 * float((S.m0 * w.abs()).sum())
+    c0, c1 = S.conservation(u0, h0), S.conservation(u1, h1)              # writeConservation (src/SWEqn_Picard.cpp:1325-1359)
+    assert abs(c1["mass"] - c0["mass"]) < 1e-13 * abs(c0["mass"])
+    assert abs(c1["energy"] - c0["energy"]) < 1e-8 * abs(c0["energy"])         # energy-conserving scheme, 2 Picard iterations
+    assert abs(c1["enstrophy"] - c0["enstrophy"]) < 1e-5 * abs(c0["enstrophy"])
     # Williamson-2 is a steady state: one step moves the fields by the (small) truncation error only
     assert float(torch.linalg.vector_norm(u1 - u0) / torch.linalg.vector_norm(u0)) < 2e-4
     assert float(torch.linalg.vector_norm(h1 - h0) / torch.linalg.vector_norm(h0)) < 2e-5

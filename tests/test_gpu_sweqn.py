@@ -82,3 +82,20 @@ def test_sw_time_step(sw, q_exact, nits, dt):
     S2 = SWEqn(eng, O.xq[eng.mesh.gidq], use_graphs=False)
     ue, he = S2.solve(_t(eng, u0), _t(eng, h0), dt, nits=nits, q_exact=q_exact)
     assert rel_l2(ue[0].cpu().numpy(), ud[0].cpu().numpy()) < 1e-11 and rel_l2(he[0].cpu().numpy(), hd[0].cpu().numpy()) < 1e-11
+
+
+def test_sw_conservation_diagnostics(sw):
+    """int2 / int0 / intE / enstrophy of SWEqn::writeConservation (src/SWEqn_Picard.cpp:1202-1359): the device evaluates them as
+    bilinear forms of the engine operators, the oracle point by point as the reference does"""
+    cs, eng, O, S, uq, hq = sw
+    u0, h0 = O.init1(uq), O.init2(hq)
+    want = O.conservation(u0, h0)
+    got = S.conservation(_t(eng, u0), _t(eng, h0))
+    for k in ("mass", "energy", "enstrophy"):
+        assert abs(got[k] - want[k]) < 1e-11 * abs(want[k]), (k, got[k], want[k])
+    assert abs(got["vorticity"] - want["vorticity"]) < 1e-9 * (np.abs(O.M0 @ O.curl(u0)).sum())
+    # a step conserves mass to round-off and changes the energy only at the level of the (coarse-mesh) truncation error
+    ud, hd = S.solve(_t(eng, u0), _t(eng, h0), 360.0, nits=3, q_exact=False)
+    after = S.conservation(ud, hd)
+    assert abs(after["mass"] - got["mass"]) < 1e-13 * abs(got["mass"])
+    assert abs(after["energy"] - got["energy"]) < 1e-4 * abs(got["energy"])
