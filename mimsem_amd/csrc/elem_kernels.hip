@@ -565,7 +565,8 @@ template <int K>
 __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ ye, long long ye_stride,
                                                     const int* __restrict__ plan, int nslots, int nlev,
                                                     int accum, double* __restrict__ y, long long ys,
-                                                    const int* __restrict__ slots /* null: every slot; else the shared ones */) {
+                                                    const int* __restrict__ slots /* null: every slot; else the shared ones */,
+                                                    int lc /* levels per thread */) {
     int s = xcd_swizzle(blockIdx.x, gridDim.x, accum >> 8)*256 + threadIdx.x;
     accum &= 1;
     if (s >= nslots) return;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ y
     int j[K];
 #pragma unroll
     for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
-    const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);
+    const int l0 = blockIdx.y*lc, l1 = min(nlev, l0 + lc);
     for (int lev = l0; lev < l1; lev++) {
         const double* src = ye + (size_t)lev*ye_stride;
         double acc = 0.0;
@@ -1119,11 +1120,12 @@ int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long 
     const int* slots = shared_only ? (form == 1 ? c->d_sh1 : c->d_sh0) : nullptr;
     const int nslots = shared_only ? (form == 1 ? c->nsh1 : c->nsh0) : (form == 1 ? c->n1 : c->n0);
     if (nslots == 0 || nlev == 0) return MIMSEM_OK;
-    const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
+    static const int lc = getenv("MIMSEM_GS_LC") ? std::max(1, atoi(getenv("MIMSEM_GS_LC"))) : GS_LC;
+    const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + lc - 1)/lc));
     hipEvent_t s0 = c->ev_k2[0], s1 = c->ev_k2[1];
 #define MIMSEM_GS(K, PLAN) \
-    if (s0) hipExtLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, s0, s1, 0, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots); \
-    else hipLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots)
+    if (s0) hipExtLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, s0, s1, 0, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots, lc); \
+    else hipLaunchKernelGGL((k_gather_sum<K>), grid, dim3(256), 0, c->stream, ye, ye_stride, PLAN, nslots, nlev, accum | (c->swz << 8), y, ys, slots, lc)
     if (form == 1) { MIMSEM_GS(2, c->d_g1); }
     else if (c->G0 == 4) { MIMSEM_GS(4, c->d_g0); }
     else { MIMSEM_GS(8, c->d_g0); }
