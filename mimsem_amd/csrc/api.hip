@@ -413,9 +413,11 @@ int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double sc
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
                          const double* x, long long xs, double* y, long long ys, double alpha) {
-    if (!c || !x || !y || nlev < 0) return MIMSEM_ERR_ARG;
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;       // empty batch: nothing to do (pointers of empty arrays may be null)
+    if (!x || !y) return MIMSEM_ERR_ARG;
     if (cf >= 0 && !f) return MIMSEM_ERR_ARG;
     if (geom_lev0 < 0 || geom_lev0 + nlev > c->nk) return MIMSEM_ERR_ARG;
     if (op == MIMSEM_OP_UTMAT && geom_lev0 + nlev > c->nk - 1) return MIMSEM_ERR_ARG;   // needs thick[lev+1]
@@ -534,11 +536,15 @@ int mimsem_incidence_apply(mimsem_ctx* c, int which, int nlev, const double* x, 
 }
 
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
-    if (!c || !idx || !v || !buf || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null
+    if (!idx || !v || !buf) return MIMSEM_ERR_ARG;
     return launch_halo_pack(c, idx, count, nlev, v, vs, buf);
 }
 int mimsem_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs) {
-    if (!c || !idx || !v || !buf || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
+    if (count == 0 || nlev == 0) return MIMSEM_OK;
+    if (!idx || !v || !buf) return MIMSEM_ERR_ARG;
     return launch_halo_unpack(c, idx, count, nlev, mode, buf, v, vs);
 }
 

@@ -72,3 +72,20 @@ def test_unsupported_configurations(small):
     assert eng.L.mimsem_ctx_create(None, 0, C.byref(ctx)) == ERR_ARG
     # the p = 7 limit of the test-upwinded operators and of the pentadiagonal Schur solve is reported, not crashed on
     assert not ctx.value
+
+
+def test_empty_inputs_are_no_ops(small):
+    """zero levels / zero-length halo lists: success, nothing written"""
+    import torch
+    eng, dm, P = small
+    x0 = torch.zeros(0, dm.n1, dtype=torch.float64, device=eng.device)
+    y = eng.apply("UMAT", x0, lev0=0, scale=SCALE)
+    assert y.shape == (0, dm.n1)
+    y1 = eng.tensor(np.ones((2, dm.n1))); keep = y1.clone()
+    idx = torch.zeros(0, dtype=torch.int32, device=eng.device)
+    buf = eng.halo_pack(idx, y1)
+    assert buf.shape == (2, 0)
+    eng.halo_unpack(idx, buf, y1, add=True)
+    assert torch.equal(y1, keep)
+    assert eng.L.mimsem_incidence_apply(eng.ctx, 1, 0, y1.data_ptr(), dm.n1, y1.data_ptr(), dm.n1) == 0
+    assert eng.L.mimsem_krylov_mdot(eng.ctx, 0, dm.n1, y1.data_ptr(), dm.n1, y1.data_ptr(), y1.data_ptr()) == 0

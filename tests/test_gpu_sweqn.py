@@ -99,3 +99,14 @@ def test_sw_conservation_diagnostics(sw):
     after = S.conservation(ud, hd)
     assert abs(after["mass"] - got["mass"]) < 1e-13 * abs(got["mass"])
     assert abs(after["energy"] - got["energy"]) < 1e-4 * abs(got["energy"])
+
+
+def test_sw_five_steps_track_the_oracle(sw):
+    """five consecutive Galewsky-style steps: device and oracle trajectories stay together (no drift of the parity)"""
+    cs, eng, O, S, uq, hq = sw
+    ur, hr = O.init1(uq), O.init2(hq)
+    ud, hd = _t(eng, ur), _t(eng, hr)
+    for step in range(5):
+        ur, hr = O.solve(ur, hr, 360.0, nits=2, q_exact=False)
+        ud, hd = S.solve(ud, hd, 360.0, nits=2, q_exact=False)
+        assert rel_l2(ud[0].cpu().numpy(), ur) < 1e-8 and rel_l2(hd[0].cpu().numpy(), hr) < 1e-9, step
