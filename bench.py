@@ -148,8 +148,12 @@ def sw_extras(local_rank, torch):
             picard += len(S.history)
         torch.cuda.synchronize(); el = time.perf_counter() - t1
         c1 = S.conservation(u, h)
+        # the reference's own verification metric (Williamson2.cpp:138-151): [L1, L2, Linf] against the steady analytic state
+        wq = 2.0 * 38.61068276698372 / 6371220.0 * torch.sin(S.lat)
+        errs = {"vorticity": S.err0(S.curl(u), wq), "velocity": S.err1(u, uq), "depth": S.err2(h, hq)}
         res[name] = {"steps_per_s": nsteps / el, "ms_per_step": 1e3 * el / nsteps, "dt": dt, "picard_iterations_per_step": picard / nsteps,
                      "relative_drift_over_timed_steps": {k: (c1[k] - c0[k]) / abs(c0[k]) for k in ("mass", "energy", "enstrophy")},
+                     "williamson2_error_norms_L1_L2_Linf": errs, "days": (nsteps + 1) * dt / 86400.0,
                      "krylov_iterations_last": dict(S.its), "elements": dm.nEl, "dofs": dm.n1 + dm.n2}
         del S, eng
     return res

@@ -189,6 +189,14 @@ int mimsem_pvec(mimsem_ctx* ctx, int geom_lev0, int nlev, double scale,
 int mimsem_incidence_apply(mimsem_ctx* ctx, int which, int nlev,
                            const double* x, long long x_stride, double* y, long long y_stride);
 
+/* Row A7, Geom::interp0 / interp1_l / interp2_l / interp1_g / interp2_g (eul/Geom.cpp:328-417) at EVERY quadrature point
+ * of every element in one launch (the reference evaluates one point per call).  x: local (ghosted) k-form vectors, one row
+ * per level.  out per level: form 0 or 2 -> [nEl][mp12]; form 1 -> [nEl][mp12][2] (u, v).  flags & MIMSEM_INTERP_GLOBAL
+ * applies the Piola push-forward of the _g variants (1-forms: J/det; 2-forms: 1/det); form 0 ignores it. */
+#define MIMSEM_INTERP_GLOBAL 1u
+int mimsem_interp_quad(mimsem_ctx* ctx, int form, unsigned flags, int nlev,
+                       const double* x, long long x_stride, double* out, long long out_stride);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,

@@ -52,6 +52,7 @@ _SIGS = {
     "mimsem_op_element_matrices_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint, c_dp, c_dp, c_dp]),
     "mimsem_pvec": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_incidence_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_interp_quad": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_colop_nblocks": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_colop_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, c_dp, c_dp, c_dp]),

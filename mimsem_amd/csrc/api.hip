@@ -535,6 +535,15 @@ int mimsem_incidence_apply(mimsem_ctx* c, int which, int nlev, const double* x, 
     return launch_incidence(c, which, nlev, x, xs, y, ys);
 }
 
+int mimsem_interp_quad(mimsem_ctx* c, int form, unsigned flags, int nlev, const double* x, long long xs, double* out, long long os) {
+    if (!c || form < 0 || form > 2 || nlev < 0 || (flags & ~MIMSEM_INTERP_GLOBAL)) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!x || !out) return MIMSEM_ERR_ARG;
+    const long long per = (long long)c->nEl*c->es.mp12*(form == 1 ? 2 : 1);
+    if (nlev > 1 && os < per) return MIMSEM_ERR_ARG;
+    return launch_interp_quad(c, form, (flags & MIMSEM_INTERP_GLOBAL) ? 1 : 0, nlev, x, xs, out, os);
+}
+
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
     if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null

@@ -784,6 +784,58 @@ __global__ __launch_bounds__(256) void k_incidence(int which, int nEl, int nlev,
     }
 }
 
+// ---- field values at the quadrature points (row A7: Geom::interp0 / interp1_l / interp2_l / interp1_g / interp2_g,
+// eul/Geom.cpp:328-417).  Work item = (level, element); lane q owns quadrature point q.  Result layout per level:
+// form 0 / 2: [nEl][mp12]; form 1: [nEl][mp12][2].  `global` applies the Piola push-forward (J/det, 1/det).
+template <int N>
+__global__ __launch_bounds__(256) void k_interp_quad(int form, int global, int nEl, int nlev,
+        const int* i0, const int* i1x, const int* i1y, const int* i2,
+        const double* __restrict__ J, const double* __restrict__ det, const double* __restrict__ E,
+        const double* __restrict__ x, long long xs, double* __restrict__ out, long long os) {
+    using D = Dims<N>;
+    constexpr int LPE = D::LPE, EPB = D::EPB;
+    __shared__ double sE[D::mp1*N];
+    __shared__ double s_x[EPB][2*LPE];
+    const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
+    if (tid < D::mp1*N) sE[tid] = E[tid];
+    const long long eg = (long long)blockIdx.x*EPB + el;
+    const bool act = eg < (long long)nEl*nlev;
+    const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
+    const double* xv = x + (size_t)lev*xs;
+    if (act) {
+        if (form == 1) {
+            if (q < D::n1e) { s_x[el][q] = xv[i1x[e*D::n1e + q]]; s_x[el][D::n1e + q] = xv[i1y[e*D::n1e + q]]; }
+        } else if (form == 2) {
+            if (q < D::n2e) s_x[el][q] = xv[i2 ? i2[e*D::n2e + q] : e*D::n2e + q];
+        } else {
+            if (q < D::n0e) s_x[el][q] = xv[i0[e*D::n0e + q]];
+        }
+    }
+    __syncthreads();
+    if (!act || q >= D::mp12) return;
+    const int qx = q%D::mp1, qy = q/D::mp1;
+    const size_t gq = (size_t)e*D::mp12 + q;
+    double u, v;
+    if (form == 1) {
+        interp_point<N, S1>(s_x[el], sE, q, qx, qy, u, v);
+        if (global) {
+            const double* Je = J + (size_t)e*4*D::mp12;
+            const double dj = det[gq];
+            const double gu = (Je[0*D::mp12 + q]*u + Je[1*D::mp12 + q]*v)/dj;
+            const double gv = (Je[2*D::mp12 + q]*u + Je[3*D::mp12 + q]*v)/dj;
+            u = gu; v = gv;
+        }
+        double* o = out + (size_t)lev*os + 2*gq;
+        o[0] = u; o[1] = v;
+    } else if (form == 2) {
+        interp_point<N, S2>(s_x[el], sE, q, qx, qy, u, v);
+        if (global) u /= det[gq];
+        out[(size_t)lev*os + gq] = u;
+    } else {
+        out[(size_t)lev*os + gq] = s_x[el][q];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_halo_pack(const int* __restrict__ idx, int count, int nlev,
                                                    const double* __restrict__ v, long long vs, double* __restrict__ buf) {
     const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -1188,6 +1240,31 @@ int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long l
     if (rc) return rc;
     if (form != 2) return launch_gather_sum(c, form, nlev, out, os, 0, y, ys);
     return MIMSEM_OK;
+}
+
+template <int N>
+static int interp_quad_n(mimsem_ctx* c, int form, int global, int nlev, const double* x, long long xs, double* out, long long os) {
+    using D = Dims<N>;
+    const long long total = (long long)c->nEl*nlev;
+    if (total == 0) return MIMSEM_OK;
+    const unsigned grid = (unsigned)((total + D::EPB - 1)/D::EPB);
+    hipLaunchKernelGGL((k_interp_quad<N>), dim3(grid), dim3(256), 0, c->stream, form, global, c->nEl, nlev,
+                       c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_J, c->d_det, c->d_E, x, xs, out, os);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int launch_interp_quad(mimsem_ctx* c, int form, int global, int nlev, const double* x, long long xs, double* out, long long os) {
+    switch (c->es.n) {
+    case 1: return interp_quad_n<1>(c, form, global, nlev, x, xs, out, os);
+    case 2: return interp_quad_n<2>(c, form, global, nlev, x, xs, out, os);
+    case 3: return interp_quad_n<3>(c, form, global, nlev, x, xs, out, os);
+    case 4: return interp_quad_n<4>(c, form, global, nlev, x, xs, out, os);
+    case 5: return interp_quad_n<5>(c, form, global, nlev, x, xs, out, os);
+    case 6: return interp_quad_n<6>(c, form, global, nlev, x, xs, out, os);
+    case 7: return interp_quad_n<7>(c, form, global, nlev, x, xs, out, os);
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,

@@ -282,6 +282,18 @@ class Engine:
         check(self.L.mimsem_incidence_apply(self.ctx, w, x2.shape[0], _ptr(x2), x2.stride(0), _ptr(y), y.stride(0)), "incidence")
         return y if x.dim() == 2 else y[0]
 
+    def interp_quad(self, form, x, push_forward=True):
+        """Row A7, Geom::interp0 / interp1_l|_g / interp2_l|_g (eul/Geom.cpp:328-417) at every quadrature point:
+        x [nlev, n_form] (or [n_form]) -> [nlev, nEl, mp12] (forms 0, 2) or [nlev, nEl, mp12, 2] (1-forms)."""
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        assert x2.shape[1] == self.sizes[form], (form, x2.shape)
+        nc = 2 if form == 1 else 1
+        out = torch.empty(x2.shape[0], self.nEl*self.mp12*nc, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_interp_quad(self.ctx, form, 1 if push_forward else 0, x2.shape[0], _ptr(x2), x2.stride(0),
+                                        _ptr(out), out.stride(0)), "interp_quad")
+        out = out.view(x2.shape[0], self.nEl, self.mp12, 2) if form == 1 else out.view(x2.shape[0], self.nEl, self.mp12)
+        return out if x.dim() == 2 else out[0]
+
     # ---- column operators -------------------------------------------------------------------
     def l2_horiz_to_vert(self, vh):
         nkv = vh.shape[0]
@@ -417,6 +429,10 @@ class Engine:
     def wsum(self, form, t):
         """sum over the GLOBAL vector of one form (every DoF once); DistEngine weights by ownership and all-reduces"""
         return t.sum()
+
+    def allreduce(self, t, op="sum"):
+        """sum / max over the ranks of a DistEngine; the identity on one rank"""
+        return t
 
     def space(self, key):
         """context manager naming the vector space of the inner products inside (0, 1, 2 or "uh" = packed [1-form, 2-form]);

@@ -35,15 +35,16 @@ class DistEngine:
             self.halo[form].sum_all(y)             # edges: one symmetric exchange; nodes shared by > 2 ranks: owner sums, then scatters
         return y
 
-    def allreduce(self, t):
+    def allreduce(self, t, op="sum"):
         if self.world == 1:
             return t
+        rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
         if self._host is None:
             self._host = dist.get_backend() == "gloo"
         if self._host and t.is_cuda:
-            h = t.cpu(); dist.all_reduce(h); t.copy_(h)
+            h = t.cpu(); dist.all_reduce(h, op=rop); t.copy_(h)
         else:
-            dist.all_reduce(t)
+            dist.all_reduce(t, op=rop)
         return t
 
     def space(self, key):

@@ -32,6 +32,13 @@ def gll_points(n):
     raise ValueError("invalid gauss-lobatto quadrature order: %d" % n)
 
 
+def gll_weights(n):
+    """GLL weights w_i = 2 / (n (n+1) P_n(x_i)^2) (the values tabulated in eul/Basis.cpp:31-89)"""
+    x = gll_points(n)
+    pn = np.polynomial.legendre.legval(x, [0.0] * n + [1.0])
+    return 2.0 / (n * (n + 1) * pn * pn)
+
+
 class Geom:
     def __init__(self, topo, quad_sphere, coords, nk=1, radius=RAD_SPHERE, signed_det=False):
         """topo: Topo of this patch; quad_sphere: CubedSphere built with the QUADRATURE order (the

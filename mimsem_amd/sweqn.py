@@ -6,8 +6,10 @@ src/ flavour: no SCALE, no layer thickness (the engine runs with nk = 1 and unit
 Single GPU, global numbering: the reference's local (`*l`) and global vectors coincide, so its VecScatters are identities."""
 import math
 
+import numpy as np
 import torch
 
+from .geom import gll_weights
 from .krylov import GraphedGMRES, gmres, pcg_engine
 
 RAD_EARTH = 6371220.0          # src/SWEqn_Picard.cpp:22-23
@@ -214,6 +216,52 @@ class SWEqn:
         q = self.diagnose_q(0.0, u, h)
         enst = float(eng.wsum(0, q * (eng.pvec(0, 1, 1.0, h2=h) * q)))
         return dict(mass=mass, vorticity=vort, energy=pot + kin, enstrophy=enst)
+
+    # ---- analytic-solution error norms (err0 :981-1060, err1 :1062-1145, err2 :1147-1200) ----------------------------------
+    def _quad_measure(self):
+        """w_q det_q per (element, quadrature point) and the quadrature-grid slot of each point"""
+        if getattr(self, "_wd", None) is None:
+            m = self.eng.mesh
+            g1 = gll_weights(m.m)
+            w2 = np.outer(g1, g1).ravel()
+            self._wd = torch.as_tensor(m.det.reshape(m.nEl, -1) * w2[None, :], dtype=torch.float64, device=self.eng.device)
+            self._iq = torch.as_tensor(np.asarray(m.indsq).reshape(m.nEl, -1), device=self.eng.device).long()
+        return self._wd, self._iq
+
+    def _norms(self, wd, err1, ref1, err2, ref2, mask=None):
+        """[L1, L2, Linf] exactly as the reference accumulates them: sums of wd*|.| and wd*(.)^2 over all points, the largest
+        wd*|err| with the wd*|ref| of THAT point -- and, across ranks, MPI_MAX of both separately (:1050-1052)."""
+        if mask is not None:
+            wd = wd * mask
+        sums = torch.stack([(wd * err1).sum(), (wd * ref1).sum(), (wd * err2).sum(), (wd * ref2).sum()])
+        li = (wd * err1).reshape(-1)
+        k = torch.argmax(li)
+        mx = torch.stack([li[k], (wd * ref1).reshape(-1)[k].abs()])
+        sums = self.eng.allreduce(sums); mx = self.eng.allreduce(mx, op="max")
+        return [float(sums[0] / sums[1]), float(torch.sqrt(sums[2] / sums[3])), float(mx[0] / mx[1])]
+
+    def err0(self, w, wq):
+        """err0(ug, fw, NULL, NULL): 0-form w [1, n0] against wq [nq] at the quadrature-grid points"""
+        wd, iq = self._quad_measure()
+        un = self.eng.interp_quad(0, w)[0]
+        ua = wq[iq]
+        return self._norms(wd, (un - ua).abs(), ua.abs(), (un - ua) ** 2, ua * ua)
+
+    def err1(self, u, uq):
+        """err1(ug, fu, fv, NULL): 1-form u [1, n1] against uq [nq, 2] (zonal, meridional)"""
+        wd, iq = self._quad_measure()
+        un = self.eng.interp_quad(1, u)[0]
+        ua = uq[iq]
+        d = un - ua
+        return self._norms(wd, d.abs().sum(-1), ua.abs().sum(-1), (d * d).sum(-1), (ua * ua).sum(-1))
+
+    def err2(self, h, hq):
+        """err2(ug, fu): 2-form h [1, n2] against hq [nq]; points with |latitude| > 0.45 pi are skipped (:1167)"""
+        wd, iq = self._quad_measure()
+        un = self.eng.interp_quad(2, h)[0]
+        ua = hq[iq]
+        mask = (self.lat[iq].abs() <= 0.45 * math.pi).to(torch.float64)
+        return self._norms(wd, (un - ua).abs(), ua.abs(), (un - ua) ** 2, ua * ua, mask)
 
     def _int2_weights(self):
         """sum_q w_q W[q][j] per 2-form DoF (= 1 up to round-off: the edge functions integrate to one and GLL is exact for them)"""

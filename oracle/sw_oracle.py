@@ -264,6 +264,30 @@ class SWOracle:
         enst = float(q @ (self.M0h(h) @ q))
         return dict(mass=mass, vorticity=vort, energy=ener, enstrophy=enst)
 
+    def err_norms(self, form, vg, exact, lat_cut=False):
+        """SWEqn::err0 / err1 / err2 (:981-1200) with fu = NULL gradients: [L1, L2, Linf], point by point.
+        exact: values at the quadrature-grid points ([nq] or [nq, 2]), indexed like geom->x."""
+        l1 = [0.0, 0.0]; l2 = [0.0, 0.0]; li = [0.0, 0.0]
+        for t, g, P in zip(self.topos, self.geoms, self.P):
+            vl = (self._local0, self._local1, self._local2)[form](t, vg)
+            Q = P.arr("Q", (P.mp12,))
+            inds0 = g.all_inds0_l()
+            for e in range(P.nEl):
+                ex, ey = e % P.nElsX, e // P.nElsX
+                for ii in range(P.mp12):
+                    if lat_cut and abs(g.s[inds0[e, ii], 1]) > 0.45 * np.pi:
+                        continue
+                    px, py = ii % P.mp1, ii // P.mp1
+                    wd = P.det[e, ii] * Q[ii]
+                    ua = np.atleast_1d(exact[g.loc0[inds0[e, ii]]])
+                    un = P.interp(("0", "1g", "2g")[form], ex, ey, px, py, vl)[:ua.size]
+                    a1, r1 = np.abs(un - ua).sum(), np.abs(ua).sum()
+                    l1[0] += wd * a1; l1[1] += wd * r1
+                    l2[0] += wd * ((un - ua) ** 2).sum(); l2[1] += wd * (ua * ua).sum()
+                    if abs(wd * a1) > li[0]:
+                        li = [abs(wd * a1), abs(wd * r1)]
+        return [l1[0] / l1[1], np.sqrt(l2[0] / l2[1]), li[0] / li[1]]
+
     def init1(self, uq):
         return np.linalg.solve(self.M1, self.project(2, uq))             # :880-932
 

@@ -303,3 +303,25 @@ def test_opt_in_scatter_variants_agree_with_default(setup, env, monkeypatch):
     eng.apply("UMAT", eng.tensor(x1), lev0=0, scale=SCALE, flags=3, alpha=0.25, out=ya)      # accumulate
     alt.apply("UMAT", alt.tensor(x1), lev0=0, scale=SCALE, flags=3, alpha=0.25, out=yb)
     assert rel_l2(yb.cpu().numpy(), ya.cpu().numpy()) < 1e-13
+
+
+@pytest.mark.parametrize("kind,form,push", [("0", 0, True), ("1l", 1, False), ("1g", 1, True), ("2l", 2, False), ("2g", 2, True)])
+def test_interp_quad_matches_oracle_points(setup, kind, form, push):
+    """row A7: one launch gives what Geom::interp* (eul/Geom.cpp:328-417) gives point by point"""
+    eng, P, rng = setup
+    r = np.random.default_rng(31)
+    x = r.standard_normal((2, (P.n0, P.n1, P.n2)[form]))
+    got = eng.interp_quad(form, eng.tensor(x), push_forward=push).cpu().numpy()
+    mp1 = P.mp1 if hasattr(P, "mp1") else eng.mesh.m + 1
+    nex = P.nElsX
+    nc = 2 if form == 1 else 1
+    want = np.zeros((2, nex * nex, mp1 * mp1, nc))
+    for lev in range(2):
+        for ey in range(nex):
+            for ex in range(nex):
+                for q in range(mp1 * mp1):
+                    want[lev, ey * nex + ex, q] = P.interp(kind, ex, ey, q % mp1, q // mp1, x[lev])[:nc]
+    got = got.reshape(want.shape)
+    assert rel_l2(got, want) < 1e-13, kind
+    one = eng.interp_quad(form, eng.tensor(x[1]), push_forward=push).cpu().numpy().reshape(want.shape[1:])
+    assert np.array_equal(one, got[1])

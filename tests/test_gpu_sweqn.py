@@ -110,3 +110,25 @@ def test_sw_five_steps_track_the_oracle(sw):
         ur, hr = O.solve(ur, hr, 360.0, nits=2, q_exact=False)
         ud, hd = S.solve(ud, hd, 360.0, nits=2, q_exact=False)
         assert rel_l2(ud[0].cpu().numpy(), ur) < 1e-8 and rel_l2(hd[0].cpu().numpy(), hr) < 1e-9, step
+
+
+def test_sw_error_norms(sw):
+    """SWEqn::err0 / err1 / err2 (src/SWEqn_Picard.cpp:981-1200), the reference's own verification metric (Williamson2.cpp:138-151):
+    the initial state (Williamson-2 + perturbation) measured against the unperturbed analytic fields"""
+    import torch
+    cs, eng, O, S, uq, hq = sw
+    u0, h0 = O.init1(uq), O.init2(hq)
+    w0 = O.curl(u0)
+    th = np.arcsin(O.xq[:, 2] / 6371220.0)
+    U0, H0 = 38.61068276698372, 2998.1154702758267
+    ua = np.stack([U0 * np.cos(th), np.zeros_like(th)], axis=1)
+    ha = H0 - (6371220.0 * 7.292e-5 * U0 + 0.5 * U0 * U0) * np.sin(th) ** 2 / 9.80616
+    wa = 2.0 * U0 / 6371220.0 * np.sin(th)
+    gq = eng.mesh.gidq
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a[gq]), device=eng.device)
+    pairs = [(S.err0(_t(eng, w0), dev(wa)), O.err_norms(0, w0, wa)),
+             (S.err1(_t(eng, u0), dev(ua)), O.err_norms(1, u0, ua)),
+             (S.err2(_t(eng, h0), dev(ha)), O.err_norms(2, h0, ha, lat_cut=True))]
+    for got, want in pairs:
+        assert all(np.isfinite(want)) and want[1] > 1e-6          # the perturbation is visible
+        assert np.allclose(got, want, rtol=1e-10, atol=0), (got, want)
