@@ -107,6 +107,13 @@ public:
         check(mimsem_malloc(&p, (long long)(n*sizeof(double))), "mimsem_malloc");
         return (double*)p;
     }
+    // Geom::interp0 / interp1_l / interp1_g / interp2_l / interp2_g (eul/Geom.cpp:328-417) for EVERY quadrature point of the patch:
+    // x = device pointer to the local k-form array the reference passes (VecGetArray of the `*l` Vec); out [nEl][mp12] ([..][2] for 1-forms)
+    void interp0(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 0, 0, 1, x, 0, out, 0), "interp0"); }
+    void interp1_l(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 1, 0, 1, x, 0, out, 0), "interp1_l"); }
+    void interp1_g(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 1, MIMSEM_INTERP_GLOBAL, 1, x, 0, out, 0), "interp1_g"); }
+    void interp2_l(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 2, 0, 1, x, 0, out, 0), "interp2_l"); }
+    void interp2_g(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 2, MIMSEM_INTERP_GLOBAL, 1, x, 0, out, 0), "interp2_g"); }
     const Topo* topo; const Geom* geom; mimsem_ctx* ctx = nullptr;
     int nEl_ = 0, n2e = 0;
 };

@@ -91,6 +91,25 @@ int main() {
         std::printf("%-8s rel L2 = %.3e\n", "PtQmat", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
         mimsem_free(d_x0); mimsem_free(d_y1); mimsem_free(d_y2); mimsem_free(d_p); mimsem_free(d_xq);
     }
+    // ---- geom->interp1_g(ex, ey, px, py, array_1, un) / interp2_g at every point (src/SWEqn_Picard.cpp:1101, 1168) -------------
+    {
+        std::vector<double> g1((size_t)nEl*mp12*2), g2((size_t)nEl*mp12);
+        double *d_g1 = mesh.device_alloc(g1.size()), *d_g2 = mesh.device_alloc(g2.size());
+        mesh.interp1_g(d_u, d_g1); mesh.interp2_g(d_h, d_g2);
+        mesh.to_host(g1.data(), d_g1, g1.size()); mesh.to_host(g2.data(), d_g2, g2.size());
+        double num = 0, den = 0;
+        for (int e = 0; e < nEl; e++) for (int q = 0; q < mp12; q++) {
+            double un[2], hn[1];
+            orc_interp1_g(P, e%nels, e/nels, q%(n + 1), q/(n + 1), u.data(), un);
+            orc_interp2_g(P, e%nels, e/nels, q%(n + 1), q/(n + 1), h.data(), hn);
+            const double* a = &g1[((size_t)e*mp12 + q)*2];
+            num += (a[0] - un[0])*(a[0] - un[0])/(un[0]*un[0] + un[1]*un[1]) + (a[1] - un[1])*(a[1] - un[1])/(un[0]*un[0] + un[1]*un[1]);
+            num += (g2[(size_t)e*mp12 + q] - hn[0])*(g2[(size_t)e*mp12 + q] - hn[0])/(hn[0]*hn[0]);
+            den += 2.0;
+        }
+        std::printf("%-8s rel L2 = %.3e\n", "interp_g", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-12)) fails++;
+        mimsem_free(d_g1); mimsem_free(d_g2);
+    }
     // ---- L2Vecs, VertOps, VertSolve: the column path as eul/VertSolve.cpp drives it ---------------------------
     {
         const int n2e = P->n2e, N = nk*n2e;
