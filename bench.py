@@ -115,6 +115,47 @@ def column_extras(eng, dm, rng, torch):
     return res
 
 
+def sweep_extras(local_rank, torch):
+    """SURVEY 8(d) throughput sweep: applies/s of the operator families B1, B3, B4, B8, B9, B11 at the batch sizes of the BASELINE
+    configurations (384 / 1 536 / 3 456 / 103 680 element-level pairs) and ~1e6 pairs (the config 4 sphere with 290 levels),
+    with the HBM GB/s the algorithmic bytes of SURVEY 8(d) imply.  Wall clock over back-to-back launches, inputs resident."""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from tests.helpers import z_levels
+    fam_bytes = {"UMAT": 1440, "WMAT": 400, "UHMAT": 1512, "WTQUMAT": 1320, "ROTMAT": 1632, "WHMAT": 472}     # B1 B3 B4 B8 B9 B11
+    rng = np.random.default_rng(20241024)
+    res = {}
+    for ne, nk in ((8, 1), (16, 1), (24, 1), (24, 30), (24, 290)):
+        cs = CubedSphere(PN, ne, 6); coords = sphere_coords(PN, ne)
+        topos = [Topo(cs, p, nk) for p in range(6)]
+        geoms = [Geom(t, cs, coords, nk) for t in topos]
+        for g in geoms:
+            g.set_levels(z_levels(nk, g.n0))
+        dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+        eng = Engine(dm, device=local_rank)
+        units = dm.nEl * nk
+        x1 = eng.tensor(rng.standard_normal((nk, dm.n1))); x2 = eng.tensor(rng.standard_normal((nk, dm.n2)))
+        h = eng.tensor(rng.uniform(1, 2, (nk, dm.n2)) * 1e3); q0 = eng.tensor(rng.standard_normal((nk, dm.n0)) * 1e-4)
+        y1, y2 = eng.zeros(nk, dm.n1), eng.zeros(nk, dm.n2)
+        row = {}
+        for op, xin, f, fl, out in (("UMAT", x1, None, 1, y1), ("WMAT", x2, None, 1, y2), ("UHMAT", x1, h, 1, y1),
+                                    ("WTQUMAT", x1, x1, 0, y2), ("ROTMAT", x1, q0, 0, y1), ("WHMAT", x2, h, 1, y2)):
+            reps = 200 if units < 500000 else 30
+            for _ in range(5):
+                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl, out=out)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl, out=out)
+            torch.cuda.synchronize(); el = (time.perf_counter() - t1) / reps
+            row[op] = {"applies_per_s": units / el, "us_per_apply_call": el * 1e6, "GBs_algorithmic": units * fam_bytes[op] / el / 1e9}
+        res["%dx%dx6_x%d_levels_%d_units" % (ne, ne, nk, units)] = row
+        del eng, x1, x2, h, q0, y1, y2
+        torch.cuda.empty_cache()
+    return res
+
+
 def sw_extras(local_rank, torch):
     """SW time steps/s (the second half of BASELINE's metric): SWEqn::solve as the reference drivers call it, on the
     config 2 (16x16x6, Williamson-2: q from the mean state, iterate to 1e-14) and config 3 (24x24x6, Galewsky: 2 Picard
@@ -171,6 +212,7 @@ def main():
     ap.add_argument("--pcie", action="store_true", help="extra: the same step with the input copied host->device and the result device->host "
                                                         "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
     ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
+    ap.add_argument("--sweep", action="store_true", help="extra: SURVEY 8(d) batch-size sweep of six operator families (384 ... 1e6 element-level pairs)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
@@ -379,6 +421,8 @@ def main():
                             "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
     if a.sw and rank == 0 and world == 1:
         out["sw"] = sw_extras(local_rank, torch)
+    if a.sweep and rank == 0 and world == 1:
+        out["sweep"] = sweep_extras(local_rank, torch)
     if a.cold and rank == 0 and world == 1:
         R = a.cold
         dmc = replicate(dm, R)
