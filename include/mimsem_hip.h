@@ -197,6 +197,23 @@ int mimsem_incidence_apply(mimsem_ctx* ctx, int which, int nlev,
 int mimsem_interp_quad(mimsem_ctx* ctx, int form, unsigned flags, int nlev,
                        const double* x, long long x_stride, double* out, long long out_stride);
 
+/* Row N3: the packed [u,h] operator of the shallow-water Picard step, SWEqn::assemble_operator (src/SWEqn_Picard.cpp:622-725),
+ * which the reference forms with MatMatMult / MatGetRow / MatSetValues and hands to KSPSolve(kspA):
+ *     y_u = (M1 + a R(f)) u + a g E12 M2 h        y_h = M2 (a H E21 u + h)        a = ROS_ALPHA dt, g = grav, H = H_MEAN
+ * applied matrix-free in ONE element pass plus the 1-form gather (all four blocks are element-local up to that gather).
+ * x, y: rows of packed vectors [u (n1 slots) | h (n2 slots)]; f0: the Coriolis 0-form (SWEqn::fg), one row per level row
+ * (f0_stride = 0 broadcasts one row).  Unit `scale`, thickness of geometry level 0 (the src/ flavour has neither). */
+int mimsem_sw_operator_apply(mimsem_ctx* ctx, int nlev, double a, double grav, double H,
+                             const double* f0, long long f0_stride,
+                             const double* x, long long x_stride, double* y, long long y_stride);
+
+/* Element-block preconditioner on packed [u | h] vectors (a PCSHELL for kspA, src/SWEqn_Picard.cpp:635-640; the reference uses
+ * PETSc's default block-Jacobi/ILU(0) on the assembled A):  z = sum_e R_e^T B_e R_e r,  R_e = the element's 2 n1e edge slots
+ * followed by its n2e face slots.  blocks: [nEl][ND][ND] with ND = 2 n1e + n2e, COLUMN-major per element (entry (r,c) at
+ * [c*ND + r]).  Orders 1..4 (ND <= 64); higher orders return MIMSEM_ERR_UNSUPPORTED.  x != y. */
+int mimsem_sw_blocks_apply(mimsem_ctx* ctx, int nlev, const double* blocks,
+                           const double* x, long long x_stride, double* y, long long y_stride);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,
@@ -285,6 +302,12 @@ int mimsem_column_solve_schur_3(mimsem_ctx* ctx, double dt, unsigned flags,
  * reduction).  maxpy: w += alpha * sum_i h[i] V_i.  Together: one classical Gram-Schmidt pass.                                   */
 int mimsem_krylov_mdot(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* w, double* h);
 int mimsem_krylov_maxpy(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, const double* h, double alpha, double* w);
+/* One classical Gram-Schmidt pass of the GMRES Arnoldi step in two launches: h = V w, then w += alpha V^T h (alpha = -1) */
+int mimsem_krylov_orthogonalize(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double alpha, double* w, double* h);
+/* End of the Arnoldi step: v = w/|w|, col[0..k) = h1 + h2 (h2 may be NULL), col[norm_slot] = |w|.  col may be pinned host
+ * memory (hipHostMalloc): the Hessenberg column then reaches the host without a copy of its own. */
+int mimsem_krylov_normalize(mimsem_ctx* ctx, long long n, const double* w, double* v, int k, const double* h1, const double* h2,
+                            double* col, int norm_slot);
 /* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in
  * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
  * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */

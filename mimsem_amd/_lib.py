@@ -53,6 +53,8 @@ _SIGS = {
     "mimsem_pvec": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_incidence_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_interp_quad": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_sw_operator_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_sw_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_colop_nblocks": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_colop_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, c_dp, c_dp, c_dp]),
@@ -67,6 +69,8 @@ _SIGS = {
     "mimsem_column_diag_theta_up": (C.c_int, [C.c_void_p, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),
     "mimsem_column_temp_forcing_hs": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mimsem_column_solve_schur_3": (C.c_int, [C.c_void_p, C.c_double, C.c_uint] + [c_dp]*14),
+    "mimsem_krylov_orthogonalize": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, C.c_double, c_dp, c_dp]),
+    "mimsem_krylov_normalize": (C.c_int, [C.c_void_p, c_ll, c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, C.c_int]),
     "mimsem_krylov_mdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp]),
     "mimsem_krylov_maxpy": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, C.c_double, c_dp]),
     "mimsem_krylov_rowdot": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp]),

@@ -544,6 +544,25 @@ int mimsem_interp_quad(mimsem_ctx* c, int form, unsigned flags, int nlev, const 
     return launch_interp_quad(c, form, (flags & MIMSEM_INTERP_GLOBAL) ? 1 : 0, nlev, x, xs, out, os);
 }
 
+int mimsem_sw_operator_apply(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                             const double* x, long long xs, double* y, long long ys) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!f0 || !x || !y || x == y) return MIMSEM_ERR_ARG;
+    const long long n = (long long)c->n1 + c->n2;
+    if (nlev > 1 && (xs < n || ys < n)) return MIMSEM_ERR_ARG;
+    return launch_sw_operator(c, nlev, a, grav, H, f0, f0s, x, xs, y, ys);
+}
+
+int mimsem_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* blocks, const double* x, long long xs, double* y, long long ys) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!blocks || !x || !y || x == y) return MIMSEM_ERR_ARG;
+    const long long n = (long long)c->n1 + c->n2;
+    if (nlev > 1 && (xs < n || ys < n)) return MIMSEM_ERR_ARG;
+    return launch_sw_blocks_apply(c, nlev, blocks, x, xs, y, ys);
+}
+
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
     if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null

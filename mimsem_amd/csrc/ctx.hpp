@@ -128,6 +128,9 @@ int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, 
                   const double* f2 = nullptr, double param = 0.0);
 int launch_incidence(mimsem_ctx* c, int which, int nlev, const double* x, long long xs, double* y, long long ys);
 int launch_interp_quad(mimsem_ctx* c, int form, int global, int nlev, const double* x, long long xs, double* out, long long os);
+int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                       const double* x, long long xs, double* y, long long ys);
+int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys);
 int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf);
 int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);
 

@@ -836,6 +836,143 @@ __global__ __launch_bounds__(256) void k_interp_quad(int form, int global, int n
     }
 }
 
+// ---- the packed [u,h] operator of the shallow-water Picard step (SWEqn::assemble_operator, src/SWEqn_Picard.cpp:622-725) --------
+//   y_u = (M1 + a R(f)) u + a g E12 M2 h          y_h = M2 (a H E21 u + h)
+// The reference forms A with MatMatMult / MatGetRow / MatSetValues and applies it inside KSPSolve.  Every term is element-local
+// up to the 1-form gather (M2, E21 and E12 M2 never leave the element), so ONE element pass evaluates all four blocks: the
+// Krylov iteration that dominates the time step issues 2 launches for A instead of 14.  Work item = (level row, element).
+template <int N>
+__global__ __launch_bounds__(256) void k_sw_operator(int nEl, int nlev, double a, double ag, double aH,
+        const int* __restrict__ i0, const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2,
+        const double* __restrict__ J, const double* __restrict__ det, const double* __restrict__ tI,
+        const double* __restrict__ E, const double* __restrict__ w,
+        const double* __restrict__ f0, long long f0s, const double* __restrict__ u, long long us,
+        const double* __restrict__ h, long long hs, double* __restrict__ ye, long long yes, double* __restrict__ yh, long long yhs) {
+    using D = Dims<N>;
+    constexpr int LPE = D::LPE, EPB = D::EPB;
+    __shared__ double sE[D::mp1*N];
+    __shared__ double s_u[EPB][2*LPE], s_h[EPB][LPE], s_w[EPB][LPE], s_m[EPB][LPE];
+    __shared__ double s_a[EPB][LPE], s_b[EPB][LPE], s_c[EPB][LPE], s_d[EPB][LPE];
+    const int tid = threadIdx.x, el = tid/LPE, q = tid%LPE;
+    if (tid < D::mp1*N) sE[tid] = E[tid];
+    const long long eg = (long long)blockIdx.x*EPB + el;
+    const bool act = eg < (long long)nEl*nlev;
+    const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
+    const int qx = q%D::mp1, qy = q/D::mp1;
+    const bool qact = act && q < D::mp12;
+    int hslot = -1;
+    if (act) {
+        const double* uv = u + (size_t)lev*us;
+        if (q < D::n1e) { s_u[el][q] = uv[i1x[e*D::n1e + q]]; s_u[el][D::n1e + q] = uv[i1y[e*D::n1e + q]]; }
+        if (q < D::n2e) { hslot = i2 ? i2[e*D::n2e + q] : e*D::n2e + q; s_h[el][q] = h[(size_t)lev*hs + hslot]; }
+    }
+    __syncthreads();                 // sE for every wave; the element's own staging needs only the wave-level order
+
+    QPoint g;
+    g.J00 = g.J01 = g.J10 = g.J11 = 0.0; g.det = 1.0; g.Q = 0.0; g.tI = 1.0; g.th0 = g.th1 = 1.0; g.tI0 = 1.0; g.param = 0.0;
+    if (qact) {
+        const double* Je = J + (size_t)e*4*D::mp12;
+        g.J00 = Je[0*D::mp12 + q]; g.J01 = Je[1*D::mp12 + q]; g.J10 = Je[2*D::mp12 + q]; g.J11 = Je[3*D::mp12 + q];
+        g.det = det[(size_t)e*D::mp12 + q];
+        g.tI = tI[(size_t)e*D::mp12 + q];                               // level 0 of the (unit-thickness) src/ flavour
+        g.Q = w[qx]*w[qy];
+        double uu, vv, hq, dmy, a1, b1, a2, b2, c, z;
+        interp_point<N, S1>(s_u[el], sE, q, qx, qy, uu, vv);
+        qpoint_op<MIMSEM_OP_UMAT>(g, 1.0, 0u, uu, vv, 0.0, 0.0, a1, b1);
+        qpoint_op<MIMSEM_OP_ROTMAT>(g, 1.0, 0u, uu, vv, f0[(size_t)lev*f0s + i0[e*D::n0e + q]], 0.0, a2, b2);
+        s_a[el][q] = a1 + a*a2; s_b[el][q] = b1 + a*b2;
+        interp_point<N, S2>(s_h[el], sE, q, qx, qy, hq, dmy);
+        qpoint_op<MIMSEM_OP_WMAT>(g, 1.0, 0u, hq, 0.0, 0.0, 0.0, c, z);
+        s_c[el][q] = c;
+    }
+    if (act && q < D::n2e) {         // a H (E21 u) + h on this element's faces (E21mat :1170-1220 restricted to one element)
+        const int jj = q%N, ii = q/N;
+        const double d21 = -s_u[el][ii*D::np1 + jj] + s_u[el][ii*D::np1 + jj + 1]
+                           - s_u[el][D::n1e + ii*N + jj] + s_u[el][D::n1e + (ii + 1)*N + jj];
+        s_w[el][q] = aH*d21 + s_h[el][q];
+    }
+    wave_lds_sync();
+    if (act && q < D::n2e) {         // M2 h, element-local
+        const int ix = q%N, iy = q/N;
+        double m = 0.0;
+#pragma unroll
+        for (int ky = 0; ky < D::mp1; ky++)
+#pragma unroll
+            for (int kx = 0; kx < D::mp1; kx++)
+                m += (sE[kx*N + ix]*sE[ky*N + iy])*s_c[el][ky*D::mp1 + kx];
+        s_m[el][q] = m;
+    }
+    if (qact) {
+        double wq, dmy, c, z;
+        interp_point<N, S2>(s_w[el], sE, q, qx, qy, wq, dmy);
+        qpoint_op<MIMSEM_OP_WMAT>(g, 1.0, 0u, wq, 0.0, 0.0, 0.0, c, z);
+        s_d[el][q] = c;
+    }
+    wave_lds_sync();
+    if (act && q < D::n1e) {
+        double yx = 0.0, yy = 0.0;
+        const int ixx = q%D::np1, iyx = q/D::np1;     // x-normal edge: node in x, edge fn in y
+        const int ixy = q%N,      iyy = q/N;          // y-normal edge: edge fn in x, node in y
+#pragma unroll
+        for (int k = 0; k < D::mp1; k++) {
+            yx += sE[k*N + iyx]*s_a[el][k*D::mp1 + ixx];
+            yy += sE[k*N + ixy]*s_b[el][iyy*D::mp1 + k];
+        }
+        // E12 = -E21^T of the element's own faces (k_incidence, which == 2)
+        double sx = 0.0, sy = 0.0;
+        if (ixx < N) sx += s_m[el][iyx*N + ixx];
+        if (ixx > 0) sx -= s_m[el][iyx*N + ixx - 1];
+        if (iyy < N) sy += s_m[el][iyy*N + ixy];
+        if (iyy > 0) sy -= s_m[el][(iyy - 1)*N + ixy];
+        double* o = ye + (size_t)lev*yes + (size_t)e*2*D::n1e;
+        o[q] = yx + ag*sx; o[D::n1e + q] = yy + ag*sy;
+    }
+    if (act && q < D::n2e) {
+        const int ix = q%N, iy = q/N;
+        double y2 = 0.0;
+#pragma unroll
+        for (int ky = 0; ky < D::mp1; ky++)
+#pragma unroll
+            for (int kx = 0; kx < D::mp1; kx++)
+                y2 += (sE[kx*N + ix]*sE[ky*N + iy])*s_d[el][ky*D::mp1 + kx];
+        yh[(size_t)lev*yhs + hslot] = y2;
+    }
+}
+
+// ---- element blocks on packed [u | h] vectors: the preconditioner of the shallow-water operator above --------------------
+// z = sum_e R_e^T B_e R_e r with R_e = the element's 2 n1e edge slots followed by its n2e face slots (ND rows).  B_e is stored
+// COLUMN-major ([c][r]) so that the lanes of an element read consecutive addresses.  Edge rows go to the element-local buffer
+// (summed by k_gather_sum), face rows straight to the result.  Work item = (level row, element), one lane per block row.
+template <int N>
+__global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long long n1,
+        const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2, const double* __restrict__ B,
+        const double* __restrict__ x, long long xs, double* __restrict__ ye, long long yes, double* __restrict__ y, long long ys) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e + D::n2e;
+    constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    static_assert(ND <= 64, "one wavefront per element");
+    __shared__ double s_x[EPB][LPE];
+    const int tid = threadIdx.x, el = tid/LPE, r = tid%LPE;
+    const long long eg = (long long)blockIdx.x*EPB + el;
+    const bool act = eg < (long long)nEl*nlev && r < ND;
+    const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
+    long long slot = 0;
+    if (act) {
+        if (r < D::n1e) slot = i1x[e*D::n1e + r];
+        else if (r < 2*D::n1e) slot = i1y[e*D::n1e + r - D::n1e];
+        else slot = n1 + (i2 ? i2[e*D::n2e + r - 2*D::n1e] : e*D::n2e + r - 2*D::n1e);
+        s_x[el][r] = x[(size_t)lev*xs + slot];
+    }
+    wave_lds_sync();
+    if (!act) return;
+    const double* Be = B + (size_t)e*ND*ND + r;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < ND; c++) s += Be[(size_t)c*ND]*s_x[el][c];
+    if (r < 2*D::n1e) ye[(size_t)lev*yes + (size_t)e*2*D::n1e + r] = s;
+    else y[(size_t)lev*ys + slot] = s;
+}
+
 __global__ __launch_bounds__(256) void k_halo_pack(const int* __restrict__ idx, int count, int nlev,
                                                    const double* __restrict__ v, long long vs, double* __restrict__ buf) {
     const long long t = (long long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -1265,6 +1402,73 @@ int launch_interp_quad(mimsem_ctx* c, int form, int global, int nlev, const doub
     case 7: return interp_quad_n<7>(c, form, global, nlev, x, xs, out, os);
     default: return MIMSEM_ERR_UNSUPPORTED;
     }
+}
+
+template <int N>
+static int sw_operator_n(mimsem_ctx* c, int nlev, double a, double ag, double aH, const double* f0, long long f0s,
+                         const double* u, long long us, const double* h, long long hs, double* ye, long long yes, double* yh, long long yhs) {
+    using D = Dims<N>;
+    const long long total = (long long)c->nEl*nlev;
+    const unsigned grid = (unsigned)((total + D::EPB - 1)/D::EPB);
+    hipLaunchKernelGGL((k_sw_operator<N>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, a, ag, aH,
+                       c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_J, c->d_det, c->d_tI, c->d_E, c->d_w,
+                       f0, f0s, u, us, h, hs, ye, yes, yh, yhs);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                       const double* x, long long xs, double* y, long long ys) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    const long long per = (long long)c->nEl*2*es.n1e;
+    int rc = c->ensure_ye(per*nlev);
+    if (rc) return rc;
+    const double* u = x; const double* h = x + c->n1;
+    double* yh = y + c->n1;
+    const double ag = a*grav, aH = a*H;
+    switch (es.n) {
+    case 1: rc = sw_operator_n<1>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 2: rc = sw_operator_n<2>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 3: rc = sw_operator_n<3>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 4: rc = sw_operator_n<4>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 5: rc = sw_operator_n<5>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 6: rc = sw_operator_n<6>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    case 7: rc = sw_operator_n<7>(c, nlev, a, ag, aH, f0, f0s, u, xs, h, xs, c->d_ye, per, yh, ys); break;
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    return launch_gather_sum(c, 1, nlev, c->d_ye, per, 0, y, ys);
+}
+
+template <int N>
+static int sw_blocks_n(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* ye, long long yes, double* y, long long ys) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e + D::n2e;
+    constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    const long long total = (long long)c->nEl*nlev;
+    const unsigned grid = (unsigned)((total + EPB - 1)/EPB);
+    hipLaunchKernelGGL((k_sw_blocks_apply<N>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, (long long)c->n1,
+                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    const long long per = (long long)c->nEl*2*es.n1e;
+    int rc = c->ensure_ye(per*nlev);
+    if (rc) return rc;
+    switch (es.n) {
+    case 1: rc = sw_blocks_n<1>(c, nlev, B, x, xs, c->d_ye, per, y, ys); break;
+    case 2: rc = sw_blocks_n<2>(c, nlev, B, x, xs, c->d_ye, per, y, ys); break;
+    case 3: rc = sw_blocks_n<3>(c, nlev, B, x, xs, c->d_ye, per, y, ys); break;
+    case 4: rc = sw_blocks_n<4>(c, nlev, B, x, xs, c->d_ye, per, y, ys); break;
+    default: return MIMSEM_ERR_UNSUPPORTED;          // 2 n1e + n2e > 64 rows: more than one wavefront per element
+    }
+    if (rc) return rc;
+    return launch_gather_sum(c, 1, nlev, c->d_ye, per, 0, y, ys);
 }
 
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,

@@ -25,6 +25,50 @@ __global__ __launch_bounds__(256) void k_maxpy(int k, long long n, const double*
     w[t] += alpha*s;
 }
 
+// One classical Gram-Schmidt pass in two launches: the partial sums of h = V w (k_rowdot_partial with w broadcast) are reduced
+// by EVERY block of the update kernel (4 lanes per basis vector, fixed order: bitwise reproducible) instead of by a launch of
+// their own; block 0 also stores h for the Hessenberg column.
+__global__ __launch_bounds__(256) void k_maxpy_reduce(int k, int nb, long long n, const double* __restrict__ V, long long ldv,
+                                                      const double* __restrict__ part, double alpha, double* __restrict__ w,
+                                                      double* __restrict__ h_out) {
+    extern __shared__ double sh[];
+    for (int base = 0; base < k; base += 64) {
+        const int i = base + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        double s = 0.0;
+        if (i < k) for (int b = sub; b < nb; b += 4) s += part[(size_t)i*nb + b];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (i < k && sub == 0) { sh[i] = s; if (blockIdx.x == 0) h_out[i] = s; }
+    }
+    __syncthreads();
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (int i = 0; i < k; i++) s += sh[i]*V[(size_t)i*ldv + t];
+    w[t] += alpha*s;
+}
+
+// v = w / |w| from the partial sums of w.w; block 0 also writes the finished Hessenberg column (h1 + h2, |w|) -- `col` may be
+// pinned host memory (one store per entry, no separate copy node in the captured graph).
+__global__ __launch_bounds__(256) void k_normalize(int nb, long long n, const double* __restrict__ part, const double* __restrict__ w,
+                                                   double* __restrict__ v, int k, const double* __restrict__ h1,
+                                                   const double* __restrict__ h2, double* __restrict__ col, int norm_slot) {
+    __shared__ double s_nrm;
+    if (threadIdx.x < 64) {
+        double s = (threadIdx.x < nb) ? part[threadIdx.x] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (threadIdx.x == 0) s_nrm = sqrt(s);
+    }
+    __syncthreads();
+    const double nrm = s_nrm;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < k; i += 256) col[i] = h1[i] + (h2 ? h2[i] : 0.0);
+        if (threadIdx.x == 0) col[norm_slot] = nrm;
+    }
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t < n) v[t] = w[t]/nrm;
+}
+
 // ---- batched (one system per row / level) CG vector kernels: per-row scalars stay in device memory -----------------
 constexpr int RD_BLOCKS = 32;       // partial sums per row
 __global__ __launch_bounds__(256) void k_rowdot_partial(long long n, long long chunk, const double* __restrict__ A, long long lda,
@@ -112,6 +156,41 @@ int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A,
 int mimsem_krylov_mdot(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, const double* w, double* h) {
     if (!c || !V || !w || !h || k < 0 || n < 0 || ldv < n) return MIMSEM_ERR_ARG;
     return mimsem_krylov_rowdot(c, k, n, V, ldv, w, 0, h);
+}
+
+static int rowdot_partials(mimsem_ctx* c, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, int* nb_out) {
+    const int nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+    const long long chunk = (n + nb - 1)/nb;
+    int rc = c->ensure_kry((long long)nb*nrows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rowdot_partial, dim3(nb, nrows), dim3(256), 0, c->stream, n, chunk, A, lda, B, ldb, c->d_kry);
+    *nb_out = nb;
+    return MIMSEM_OK;
+}
+
+// h = V w ; w += alpha V^T h  (one classical Gram-Schmidt pass, two launches)
+int mimsem_krylov_orthogonalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double alpha, double* w, double* h) {
+    if (!c || !V || !w || !h || k < 0 || n < 0 || ldv < n) return MIMSEM_ERR_ARG;
+    if (k == 0 || n == 0) return MIMSEM_OK;
+    int nb = 0;
+    int rc = rowdot_partials(c, k, n, V, ldv, w, 0, &nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_maxpy_reduce, dim3((unsigned)((n + 255)/256)), dim3(256), (size_t)k*sizeof(double), c->stream,
+                       k, nb, n, V, ldv, c->d_kry, alpha, w, h);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+// v = w/|w| ; col[0..k) = h1 + h2 (h2 may be null) ; col[norm_slot] = |w|   (two launches; col: device or pinned host memory)
+int mimsem_krylov_normalize(mimsem_ctx* c, long long n, const double* w, double* v, int k, const double* h1, const double* h2,
+                            double* col, int norm_slot) {
+    if (!c || !w || !v || !col || k < 0 || n <= 0 || norm_slot < 0 || (k > 0 && !h1)) return MIMSEM_ERR_ARG;
+    int nb = 0;
+    int rc = rowdot_partials(c, 1, n, w, n, w, n, &nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_normalize, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, nb, n, c->d_kry, w, v, k, h1, h2, col, norm_slot);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
 }
 
 int mimsem_krylov_maxpy(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, const double* h, double alpha, double* w) {

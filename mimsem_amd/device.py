@@ -294,6 +294,29 @@ class Engine:
         out = out.view(x2.shape[0], self.nEl, self.mp12, 2) if form == 1 else out.view(x2.shape[0], self.nEl, self.mp12)
         return out if x.dim() == 2 else out[0]
 
+    def sw_operator(self, a, grav, H, f0, x, out=None):
+        """SWEqn::assemble_operator + MatMult (src/SWEqn_Picard.cpp:622-725) in one element pass: x, y packed rows [u | h]"""
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        assert x2.shape[1] == self.sizes[1] + self.sizes[2] and x2.stride(1) == 1, x2.shape
+        f2 = f0 if f0.dim() == 2 else f0.unsqueeze(0)
+        assert f2.shape[1] == self.sizes[0] and f2.shape[0] in (1, x2.shape[0])
+        y = out if out is not None else torch.empty(x2.shape[0], x2.shape[1], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        check(self.L.mimsem_sw_operator_apply(self.ctx, x2.shape[0], a, grav, H, f2.data_ptr(), 0 if f2.shape[0] == 1 else f2.stride(0),
+                                              x2.data_ptr(), x2.stride(0), y2.data_ptr(), y2.stride(0)), "sw_operator")
+        return y if (x.dim() == 2 or out is not None) else y[0]
+
+    def sw_blocks_apply(self, blocks, x, out=None):
+        """z = sum_e R_e^T B_e R_e x on packed rows [u | h]; blocks [nEl, ND, ND] stored column-major per element (mimsem_sw_blocks_apply)"""
+        nd = 2 * self.n1e + self.n2e
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        assert x2.shape[1] == self.sizes[1] + self.sizes[2] and x2.stride(1) == 1 and blocks.shape == (self.nEl, nd, nd)
+        y = out if out is not None else torch.empty(x2.shape[0], x2.shape[1], dtype=torch.float64, device=self.device)
+        y2 = y if y.dim() == 2 else y.unsqueeze(0)
+        check(self.L.mimsem_sw_blocks_apply(self.ctx, x2.shape[0], _ptr(blocks), x2.data_ptr(), x2.stride(0), y2.data_ptr(), y2.stride(0)),
+              "sw_blocks_apply")
+        return y if (x.dim() == 2 or out is not None) else y[0]
+
     # ---- column operators -------------------------------------------------------------------
     def l2_horiz_to_vert(self, vh):
         nkv = vh.shape[0]
@@ -401,6 +424,21 @@ class Engine:
         k = V.shape[0] if k is None else k
         check(self.L.mimsem_krylov_maxpy(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(h), alpha, _ptr(w)), "krylov_maxpy")
         return w
+
+    def orthogonalize(self, V, w, h, k=None, alpha=-1.0):
+        """one classical Gram-Schmidt pass in two launches: h[:k] = V[:k] w, then w += alpha V[:k]^T h (in place)"""
+        k = V.shape[0] if k is None else k
+        check(self.L.mimsem_krylov_orthogonalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), alpha, _ptr(w), _ptr(h)), "krylov_orthogonalize")
+        return w
+
+    def normalize(self, w, v, k, h1, h2, col, norm_slot):
+        """v = w/|w|; col[:k] = h1 + h2; col[norm_slot] = |w|.  col: device tensor or PINNED host tensor (written by the kernel)"""
+        assert w.numel() == v.numel() and v.is_contiguous() and col.dtype == torch.float64 and col.is_contiguous()
+        assert col.is_cuda or col.is_pinned(), "col must be device or pinned host memory"
+        assert col.numel() > max(k - 1, norm_slot)
+        check(self.L.mimsem_krylov_normalize(self.ctx, w.numel(), _ptr(w), _ptr(v), k, _ptr(h1), _ptr(h2) if h2 is not None else None,
+                                             col.data_ptr(), norm_slot), "krylov_normalize")
+        return v
 
     def rowdot(self, A, B, out=None):
         """out[i] = <A[i], B[i]> for [nrows, n] tensors (rows contiguous)"""

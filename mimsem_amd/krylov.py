@@ -5,6 +5,9 @@ SURVEY 8(f) row N1 -- the first "next" row after the operator engine.
 The mass matrices are symmetric positive definite, so a preconditioned CG converges to the same (unique) solution
 the reference's GMRES does; all levels are solved at once (one independent system per level, per-level scalars kept
 on the device: no host synchronisation inside the iteration).  Mat-vecs are the matrix-free engine applies."""
+import math
+import os
+
 import torch
 
 
@@ -259,23 +262,19 @@ class GraphedGMRES:
         self.h = torch.zeros(restart + 1, dtype=dtype, device=dev)
         self.h2 = torch.zeros(restart + 1, dtype=dtype, device=dev)
         self.col = torch.zeros(restart + 2, dtype=dtype, device=dev)
-        self.col_host = torch.zeros(restart + 2, dtype=dtype).pin_memory()
+        self.col_host = torch.zeros(restart, restart + 2, dtype=dtype).pin_memory()     # row j: Hessenberg column of step j
         self.graphs = [None] * restart
         self.pool = None
+        self.lookahead = int(os.environ.get("MIMSEM_GMRES_LOOKAHEAD", "8"))
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1
         w = self.body(V[j:j + 1]).reshape(-1)
         if not w.is_contiguous():
             w = w.contiguous()
-        eng.mdot(V, w, k=k, out=self.h); eng.maxpy(V, self.h, w, alpha=-1.0, k=k)
-        eng.mdot(V, w, k=k, out=self.h2); eng.maxpy(V, self.h2, w, alpha=-1.0, k=k)      # re-orthogonalisation
-        hn2 = self.col[self.m + 1:self.m + 2]
-        eng.mdot(w.view(1, -1), w, k=1, out=hn2)
-        hn2.sqrt_()
-        torch.div(w, hn2, out=V[j + 1])
-        torch.add(self.h[:k], self.h2[:k], out=self.col[:k])
-        self.col_host.copy_(self.col, non_blocking=True)
+        eng.orthogonalize(V, w, self.h, k=k)
+        eng.orthogonalize(V, w, self.h2, k=k)                                            # re-orthogonalisation
+        eng.normalize(w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1)      # Hessenberg column straight to pinned memory
 
     def _graph(self, j):
         if self.graphs[j] is None:
@@ -321,25 +320,40 @@ class GraphedGMRES:
             cs, sn, g = [0.0] * m, [0.0] * m, [0.0] * (m + 1)
             g[0] = beta
             k = 0
-            for j in range(m):
-                self._graph(j).replay()
+            j0, done = 0, False
+            hist = [beta]
+            while j0 < m and not done:
+                # Arnoldi steps j0 .. j0+s-1 are queued back to back and the host looks at their Hessenberg columns afterwards:
+                # the device never waits for the host's Givens rotations.  s follows the observed convergence rate so that at
+                # most about one step is computed beyond the one that meets the tolerance (its column is then ignored).
+                s = 1
+                if self.lookahead > 1 and len(hist) >= 3 and 0.0 < hist[-1] < hist[-3]:
+                    rate = (hist[-1] / hist[-3]) ** 0.5
+                    s = int(math.log(max(tol, 1e-300) / hist[-1]) / math.log(rate)) if hist[-1] > tol else 1
+                s = max(1, min(s, self.lookahead, m - j0, maxit - its))
+                for j in range(j0, j0 + s):
+                    self._graph(j).replay()
                 torch.cuda.current_stream(dev).synchronize()
-                col = self.col_host.tolist()
-                for i in range(j + 1):
-                    H[i][j] = col[i]
-                H[j + 1][j] = col[m + 1]
-                for i in range(j):
-                    t = cs[i] * H[i][j] + sn[i] * H[i + 1][j]
-                    H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j]
-                    H[i][j] = t
-                d = (H[j][j] ** 2 + H[j + 1][j] ** 2) ** 0.5
-                cs[j], sn[j] = (1.0, 0.0) if d == 0.0 else (H[j][j] / d, H[j + 1][j] / d)
-                H[j][j] = d; H[j + 1][j] = 0.0
-                g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j]
-                its += 1; k = j + 1
-                res = abs(g[j + 1])
-                if res <= tol or its >= maxit or col[m + 1] == 0.0:
-                    break
+                for j in range(j0, j0 + s):
+                    col = self.col_host[j].tolist()
+                    for i in range(j + 1):
+                        H[i][j] = col[i]
+                    H[j + 1][j] = col[m + 1]
+                    for i in range(j):
+                        t = cs[i] * H[i][j] + sn[i] * H[i + 1][j]
+                        H[i + 1][j] = -sn[i] * H[i][j] + cs[i] * H[i + 1][j]
+                        H[i][j] = t
+                    d = (H[j][j] ** 2 + H[j + 1][j] ** 2) ** 0.5
+                    cs[j], sn[j] = (1.0, 0.0) if d == 0.0 else (H[j][j] / d, H[j + 1][j] / d)
+                    H[j][j] = d; H[j + 1][j] = 0.0
+                    g[j + 1] = -sn[j] * g[j]; g[j] = cs[j] * g[j]
+                    its += 1; k = j + 1
+                    res = abs(g[j + 1])
+                    hist.append(res)
+                    if res <= tol or its >= maxit or col[m + 1] == 0.0:
+                        done = True
+                        break
+                j0 += s
             y = [0.0] * k
             for i in range(k - 1, -1, -1):
                 sacc = g[i] - sum(H[i][l] * y[l] for l in range(i + 1, k))

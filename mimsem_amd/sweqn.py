@@ -5,6 +5,7 @@ packed [u,h] operator A) is applied matrix-free through the C-ABI engine; the KS
 src/ flavour: no SCALE, no layer thickness (the engine runs with nk = 1 and unit thickness), signed Jacobian determinant.
 Single GPU, global numbering: the reference's local (`*l`) and global vectors coincide, so its VecScatters are identities."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,8 @@ class SWEqn:
         self.its = {}
         self.graphs = use_graphs and not hasattr(eng, "halo")       # the hipGraph Arnoldi step is single-rank (no collectives inside)
         self._gA = None
+        self._pcA = None
+        self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
     def M1(self, u): return self.eng.apply("UMAT", u)
@@ -142,7 +145,16 @@ class SWEqn:
         return self.pack(mu + dt * fu, mh + dt * fh)
 
     def apply_A(self, x, dt):
-        """:609-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]]"""
+        """:622-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]] -- one fused element pass
+        (mimsem_sw_operator_apply) + the 1-form gather; sharded: local partial sums, then one halo reduction"""
+        eng, n1 = self.eng, self.n1
+        loc = getattr(eng, "eng", eng)
+        y = loc.sw_operator(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, x)
+        eng.complete(1, y[:, :n1])
+        return y
+
+    def apply_A_composed(self, x, dt):
+        """the same operator from the individual engine operators (the parity check of the fused kernel)"""
         eng, n1 = self.eng, self.n1
         loc = getattr(eng, "eng", eng)                             # sharded: add the LOCAL partial sums first, reduce the halo once
         u, h = x[:, :n1], x[:, n1:]                                # views of the packed vector (one row => contiguous)
@@ -159,9 +171,52 @@ class SWEqn:
         eng.apply("WMAT", w, out=yh)                                                      # M2 (a H E21 u + h)
         return y
 
-    def precond_A(self, r):
-        """block diagonal: the element-block preconditioner on M1, the exact element-wise inverse on M2 (WmatInv)"""
+    def _coupled_element_blocks(self, dt):
+        """Element blocks of A itself, inverted: A_e = [[M1_e + a R_e(f), a g E12_e M2_e], [a H M2_e E21_e, M2_e]] with the element's
+        own 2 n1e edges and n2e faces (E21_e = the +-1 face-edge stencil of one element, E12_e = -E21_e^T).  The preconditioner is
+        P^-1 = sum_e R_e^T D_e A_e^-1 D_e R_e (D_e = 1/multiplicity on the edges, 1 on the faces): the gravity-wave coupling INSIDE
+        an element is inverted exactly, which the block-diagonal {M1, M2} preconditioner ignores -- 62 -> ~20 GMRES iterations
+        on the 24x24x6 sphere at dt = 360 s.  Stored column-major per element for mimsem_sw_blocks_apply."""
+        eng = self.eng
+        loc = getattr(eng, "eng", eng)
+        n, n1e, n2e, nEl = eng.mesh.n, eng.n1e, eng.n2e, eng.nEl
+        a = ROS_ALPHA * dt
+        dev = eng.device
+        em = loc.element_matrices("UMAT").view(nEl, 2, 2, n1e, n1e)
+        M1e = em.permute(0, 1, 3, 2, 4).reshape(nEl, 2 * n1e, 2 * n1e)
+        rot = loc.element_matrices("ROTMAT", f=self.fg[0].contiguous()).view(nEl, 2, n1e, n1e)       # UtQV (x rows, y cols), VtQU
+        Re = torch.zeros_like(M1e)
+        Re[:, :n1e, n1e:] = rot[:, 0]; Re[:, n1e:, :n1e] = rot[:, 1]
+        M2e = loc.element_matrices("WMAT").view(nEl, n2e, n2e)
+        E21 = torch.zeros(n2e, 2 * n1e, dtype=torch.float64, device=dev)
+        for q in range(n2e):
+            jj, ii = q % n, q // n
+            E21[q, ii * (n + 1) + jj] = -1.0; E21[q, ii * (n + 1) + jj + 1] = 1.0
+            E21[q, n1e + ii * n + jj] = -1.0; E21[q, n1e + (ii + 1) * n + jj] = 1.0
+        Ae = torch.zeros(nEl, 2 * n1e + n2e, 2 * n1e + n2e, dtype=torch.float64, device=dev)
+        Ae[:, :2 * n1e, :2 * n1e] = M1e + a * Re
+        Ae[:, :2 * n1e, 2 * n1e:] = (a * self.grav) * (-E21.T) @ M2e
+        Ae[:, 2 * n1e:, :2 * n1e] = (a * H_MEAN) * M2e @ E21
+        Ae[:, 2 * n1e:, 2 * n1e:] = M2e
+        idx = torch.cat([torch.as_tensor(eng.mesh.inds1x, device=dev), torch.as_tensor(eng.mesh.inds1y, device=dev)], dim=1).long()
+        mult = torch.zeros(1, eng.sizes[1], dtype=torch.float64, device=dev)
+        mult[0].index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=dev))
+        mult = eng.complete(1, mult)[0]
+        d = torch.cat([1.0 / mult[idx], torch.ones(nEl, n2e, dtype=torch.float64, device=dev)], dim=1)
+        C = d[:, :, None] * torch.linalg.inv(Ae) * d[:, None, :]
+        return C.transpose(1, 2).contiguous()                     # column-major per element
+
+    def precond_A(self, r, dt=None):
+        """dt given (and order <= 4): the coupled element blocks above; otherwise block diagonal -- the element-block preconditioner
+        on M1, the exact element-wise inverse on M2 (WmatInv)"""
         n1 = self.n1
+        if dt is not None and self.eng.mesh.n <= 4 and self.coupled_pc:
+            if self._pcA is None or self._pcA[0] != dt:
+                self._pcA = (dt, self._coupled_element_blocks(dt))
+            loc = getattr(self.eng, "eng", self.eng)
+            z = loc.sw_blocks_apply(self._pcA[1], r)
+            self.eng.complete(1, z[:, :n1])
+            return z
         y = torch.empty_like(r)
         self.precond_M1(r[:, :n1], out=y[:, :n1])
         self.eng.blocks_apply(2, self.m2_inv, r[:, n1:], out=y[:, n1:])
@@ -178,11 +233,11 @@ class SWEqn:
             if self.graphs:
                 if self._gA is None or self._gA[0] != (dt, restart):       # the operator is fixed for a given dt: capture once
                     self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2,
-                                                            lambda v: self.precond_A(self.apply_A(v, dt)), restart=restart))
-                dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, self.precond_A, rtol=self.rtol, maxit=1000)
+                                                            lambda v: self.precond_A(self.apply_A(v, dt), dt), restart=restart))
+                dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, lambda r: self.precond_A(r, dt), rtol=self.rtol, maxit=1000)
             else:
                 with self.eng.space("uh"):
-                    dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=self.precond_A, rtol=self.rtol,
+                    dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=lambda r: self.precond_A(r, dt), rtol=self.rtol,
                                          restart=restart, maxit=1000, eng=self.eng)
             self.its["A"] = its
             x = x + dx

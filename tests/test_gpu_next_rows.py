@@ -126,6 +126,34 @@ def test_krylov_mdot_maxpy(sphere):
         assert float((w2 - ref2).abs().max()) < 1e-10 * float(ref2.abs().max())
 
 
+def test_krylov_fused_gram_schmidt_and_normalize(sphere):
+    """mimsem_krylov_orthogonalize (h = V w, w -= V^T h in two launches) and mimsem_krylov_normalize (v = w/|w| plus the finished
+    Hessenberg column written to device or pinned host memory) against torch, bitwise reproducible"""
+    import torch
+    cs, eng, mats, rng = sphere
+    n, m = 93312, 61
+    V = eng.tensor(rng.standard_normal((m, n))); w0 = eng.tensor(rng.standard_normal(n))
+    for k in (1, 5, 60):
+        w = w0.clone(); h = torch.zeros(m, dtype=torch.float64, device=eng.device)
+        eng.orthogonalize(V, w, h, k=k)
+        href = V[:k] @ w0
+        assert float((h[:k] - href).abs().max() / href.abs().max()) < 1e-13
+        wref = w0 - href @ V[:k]
+        assert float((w - wref).abs().max()) < 1e-11 * float(wref.abs().max())
+        wb = w0.clone(); hb = torch.zeros_like(h); eng.orthogonalize(V, wb, hb, k=k)
+        assert torch.equal(w, wb) and torch.equal(h, hb)
+        h2 = eng.tensor(rng.standard_normal(m))
+        for col in (torch.zeros(m + 2, dtype=torch.float64, device=eng.device), torch.zeros(m + 2, dtype=torch.float64).pin_memory()):
+            v = torch.empty_like(w)
+            eng.normalize(w, v, k, h, h2, col, m + 1)
+            torch.cuda.synchronize()
+            nrm = float(torch.linalg.vector_norm(w))
+            assert abs(float(col[m + 1]) - nrm) < 1e-13 * nrm
+            assert float((v - w / col[m + 1].item()).abs().max()) < 1e-15 * float(v.abs().max())
+            assert torch.equal(col[:k].to(eng.device), (h + h2)[:k])
+            assert float(col[k:m + 1].abs().max()) == 0.0 if k < m + 1 else True
+
+
 def test_horizsolve_right_hand_sides(oracle):
     """N2: HorizSolve::advection_rhs_ec / momentum_rhs_ec (eul/HorizSolve.cpp:380-417, 637-786) for all levels at once vs
     the dense restatement oracle/horiz_oracle.py (per-level dense matrices, LU for the KSP solves)"""
