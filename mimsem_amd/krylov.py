@@ -362,3 +362,51 @@ class GraphedGMRES:
             if res <= tol:
                 break
         return x.view(shape), its, res / bnorm
+
+
+class GraphedRichardson:
+    """x <- x + P^-1 (b - A x) with `chunk` iterations per hipGraph replay, for systems whose preconditioned operator is a small
+    perturbation of the identity: the 1-form mass matrix under its element-block preconditioner (spectrum of P^-1 M1 within
+    ~[0.9, 1.1]) and the upwinded lumped 0-form mass under its diagonal (GMRES needs 8 iterations).  No inner products and no
+    host synchronisation inside a chunk: 3-6 launches per iteration against 10 for PCG / 9 for a GMRES step, and the norm of
+    the last update IS the preconditioned residual |P^-1 (b - A x)| that the reference's KSP monitors, so the stopping rule is
+    unchanged (one scalar read per replay).  solve() returns None when the iteration does not contract (the caller then falls
+    back to its Krylov solver).
+
+    update(x, b) -> P^-1 (b - A x) must be capturable: fixed shapes, engine calls / torch ops only, coefficients read from
+    fixed buffers."""
+
+    def __init__(self, eng, shape, update, chunk=8, dtype=torch.float64):
+        self.eng, self.update, self.chunk = eng, update, chunk
+        self.x = torch.zeros(shape, dtype=dtype, device=eng.device)
+        self.b = torch.zeros(shape, dtype=dtype, device=eng.device)
+        self.dn = torch.zeros(1, dtype=dtype, device=eng.device)
+        self.graph = None
+
+    def _chunk(self):
+        for _ in range(self.chunk):
+            d = self.update(self.x, self.b)
+            self.x.add_(d)
+        d1 = d.reshape(1, -1)
+        self.eng.rowdot(d1, d1, out=self.dn)
+
+    def solve(self, b, precond, rtol=1e-14, max_replays=12):
+        self.b.copy_(b)
+        self.x.copy_(precond(b))
+        bnorm = float(torch.linalg.vector_norm(self.x))
+        if bnorm == 0.0:
+            return self.x.clone(), 0
+        if self.graph is None:
+            keep = self.x.clone()
+            self.graph, _ = self.eng.capture(self._chunk)
+            self.x.copy_(keep)
+        prev = None
+        for rep in range(1, max_replays + 1):
+            self.graph.replay()
+            dn = float(self.dn.item()) ** 0.5
+            if dn <= rtol * bnorm:
+                return self.x.clone(), rep * self.chunk
+            if not (dn == dn) or (prev is not None and dn > 0.5 * prev):     # NaN, or less than one bit per chunk: not contracting
+                return None
+            prev = dn
+        return None

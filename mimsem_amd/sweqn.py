@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .geom import gll_weights
-from .krylov import GraphedGMRES, gmres, pcg_engine
+from .krylov import GraphedGMRES, GraphedRichardson, gmres, pcg_engine
 
 RAD_EARTH = 6371220.0          # src/SWEqn_Picard.cpp:22-23
 RAD_SPHERE = 6371220.0
@@ -41,6 +41,10 @@ class SWEqn:
         self.graphs = use_graphs and not hasattr(eng, "halo")       # the hipGraph Arnoldi step is single-rank (no collectives inside)
         self._gA = None
         self._pcA = None
+        self._gq = None
+        self._rq = None
+        self._rM1 = None
+        self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
         self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
@@ -72,7 +76,15 @@ class SWEqn:
         return self.eng.blocks_apply(1, self.m1_pre, r, transpose=True, out=out)        # symmetric blocks: the coalesced read order
 
     def solve_M1(self, b, key="M1"):
-        """KSPSolve(ksp, b, x) on M1 (:84-92): SPD => preconditioned CG reaches the same solution"""
+        """KSPSolve(ksp, b, x) on M1 (:84-92).  Single rank: hipGraph-captured preconditioned Richardson sweeps (P^-1 M1 is within
+        ~10 % of the identity); otherwise / if they do not contract: SPD => preconditioned CG reaches the same solution"""
+        if self.graphs and self.richardson:
+            if self._rM1 is None or self._rM1.x.shape != b.shape:
+                self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=8)
+            res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol)
+            if res is not None:
+                self.its[key] = res[1]
+                return res[0]
         with self.eng.space(1):
             x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
         self.its[key] = its
@@ -113,6 +125,27 @@ class SWEqn:
         m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
         if dt > 1.0e-6:
             A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
+            if self.graphs:
+                # the Arnoldi step is captured once per dt on FIXED coefficient buffers (a hipGraph records pointers, not values);
+                # every later solve copies its (h, u, lumped M0h) in and replays
+                if self._gq is None or self._gq[0] != dt:
+                    bh, bu, bm = torch.empty_like(h), torch.empty_like(u), torch.empty_like(m0h)
+                    body = lambda v: self.eng.apply_up("PHMAT_UP", v, bh, bu, fac=UP_TAU, dt=dt) / bm
+                    self._gq = (dt, GraphedGMRES(self.eng, self.eng.sizes[0], body, restart=30), bh, bu, bm)
+                _, g, bh, bu, bm = self._gq
+                bh.copy_(h); bu.copy_(u); bm.copy_(m0h)
+                if self.richardson:
+                    if self._rq is None or self._rq[0] != dt:
+                        upd = lambda x, b: (b - self.eng.apply_up("PHMAT_UP", x, bh, bu, fac=UP_TAU, dt=dt)) / bm
+                        self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), upd, chunk=8), bh)
+                    if self._rq[2] is bh:
+                        res = self._rq[1].solve(rhs, lambda r: r / m0h, rtol=self.rtol)
+                        if res is not None:
+                            self.its["q"] = res[1]
+                            return res[0]
+                q, its, _ = g.solve(A, rhs, lambda r: r / m0h, rtol=self.rtol, maxit=1000)
+                self.its["q"] = its
+                return q
             with self.eng.space(0):
                 q, its, _ = gmres(A, rhs, precond=lambda r: r / m0h, rtol=self.rtol, restart=30, maxit=1000, eng=self.eng)
             self.its["q"] = its
@@ -123,8 +156,9 @@ class SWEqn:
     def pack(self, u, h): return torch.cat([u, h], dim=1)
     def unpack(self, x): return x[:, :self.n1].contiguous(), x[:, self.n1:].contiguous()
 
-    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None):
-        """:402-607"""
+    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None):
+        """:402-607.  qi / qj: potential vorticities already diagnosed from (ui, hi) / (uj, hj) -- the reference re-solves for qi in
+        every Picard iteration although (ui, hi) is the fixed start-of-step state; solve() passes the first result back in."""
         F = self.diagnose_F(ui, uj, hi, hj)
         Phi = self.diagnose_Phi(ui, uj, hi, hj)
         if bot is not None:
@@ -135,8 +169,8 @@ class SWEqn:
             q = self.diagnose_q(0.0, um, hm)
             fu = fu + self.R(q, F)
         else:
-            qi = self.diagnose_q(dt, ui, hi)
-            qj = self.diagnose_q(dt, uj, hj)
+            qi = self.diagnose_q(dt, ui, hi) if qi is None else qi
+            qj = self.diagnose_q(dt, uj, hj) if qj is None else qj
             fu = fu + 0.5 * self.R_up(qi, ui, dt, F)
             fu = fu + 0.5 * self.R_up(qj, uj, dt, F)
         fh = self.M2(self.E("E21", F))                            # continuity term
@@ -228,8 +262,9 @@ class SWEqn:
         uj, hj = un.clone(), hn.clone()
         x = self.pack(uj, hj)
         it, hist = 0, []
+        qi = None if q_exact else self.diagnose_q(dt, ui, hi)             # depends on the start-of-step state only
         while True:
-            f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot)
+            f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot, qi=qi, qj=qi if it == 0 else None)   # iteration 0: uj = ui, hj = hi
             if self.graphs:
                 if self._gA is None or self._gA[0] != (dt, restart):       # the operator is fixed for a given dt: capture once
                     self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2,
