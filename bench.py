@@ -7,6 +7,7 @@ the p=3, 24x24x6 cubed sphere with 30 levels (BASELINE config 4 grid, 103 680 pa
 N>1: the 24 patches (12x12 elements) are dealt to the ranks (strong scaling) and each step ends with the
 halo reduce (RCCL send/recv over xGMI) that replaces the reference's VecScatter REVERSE/ADD.
 
+At N = 1 the same line also carries "sw": shallow-water time steps/s (the second half of BASELINE's metric; --no-sw skips it).
 Prints ONE JSON line (rank 0).  roofline: dominant kernel k_elem_apply<3,UMAT>, HIP-event timed inside the
 timed region.  cpu_baseline: the oracle's reference-structure (assemble CSR + SpMV) path on host cores.
 """
@@ -213,6 +214,7 @@ def main():
                                                         "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
     ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
     ap.add_argument("--sweep", action="store_true", help="extra: SURVEY 8(d) batch-size sweep of six operator families (384 ... 1e6 element-level pairs)")
+    ap.add_argument("--no-sw", action="store_true", help="skip the shallow-water time-steps/s extra (reported by default at N = 1, ~20 s)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
                     help="extra (not the headline): the same step on R independent copies of the sphere, "
@@ -419,7 +421,7 @@ def main():
         out["horiz_rhs"] = {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels per evaluation",
                             "ms_per_evaluation_eager": 1e3 * el, "ms_per_evaluation_hipgraph": 1e3 * elg, "evaluations_per_s": 1.0 / elg,
                             "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
-    if a.sw and rank == 0 and world == 1:
+    if (a.sw or not a.no_sw) and rank == 0 and world == 1:        # the second half of BASELINE's metric: on by default at N = 1
         out["sw"] = sw_extras(local_rank, torch)
     if a.sweep and rank == 0 and world == 1:
         out["sweep"] = sweep_extras(local_rank, torch)

@@ -214,6 +214,23 @@ int mimsem_sw_operator_apply(mimsem_ctx* ctx, int nlev, double a, double grav, d
 int mimsem_sw_blocks_apply(mimsem_ctx* ctx, int nlev, const double* blocks,
                            const double* x, long long x_stride, double* y, long long y_stride);
 
+/* Richardson sweeps on the engine operators (row N1: the KSPSolve that follows almost every apply, eul/HorizSolve.cpp:77-96,
+ * src/SWEqn_Picard.cpp:84-92, :348-353), for systems whose preconditioned operator is close to the identity.  The operator
+ * result is never written: the gather pass applies the update  x += P (b - Op x)  directly.  upd (may be NULL) receives the
+ * update P (b - Op x) itself -- its norm is the preconditioned residual a KSP monitors.
+ *   mimsem_op_richardson_sweep:    P = diag(dinv); any operator with equal 0- or 1-form input and result spaces (incl. the
+ *                                  upwinded ones: tau, u as in mimsem_op_apply_up); two launches.
+ *   mimsem_block_richardson_sweep: P = sum_e R_e^T B_e R_e on 1-forms, blocks [nEl][2 n1e][2 n1e] COLUMN-major per element
+ *                                  (the PCBJACOBI-per-element preconditioner with its inverse blocks supplied); three launches. */
+int mimsem_op_richardson_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
+                               const double* f, long long f_stride, const double* u, long long u_stride,
+                               const double* b, long long b_stride, const double* dinv, long long dinv_stride,
+                               double* x, long long x_stride, double* upd, long long upd_stride);
+int mimsem_block_richardson_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                  const double* f, long long f_stride, const double* blocks,
+                                  const double* b, long long b_stride, double* x, long long x_stride,
+                                  double* upd, long long upd_stride);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,

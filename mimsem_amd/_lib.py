@@ -55,6 +55,10 @@ _SIGS = {
     "mimsem_interp_quad": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_op_richardson_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
+                                             c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_block_richardson_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint,
+                                                c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_colop_nblocks": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_colop_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, c_dp, c_dp, c_dp]),

@@ -385,7 +385,8 @@ int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
 // ---- horizontal operators --------------------------------------------------------------------
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
-                         const double* x, long long xs, double* y, long long ys, double alpha);
+                         const double* x, long long xs, double* y, long long ys, double alpha,
+                         const GatherEpilogue* epi = nullptr, const double* blocks = nullptr);
 static bool is_up_op(int op);
 
 int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
@@ -412,7 +413,8 @@ int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double sc
 
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
-                         const double* x, long long xs, double* y, long long ys, double alpha) {
+                         const double* x, long long xs, double* y, long long ys, double alpha,
+                         const GatherEpilogue* epi, const double* blocks) {
     if (!c || nlev < 0) return MIMSEM_ERR_ARG;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
@@ -456,6 +458,22 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     }
     a.fperm = nullptr; a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0;
     a.d0 = a.d1x = a.d1y = nullptr; a.y = nullptr; a.ys = 0;
+    if (epi) {
+        // Richardson sweep: element pass into the workspace, then the gather with the update epilogue (y is the iterate);
+        // with `blocks` the element-block preconditioner runs in between on the second half of the workspace
+        const long long per = (long long)c->nEl*(outsp == 1 ? 2*es.n1e : es.n0e);
+        if ((rc = c->ensure_ye(per*nlev*(blocks ? 2 : 1)))) return rc;
+        a.out = c->d_ye; a.os = per;
+        a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+        if ((rc = launch_elem_apply(c, op, a))) return rc;
+        const double* src = c->d_ye;
+        if (blocks) {
+            double* ze = c->d_ye + per*nlev;
+            if ((rc = launch_blocks_residual(c, nlev, blocks, c->d_ye, per, epi->b, epi->bs, ze, per))) return rc;
+            src = ze;
+        }
+        return launch_gather_epilogue(c, outsp, nlev, src, per, *epi, y, ys);
+    }
     if (outsp == 1 && c->fused1 && op < MIMSEM_OP_UMAT_UP && op != MIMSEM_OP_UMAT_RAY) {
         // fused path: group-local sums in LDS, complete slots written straight to y, perimeter partials to the workspace
         if ((rc = c->ensure_ye((long long)std::max(c->f_npart, 1)*nlev))) return rc;
@@ -561,6 +579,29 @@ int mimsem_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* blocks, const 
     const long long n = (long long)c->n1 + c->n2;
     if (nlev > 1 && (xs < n || ys < n)) return MIMSEM_ERR_ARG;
     return launch_sw_blocks_apply(c, nlev, blocks, x, xs, y, ys);
+}
+
+int mimsem_op_richardson_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
+                               const double* f, long long fs, const double* u, long long us,
+                               const double* b, long long bs, const double* dinv, long long ds,
+                               double* x, long long xs, double* upd, long long upds) {
+    if (!c || !b || !dinv || !x || (flags & MIMSEM_FLAG_ACCUM)) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp) || outsp == 2 || in != outsp) return MIMSEM_ERR_ARG;     // square operators on gathered spaces
+    if (is_up_op(op) && !u) return MIMSEM_ERR_ARG;
+    GatherEpilogue g{1, b, bs, dinv, ds, upd, upds};
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, x, xs, 1.0, &g);
+}
+
+int mimsem_block_richardson_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                  const double* f, long long fs, const double* blocks,
+                                  const double* b, long long bs, double* x, long long xs, double* upd, long long upds) {
+    if (!c || !b || !blocks || !x || (flags & MIMSEM_FLAG_ACCUM)) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp) || outsp != 1 || in != 1 || is_up_op(op)) return MIMSEM_ERR_ARG;
+    if (c->es.n > 5) return MIMSEM_ERR_UNSUPPORTED;
+    GatherEpilogue g{2, b, bs, nullptr, 0, upd, upds};
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, x, xs, 1.0, &g, blocks);
 }
 
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {

@@ -115,6 +115,17 @@ struct ElemArgs {
     const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
 };
 
+// pass 2 with an epilogue (the Richardson sweeps): what happens to the gathered sum `acc` of a slot
+struct GatherEpilogue {
+    int mode;                        // 1: d = dinv*(b - acc) ; 2: d = acc.   Then x += d and, if upd, upd = d
+    const double* b; long long bs;
+    const double* dinv; long long ds;
+    double* upd; long long us;
+};
+int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, const GatherEpilogue& g,
+                           double* x, long long xs);
+int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes,
+                           const double* b, long long bs, double* ze, long long zes);
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,

@@ -585,6 +585,62 @@ __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ y
     }
 }
 
+// pass 2 of a Richardson sweep: the gathered operator result never reaches memory -- x[s] += dinv[s] (b[s] - acc) (diagonal
+// preconditioner) or x[s] += acc (acc already is the preconditioned update); the update itself is stored on request (its
+// norm is the preconditioned residual the solver monitors).  Same plan, same summation order as k_gather_sum.
+template <int K>
+__global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restrict__ ye, long long ye_stride,
+                                                         const int* __restrict__ plan, int nslots, int nlev, GatherEpilogue g,
+                                                         double* __restrict__ x, long long xs) {
+    const int s = blockIdx.x*256 + threadIdx.x;
+    if (s >= nslots) return;
+    int j[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
+    for (int lev = 0; lev < nlev; lev++) {
+        const double* src = ye + (size_t)lev*ye_stride;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
+        const double d = (g.mode == 1) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
+        x[(size_t)lev*xs + s] += d;
+        if (g.upd) g.upd[(size_t)lev*g.us + s] = d;
+    }
+}
+
+// block-preconditioned Richardson, middle pass: r_e = (b - gather(ye)) restricted to the element (gathered on the fly through
+// the 1-form plan), z_e = B_e r_e with B_e stored column-major ([c][r]); z_e goes to the second element-local buffer.
+template <int N>
+__global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, const int* __restrict__ i1x, const int* __restrict__ i1y,
+        const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
+        const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e;
+    constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    static_assert(ND <= 64, "one wavefront per element");
+    __shared__ double s_x[EPB][LPE];
+    const int tid = threadIdx.x, el = tid/LPE, r = tid%LPE;
+    const long long eg = (long long)blockIdx.x*EPB + el;
+    const bool act = eg < (long long)nEl*nlev && r < ND;
+    const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
+    if (act) {
+        const int slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
+        const int p0 = plan[(size_t)slot*2], p1 = plan[(size_t)slot*2 + 1];
+        const double* src = ye + (size_t)lev*yes;
+        double acc = 0.0;
+        if (p0 >= 0) acc += src[p0];
+        if (p1 >= 0) acc += src[p1];
+        s_x[el][r] = b[(size_t)lev*bs + slot] - acc;
+    }
+    wave_lds_sync();
+    if (!act) return;
+    const double* Be = B + (size_t)e*ND*ND + r;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < ND; c++) s += Be[(size_t)c*ND]*s_x[el][c];
+    ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
+}
+
 // perimeter pass of the fused scatter-add: slots shared by two element groups sum their two partials
 __global__ __launch_bounds__(256) void k_gather_perim(const double* __restrict__ yp, long long yps, const int* __restrict__ pslot,
         const int* __restrict__ ppart, int nps, int nlev, int accum, double* __restrict__ y, long long ys) {
@@ -1321,6 +1377,44 @@ int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long 
 #undef MIMSEM_GS
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
+}
+
+int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, const GatherEpilogue& g,
+                           double* x, long long xs) {
+    const int nslots = form == 1 ? c->n1 : c->n0;
+    if (nslots == 0 || nlev == 0) return MIMSEM_OK;
+    const dim3 grid((unsigned)((nslots + 255)/256));
+    if (form == 1) hipLaunchKernelGGL((k_gather_epilogue<2>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g1, nslots, nlev, g, x, xs);
+    else if (c->G0 == 4) hipLaunchKernelGGL((k_gather_epilogue<4>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, g, x, xs);
+    else hipLaunchKernelGGL((k_gather_epilogue<8>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, g, x, xs);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+template <int N>
+static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes, const double* b, long long bs,
+                             double* ze, long long zes) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e;
+    constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    const long long total = (long long)c->nEl*nlev;
+    hipLaunchKernelGGL((k_blocks_residual<N>), dim3((unsigned)((total + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev,
+                       c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes,
+                           const double* b, long long bs, double* ze, long long zes) {
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    switch (c->es.n) {
+    case 1: return blocks_residual_n<1>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    case 2: return blocks_residual_n<2>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    case 3: return blocks_residual_n<3>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    case 4: return blocks_residual_n<4>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    case 5: return blocks_residual_n<5>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    default: return MIMSEM_ERR_UNSUPPORTED;          // 2 n1e > 64 rows
+    }
 }
 
 int launch_elmats(mimsem_ctx* c, int op, int lev, double scale, unsigned flags, const double* f, double* out,

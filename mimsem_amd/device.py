@@ -194,6 +194,31 @@ class Engine:
                                         _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply_up(%s)" % op)
         return y if x.dim() == 2 else y2[0]
 
+    def richardson_sweep(self, op, x, b, dinv, f=None, u=None, tau=0.0, lev0=0, scale=1.0, flags=0, upd=None):
+        """x += dinv * (b - Op x) in place (mimsem_op_richardson_sweep: element pass + gather with the update epilogue);
+        upd (optional, same shape) receives the update.  [nlev, n] tensors."""
+        sin, sf, sout = self._SPACES[op]
+        nlev = x.shape[0]
+        assert sin == sout and x.dim() == 2 and x.shape == b.shape == dinv.shape and x.shape[1] == self.sizes[sin]
+        assert upd is None or upd.shape == x.shape
+        check(self.L.mimsem_op_richardson_sweep(self.ctx, OPS[op], lev0, nlev, scale, tau, flags,
+                                                _ptr(f), f.stride(0) if f is not None else 0, _ptr(u), u.stride(0) if u is not None else 0,
+                                                _ptr(b), b.stride(0), _ptr(dinv), dinv.stride(0), _ptr(x), x.stride(0),
+                                                _ptr(upd), upd.stride(0) if upd is not None else 0), "richardson_sweep(%s)" % op)
+        return x
+
+    def block_richardson_sweep(self, op, blocks, x, b, f=None, lev0=0, scale=1.0, flags=0, upd=None):
+        """x += sum_e R_e^T B_e R_e (b - Op x) in place on 1-forms; blocks [nEl, 2 n1e, 2 n1e] column-major per element
+        (mimsem_block_richardson_sweep: element pass, block pass with on-the-fly gathered residual, gather with update)"""
+        nd = 2 * self.n1e
+        assert x.dim() == 2 and x.shape == b.shape and x.shape[1] == self.sizes[1] and blocks.shape == (self.nEl, nd, nd)
+        assert upd is None or upd.shape == x.shape
+        check(self.L.mimsem_block_richardson_sweep(self.ctx, OPS[op], lev0, x.shape[0], scale, flags,
+                                                   _ptr(f), f.stride(0) if f is not None else 0, _ptr(blocks),
+                                                   _ptr(b), b.stride(0), _ptr(x), x.stride(0),
+                                                   _ptr(upd), upd.stride(0) if upd is not None else 0), "block_richardson_sweep(%s)" % op)
+        return x
+
     def apply_ray(self, x, exner, exner_s, dt, lev0=0, scale=1.0, alpha=1.0, flags=0, out=None):
         """Umat_ray (Held-Suarez friction): x [nlev, n1], exner [nlev, n2] (levels lev0..), exner_s [n2] = level 0."""
         x2 = x if x.dim() == 2 else x.unsqueeze(0); f2 = exner if exner.dim() == 2 else exner.unsqueeze(0)

@@ -376,26 +376,38 @@ class GraphedRichardson:
     update(x, b) -> P^-1 (b - A x) must be capturable: fixed shapes, engine calls / torch ops only, coefficients read from
     fixed buffers."""
 
-    def __init__(self, eng, shape, update, chunk=8, dtype=torch.float64):
-        self.eng, self.update, self.chunk = eng, update, chunk
+    def __init__(self, eng, shape, update=None, chunk=8, dtype=torch.float64, sweep=None):
+        """update(x, b) -> P^-1 (b - A x)   or   sweep(x, b, upd): x += P^-1 (b - A x) in place, the update stored in upd when
+        upd is not None (the engine's fused mimsem_*_richardson_sweep entry points)"""
+        assert (update is None) != (sweep is None)
+        self.eng, self.update, self.sweep, self.chunk = eng, update, sweep, chunk
+        self.upd = torch.zeros(shape, dtype=dtype, device=eng.device) if sweep is not None else None
         self.x = torch.zeros(shape, dtype=dtype, device=eng.device)
         self.b = torch.zeros(shape, dtype=dtype, device=eng.device)
         self.dn = torch.zeros(1, dtype=dtype, device=eng.device)
         self.graph = None
 
     def _chunk(self):
-        for _ in range(self.chunk):
-            d = self.update(self.x, self.b)
-            self.x.add_(d)
+        if self.sweep is not None:
+            for i in range(self.chunk):
+                self.sweep(self.x, self.b, self.upd if i == self.chunk - 1 else None)
+            d = self.upd
+        else:
+            for _ in range(self.chunk):
+                d = self.update(self.x, self.b)
+                self.x.add_(d)
         d1 = d.reshape(1, -1)
         self.eng.rowdot(d1, d1, out=self.dn)
 
-    def solve(self, b, precond, rtol=1e-14, max_replays=12):
+    def solve(self, b, precond, rtol=1e-14, max_replays=12, x0=None):
+        """x0: initial guess (e.g. the solution of the previous, nearby system); the tolerance stays relative to |P^-1 b|"""
         self.b.copy_(b)
         self.x.copy_(precond(b))
         bnorm = float(torch.linalg.vector_norm(self.x))
         if bnorm == 0.0:
             return self.x.clone(), 0
+        if x0 is not None:
+            self.x.copy_(x0)
         if self.graph is None:
             keep = self.x.clone()
             self.graph, _ = self.eng.capture(self._chunk)

@@ -44,6 +44,9 @@ class SWEqn:
         self._gq = None
         self._rq = None
         self._rM1 = None
+        self._guess = {}
+        self.fused_sweeps = os.environ.get("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
+        self.warm_start = os.environ.get("MIMSEM_SW_WARM_START", "1") == "1"
         self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
         self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
 
@@ -80,10 +83,17 @@ class SWEqn:
         ~10 % of the identity); otherwise / if they do not contract: SPD => preconditioned CG reaches the same solution"""
         if self.graphs and self.richardson:
             if self._rM1 is None or self._rM1.x.shape != b.shape:
-                self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=8)
-            res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol)
+                if self.eng.mesh.n <= 5 and self.fused_sweeps:
+                    cm = self.m1_pre.transpose(1, 2).contiguous()          # column-major blocks for the fused three-launch sweep
+                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), chunk=8,
+                                                  sweep=lambda x, rhs, upd: self.eng.block_richardson_sweep("UMAT", cm, x, rhs, upd=upd))
+                else:
+                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=8)
+            x0 = self._guess.get(key) if self.warm_start else None      # the previous solution of the same diagnostic: a nearby system
+            res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol, x0=x0 if (x0 is not None and x0.shape == b.shape) else None)
             if res is not None:
                 self.its[key] = res[1]
+                self._guess[key] = res[0]
                 return res[0]
         with self.eng.space(1):
             x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
@@ -136,12 +146,22 @@ class SWEqn:
                 bh.copy_(h); bu.copy_(u); bm.copy_(m0h)
                 if self.richardson:
                     if self._rq is None or self._rq[0] != dt:
-                        upd = lambda x, b: (b - self.eng.apply_up("PHMAT_UP", x, bh, bu, fac=UP_TAU, dt=dt)) / bm
-                        self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), upd, chunk=8), bh)
+                        if self.fused_sweeps:
+                            bmi = torch.empty_like(bm)
+                            tau = 1.0 / (1.0 / (UP_TAU * dt))
+                            swp = lambda x, b, upd: self.eng.richardson_sweep("PHMAT_UP", x, b, bmi, f=bh, u=bu, tau=tau, upd=upd)
+                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), chunk=8, sweep=swp), bh, bmi)
+                        else:
+                            upd = lambda x, b: (b - self.eng.apply_up("PHMAT_UP", x, bh, bu, fac=UP_TAU, dt=dt)) / bm
+                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), upd, chunk=8), bh, None)
                     if self._rq[2] is bh:
-                        res = self._rq[1].solve(rhs, lambda r: r / m0h, rtol=self.rtol)
+                        if self._rq[3] is not None:
+                            torch.reciprocal(m0h, out=self._rq[3])
+                        x0 = self._guess.get("q") if self.warm_start else None
+                        res = self._rq[1].solve(rhs, lambda r: r / m0h, rtol=self.rtol, x0=x0)
                         if res is not None:
                             self.its["q"] = res[1]
+                            self._guess["q"] = res[0]
                             return res[0]
                 q, its, _ = g.solve(A, rhs, lambda r: r / m0h, rtol=self.rtol, maxit=1000)
                 self.its["q"] = its

@@ -176,3 +176,31 @@ def test_sw_coupled_block_preconditioner(sw):
     for x in (x1, x2):                              # left preconditioning monitors P^-1 (b - A x); the true residual follows it
         assert rel_l2(S.apply_A(x, dt)[0].cpu().numpy(), b[0].cpu().numpy()) < 1e-7
     assert its_c * 2 <= its_d, (its_c, its_d)
+
+
+def test_richardson_sweeps_match_composition(sw):
+    """mimsem_block_richardson_sweep / mimsem_op_richardson_sweep (operator result never written, update applied in the gather pass)
+    against the same sweep composed from the individual engine calls"""
+    import torch
+    cs, eng, O, S, uq, hq = sw
+    r = np.random.default_rng(9)
+    dm = eng.mesh
+    x = _t(eng, r.standard_normal(dm.n1)); b = _t(eng, r.standard_normal(dm.n1))
+    cm = S.m1_pre.transpose(1, 2).contiguous()
+    ref = S.precond_M1(b - S.M1(x))
+    x1 = x.clone(); upd = torch.zeros_like(x)
+    eng.block_richardson_sweep("UMAT", cm, x1, b, upd=upd)
+    assert rel_l2(upd.cpu().numpy(), ref.cpu().numpy()) < 1e-13
+    assert torch.equal(x1, x + upd)
+    x2 = x.clone(); eng.block_richardson_sweep("UMAT", cm, x2, b)
+    assert torch.equal(x1, x2)
+    # diagonal variant on the upwinded lumped 0-form mass (the potential-vorticity system)
+    u0, h0 = _t(eng, O.init1(uq)), _t(eng, O.init2(hq))
+    q = _t(eng, r.standard_normal(dm.n0)); bq = _t(eng, r.standard_normal(dm.n0))
+    dinv = 1.0 / eng.pvec(0, 1, 1.0, h2=h0)
+    tau = 1.0 / (1.0 / (0.5 * 360.0))
+    refq = dinv * (bq - eng.apply_up("PHMAT_UP", q, h0, u0, fac=0.5, dt=360.0))
+    q1 = q.clone(); updq = torch.zeros_like(q)
+    eng.richardson_sweep("PHMAT_UP", q1, bq, dinv, f=h0, u=u0, tau=tau, upd=updq)
+    assert rel_l2(updq.cpu().numpy(), refq.cpu().numpy()) < 1e-13
+    assert torch.equal(q1, q + updq)
