@@ -385,22 +385,31 @@ class GraphedRichardson:
         self.x = torch.zeros(shape, dtype=dtype, device=eng.device)
         self.b = torch.zeros(shape, dtype=dtype, device=eng.device)
         self.dn = torch.zeros(1, dtype=dtype, device=eng.device)
-        self.graph = None
+        self.graphs = {}                 # sweeps per replay -> captured graph
 
-    def _chunk(self):
+    def _chunk(self, n):
         if self.sweep is not None:
-            for i in range(self.chunk):
-                self.sweep(self.x, self.b, self.upd if i == self.chunk - 1 else None)
+            for i in range(n):
+                self.sweep(self.x, self.b, self.upd if i == n - 1 else None)
             d = self.upd
         else:
-            for _ in range(self.chunk):
+            for _ in range(n):
                 d = self.update(self.x, self.b)
                 self.x.add_(d)
         d1 = d.reshape(1, -1)
         self.eng.rowdot(d1, d1, out=self.dn)
 
-    def solve(self, b, precond, rtol=1e-14, max_replays=12, x0=None):
-        """x0: initial guess (e.g. the solution of the previous, nearby system); the tolerance stays relative to |P^-1 b|"""
+    def _graph(self, n):
+        if n not in self.graphs:
+            keep = self.x.clone()
+            self.graphs[n], _ = self.eng.capture(lambda: self._chunk(n))
+            self.x.copy_(keep)
+        return self.graphs[n]
+
+    def solve(self, b, precond, rtol=1e-14, max_sweeps=200, x0=None):
+        """x0: initial guess (e.g. the solution of the previous, nearby system); the tolerance stays relative to |P^-1 b|.
+        One graph launch and one scalar read per `chunk` sweeps (an adaptive first-replay length was measured: the extra graph
+        captures cost more than the saved sweeps)."""
         self.b.copy_(b)
         self.x.copy_(precond(b))
         bnorm = float(torch.linalg.vector_norm(self.x))
@@ -408,17 +417,14 @@ class GraphedRichardson:
             return self.x.clone(), 0
         if x0 is not None:
             self.x.copy_(x0)
-        if self.graph is None:
-            keep = self.x.clone()
-            self.graph, _ = self.eng.capture(self._chunk)
-            self.x.copy_(keep)
-        prev = None
-        for rep in range(1, max_replays + 1):
-            self.graph.replay()
+        done, prev, n = 0, None, self.chunk
+        while done < max_sweeps:
+            self._graph(n).replay()
+            done += n
             dn = float(self.dn.item()) ** 0.5
             if dn <= rtol * bnorm:
-                return self.x.clone(), rep * self.chunk
-            if not (dn == dn) or (prev is not None and dn > 0.5 * prev):     # NaN, or less than one bit per chunk: not contracting
+                return self.x.clone(), done
+            if not (dn == dn) or (prev is not None and dn > 0.9 * prev):     # NaN or not contracting
                 return None
             prev = dn
         return None

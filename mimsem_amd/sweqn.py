@@ -45,6 +45,7 @@ class SWEqn:
         self._rq = None
         self._rM1 = None
         self._guess = {}
+        self.chunk = int(os.environ.get("MIMSEM_SW_CHUNK", "10"))
         self.fused_sweeps = os.environ.get("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
         self.warm_start = os.environ.get("MIMSEM_SW_WARM_START", "1") == "1"
         self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
@@ -85,10 +86,10 @@ class SWEqn:
             if self._rM1 is None or self._rM1.x.shape != b.shape:
                 if self.eng.mesh.n <= 5 and self.fused_sweeps:
                     cm = self.m1_pre.transpose(1, 2).contiguous()          # column-major blocks for the fused three-launch sweep
-                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), chunk=8,
+                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), chunk=self.chunk,
                                                   sweep=lambda x, rhs, upd: self.eng.block_richardson_sweep("UMAT", cm, x, rhs, upd=upd))
                 else:
-                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=8)
+                    self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=self.chunk)
             x0 = self._guess.get(key) if self.warm_start else None      # the previous solution of the same diagnostic: a nearby system
             res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol, x0=x0 if (x0 is not None and x0.shape == b.shape) else None)
             if res is not None:
@@ -150,10 +151,10 @@ class SWEqn:
                             bmi = torch.empty_like(bm)
                             tau = 1.0 / (1.0 / (UP_TAU * dt))
                             swp = lambda x, b, upd: self.eng.richardson_sweep("PHMAT_UP", x, b, bmi, f=bh, u=bu, tau=tau, upd=upd)
-                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), chunk=8, sweep=swp), bh, bmi)
+                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), chunk=self.chunk, sweep=swp), bh, bmi)
                         else:
                             upd = lambda x, b: (b - self.eng.apply_up("PHMAT_UP", x, bh, bu, fac=UP_TAU, dt=dt)) / bm
-                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), upd, chunk=8), bh, None)
+                            self._rq = (dt, GraphedRichardson(self.eng, tuple(rhs.shape), upd, chunk=self.chunk), bh, None)
                     if self._rq[2] is bh:
                         if self._rq[3] is not None:
                             torch.reciprocal(m0h, out=self._rq[3])
