@@ -46,6 +46,22 @@ def test_argument_errors(small):
     assert L.mimsem_column_incidence(ctx, 3, ph, ph) == ERR_ARG
     assert L.mimsem_elem_blocks_apply(ctx, 4, 1, 0, px, 0, None, 0, px, dm.n1, py, dm.n1, 1.0) == ERR_ARG
     assert L.mimsem_halo_segments(ctx, px, 65, px, 0, 1, 1, 0, px, py, dm.n1) == ERR_ARG                            # too many segments
+    # the entry points added with the shallow-water step
+    p0 = eng.zeros(1, dm.n0).data_ptr(); pk = eng.zeros(1, dm.n1 + dm.n2).data_ptr(); pk2 = eng.zeros(1, dm.n1 + dm.n2).data_ptr()
+    assert L.mimsem_interp_quad(ctx, 3, 0, 1, px, dm.n1, py, dm.n1) == ERR_ARG                                       # no such form
+    assert L.mimsem_interp_quad(ctx, 1, 2, 1, px, dm.n1, py, dm.n1) == ERR_ARG                                       # unknown flag
+    assert L.mimsem_interp_quad(ctx, 1, 1, 1, None, dm.n1, py, dm.n1) == ERR_ARG
+    assert L.mimsem_sw_operator_apply(ctx, 1, 1.0, 9.8, 1e4, p0, 0, pk, 0, pk, 0) == ERR_ARG                         # in place
+    assert L.mimsem_sw_operator_apply(ctx, 1, 1.0, 9.8, 1e4, None, 0, pk, 0, pk2, 0) == ERR_ARG
+    assert L.mimsem_sw_operator_apply(ctx, 2, 1.0, 9.8, 1e4, p0, 0, pk, 5, pk2, 5) == ERR_ARG                        # rows overlap
+    assert L.mimsem_sw_blocks_apply(ctx, 1, None, pk, 0, pk2, 0) == ERR_ARG
+    assert L.mimsem_op_richardson_sweep(ctx, OPS["WMAT"], 0, 1, 1.0, 0.0, 0, None, 0, None, 0, ph, 0, ph, 0, ph, 0, None, 0) == ERR_ARG     # 2-form result: no gather pass
+    assert L.mimsem_op_richardson_sweep(ctx, OPS["WTQUMAT"], 0, 1, 1.0, 0.0, 0, px, 0, None, 0, px, 0, px, 0, py, 0, None, 0) == ERR_ARG   # not square
+    assert L.mimsem_op_richardson_sweep(ctx, OPS["PHMAT_UP"], 0, 1, 1.0, 1.0, 0, ph, 0, None, 0, p0, 0, p0, 0, p0, 0, None, 0) == ERR_ARG  # velocity missing
+    assert L.mimsem_block_richardson_sweep(ctx, OPS["PMAT"], 0, 1, 1.0, 0, None, 0, px, p0, 0, p0, 0, None, 0) == ERR_ARG                  # 1-forms only
+    assert L.mimsem_block_richardson_sweep(ctx, OPS["UMAT"], 0, 1, 1.0, 0, None, 0, None, px, 0, py, 0, None, 0) == ERR_ARG
+    assert L.mimsem_krylov_normalize(ctx, 0, px, py, 0, None, None, py, 0) == ERR_ARG
+    assert L.mimsem_krylov_orthogonalize(ctx, 2, dm.n1, px, 5, -1.0, py, py) == ERR_ARG                              # ldv < n
     for code in (-1, -2, -3, -4, -5):
         assert len(L.mimsem_strerror(code)) > 5
     with pytest.raises(AssertionError):                                  # vector lengths are checked by the host layer
