@@ -956,6 +956,13 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// the same hand-off when only LDS data crosses lanes: the fences name the local address space, so outstanding GLOBAL loads /
+// stores (the prefetch of the next level, the stores of G and D^-1) are not waited for
+__device__ __forceinline__ void wsync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <int N2>
 __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* __restrict__ L, const double* __restrict__ f,
                                                           double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws,
@@ -1071,6 +1078,148 @@ __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* 
     }
 }
 
+// rotate within each row of 16 lanes (DPP row_ror: a VALU modifier, no LDS crossbar trip like ds_bpermute)
+template <int N> __device__ __forceinline__ int row_ror(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N> __device__ __forceinline__ double row_ror(double v) {
+    return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
+}
+
+// The same sweep with ONE ROW PER LANE: 16 lanes per column (4 columns per wavefront), the running diagonal block lives in
+// registers (row r in lane r) and the Gauss-Jordan steps talk through cross-lane shuffles instead of LDS round trips:
+// pivot search = 4 butterfly rounds, pivot row = N2 broadcasts.  Rows are never swapped -- the lane chosen at step c keeps the
+// row and remembers c; the in-place inverse T then satisfies  D^-1[c_l][p_c] = T[l][c]  (c_l: step at which lane l was the pivot,
+// p_c: pivot lane of step c), which is how it is scattered into LDS.  LDS only carries the operands of the two block products.
+template <int N2>
+__global__ __launch_bounds__(64) void k_block_thomas_rows(int nEl, int nk, const double* __restrict__ L, const double* __restrict__ f,
+                                                          double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws,
+                                                          double* __restrict__ Dinv) {
+    constexpr int nn = N2*N2, GW = 16, CPW = 64/GW;
+    static_assert(N2 <= GW, "one lane per block row");
+    __shared__ double sG[CPW][nn], sU[CPW][nn], sI[CPW][nn], sy[CPW][N2], sv[CPW][N2];
+    const int lane = threadIdx.x, g = lane/GW, r = lane%GW;
+    const int e0 = blockIdx.x*CPW + g;
+    const bool act = r < N2 && e0 < nEl;
+    const int e = e0 < nEl ? e0 : nEl - 1, rr = r < N2 ? r : 0;           // clamped: idle lanes compute on valid addresses, store nothing
+    const double* Le = L + (size_t)e*nk*3*nn;
+    double* G = Gws + (size_t)e*nk*nn;
+    double* yv = yws + (size_t)e*nk*N2;
+    double S[N2], T[N2], U[N2], Sn[N2], Tn[N2], Un[N2], fn;
+    auto fetch = [&](int k) {                     // this lane's rows of level k; issued one level ahead of their use
+        const double* row = Le + (size_t)k*3*nn + rr*N2;
+#pragma unroll
+        for (int j = 0; j < N2; j++) { Sn[j] = row[j]; Tn[j] = row[nn + j]; Un[j] = row[2*nn + j]; }
+        fn = f[((size_t)e*nk + k)*N2 + rr];
+    };
+    // results of a level are stored at the START of the next one, ahead of the prefetch: the in-order vmcnt wait for the prefetched
+    // rows at the loop head then covers stores issued a whole level earlier instead of stalling on fresh ones
+    double Gst[N2], Ist[N2], yst = 0.0;
+    auto flush = [&](int k) {
+        if (!act) return;
+#pragma unroll
+        for (int j = 0; j < N2; j++) G[(size_t)k*nn + r*N2 + j] = Gst[j];
+        yv[(size_t)k*N2 + r] = yst;
+        if (Dinv) {
+#pragma unroll
+            for (int m = 0; m < N2; m++) Dinv[((size_t)e*nk + k)*nn + r*N2 + m] = Ist[m];
+        }
+    };
+    fetch(0);
+    for (int k = 0; k < nk; k++) {
+#pragma unroll
+        for (int j = 0; j < N2; j++) { S[j] = Sn[j]; T[j] = Tn[j]; U[j] = Un[j]; }
+        double vv = fn;
+        if (k > 0) flush(k - 1);
+        if (k + 1 < nk) fetch(k + 1);
+        if (k > 0) {
+#pragma unroll
+            for (int m = 0; m < N2; m++) {
+                const double sm = S[m];
+#pragma unroll
+                for (int j = 0; j < N2; j++) T[j] -= sm*sG[g][m*N2 + j];
+                vv -= sm*sy[g][m];
+            }
+        }
+        // in-place Gauss-Jordan inverse, implicit row pivoting
+        bool used = !act;
+        int myc = 0, piv[N2];
+#pragma unroll
+        for (int c = 0; c < N2; c++) {
+            double cand = used ? -1.0 : fabs(T[c]);
+            int bl = r;
+            // arg-max over the 16 lanes of the column: rotations by 1, 2, 4, 8 (ties -> lowest lane, so every lane agrees)
+#define MIMSEM_ARGMAX_ROUND(N) { const double oc = row_ror<N>(cand); const int ol = row_ror<N>(bl); \
+                                 if (oc > cand || (oc == cand && ol < bl)) { cand = oc; bl = ol; } }
+            MIMSEM_ARGMAX_ROUND(1) MIMSEM_ARGMAX_ROUND(2) MIMSEM_ARGMAX_ROUND(4) MIMSEM_ARGMAX_ROUND(8)
+#undef MIMSEM_ARGMAX_ROUND
+            piv[c] = bl;
+            double pr[N2];
+#pragma unroll
+            for (int j = 0; j < N2; j++) pr[j] = __shfl(T[j], bl, GW);
+            const double pinv = 1.0/pr[c];
+            if (r == bl) {
+#pragma unroll
+                for (int j = 0; j < N2; j++) T[j] = pr[j]*pinv;
+                T[c] = pinv; used = true; myc = c;
+            } else {
+                const double fct = T[c];
+#pragma unroll
+                for (int j = 0; j < N2; j++) T[j] -= fct*(pr[j]*pinv);
+                T[c] = -fct*pinv;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < N2; c++) sI[g][myc*N2 + piv[c]] = T[c];
+#pragma unroll
+            for (int j = 0; j < N2; j++) sU[g][r*N2 + j] = U[j];
+            sv[g][r] = vv;
+        }
+        wsync_lds();
+        double Ir[N2], Gr[N2], y = 0.0;
+#pragma unroll
+        for (int m = 0; m < N2; m++) { Ir[m] = sI[g][rr*N2 + m]; y += Ir[m]*sv[g][m]; }
+#pragma unroll
+        for (int j = 0; j < N2; j++) Gr[j] = 0.0;
+        if (k < nk - 1) {
+#pragma unroll
+            for (int m = 0; m < N2; m++) {
+                const double im = Ir[m];
+#pragma unroll
+                for (int j = 0; j < N2; j++) Gr[j] += im*sU[g][m*N2 + j];
+            }
+        }
+        wsync_lds();                                  // every lane has read sI/sU/sv and the previous sG/sy
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < N2; j++) sG[g][r*N2 + j] = Gr[j];
+            sy[g][r] = y;
+        }
+#pragma unroll
+        for (int j = 0; j < N2; j++) { Gst[j] = Gr[j]; Ist[j] = Ir[j]; }
+        yst = y;
+        wsync_lds();
+    }
+    flush(nk - 1);
+    // back substitution d_k = y_k - G_k d_{k+1}: each lane re-reads its own row of G_k (its own stores)
+    for (int k = nk - 1; k >= 0; k--) {
+        double s = 0.0;
+        if (act) {
+            s = yv[(size_t)k*N2 + r];
+            if (k < nk - 1) {
+                const double* Gk = G + (size_t)k*nn + r*N2;
+#pragma unroll
+                for (int m = 0; m < N2; m++) s -= Gk[m]*sy[g][m];
+            }
+            d[((size_t)e*nk + k)*N2 + r] = s;
+        }
+        wsync();
+        if (act) sy[g][r] = s;
+        wsync();
+    }
+}
+
 // re-solve with the factors of a previous sweep (Dinv_k = D'_k^-1, G_k = D'_k^-1 sup_k): forward y_k = Dinv_k (f_k - sub_k y_{k-1}),
 // backward d_k = y_k - G_k d_{k+1}.  One thread per (column, row), the column's recurrences run in LDS (columns do not interact).
 template <int N2>
@@ -1121,6 +1270,16 @@ __global__ __launch_bounds__(64) void k_block_thomas_resolve(int nEl, int nk, co
 
 int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* Dinv = nullptr) {
     const int n2 = c->es.n2e, nn = n2*n2;
+    static const bool rows = !getenv("MIMSEM_THOMAS_WAVE");          // row-per-lane kernel (4 columns per wavefront); the wave-per-column one stays selectable
+    if (rows && !getenv("MIMSEM_THOMAS_WG") && (n2 == 4 || n2 == 9 || n2 == 16)) {
+        const unsigned grid = (unsigned)((c->nEl + 3)/4);
+        switch (n2) {
+#define MIMSEM_TRW(N) case N: hipLaunchKernelGGL((k_block_thomas_rows<N>), dim3(grid), dim3(64), 0, c->stream, c->nEl, c->nk, L, f, d, Gws, yws, Dinv); \
+                     MIMSEM_HIP_TRY(hipGetLastError()); return MIMSEM_OK;
+        MIMSEM_TRW(4) MIMSEM_TRW(9) MIMSEM_TRW(16)
+#undef MIMSEM_TRW
+        }
+    }
     if (!getenv("MIMSEM_THOMAS_WG")) {
         switch (n2) {
 #define MIMSEM_TW(N) case N: hipLaunchKernelGGL((k_block_thomas_wave<N>), dim3(c->nEl), dim3(64), 0, c->stream, c->nk, L, f, d, Gws, yws, Dinv); \

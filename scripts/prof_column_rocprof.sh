@@ -1,0 +1,13 @@
+#!/bin/bash
+# kernel-level profile of the column Schur sweep (scripts/prof_column.py) -> gpurun_out/prof_col/
+R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_col -o r01 -- python3 $R/scripts/prof_column.py > $R/gpurun_out/prof_col.log 2>&1
+grep -v amdgpu.ids $R/gpurun_out/prof_col.log | tail -1
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open("$R/gpurun_out/prof_col/r01_kernel_stats.csv")))
+tot=sum(int(r["TotalDurationNs"]) for r in rows); calls=sum(int(r["Calls"]) for r in rows)
+print("total kernel ms per sweep", tot/1e6/8, "launches per sweep", calls/8)
+for r in rows[:30]:
+    print("%-90s %5s calls %8.1f us avg %5s%%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"]))
+PY
