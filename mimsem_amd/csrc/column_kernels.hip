@@ -13,6 +13,7 @@
 // factor is block-diagonal or block-bidiagonal, so L_pi is block-tridiagonal -- no
 // sparse mat-mat products, no symbolic phases, no per-column PETSc objects.
 #include <cstdlib>
+#include <cstring>
 #include "ctx.hpp"
 
 #define RD 287.0
@@ -1572,6 +1573,308 @@ __global__ __launch_bounds__(256) void k_schur_interfaces(FusedArgs a) {
     WBk::store(a.Gu + off, Rr, lane);
 }
 
+// ---- the same two fused kernels on ROW-PER-LANE block algebra: 16 lanes per task (4 tasks per wavefront), every block of a task
+// lives in registers (its row r in lane r), Gauss-Jordan as in k_block_thomas_rows (DPP row rotations for the pivot search,
+// bpermute broadcasts of the pivot row, implicit pivoting); LDS only holds the right-hand operand of a product.
+template <int N>
+struct RowBlocks {
+    static constexpr int N2 = N*N, nn = N2*N2, MP1 = N + 1, MP12 = MP1*MP1, GW = 16;
+    static_assert(N2 <= GW, "one lane per block row");
+    // my row of W^T diag(c) W (same association order as WaveBlocks::assemble)
+    __device__ static void assemble(double (&M)[N2], const double* c, const double* sE, int r) {
+        const int iy = r/N, ix = r%N;
+#pragma unroll
+        for (int jy = 0; jy < N; jy++) {
+            double t1[MP1];
+#pragma unroll
+            for (int qx = 0; qx < MP1; qx++) {
+                double s = 0.0;
+#pragma unroll
+                for (int qy = 0; qy < MP1; qy++) s += (sE[qy*N + iy]*c[qy*MP1 + qx])*sE[qy*N + jy];
+                t1[qx] = s;
+            }
+#pragma unroll
+            for (int jx = 0; jx < N; jx++) {
+                double s = 0.0;
+#pragma unroll
+                for (int qx = 0; qx < MP1; qx++) s += (sE[qx*N + ix]*sE[qx*N + jx])*t1[qx];
+                M[jy*N + jx] = s;
+            }
+        }
+    }
+    // T <- my row of T^-1 (natural row order); sI: this task's nn doubles of LDS scratch
+    __device__ static void inverse(double (&T)[N2], double* sI, int r, bool act) {
+        bool used = !act;
+        int myc = 0, piv[N2];
+#pragma unroll
+        for (int c = 0; c < N2; c++) {
+            double cand = used ? -1.0 : fabs(T[c]);
+            int bl = r;
+#define MIMSEM_ARGMAX_ROUND(K) { const double oc = row_ror<K>(cand); const int ol = row_ror<K>(bl); \
+                                 if (oc > cand || (oc == cand && ol < bl)) { cand = oc; bl = ol; } }
+            MIMSEM_ARGMAX_ROUND(1) MIMSEM_ARGMAX_ROUND(2) MIMSEM_ARGMAX_ROUND(4) MIMSEM_ARGMAX_ROUND(8)
+#undef MIMSEM_ARGMAX_ROUND
+            piv[c] = bl;
+            double pr[N2];
+#pragma unroll
+            for (int j = 0; j < N2; j++) pr[j] = __shfl(T[j], bl, GW);
+            const double pinv = 1.0/pr[c];
+            if (r == bl) {
+#pragma unroll
+                for (int j = 0; j < N2; j++) T[j] = pr[j]*pinv;
+                T[c] = pinv; used = true; myc = c;
+            } else {
+                const double fct = T[c];
+#pragma unroll
+                for (int j = 0; j < N2; j++) T[j] -= fct*(pr[j]*pinv);
+                T[c] = -fct*pinv;
+            }
+        }
+        wsync_lds();                                 // earlier readers of sI are done
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < N2; c++) sI[myc*N2 + piv[c]] = T[c];
+        }
+        wsync_lds();
+        const int rr = act ? r : 0;
+#pragma unroll
+        for (int m = 0; m < N2; m++) T[m] = sI[rr*N2 + m];
+    }
+    // publish my row of a block as the right-hand operand of the next product(s)
+    __device__ static void put(double* sB, const double (&R)[N2], int r, bool act) {
+        wsync_lds();
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < N2; j++) sB[r*N2 + j] = R[j];
+        }
+        wsync_lds();
+    }
+    // my row of alpha * A . B  (A: my row in registers, B: published in LDS)
+    __device__ static void mul(double (&C)[N2], const double (&A)[N2], const double* sB, double alpha) {
+#pragma unroll
+        for (int j = 0; j < N2; j++) C[j] = 0.0;
+#pragma unroll
+        for (int m = 0; m < N2; m++) {
+            const double am = A[m];
+#pragma unroll
+            for (int j = 0; j < N2; j++) C[j] += am*sB[m*N2 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < N2; j++) C[j] *= alpha;
+    }
+    __device__ static void store(double* dst, const double (&R)[N2], int r, bool act) {
+        if (!act) return;
+#pragma unroll
+        for (int j = 0; j < N2; j++) dst[r*N2 + j] = R[j];
+    }
+    // global <-> LDS as ONE contiguous run per block: the 16 lanes of the task move nn consecutive doubles (a lane reading or
+    // writing its own row touches 9 doubles at a stride of 9 -- nine partially used transactions per row)
+    static constexpr int CHUNKS = (nn + GW - 1)/GW;
+    __device__ static void copy_in(double* sDst, const double* src, int r, bool live) {           // no sync: caller publishes
+#pragma unroll
+        for (int i = 0; i < CHUNKS; i++) { const int x = r + GW*i; if (x < nn) sDst[x] = live ? src[x] : 0.0; }
+    }
+    __device__ static void row_of(double (&R)[N2], const double* sSrc, int rr) {
+#pragma unroll
+        for (int j = 0; j < N2; j++) R[j] = sSrc[rr*N2 + j];
+    }
+    // my row -> scratch block in LDS -> one contiguous run in global memory
+    __device__ static void store_block(double* dst, double* sTmp, const double (&R)[N2], int r, bool act, bool live) {
+        put(sTmp, R, r, act);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < CHUNKS; i++) { const int x = r + GW*i; if (x < nn) dst[x] = sTmp[x]; }
+        }
+    }
+};
+
+template <int N>
+__global__ __launch_bounds__(64) void k_schur_levels_rows(FusedArgs a) {
+    using RB = RowBlocks<N>;
+    constexpr int N2 = RB::N2, nn = RB::nn, MP1 = RB::MP1, MP12 = RB::MP12, TPB = 4;
+    __shared__ double sE[MP1*N], sw[MP1], cq[TPB][3*MP12], sB[TPB][nn], sT[TPB][nn], sI[TPB][nn];
+    const CG& g = a.g;
+    const int lane = threadIdx.x, t = lane/16, r = lane%16;
+    if (lane < MP1*N) sE[lane] = g.E[lane];
+    if (lane < MP1) sw[lane] = g.w[lane];
+    __syncthreads();
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)g.nEl*g.nk;
+    const bool live = task0 < ntask, act = live && r < N2;
+    const long long task = live ? task0 : ntask - 1;
+    const int k = (int)(task%g.nk), e = (int)(task/g.nk), rr = r < N2 ? r : 0;
+    CG gl = g; gl.E = sE; gl.w = sw;
+    for (int q = r; q < MP12; q += 16) {
+        cq[t][q]          = colop_coef(gl, MIMSEM_V_CONST, 0, e, k, 0, q, nullptr, nullptr);
+        cq[t][MP12 + q]   = colop_coef(gl, MIMSEM_V_CONST_RHO, 0, e, k, 0, q, a.pi, nullptr);
+        cq[t][2*MP12 + q] = colop_coef(gl, MIMSEM_V_CONST_RHO, 0, e, k, 0, q, a.rho, nullptr);
+    }
+    wsync_lds();
+    const size_t off = ((size_t)e*g.nk + k)*nn;
+    double Bk[N2], T[N2], t1[N2], t2[N2];
+    RB::assemble(Bk, cq[t], sE, rr);
+    RB::store(a.B + off, Bk, r, act);
+    RB::put(sB[t], Bk, r, act);                          // B stays published for the whole task
+#pragma unroll
+    for (int j = 0; j < N2; j++) T[j] = Bk[j];
+    RB::inverse(T, sI[t], r, act);
+    RB::store(a.Binv + off, T, r, act);
+#pragma unroll 1
+    for (int which = 0; which < 2; which++) {
+        RB::assemble(T, cq[t] + (1 + which)*MP12, sE, rr);
+        RB::inverse(T, sI[t], r, act);
+        RB::mul(t1, T, sB[t], 1.0);                      // B(f)^-1 B
+        RB::put(sT[t], t1, r, act);
+        RB::mul(t2, Bk, sT[t], 1.0);                     // B (B(f)^-1 B)
+        RB::store((which ? a.Nrho : a.Npi) + off, t2, r, act);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_schur_interfaces_rows(FusedArgs a) {
+    using RB = RowBlocks<N>;
+    constexpr int N2 = RB::N2, nn = RB::nn, MP1 = RB::MP1, MP12 = RB::MP12, TPB = 4;
+    __shared__ double sE[MP1*N], sw[MP1], cq[TPB][3*MP12], sB[TPB][nn], sT[TPB][nn], sI[TPB][nn], sv[TPB][N2];
+    const CG& g = a.g;
+    const int nk = g.nk, nm = nk - 1;
+    const int lane = threadIdx.x, t = lane/16, r = lane%16;
+    if (lane < MP1*N) sE[lane] = g.E[lane];
+    if (lane < MP1) sw[lane] = g.w[lane];
+    __syncthreads();
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)g.nEl*nm;
+    const bool live = task0 < ntask, act = live && r < N2;
+    const long long task = live ? task0 : ntask - 1;
+    const int i = (int)(task%nm), e = (int)(task/nm), rr = r < N2 ? r : 0;
+    CG gl = g; gl.E = sE; gl.w = sw;
+    for (int q = r; q < MP12; q += 16) {
+        cq[t][q]          = colop_coef(gl, MIMSEM_V_LINEAR_INV, 0, e, i, 0, q, nullptr, nullptr);
+        cq[t][MP12 + q]   = colop_coef(gl, MIMSEM_V_LINEAR_RT, MIMSEM_FLAG_VERT, e, i, 0, q, a.theta, nullptr);
+        cq[t][2*MP12 + q] = colop_coef(gl, MIMSEM_V_LINEAR_RT, MIMSEM_FLAG_VERT, e, i, 0, q, a.rho, nullptr);
+    }
+    wsync_lds();
+    const size_t off = ((size_t)e*nm + i)*nn;
+    // ordered so that few blocks are live at a time (each is 2 N2 VGPRs): A^-1 first, VA(rho) only for X, VA(theta) last
+    double Ai[N2], R[N2], t1[N2];
+    RB::assemble(Ai, cq[t], sE, rr);
+    RB::inverse(Ai, sI[t], r, act);
+    RB::store(a.Ainv + off, Ai, r, act);
+    RB::assemble(R, cq[t] + 2*MP12, sE, rr);
+    RB::put(sT[t], R, r, act);
+    RB::mul(t1, Ai, sT[t], 1.0);                          // X = VA_inv VA(rho)
+    RB::store(a.X + off, t1, r, act);
+    {
+        double B0[N2], B1[N2];
+        const double* b0 = a.B + ((size_t)e*nk + i)*nn + rr*N2;
+#pragma unroll
+        for (int j = 0; j < N2; j++) { B0[j] = b0[j]; B1[j] = b0[nn + j]; }
+        // grad f = A^-1 (B_{i+1} f_{i+1} - B_i f_i)  for f = pi, eta
+#pragma unroll 1
+        for (int which = 0; which < 2; which++) {
+            const double* f0 = (which ? a.eta : a.pi) + ((size_t)e*nk + i)*N2;
+            double s = 0.0, s0 = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) s += B1[m]*f0[N2 + m];
+#pragma unroll
+            for (int m = 0; m < N2; m++) s0 += B0[m]*f0[m];
+            wsync_lds();
+            if (act) sv[t][r] = s - s0;
+            wsync_lds();
+            double gsum = 0.0;
+#pragma unroll
+            for (int m = 0; m < N2; m++) gsum += Ai[m]*sv[t][m];
+            if (act) (which ? a.geta : a.gpi)[((size_t)e*nm + i)*N2 + r] = gsum;
+        }
+        RB::put(sT[t], B0, r, act);
+        RB::mul(t1, Ai, sT[t], 1.0);                      // A^-1 B_i
+        RB::put(sB[t], t1, r, act);
+        RB::put(sT[t], B1, r, act);
+        RB::mul(t1, Ai, sT[t], 1.0);                      // A^-1 B_{i+1}
+        RB::put(sI[t], t1, r, act);                       // (the inverse scratch is free by now)
+    }
+    RB::assemble(R, cq[t] + MP12, sE, rr);                // T = VA(theta)
+    RB::mul(t1, R, sB[t], -a.hdt);                        // G(i,i)   = -h T A^-1 B_i
+    RB::store(a.Gl + off, t1, r, act);
+    RB::mul(t1, R, sI[t], +a.hdt);                        // G(i,i+1) = +h T A^-1 B_{i+1}
+    RB::store(a.Gu + off, t1, r, act);
+}
+
+// level k of column e, after the interface factors exist: the two DIV blocks of the row (scaled by the lumped inverse of L_eta)
+// and the three blocks of the Helmholtz row  L_pi = N_pi - gam DIV G_pi  (VertSolve.cpp:754-767) -- what the pipeline of wide
+// kernels does with two batched products, a scaling pass and k_helmholtz_rows; no intermediate block leaves the chip.
+struct RowsArgs {
+    int nEl, nk; double hdt, gam;
+    const double *Nrho, *Npi, *X, *Cw, *rl, *Gl, *Gu;
+    double *DIVl, *DIVu, *L;
+};
+template <int N>
+__global__ __launch_bounds__(64) void k_schur_rows(RowsArgs a) {
+    using RB = RowBlocks<N>;
+    constexpr int N2 = RB::N2, nn = RB::nn, TPB = 4;
+    __shared__ double sX[TPB][2][nn], sGl[TPB][2][nn], sGu[TPB][2][nn];      // [.][0]: interface k-1, [.][1]: interface k
+    const int nk = a.nk, nm = nk - 1;
+    const int lane = threadIdx.x, t = lane/16, r = lane%16;
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)a.nEl*nk;
+    const bool live = task0 < ntask, act = live && r < N2;
+    const long long task = live ? task0 : ntask - 1;
+    const int k = (int)(task%nk), e = (int)(task/nk), rr = r < N2 ? r : 0;
+    const bool lo = k > 0, hi = k < nk - 1;
+    {   // the six right-hand operand blocks come in as contiguous runs (16 lanes x 8 B): measured 358 -> 308 us against row-wise loads
+        const size_t om = ((size_t)e*nm + (lo ? k - 1 : 0))*nn, ok = ((size_t)e*nm + (hi ? k : 0))*nn;
+        RB::copy_in(sX[t][0], a.X + om, r, live && lo);   RB::copy_in(sX[t][1], a.X + ok, r, live && hi);
+        RB::copy_in(sGl[t][0], a.Gl + om, r, live && lo); RB::copy_in(sGl[t][1], a.Gl + ok, r, live && hi);
+        RB::copy_in(sGu[t][0], a.Gu + om, r, live && lo); RB::copy_in(sGu[t][1], a.Gu + ok, r, live && hi);
+    }
+    const size_t offk = ((size_t)e*nk + k)*nn + rr*N2;
+    double Nr[N2], Dl[N2], Du[N2], tt[N2], t2[N2];
+#pragma unroll
+    for (int j = 0; j < N2; j++) Nr[j] = a.Nrho[offk + j];
+    wsync_lds();
+    // DIV(k,k-1) = (-h N_rho,k X_{k-1} + h C_{k,0}) diag(rlump_{k-1}),  DIV(k,k) = (+h N_rho,k X_k + h C_{k,1}) diag(rlump_k)
+    RB::mul(tt, Nr, sX[t][0], -a.hdt);
+    {
+        const double* c0 = a.Cw + ((size_t)e*2*nk + 2*k)*nn + rr*N2;
+        const double* rl = a.rl + ((size_t)e*nm + (lo ? k - 1 : 0))*N2;
+#pragma unroll
+        for (int j = 0; j < N2; j++) Dl[j] = lo ? (tt[j] + a.hdt*c0[j])*rl[j] : 0.0;
+    }
+    RB::mul(tt, Nr, sX[t][1], +a.hdt);
+    {
+        const double* c1 = a.Cw + ((size_t)e*2*nk + 2*k + 1)*nn + rr*N2;
+        const double* rl = a.rl + ((size_t)e*nm + (hi ? k : 0))*N2;
+#pragma unroll
+        for (int j = 0; j < N2; j++) Du[j] = hi ? (tt[j] + a.hdt*c1[j])*rl[j] : 0.0;
+    }
+    RB::store(a.DIVl + ((size_t)e*nk + k)*nn, Dl, r, act);
+    RB::store(a.DIVu + ((size_t)e*nk + k)*nn, Du, r, act);
+    double* Lk = a.L + ((size_t)e*nk + k)*3*nn;
+    RB::mul(tt, Dl, sGl[t][0], -a.gam);                   // L(k,k-1) = -gam DIV(k,k-1) G(k-1,k-1)
+    RB::store(Lk, tt, r, act);
+    RB::mul(tt, Du, sGu[t][1], -a.gam);                   // L(k,k+1) = -gam DIV(k,k)   G(k,k+1)
+    RB::store(Lk + 2*nn, tt, r, act);
+    RB::mul(tt, Dl, sGu[t][0], 1.0);                      // DIV(k,k-1) G(k-1,k)
+    RB::mul(t2, Du, sGl[t][1], 1.0);                      // DIV(k,k)   G(k,k)
+#pragma unroll
+    for (int j = 0; j < N2; j++) tt[j] = (-1.0*a.gam)*(tt[j] + t2[j]) + a.Npi[offk + j];
+    RB::store(Lk + nn, tt, r, act);
+}
+
+template <int N>
+int launch_schur_rows(mimsem_ctx* c, const RowsArgs& a) {
+    const long long tl = (long long)a.nEl*a.nk;
+    hipLaunchKernelGGL((k_schur_rows<N>), dim3((unsigned)((tl + 3)/4)), dim3(64), 0, c->stream, a);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+template <int N>
+int launch_schur_fused_rows(mimsem_ctx* c, const FusedArgs& a) {
+    const CG& g = a.g;
+    const long long tl = (long long)g.nEl*g.nk, ti = (long long)g.nEl*(g.nk - 1);
+    hipLaunchKernelGGL((k_schur_levels_rows<N>), dim3((unsigned)((tl + 3)/4)), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL((k_schur_interfaces_rows<N>), dim3((unsigned)((ti + 3)/4)), dim3(64), 0, c->stream, a);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 template <int N2>
 int launch_schur_fused(mimsem_ctx* c, const FusedArgs& a) {
     const CG& g = a.g;
@@ -1751,6 +2054,7 @@ struct Schur {
     BA B, Binv, Ainv, T, Rr, X, Npi, Nrho, R2, C2, DIVl, DIVu, Gl, Gu, M1, L, G, AB0, AB1;
     double *gpi, *geta, *rlump, *tA, *tB, *tC;
     bool fused = false;            // G_pi (Gl, Gu) already built by k_schur_interfaces
+    bool rows = false;             // ... by the row-per-lane kernels: DIV and the Helmholtz rows follow in k_schur_rows
 };
 
 // assemble every factor of the Helmholtz operator; see the derivation in DESIGN.md ("C5")
@@ -1775,7 +2079,11 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
     S.tC = w.take((long long)nEl*nk*n2);
     if (w.used > w.cap) return MIMSEM_ERR_STATE;
 
-    if ((n2 == 4 || n2 == 9 || n2 == 16) && getenv("MIMSEM_SCHUR_FUSED")) {
+    // fused assembly of the level / interface factors: default = the row-per-lane kernels where their blocks fit the register
+    // file without spilling (2x2, 3x3 faces); "0" = the pipeline of wide kernels, "wave" = the earlier one-wave-per-task kernels
+    const char* fmode = getenv("MIMSEM_SCHUR_FUSED");
+    if (!fmode) fmode = (n2 == 4 || n2 == 9) ? "rows" : "0";
+    if ((n2 == 4 || n2 == 9 || n2 == 16) && strcmp(fmode, "0") != 0) {
         // fused path: one wave per (column, level) / (column, interface), intermediates in LDS.  Measured SLOWER than the
         // pipeline of wide kernels below (2 x 0.70 ms for what costs 1.0 ms there: three wave-cooperative Gauss-Jordan sweeps
         // per task are latency-bound, the thread-per-block register inverse is not) -- profiles/r01_schur_fused_ab.txt; opt-in.
@@ -1783,10 +2091,13 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
         fa.g = make_cg(c); fa.hdt = 0.5*dt; fa.theta = theta; fa.rho = rho; fa.eta = eta; fa.pi = pi;
         fa.B = S.B.p; fa.Binv = S.Binv.p; fa.Npi = S.Npi.p; fa.Nrho = S.Nrho.p;
         fa.Ainv = S.Ainv.p; fa.X = S.X.p; fa.Gl = S.Gl.p; fa.Gu = S.Gu.p; fa.gpi = S.gpi; fa.geta = S.geta;
-        if ((rc = (n2 == 4 ? launch_schur_fused<4>(c, fa) : (n2 == 9 ? launch_schur_fused<9>(c, fa) : launch_schur_fused<16>(c, fa))))) return rc;
+        const bool rows = strcmp(fmode, "wave") != 0;
+        if (rows) rc = (n2 == 4 ? launch_schur_fused_rows<2>(c, fa) : (n2 == 9 ? launch_schur_fused_rows<3>(c, fa) : launch_schur_fused_rows<4>(c, fa)));
+        else rc = (n2 == 4 ? launch_schur_fused<4>(c, fa) : (n2 == 9 ? launch_schur_fused<9>(c, fa) : launch_schur_fused<16>(c, fa)));
+        if (rc) return rc;
         if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_RHODPI, 0, theta, S.gpi, R2.p, cq, tmpM))) return rc;       // :701
         if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_W, 0, S.geta, nullptr, C2.p, cq, tmpM))) return rc;         // :730
-        S.fused = true;
+        S.fused = true; S.rows = rows;
         return MIMSEM_OK;
     }
     // VB, VB_inv, VA_inv   (VertSolve.cpp:690-692)
@@ -1906,6 +2217,10 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
             for (int k = 0; k < n2; k++) s += m[a*n2 + k]*(hdt*Ci[k*n2 + a]);
             rl[x] = 1.0/(-1.0*s + va);
         }))) return rc;
+    }
+    if (S.rows) {
+        RowsArgs ra{nEl, nk, hdt, gam, S.Nrho.p, S.Npi.p, S.X.p, C2.p, S.rlump, S.Gl.p, S.Gu.p, S.DIVl.p, S.DIVu.p, S.L.p};
+        return n2 == 4 ? launch_schur_rows<2>(c, ra) : (n2 == 9 ? launch_schur_rows<3>(c, ra) : launch_schur_rows<4>(c, ra));
     }
     // DIV (N x Nm), row k:  DIVl_k = (k,k-1),  DIVu_k = (k,k)                           (:754-761)
     //   = 0.5dt ( -+ CM_k B_k X_j ) + 0.5dt C_j , then column-scaled by rlump_j ;  CM_k B_k = N_rho_k Binv_k B_k = N_rho_k

@@ -298,8 +298,10 @@ def test_vertical_incidence(setup):
     assert np.array_equal(eng.column_incidence("V10_full", eng.tensor(xp)).cpu().numpy(), xp @ V10f.T)
 
 
-def test_fused_schur_assembly_matches_default(setup, monkeypatch):
-    """the opt-in fused assembly of the Schur factors (one wave per (column, level) / (column, interface)) gives the default result"""
+@pytest.mark.parametrize("mode", ["rows", "wave", "0"])
+def test_fused_schur_assembly_matches_default(setup, monkeypatch, mode):
+    """the fused assembly of the Schur factors -- row-per-lane (16 lanes per (column, level) / (column, interface) task) or the
+    earlier one-wave-per-task kernels -- and the unfused pipeline ("0") give the same Helmholtz operator and solution"""
     eng, P = setup
     if P.n2e not in (4, 9, 16):
         pytest.skip("fused kernels are built for 2x2, 3x3, 4x4 blocks")
@@ -311,7 +313,7 @@ def test_fused_schur_assembly_matches_default(setup, monkeypatch):
     args = (75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]))
     base = eng.solve_schur_eta(*args, *[t(f) for f in Fs])
     L0 = eng.helmholtz_blocks(*args)
-    monkeypatch.setenv("MIMSEM_SCHUR_FUSED", "1")
+    monkeypatch.setenv("MIMSEM_SCHUR_FUSED", mode)
     alt = eng.solve_schur_eta(*args, *[t(f) for f in Fs])
     L1 = eng.helmholtz_blocks(*args)
     assert rel_l2(L1.cpu().numpy(), L0.cpu().numpy()) < 1e-9
