@@ -327,6 +327,11 @@ def main():
                            "traffic_note": "bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/pmc_traffic.json",
                            "algorithmic_bytes_per_launch": units_rank * BYTES_K1_B1,
                            "avg_kernel_us": k1 * 1e6, "bytes_per_unit": BYTES_K1_B1, "units_per_launch": units_rank}
+        if traffic1:
+            # the same kernel time against the bytes the PMC counters saw: < achieved because the level-invariant Jacobian /
+            # determinant (640 of the 1 248 algorithmic bytes per unit) are read once per element and level chunk, not once per unit
+            out["roofline"]["traffic_GBs"] = traffic1 / k1 / 1e9
+            out["roofline"]["traffic_frac"] = traffic1 / k1 / 1e9 / HBM_PEAK_GBS
         a12 = units_rank * BYTES_OP_B1 / k12 / 1e9
         out["roofline_op"] = {"bound": "hbm", "kernels": "k_elem_apply<3,UMAT> + k_gather_sum<2>", "achieved": a12,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a12 / HBM_PEAK_GBS,
