@@ -1464,6 +1464,8 @@ struct FusedArgs {
     const double *theta, *rho, *eta, *pi;
     double *B, *Binv, *Npi, *Nrho;                 // level outputs   [nEl][nk][nn]
     double *Ainv, *X, *Gl, *Gu, *gpi, *geta;       // interface outputs [nEl][nk-1][nn] / [nEl][nk-1][n2]
+    // row-per-lane path with a right-hand side: tE = VB^-1 F_eta, tR = VB^-1 F_rho per level, while VB^-1 is in registers
+    const double *F_eta = nullptr, *F_rho = nullptr; double *tE = nullptr, *tR = nullptr;
 };
 
 // level k of column e: B = VB, Binv = VB^-1, N_pi = B B(pi)^-1 B, N_rho = B B(rho)^-1 B     (VertSolve.cpp:690-692, :736-739)
@@ -1718,6 +1720,13 @@ __global__ __launch_bounds__(64) void k_schur_levels_rows(FusedArgs a) {
     for (int j = 0; j < N2; j++) T[j] = Bk[j];
     RB::inverse(T, sI[t], r, act);
     RB::store(a.Binv + off, T, r, act);
+    if (a.F_eta) {                                       // (VertSolve.cpp:772, :777: VB_inv F_eta, VB_inv F_rho)
+        const double* fe = a.F_eta + ((size_t)e*g.nk + k)*N2; const double* fr = a.F_rho + ((size_t)e*g.nk + k)*N2;
+        double se = 0.0, sr = 0.0;
+#pragma unroll
+        for (int m = 0; m < N2; m++) { se += T[m]*fe[m]; sr += T[m]*fr[m]; }
+        if (act) { a.tE[((size_t)e*g.nk + k)*N2 + r] = se; a.tR[((size_t)e*g.nk + k)*N2 + r] = sr; }
+    }
 #pragma unroll 1
     for (int which = 0; which < 2; which++) {
         RB::assemble(T, cq[t] + (1 + which)*MP12, sE, rr);
@@ -1804,6 +1813,8 @@ struct RowsArgs {
     int nEl, nk; double hdt, gam;
     const double *Nrho, *Npi, *X, *Cw, *rl, *Gl, *Gu;
     double *DIVl, *DIVu, *L;
+    // optional: F_pi = -F_pi + gam DIV F_u - gam CM F_rho - gam F_eta  (:775-780), tR = VB^-1 F_rho, F_u already updated
+    double* F_pi = nullptr; const double *F_u = nullptr, *tR = nullptr, *F_eta = nullptr;
 };
 template <int N>
 __global__ __launch_bounds__(64) void k_schur_rows(RowsArgs a) {
@@ -1845,6 +1856,26 @@ __global__ __launch_bounds__(64) void k_schur_rows(RowsArgs a) {
     }
     RB::store(a.DIVl + ((size_t)e*nk + k)*nn, Dl, r, act);
     RB::store(a.DIVu + ((size_t)e*nk + k)*nn, Du, r, act);
+    if (a.F_pi) {
+        double div = 0.0, cm = 0.0;
+        if (lo) { const double* v = a.F_u + ((size_t)e*nm + k - 1)*N2;
+#pragma unroll
+                  for (int p = 0; p < N2; p++) div += Dl[p]*v[p]; }
+        if (hi) { const double* v = a.F_u + ((size_t)e*nm + k)*N2;
+#pragma unroll
+                  for (int p = 0; p < N2; p++) div += Du[p]*v[p]; }
+        const double* v = a.tR + ((size_t)e*nk + k)*N2;
+#pragma unroll
+        for (int p = 0; p < N2; p++) cm += Nr[p]*v[p];
+        if (act) {
+            const size_t x = ((size_t)e*nk + k)*N2 + r;
+            double f = -1.0*a.F_pi[x];
+            f += (+1.0*a.gam)*div;
+            f += (-1.0*a.gam)*cm;
+            f += (-1.0*a.gam)*a.F_eta[x];
+            a.F_pi[x] = f;
+        }
+    }
     double* Lk = a.L + ((size_t)e*nk + k)*3*nn;
     RB::mul(tt, Dl, sGl[t][0], -a.gam);                   // L(k,k-1) = -gam DIV(k,k-1) G(k-1,k-1)
     RB::store(Lk, tt, r, act);
@@ -1855,6 +1886,125 @@ __global__ __launch_bounds__(64) void k_schur_rows(RowsArgs a) {
 #pragma unroll
     for (int j = 0; j < N2; j++) tt[j] = (-1.0*a.gam)*(tt[j] + t2[j]) + a.Npi[offk + j];
     RB::store(Lk + nn, tt, r, act);
+}
+
+// interface i of column e: the scalar lumped inverse of  L_eta = VA - (G_rt VB_inv) A_eta  (VertSolve.cpp:742-751).  The block
+// M1_i = h (R^t_i Binv_i + R^b_{i+1} Binv_{i+1}) is only ever needed for this diagonal, so it stays in registers.
+struct LumpArgs {
+    CG g; double hdt;
+    const double *R2, *Binv, *Cw;          // RHODPI blocks [nEl][2 nk][nn], VB^-1 [nEl][nk][nn], CONLIN_W blocks [nEl][2 nk][nn]
+    double* rl;                            // [nEl][nk-1][n2]
+    double* F_u = nullptr; const double* tE = nullptr;      // optional: F_u -= (G_rt VB_inv) F_eta  (:772-773), tE = VB^-1 F_eta
+};
+template <int N>
+__global__ __launch_bounds__(64) void k_schur_lump_rows(LumpArgs a) {
+    using RB = RowBlocks<N>;
+    constexpr int N2 = RB::N2, nn = RB::nn, MP1 = RB::MP1, MP12 = RB::MP12, TPB = 4;
+    __shared__ double sE[MP1*N], sw[MP1], cq[TPB][MP12], sB0[TPB][nn], sB1[TPB][nn], sC[TPB][nn];
+    const CG& g = a.g;
+    const int nk = g.nk, nm = nk - 1;
+    const int lane = threadIdx.x, t = lane/16, r = lane%16;
+    if (lane < MP1*N) sE[lane] = g.E[lane];
+    if (lane < MP1) sw[lane] = g.w[lane];
+    __syncthreads();
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)g.nEl*nm;
+    const bool live = task0 < ntask, act = live && r < N2;
+    const long long task = live ? task0 : ntask - 1;
+    const int i = (int)(task%nm), e = (int)(task/nm), rr = r < N2 ? r : 0;
+    CG gl = g; gl.E = sE; gl.w = sw;
+    for (int q = r; q < MP12; q += 16) cq[t][q] = colop_coef(gl, MIMSEM_V_LINEAR, 0, e, i, 0, q, nullptr, nullptr);
+    RB::copy_in(sB0[t], a.Binv + ((size_t)e*nk + i)*nn, r, live);
+    RB::copy_in(sB1[t], a.Binv + ((size_t)e*nk + i + 1)*nn, r, live);
+    RB::copy_in(sC[t], a.Cw + ((size_t)e*2*nk + 2*i + 1)*nn, r, live);
+    double Rt[N2], Rb[N2], m0[N2], m1[N2];
+    const double* rt = a.R2 + ((size_t)e*2*nk + 2*i + 1)*nn + rr*N2;
+#pragma unroll
+    for (int j = 0; j < N2; j++) { Rt[j] = rt[j]; Rb[j] = rt[nn + j]; }          // R^b_{i+1} = R2[2(i+1)] is the next stored block
+    wsync_lds();
+    RB::mul(m0, Rt, sB0[t], 1.0);
+    RB::mul(m1, Rb, sB1[t], 1.0);
+    double s = 0.0, va = 0.0;
+#pragma unroll
+    for (int k = 0; k < N2; k++) s += (a.hdt*(m0[k] + m1[k]))*(a.hdt*sC[t][k*N2 + rr]);
+#pragma unroll
+    for (int q = 0; q < MP12; q++) {
+        const double wq = sE[(q%MP1)*N + rr%N]*sE[(q/MP1)*N + rr/N];
+        va += (wq*cq[t][q])*wq;
+    }
+    if (act) a.rl[((size_t)e*nm + i)*N2 + r] = 1.0/(-1.0*s + va);
+    if (a.F_u) {
+        const double* v0 = a.tE + ((size_t)e*nk + i)*N2;
+        double su = 0.0;
+#pragma unroll
+        for (int k = 0; k < N2; k++) su += Rt[k]*v0[k] + Rb[k]*v0[N2 + k];
+        if (act) a.F_u[((size_t)e*nm + i)*N2 + r] += -1.0*(a.hdt*su);
+    }
+}
+
+template <int N>
+int launch_schur_lump(mimsem_ctx* c, const LumpArgs& a) {
+    const long long ti = (long long)a.g.nEl*(a.g.nk - 1);
+    hipLaunchKernelGGL((k_schur_lump_rows<N>), dim3((unsigned)((ti + 3)/4)), dim3(64), 0, c->stream, a);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+// level k of column e, after the Helmholtz solve and d_u: the rest of the back substitution in one pass (VertSolve.cpp:800-815)
+//   F_eta <- -(F_eta + A_eta d_u),  d_eta = VB^-1 F_eta;   F_rho <- -(F_rho + h VB (V10 X d_u)),  d_rho = VB^-1 F_rho
+// -- five launches of the wide pipeline (two of them re-reading VB^-1); one lane per block row, vectors exchanged through LDS.
+struct BackArgs {
+    int nEl, nk; double hdt;
+    const double *Cw, *X, *B, *Binv, *d_u;
+    double *F_eta, *F_rho, *d_eta, *d_rho;
+};
+template <int N>
+__global__ __launch_bounds__(64) void k_schur_backsub_rows(BackArgs a) {
+    constexpr int N2 = N*N, nn = N2*N2, TPB = 4;
+    __shared__ double sv[TPB][3][N2];
+    const int nk = a.nk, nm = nk - 1;
+    const int lane = threadIdx.x, t = lane/16, r = lane%16;
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)a.nEl*nk;
+    const bool live = task0 < ntask, act = live && r < N2;
+    const long long task = live ? task0 : ntask - 1;
+    const int k = (int)(task%nk), e = (int)(task/nk), rr = r < N2 ? r : 0;
+    const bool lo = k > 0, hi = k < nk - 1;
+    const double* dum = a.d_u + ((size_t)e*nm + (lo ? k - 1 : 0))*N2;      // d_u on the interface below / above this level
+    const double* duk = a.d_u + ((size_t)e*nm + (hi ? k : 0))*N2;
+    const size_t x = ((size_t)e*nk + k)*N2 + rr;
+    // F_eta += A_eta d_u   (A_eta = h CONLIN_W, stored [k][2]: (k,k-1), (k,k))
+    double s = 0.0, xm = 0.0, xk = 0.0;
+    if (lo) {
+        const double* m = a.Cw + ((size_t)e*2*nk + 2*k)*nn + rr*N2; const double* xr = a.X + ((size_t)e*nm + k - 1)*nn + rr*N2;
+#pragma unroll
+        for (int p = 0; p < N2; p++) { s += (a.hdt*m[p])*dum[p]; xm += xr[p]*dum[p]; }
+    }
+    if (hi) {
+        const double* m = a.Cw + ((size_t)e*2*nk + 2*k + 1)*nn + rr*N2; const double* xr = a.X + ((size_t)e*nm + k)*nn + rr*N2;
+#pragma unroll
+        for (int p = 0; p < N2; p++) { s += (a.hdt*m[p])*duk[p]; xk += xr[p]*duk[p]; }
+    }
+    const double fe = -1.0*(a.F_eta[x] + s);
+    if (act) { a.F_eta[x] = fe; sv[t][0][r] = fe; sv[t][1][r] = xk - xm; }       // (V10 X d_u)_k = X_k du_k - X_{k-1} du_{k-1}
+    wsync_lds();
+    const double* bi = a.Binv + ((size_t)e*nk + k)*nn + rr*N2;
+    const double* bk = a.B + ((size_t)e*nk + k)*nn + rr*N2;
+    double Bi[N2], de = 0.0, sb = 0.0;
+#pragma unroll
+    for (int m = 0; m < N2; m++) { Bi[m] = bi[m]; de += Bi[m]*sv[t][0][m]; sb += bk[m]*sv[t][1][m]; }
+    const double fr = -1.0*(a.F_rho[x] + a.hdt*sb);
+    if (act) { a.d_eta[x] = de; a.F_rho[x] = fr; sv[t][2][r] = fr; }
+    wsync_lds();
+    double dr = 0.0;
+#pragma unroll
+    for (int m = 0; m < N2; m++) dr += Bi[m]*sv[t][2][m];
+    if (act) a.d_rho[x] = dr;
+}
+template <int N>
+int launch_schur_backsub(mimsem_ctx* c, const BackArgs& a) {
+    const long long tl = (long long)a.nEl*a.nk;
+    hipLaunchKernelGGL((k_schur_backsub_rows<N>), dim3((unsigned)((tl + 3)/4)), dim3(64), 0, c->stream, a);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
 }
 
 template <int N>
@@ -2055,6 +2205,9 @@ struct Schur {
     double *gpi, *geta, *rlump, *tA, *tB, *tC;
     bool fused = false;            // G_pi (Gl, Gu) already built by k_schur_interfaces
     bool rows = false;             // ... by the row-per-lane kernels: DIV and the Helmholtz rows follow in k_schur_rows
+    // right-hand sides of the solve (null for mimsem_column_helmholtz_blocks); the row-per-lane kernels update them on the way
+    double *F_u = nullptr, *F_pi = nullptr; const double *F_eta = nullptr, *F_rho = nullptr;
+    bool rhs_done = false;
 };
 
 // assemble every factor of the Helmholtz operator; see the derivation in DESIGN.md ("C5")
@@ -2091,6 +2244,7 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
         fa.g = make_cg(c); fa.hdt = 0.5*dt; fa.theta = theta; fa.rho = rho; fa.eta = eta; fa.pi = pi;
         fa.B = S.B.p; fa.Binv = S.Binv.p; fa.Npi = S.Npi.p; fa.Nrho = S.Nrho.p;
         fa.Ainv = S.Ainv.p; fa.X = S.X.p; fa.Gl = S.Gl.p; fa.Gu = S.Gu.p; fa.gpi = S.gpi; fa.geta = S.geta;
+        if (S.F_u && strcmp(fmode, "wave") != 0) { fa.F_eta = S.F_eta; fa.F_rho = S.F_rho; fa.tE = S.tA; fa.tR = S.tC; }
         const bool rows = strcmp(fmode, "wave") != 0;
         if (rows) rc = (n2 == 4 ? launch_schur_fused_rows<2>(c, fa) : (n2 == 9 ? launch_schur_fused_rows<3>(c, fa) : launch_schur_fused_rows<4>(c, fa)));
         else rc = (n2 == 4 ? launch_schur_fused<4>(c, fa) : (n2 == 9 ? launch_schur_fused<9>(c, fa) : launch_schur_fused<16>(c, fa)));
@@ -2177,6 +2331,15 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
     int rc;
     if ((rc = schur_assemble(c, dt, theta, rho, eta, pi, S))) return rc;
     BA R2 = S.R2, C2 = S.C2;
+    if (S.rows) {
+        // row-per-lane path: the lumped inverse straight from R2, VB^-1 and CONLIN_W (M1 never stored), then DIV + Helmholtz rows
+        LumpArgs la{make_cg(c), hdt, R2.p, S.Binv.p, C2.p, S.rlump};
+        if (S.F_u) { la.F_u = S.F_u; la.tE = S.tA; }
+        if ((rc = (n2 == 4 ? launch_schur_lump<2>(c, la) : (n2 == 9 ? launch_schur_lump<3>(c, la) : launch_schur_lump<4>(c, la))))) return rc;
+        RowsArgs ra{nEl, nk, hdt, gam, S.Nrho.p, S.Npi.p, S.X.p, C2.p, S.rlump, S.Gl.p, S.Gu.p, S.DIVl.p, S.DIVu.p, S.L.p};
+        if (S.F_u) { ra.F_pi = S.F_pi; ra.F_u = S.F_u; ra.tR = S.tC; ra.F_eta = S.F_eta; S.rhs_done = true; }
+        return n2 == 4 ? launch_schur_rows<2>(c, ra) : (n2 == 9 ? launch_schur_rows<3>(c, ra) : launch_schur_rows<4>(c, ra));
+    }
     // M1_i = 0.5dt (R^t_i Binv_i + R^b_{i+1} Binv_{i+1})   = rows of G_rt VB_inv   (:702-703, :742)
     //   R^t_i = R2[2i+1], R^b_{i+1} = R2[2(i+1)+0]; handled by an explicit kernel (strided slots)
     {
@@ -2217,10 +2380,6 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
             for (int k = 0; k < n2; k++) s += m[a*n2 + k]*(hdt*Ci[k*n2 + a]);
             rl[x] = 1.0/(-1.0*s + va);
         }))) return rc;
-    }
-    if (S.rows) {
-        RowsArgs ra{nEl, nk, hdt, gam, S.Nrho.p, S.Npi.p, S.X.p, C2.p, S.rlump, S.Gl.p, S.Gu.p, S.DIVl.p, S.DIVu.p, S.L.p};
-        return n2 == 4 ? launch_schur_rows<2>(c, ra) : (n2 == 9 ? launch_schur_rows<3>(c, ra) : launch_schur_rows<4>(c, ra));
     }
     // DIV (N x Nm), row k:  DIVl_k = (k,k-1),  DIVu_k = (k,k)                           (:754-761)
     //   = 0.5dt ( -+ CM_k B_k X_j ) + 0.5dt C_j , then column-scaled by rlump_j ;  CM_k B_k = N_rho_k Binv_k B_k = N_rho_k
@@ -2277,11 +2436,12 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
     const int nk = c->nk, nm = nk - 1, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
     const double hdt = 0.5*dt, gam = RD/CV;
     Schur S;
+    S.F_u = F_u; S.F_pi = F_pi; S.F_eta = F_eta; S.F_rho = F_rho;
     int rc = schur_operator(c, dt, theta, rho, eta, pi, S);
     if (rc) return rc;
     BA R2 = S.R2, C2 = S.C2;
     // F_u -= (G_rt VB_inv) F_eta                                                         (:772-773)
-    {
+    if (!S.rhs_done) {
         const double *R = R2.p, *Bi = S.Binv.p; double* tA = S.tA;
         if ((rc = bmv(c, nk, tA, nk, S.Binv, 0, F_eta, nk, 0, 1.0, 0))) return rc;        // tA_k = Binv_k F_eta_k
         if ((rc = each(c, (long long)nEl*nm*n2, [=] __device__(long long x) {
@@ -2295,7 +2455,7 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
         (void)Bi;
     }
     // F_pi = -F_pi + gam DIV F_u - gam CM F_rho - gam F_eta                               (:775-780)
-    {
+    if (!S.rhs_done) {
         const double *Dl = S.DIVl.p, *Du = S.DIVu.p, *Nr = S.Nrho.p; double* tA = S.tA;
         if ((rc = bmv(c, nk, tA, nk, S.Binv, 0, F_rho, nk, 0, 1.0, 0))) return rc;        // Binv F_rho
         if ((rc = each(c, (long long)nEl*nk*n2, [=] __device__(long long x) {
@@ -2331,6 +2491,10 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
             F_u[x] = f;
             d_u[x] = rl[x]*f;
         }))) return rc;
+    }
+    if (S.rows) {
+        BackArgs ba{nEl, nk, hdt, C2.p, S.X.p, S.B.p, S.Binv.p, d_u, F_eta, F_rho, d_eta, d_rho};
+        return n2 == 4 ? launch_schur_backsub<2>(c, ba) : (n2 == 9 ? launch_schur_backsub<3>(c, ba) : launch_schur_backsub<4>(c, ba));
     }
     {
         const double *Cw = C2.p, *X = S.X.p; double* tA = S.tA;
