@@ -231,6 +231,17 @@ int mimsem_block_richardson_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nl
                                   const double* b, long long b_stride, double* x, long long x_stride,
                                   double* upd, long long upd_stride);
 
+/* One step of the Chebyshev semi-iteration for  Op x = b  on 1-forms with the element-block preconditioner
+ * P = sum_e R_e^T (elem_scale[lev][e] B_e) R_e  (elem_scale may be NULL):   z = P (b - Op x);  p = z + beta p;  x += alpha p.
+ * The caller supplies alpha, beta of the step (they depend only on the spectral bounds of P Op and the step number --
+ * mimsem_amd/krylov.py ChebyshevMass) and a direction vector p that persists between steps.  No inner products, three
+ * launches, nothing but x, p (and upd = z if given) written: a mass solve with a FIXED number of steps is hipGraph-capturable. */
+int mimsem_block_chebyshev_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                 const double* f, long long f_stride, const double* blocks,
+                                 const double* elem_scale, long long elem_scale_stride,
+                                 const double* b, long long b_stride, double alpha, double beta, double* p, long long p_stride,
+                                 double* x, long long x_stride, double* upd, long long upd_stride);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,

@@ -469,7 +469,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         const double* src = c->d_ye;
         if (blocks) {
             double* ze = c->d_ye + per*nlev;
-            if ((rc = launch_blocks_residual(c, nlev, blocks, c->d_ye, per, epi->b, epi->bs, ze, per))) return rc;
+            if ((rc = launch_blocks_residual(c, nlev, blocks, c->d_ye, per, epi->b, epi->bs, ze, per, epi->escale, epi->ess))) return rc;
             src = ze;
         }
         return launch_gather_epilogue(c, outsp, nlev, src, per, *epi, y, ys);
@@ -601,6 +601,19 @@ int mimsem_block_richardson_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev
     if (op_spaces(op, &in, &cf, &outsp) || outsp != 1 || in != 1 || is_up_op(op)) return MIMSEM_ERR_ARG;
     if (c->es.n > 5) return MIMSEM_ERR_UNSUPPORTED;
     GatherEpilogue g{2, b, bs, nullptr, 0, upd, upds};
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, x, xs, 1.0, &g, blocks);
+}
+
+int mimsem_block_chebyshev_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                 const double* f, long long fs, const double* blocks, const double* elem_scale, long long es_stride,
+                                 const double* b, long long bs, double alpha, double beta, double* p, long long ps,
+                                 double* x, long long xs, double* upd, long long upds) {
+    if (!c || !b || !blocks || !x || !p || (flags & MIMSEM_FLAG_ACCUM)) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp) || outsp != 1 || in != 1 || is_up_op(op)) return MIMSEM_ERR_ARG;
+    if (c->es.n > 5) return MIMSEM_ERR_UNSUPPORTED;
+    GatherEpilogue g{3, b, bs, nullptr, 0, upd, upds};
+    g.alpha = alpha; g.beta = beta; g.p = p; g.ps = ps; g.escale = elem_scale; g.ess = es_stride;
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, x, xs, 1.0, &g, blocks);
 }
 

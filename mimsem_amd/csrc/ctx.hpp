@@ -117,15 +117,19 @@ struct ElemArgs {
 
 // pass 2 with an epilogue (the Richardson sweeps): what happens to the gathered sum `acc` of a slot
 struct GatherEpilogue {
-    int mode;                        // 1: d = dinv*(b - acc) ; 2: d = acc.   Then x += d and, if upd, upd = d
+    int mode;                        // 1: d = dinv*(b - acc) ; 2, 3: d = acc.   1, 2: x += d.   3: p = d + beta p ; x += alpha p.   upd = d if given
     const double* b; long long bs;
     const double* dinv; long long ds;
     double* upd; long long us;
+    double alpha = 1.0, beta = 0.0;  // mode 3 (Chebyshev semi-iteration)
+    double* p = nullptr; long long ps = 0;
+    const double* escale = nullptr; long long ess = 0;      // block pass: per (level, element) factor of the element blocks
 };
 int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, const GatherEpilogue& g,
                            double* x, long long xs);
 int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes,
-                           const double* b, long long bs, double* ze, long long zes);
+                           const double* b, long long bs, double* ze, long long zes,
+                           const double* escale = nullptr, long long ess = 0);
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,

@@ -597,13 +597,19 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
     int j[K];
 #pragma unroll
     for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
-    for (int lev = 0; lev < nlev; lev++) {
+    const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);      // level chunks across blockIdx.y, as k_gather_sum
+    for (int lev = l0; lev < l1; lev++) {
         const double* src = ye + (size_t)lev*ye_stride;
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
         const double d = (g.mode == 1) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
-        x[(size_t)lev*xs + s] += d;
+        if (g.mode == 3) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p
+            double* pp = g.p + (size_t)lev*g.ps + s;
+            const double pn = d + g.beta*(*pp);
+            *pp = pn;
+            x[(size_t)lev*xs + s] += g.alpha*pn;
+        } else x[(size_t)lev*xs + s] += d;
         if (g.upd) g.upd[(size_t)lev*g.us + s] = d;
     }
 }
@@ -611,34 +617,53 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
 // block-preconditioned Richardson, middle pass: r_e = (b - gather(ye)) restricted to the element (gathered on the fly through
 // the 1-form plan), z_e = B_e r_e with B_e stored column-major ([c][r]); z_e goes to the second element-local buffer.
 template <int N>
-__global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, const int* __restrict__ i1x, const int* __restrict__ i1y,
+__global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
-        const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes) {
+        const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
+        const double* __restrict__ escale, long long ess) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
     static_assert(ND <= 64, "one wavefront per element");
-    __shared__ double s_x[EPB][LPE];
+    __shared__ double s_x[2][EPB][LPE];
     const int tid = threadIdx.x, el = tid/LPE, r = tid%LPE;
-    const long long eg = (long long)blockIdx.x*EPB + el;
-    const bool act = eg < (long long)nEl*nlev && r < ND;
-    const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
+    // work item = (element, chunk of lch levels): this lane's block row stays in registers over the chunk (k_blocks_apply_reg)
+    const int nchunk = (nlev + lch - 1)/lch;
+    const long long item = (long long)blockIdx.x*EPB + el;
+    const bool eact = item < (long long)nEl*nchunk;
+    const int e = eact ? (int)(item%nEl) : 0;
+    const int l0 = eact ? (int)(item/nEl)*lch : 0, l1 = eact ? min(nlev, l0 + lch) : 0;
+    const bool act = eact && r < ND;
+    double brow[ND];
+    int slot = 0, p0 = -1, p1 = -1;
     if (act) {
-        const int slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
-        const int p0 = plan[(size_t)slot*2], p1 = plan[(size_t)slot*2 + 1];
-        const double* src = ye + (size_t)lev*yes;
-        double acc = 0.0;
-        if (p0 >= 0) acc += src[p0];
-        if (p1 >= 0) acc += src[p1];
-        s_x[el][r] = b[(size_t)lev*bs + slot] - acc;
-    }
-    wave_lds_sync();
-    if (!act) return;
-    const double* Be = B + (size_t)e*ND*ND + r;
-    double s = 0.0;
+        const double* Be = B + (size_t)e*ND*ND + r;
 #pragma unroll
-    for (int c = 0; c < ND; c++) s += Be[(size_t)c*ND]*s_x[el][c];
-    ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
+        for (int c = 0; c < ND; c++) brow[c] = Be[(size_t)c*ND];
+        slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
+        p0 = plan[(size_t)slot*2]; p1 = plan[(size_t)slot*2 + 1];
+    } else {
+#pragma unroll
+        for (int c = 0; c < ND; c++) brow[c] = 0.0;
+    }
+    for (int lev = l0; lev < l1; lev++) {
+        double* sx = s_x[lev & 1][el];
+        if (act) {
+            const double* src = ye + (size_t)lev*yes;
+            double acc = 0.0;
+            if (p0 >= 0) acc += src[p0];
+            if (p1 >= 0) acc += src[p1];
+            sx[r] = b[(size_t)lev*bs + slot] - acc;
+        }
+        wave_lds_sync();
+        if (act) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < ND; c++) s += brow[c]*sx[c];
+            if (escale) s *= escale[(size_t)lev*ess + e];
+            ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
+        }
+    }
 }
 
 // perimeter pass of the fused scatter-add: slots shared by two element groups sum their two partials
@@ -1383,7 +1408,7 @@ int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, 
                            double* x, long long xs) {
     const int nslots = form == 1 ? c->n1 : c->n0;
     if (nslots == 0 || nlev == 0) return MIMSEM_OK;
-    const dim3 grid((unsigned)((nslots + 255)/256));
+    const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
     if (form == 1) hipLaunchKernelGGL((k_gather_epilogue<2>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g1, nslots, nlev, g, x, xs);
     else if (c->G0 == 4) hipLaunchKernelGGL((k_gather_epilogue<4>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, g, x, xs);
     else hipLaunchKernelGGL((k_gather_epilogue<8>), grid, dim3(256), 0, c->stream, ye, ye_stride, c->d_g0, nslots, nlev, g, x, xs);
@@ -1393,26 +1418,28 @@ int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, 
 
 template <int N>
 static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes, const double* b, long long bs,
-                             double* ze, long long zes) {
+                             double* ze, long long zes, const double* escale, long long ess) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
-    const long long total = (long long)c->nEl*nlev;
-    hipLaunchKernelGGL((k_blocks_residual<N>), dim3((unsigned)((total + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev,
-                       c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes);
+    int lch = (int)(((long long)((c->nEl + EPB - 1)/EPB)*nlev)/(256*6));             // ~6 workgroups per CU, as k_elem_apply
+    lch = std::max(1, std::min(lch, 8)); lch = std::min(lch, std::max(nlev, 1));
+    const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
+    hipLaunchKernelGGL((k_blocks_residual<N>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
+                       c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
 
 int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes,
-                           const double* b, long long bs, double* ze, long long zes) {
+                           const double* b, long long bs, double* ze, long long zes, const double* escale, long long ess) {
     if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
     switch (c->es.n) {
-    case 1: return blocks_residual_n<1>(c, nlev, B, ye, yes, b, bs, ze, zes);
-    case 2: return blocks_residual_n<2>(c, nlev, B, ye, yes, b, bs, ze, zes);
-    case 3: return blocks_residual_n<3>(c, nlev, B, ye, yes, b, bs, ze, zes);
-    case 4: return blocks_residual_n<4>(c, nlev, B, ye, yes, b, bs, ze, zes);
-    case 5: return blocks_residual_n<5>(c, nlev, B, ye, yes, b, bs, ze, zes);
+    case 1: return blocks_residual_n<1>(c, nlev, B, ye, yes, b, bs, ze, zes, escale, ess);
+    case 2: return blocks_residual_n<2>(c, nlev, B, ye, yes, b, bs, ze, zes, escale, ess);
+    case 3: return blocks_residual_n<3>(c, nlev, B, ye, yes, b, bs, ze, zes, escale, ess);
+    case 4: return blocks_residual_n<4>(c, nlev, B, ye, yes, b, bs, ze, zes, escale, ess);
+    case 5: return blocks_residual_n<5>(c, nlev, B, ye, yes, b, bs, ze, zes, escale, ess);
     default: return MIMSEM_ERR_UNSUPPORTED;          // 2 n1e > 64 rows
     }
 }

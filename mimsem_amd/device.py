@@ -219,6 +219,20 @@ class Engine:
                                                    _ptr(upd), upd.stride(0) if upd is not None else 0), "block_richardson_sweep(%s)" % op)
         return x
 
+    def block_chebyshev_sweep(self, op, blocks, x, b, p, alpha, beta, f=None, elem_scale=None, lev0=0, scale=1.0, flags=0, upd=None):
+        """z = P (b - Op x) with P = sum_e R_e^T (elem_scale[lev, e] B_e) R_e; p = z + beta p; x += alpha p -- in place, three
+        launches (mimsem_block_chebyshev_sweep).  blocks [nEl, 2 n1e, 2 n1e] column-major per element."""
+        nd = 2 * self.n1e
+        assert x.dim() == 2 and x.shape == b.shape == p.shape and x.shape[1] == self.sizes[1] and blocks.shape == (self.nEl, nd, nd)
+        assert upd is None or upd.shape == x.shape
+        assert elem_scale is None or elem_scale.shape == (x.shape[0], self.nEl)
+        check(self.L.mimsem_block_chebyshev_sweep(self.ctx, OPS[op], lev0, x.shape[0], scale, flags,
+                                                  _ptr(f), f.stride(0) if f is not None else 0, _ptr(blocks),
+                                                  _ptr(elem_scale), elem_scale.stride(0) if elem_scale is not None else 0,
+                                                  _ptr(b), b.stride(0), alpha, beta, _ptr(p), p.stride(0), _ptr(x), x.stride(0),
+                                                  _ptr(upd), upd.stride(0) if upd is not None else 0), "block_chebyshev_sweep(%s)" % op)
+        return x
+
     def apply_ray(self, x, exner, exner_s, dt, lev0=0, scale=1.0, alpha=1.0, flags=0, out=None):
         """Umat_ray (Held-Suarez friction): x [nlev, n1], exner [nlev, n2] (levels lev0..), exner_s [n2] = level 0."""
         x2 = x if x.dim() == 2 else x.unsqueeze(0); f2 = exner if exner.dim() == 2 else exner.unsqueeze(0)

@@ -133,6 +133,10 @@ class MassSolver:
         iy = torch.as_tensor(dm.inds1y, device=eng.device).long()
         self.kind = precond
         self.fixed_its = 0          # > 0: run exactly that many PCG iterations (hipGraph capture)
+        self._cheb = None
+        # default solver for the block preconditioner on one rank: fixed-length Chebyshev on the fused sweep (no inner products)
+        self.chebyshev = (precond != "jacobi" and os.environ.get("MIMSEM_MASS_SOLVER", "chebyshev") == "chebyshev"
+                          and not hasattr(eng, "halo") and eng.mesh.n <= 5)
         if precond == "jacobi":
             diag = eng.zeros(eng.nk, dm.n1)
             for k in range(eng.nk):
@@ -162,8 +166,25 @@ class MassSolver:
     def apply(self, x, lev0=0):
         return self.eng.apply("UMAT", x, lev0=lev0, scale=self.scale, flags=self.flags)
 
+    def _chebyshev(self):
+        """the fixed-length Chebyshev solver on the fused block sweep (single rank, 2 n1e <= 64 rows); spectral bounds over all levels"""
+        if self._cheb is None:
+            eng = self.eng
+            g = torch.Generator(device="cpu"); g.manual_seed(1234)
+            b = torch.randn(eng.nk, eng.sizes[1], generator=g, dtype=torch.float64).to(eng.device)
+            lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25)
+            self._cheb = ChebyshevMass(eng, None, lmin, lmax, rtol=1e-15)
+            self._blocks_cm = self.blocks.transpose(1, 2).contiguous()
+        return self._cheb
+
     def solve(self, b, lev0=0, rtol=1e-14, maxit=300):
         nlev = b.shape[0]
+        if self.kind != "jacobi" and self.chebyshev:
+            ch = self._chebyshev()
+            es = self.escale[lev0:lev0 + nlev]
+            ch.sweep = lambda x, rhs, p, al, be, upd: self.eng.block_chebyshev_sweep(
+                "UMAT", self._blocks_cm, x, rhs, p, al, be, elem_scale=es, lev0=lev0, scale=self.scale, flags=self.flags, upd=upd)
+            return ch.solve(b), ch.steps
         if self.kind != "jacobi":
             with self.eng.space(1):
                 return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
@@ -428,3 +449,75 @@ class GraphedRichardson:
                 return None
             prev = dn
         return None
+
+
+def lanczos_bounds(apply_A, precond, b, its=25):
+    """Extreme eigenvalues of P A (A SPD, P SPD) for every row system of b, from the Lanczos tridiagonal that `its` steps of
+    preconditioned CG generate (T_kk = 1/a_k + b_{k-1}/a_{k-1}, T_{k,k+1} = sqrt(b_k)/a_k): Ritz values converge to the ends of
+    the spectrum first.  Returns (lmin, lmax) over all rows.  Setup-time helper (host synchronisation per step)."""
+    import numpy as np
+    x = torch.zeros_like(b); r = b.clone(); z = precond(r); p = z.clone()
+    dot = lambda u, v: torch.linalg.vecdot(u, v, dim=1)
+    rz = dot(r, z)
+    al, be = [], []
+    for _ in range(its):
+        Ap = apply_A(p)
+        a = rz / dot(p, Ap)
+        x = x + a[:, None] * p; r = r - a[:, None] * Ap
+        z = precond(r); rz_new = dot(r, z)
+        bt = rz_new / rz
+        al.append(a.cpu().numpy()); be.append(bt.cpu().numpy())
+        if float(rz_new.abs().max()) < 1e-28 * float(rz.abs().max() + 1e-300):
+            break
+        p = z + bt[:, None] * p; rz = rz_new
+    al, be = np.array(al), np.array(be)                     # [k, rows]
+    k = al.shape[0]
+    lo, hi = np.inf, 0.0
+    for row in range(al.shape[1]):
+        T = np.zeros((k, k))
+        for j in range(k):
+            T[j, j] = 1.0 / al[j, row] + (be[j - 1, row] / al[j - 1, row] if j > 0 else 0.0)
+            if j + 1 < k:
+                T[j, j + 1] = T[j + 1, j] = np.sqrt(max(be[j, row], 0.0)) / al[j, row]
+        ev = np.linalg.eigvalsh(T)
+        lo, hi = min(lo, ev[0]), max(hi, ev[-1])
+    return float(lo), float(hi)
+
+
+class ChebyshevMass:
+    """M1 x = b (all rows at once) by a FIXED-length Chebyshev semi-iteration on the engine's fused block sweep
+    (mimsem_block_chebyshev_sweep: element pass, block pass fed by the on-the-fly gathered residual, gather pass applying
+    p = z + beta p, x += alpha p).  The spectrum of P M1 is that of a fixed mesh: its ends are estimated once (Lanczos on 25 CG
+    steps, widened by 5 % / 10 %), after which the number of steps for a tolerance and every alpha, beta are known in advance --
+    no inner products, no host synchronisation, 3 launches per step against 10 per PCG iteration, and the whole solve can sit
+    inside a captured hipGraph.  The norm of the last preconditioned residual is available for a check (`last`)."""
+
+    def __init__(self, eng, sweep, lmin, lmax, rtol=1e-14):
+        """sweep(x, b, p, alpha, beta, upd): one fused step (closure over op, blocks, elem_scale, lev0, scale, flags)"""
+        self.eng, self.sweep = eng, sweep
+        self.lmin, self.lmax = 0.90 * lmin, 1.05 * lmax
+        th, de = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
+        kappa = self.lmax / self.lmin
+        sg = (math.sqrt(kappa) - 1.0) / (math.sqrt(kappa) + 1.0)
+        self.steps = max(2, int(math.ceil(math.log(2.0 / rtol) / math.log(1.0 / sg))))
+        # x_{k+1} = x_k + c1_k z_k + c2_k (x_k - x_{k-1}) written as q_k = z_k + beta_k q_{k-1}, x += alpha_k q_k
+        s1 = th / de
+        rho_prev = 1.0 / s1
+        c1_prev = 1.0 / th
+        self.coef = [(c1_prev, 0.0)]
+        for _ in range(1, self.steps):
+            rho = 1.0 / (2.0 * s1 - rho_prev)
+            c1, c2 = 2.0 * rho / de, rho * rho_prev
+            self.coef.append((c1, c2 * c1_prev / c1))
+            rho_prev, c1_prev = rho, c1
+        self.p = None
+        self.upd = None
+
+    def solve(self, b, x0=None, want_residual=False):
+        """returns x; capturable (fixed shapes and step count, no host synchronisation unless want_residual)"""
+        if self.p is None or self.p.shape != b.shape:
+            self.p = torch.zeros_like(b); self.upd = torch.zeros_like(b)
+        x = torch.zeros_like(b) if x0 is None else x0.clone()
+        for k, (alpha, beta) in enumerate(self.coef):
+            self.sweep(x, b, self.p, alpha, beta, self.upd if (want_residual and k == self.steps - 1) else None)
+        return x

@@ -55,6 +55,32 @@ def test_device_cg_mass_solve(sphere):
         assert np.linalg.norm(x[k].cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-10
 
 
+def test_chebyshev_mass_solver(sphere):
+    """the default mass solver on one rank: fixed-length Chebyshev semi-iteration on the fused block sweep
+    (mimsem_block_chebyshev_sweep) -- one sweep against its composition, the Lanczos spectral bounds, the solve against PCG"""
+    import torch
+    from mimsem_amd.krylov import MassSolver
+    cs, eng, mats, rng = sphere
+    ms = MassSolver(eng, SCALE, True)
+    assert ms.chebyshev
+    b = eng.tensor(rng.standard_normal((eng.nk, cs.nDofs1G)) * 1e9)
+    x1, steps = ms.solve(b)
+    ch = ms._cheb
+    assert 0.3 < ch.lmin < 1.0 < ch.lmax < 2.5 and steps == ch.steps and 4 <= steps <= 30
+    ms.chebyshev = False
+    x2, its = ms.solve(b, rtol=1e-15)
+    assert float(torch.linalg.vector_norm(x1 - x2) / torch.linalg.vector_norm(x2)) < 1e-12
+    # one sweep: z = P (b - M1 x); p = z + beta p; x += alpha p
+    x = eng.tensor(rng.standard_normal((eng.nk, cs.nDofs1G))); p = eng.tensor(rng.standard_normal((eng.nk, cs.nDofs1G)))
+    z = ms.precond(b - ms.apply(x))
+    pref = z + 0.37 * p; xref = x + 1.9 * pref
+    upd = torch.zeros_like(x)
+    eng.block_chebyshev_sweep("UMAT", ms.blocks.transpose(1, 2).contiguous(), x, b, p, 1.9, 0.37, elem_scale=ms.escale,
+                              scale=SCALE, flags=ms.flags, upd=upd)
+    for got, want in ((upd, z), (p, pref), (x, xref)):
+        assert float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)) < 1e-13
+
+
 def test_weak_gradient_matches_dense(sphere):
     from mimsem_amd.horizsolve import HorizSolve
     cs, eng, mats, rng = sphere
