@@ -134,6 +134,7 @@ class MassSolver:
         self.kind = precond
         self.fixed_its = 0          # > 0: run exactly that many PCG iterations (hipGraph capture)
         self._cheb = None
+        self._cheb_checked = False
         # default solver for the block preconditioner on one rank: fixed-length Chebyshev on the fused sweep (no inner products)
         self.chebyshev = (precond != "jacobi" and os.environ.get("MIMSEM_MASS_SOLVER", "chebyshev") == "chebyshev"
                           and not hasattr(eng, "halo") and eng.mesh.n <= 5)
@@ -184,7 +185,16 @@ class MassSolver:
             es = self.escale[lev0:lev0 + nlev]
             ch.sweep = lambda x, rhs, p, al, be, upd: self.eng.block_chebyshev_sweep(
                 "UMAT", self._blocks_cm, x, rhs, p, al, be, elem_scale=es, lev0=lev0, scale=self.scale, flags=self.flags, upd=upd)
-            return ch.solve(b), ch.steps
+            x = ch.solve(b)
+            if not self._cheb_checked and not torch.cuda.is_current_stream_capturing():
+                # one-time check of the spectral bounds on a real right-hand side: a step count derived from wrong bounds would
+                # silently under-solve; fall back to PCG for good if the true residual is not at round-off
+                res = torch.linalg.vector_norm(b - self.apply(x, lev0), dim=1) / torch.linalg.vector_norm(b, dim=1).clamp_min(1e-300)
+                self._cheb_checked = True
+                if not bool(res.max() < 1e-11):
+                    self.chebyshev = False
+                    return self.solve(b, lev0, rtol, maxit)
+            return x, ch.steps
         if self.kind != "jacobi":
             with self.eng.space(1):
                 return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
