@@ -242,6 +242,13 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nle
                                  const double* b, long long b_stride, double alpha, double beta, double* p, long long p_stride,
                                  double* x, long long x_stride, double* upd, long long upd_stride);
 
+/* z = P (A x) for the left-preconditioned Krylov iteration on the shallow-water operator: mimsem_sw_operator_apply followed by
+ * mimsem_sw_blocks_apply in three launches instead of four -- the block pass reads the operator's element-local results through
+ * the gather plan, the assembled A x is never written. */
+int mimsem_sw_operator_precond_apply(mimsem_ctx* ctx, int nlev, double a, double grav, double H,
+                                     const double* f0, long long f0_stride, const double* blocks,
+                                     const double* x, long long x_stride, double* z, long long z_stride);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,
@@ -336,6 +343,10 @@ int mimsem_krylov_orthogonalize(mimsem_ctx* ctx, int k, long long n, const doubl
  * memory (hipHostMalloc): the Hessenberg column then reaches the host without a copy of its own. */
 int mimsem_krylov_normalize(mimsem_ctx* ctx, long long n, const double* w, double* v, int k, const double* h1, const double* h2,
                             double* col, int norm_slot);
+/* Second Gram-Schmidt pass and normalisation together, three launches: h2 = V w; w -= V^T h2 (the norm of the result is
+ * accumulated by the same kernel); v = w/|w|, col[0..k) = h1 + h2, col[norm_slot] = |w|. */
+int mimsem_krylov_reorthonormalize(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                                   const double* h1, double* h2, double* col, int norm_slot);
 /* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in
  * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
  * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */

@@ -130,16 +130,18 @@ int op_spaces(int op, int* in, int* cf, int* out) {
 
 }  // namespace
 
+// Workspaces only ever grow, and an outgrown buffer is RETIRED, not freed: a hipGraph captured earlier (Krylov / Richardson steps)
+// has the old address baked into its kernel arguments and must keep working on it; retired buffers go with the context.
 int mimsem_ctx::ensure_ye(long long doubles) {
     if (doubles <= ye_doubles) return MIMSEM_OK;
-    if (d_ye) { MIMSEM_HIP_TRY(hipFree(d_ye)); bytes -= ye_doubles*8; d_ye = nullptr; ye_doubles = 0; }
+    if (d_ye) { retired.push_back(d_ye); d_ye = nullptr; ye_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_ye, (size_t)doubles*sizeof(double)));
     ye_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
 }
 int mimsem_ctx::ensure_kry(long long doubles) {
     if (doubles <= kry_doubles) return MIMSEM_OK;
-    if (d_kry) { MIMSEM_HIP_TRY(hipFree(d_kry)); bytes -= kry_doubles*8; d_kry = nullptr; kry_doubles = 0; }
+    if (d_kry) { retired.push_back(d_kry); d_kry = nullptr; kry_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_kry, (size_t)doubles*sizeof(double)));
     kry_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
@@ -322,7 +324,8 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         c->bytes += 2*(long long)cnt*8;
     }
     if ((rc = mimsem_ctx_set_levels(c, d->thick, d->thickInv))) return fail(rc);
-    if ((rc = c->ensure_ye((long long)d->nk*d->nEl*std::max(2*es.n1e, es.n0e)))) return fail(rc);
+    // two element-local buffers + one packed [1-form | 2-form] row per level: the largest request of any entry point at nlev <= nk
+    if ((rc = c->ensure_ye((long long)d->nk*(2LL*d->nEl*std::max(2*es.n1e, es.n0e) + d->n1 + d->n2)))) return fail(rc);
     *out = c;
     return MIMSEM_OK;
 }
@@ -334,6 +337,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
                     c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : c->retired) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -615,6 +619,16 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev,
     GatherEpilogue g{3, b, bs, nullptr, 0, upd, upds};
     g.alpha = alpha; g.beta = beta; g.p = p; g.ps = ps; g.escale = elem_scale; g.ess = es_stride;
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, x, xs, 1.0, &g, blocks);
+}
+
+int mimsem_sw_operator_precond_apply(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                                     const double* blocks, const double* x, long long xs, double* z, long long zs) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!f0 || !blocks || !x || !z || x == z) return MIMSEM_ERR_ARG;
+    const long long n = (long long)c->n1 + c->n2;
+    if (nlev > 1 && (xs < n || zs < n)) return MIMSEM_ERR_ARG;
+    return launch_sw_operator_precond(c, nlev, a, grav, H, f0, f0s, blocks, x, xs, z, zs);
 }
 
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {

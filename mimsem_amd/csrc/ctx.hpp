@@ -86,6 +86,7 @@ struct mimsem_ctx {
     hipEvent_t ev_k1[2] = {nullptr, nullptr};   // start/stop events of the next element kernel (null = not profiling)
     hipEvent_t ev_k2[2] = {nullptr, nullptr};   // ... of the next gather-sum kernel
 
+    std::vector<void*> retired;          // outgrown workspaces (still referenced by captured graphs), freed with the context
     int ensure_ye(long long doubles);
     int ensure_col(long long doubles);
     double* d_kry = nullptr;            // partial sums of the Krylov multi-dot
@@ -146,6 +147,8 @@ int launch_interp_quad(mimsem_ctx* c, int form, int global, int nlev, const doub
 int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                        const double* x, long long xs, double* y, long long ys);
 int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys);
+int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                               const double* B, const double* x, long long xs, double* z, long long zs);
 int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf);
 int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);
 

@@ -1027,7 +1027,8 @@ __global__ __launch_bounds__(256) void k_sw_operator(int nEl, int nlev, double a
 template <int N>
 __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long long n1,
         const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2, const double* __restrict__ B,
-        const double* __restrict__ x, long long xs, double* __restrict__ ye, long long yes, double* __restrict__ y, long long ys) {
+        const double* __restrict__ x, long long xs, double* __restrict__ ye, long long yes, double* __restrict__ y, long long ys,
+        const double* __restrict__ ye_in, long long yis, const int* __restrict__ plan /* edge entries of x = gather of ye_in (or null) */) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e + D::n2e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
@@ -1042,7 +1043,14 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
         if (r < D::n1e) slot = i1x[e*D::n1e + r];
         else if (r < 2*D::n1e) slot = i1y[e*D::n1e + r - D::n1e];
         else slot = n1 + (i2 ? i2[e*D::n2e + r - 2*D::n1e] : e*D::n2e + r - 2*D::n1e);
-        s_x[el][r] = x[(size_t)lev*xs + slot];
+        if (ye_in && r < 2*D::n1e) {           // the operator's element-local results, summed on the fly (same order as k_gather_sum)
+            const int p0 = plan[(size_t)slot*2], p1 = plan[(size_t)slot*2 + 1];
+            const double* src = ye_in + (size_t)lev*yis;
+            double acc = 0.0;
+            if (p0 >= 0) acc += src[p0];
+            if (p1 >= 0) acc += src[p1];
+            s_x[el][r] = acc;
+        } else s_x[el][r] = x[(size_t)lev*xs + slot];
     }
     wave_lds_sync();
     if (!act) return;
@@ -1563,14 +1571,15 @@ int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H,
 }
 
 template <int N>
-static int sw_blocks_n(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* ye, long long yes, double* y, long long ys) {
+static int sw_blocks_n(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* ye, long long yes, double* y, long long ys,
+                       const double* ye_in = nullptr, long long yis = 0) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e + D::n2e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
     const long long total = (long long)c->nEl*nlev;
     const unsigned grid = (unsigned)((total + EPB - 1)/EPB);
     hipLaunchKernelGGL((k_sw_blocks_apply<N>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, (long long)c->n1,
-                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys);
+                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys, ye_in, yis, c->d_g1);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
@@ -1590,6 +1599,29 @@ int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const doubl
     }
     if (rc) return rc;
     return launch_gather_sum(c, 1, nlev, c->d_ye, per, 0, y, ys);
+}
+
+// z = P (A x): the operator's element pass, the block pass reading the operator result through the gather plan, one gather
+// (three launches; the assembled A x never exists).  Workspace: two element-local buffers + one packed row per level.
+int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                               const double* B, const double* x, long long xs, double* z, long long zs) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    if (es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
+    const long long per = (long long)c->nEl*2*es.n1e, nrow = (long long)c->n1 + c->n2;
+    int rc = c->ensure_ye(2*per*nlev + nrow*nlev);
+    if (rc) return rc;
+    double* ye0 = c->d_ye; double* ye1 = c->d_ye + per*nlev; double* yt = c->d_ye + 2*per*nlev;
+    const double ag = a*grav, aH = a*H;
+    switch (es.n) {
+#define MIMSEM_SWP(N) case N: rc = sw_operator_n<N>(c, nlev, a, ag, aH, f0, f0s, x, xs, x + c->n1, xs, ye0, per, yt + c->n1, nrow); \
+                      if (!rc) rc = sw_blocks_n<N>(c, nlev, B, yt, nrow, ye1, per, z, zs, ye0, per); break;
+    MIMSEM_SWP(1) MIMSEM_SWP(2) MIMSEM_SWP(3) MIMSEM_SWP(4)
+#undef MIMSEM_SWP
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    return launch_gather_sum(c, 1, nlev, ye1, per, 0, z, zs);
 }
 
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void k_maxpy(int k, long long n, const double*
 // their own; block 0 also stores h for the Hessenberg column.
 __global__ __launch_bounds__(256) void k_maxpy_reduce(int k, int nb, long long n, const double* __restrict__ V, long long ldv,
                                                       const double* __restrict__ part, double alpha, double* __restrict__ w,
-                                                      double* __restrict__ h_out) {
+                                                      double* __restrict__ h_out, double* __restrict__ npart /* null, or [gridDim.x]: sum of the updated w^2 per block */) {
     extern __shared__ double sh[];
+    __shared__ double red[4];
     for (int base = 0; base < k; base += 64) {
         const int i = base + (threadIdx.x >> 2), sub = threadIdx.x & 3;
         double s = 0.0;
@@ -42,10 +43,20 @@ __global__ __launch_bounds__(256) void k_maxpy_reduce(int k, int nb, long long n
     }
     __syncthreads();
     const long long t = (long long)blockIdx.x*256 + threadIdx.x;
-    if (t >= n) return;
-    double s = 0.0;
-    for (int i = 0; i < k; i++) s += sh[i]*V[(size_t)i*ldv + t];
-    w[t] += alpha*s;
+    double wn = 0.0;
+    if (t < n) {
+        double s = 0.0;
+        for (int i = 0; i < k; i++) s += sh[i]*V[(size_t)i*ldv + t];
+        wn = w[t] + alpha*s;
+        w[t] = wn;
+    }
+    if (npart) {                     // the norm of the result rides along: one launch less before the normalisation
+        double q = wn*wn;
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) npart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
 }
 
 // v = w / |w| from the partial sums of w.w; block 0 also writes the finished Hessenberg column (h1 + h2, |w|) -- `col` may be
@@ -55,7 +66,8 @@ __global__ __launch_bounds__(256) void k_normalize(int nb, long long n, const do
                                                    const double* __restrict__ h2, double* __restrict__ col, int norm_slot) {
     __shared__ double s_nrm;
     if (threadIdx.x < 64) {
-        double s = (threadIdx.x < nb) ? part[threadIdx.x] : 0.0;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (threadIdx.x == 0) s_nrm = sqrt(s);
     }
@@ -176,7 +188,24 @@ int mimsem_krylov_orthogonalize(mimsem_ctx* c, int k, long long n, const double*
     int rc = rowdot_partials(c, k, n, V, ldv, w, 0, &nb);
     if (rc) return rc;
     hipLaunchKernelGGL(k_maxpy_reduce, dim3((unsigned)((n + 255)/256)), dim3(256), (size_t)k*sizeof(double), c->stream,
-                       k, nb, n, V, ldv, c->d_kry, alpha, w, h);
+                       k, nb, n, V, ldv, c->d_kry, alpha, w, h, (double*)nullptr);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+// second Gram-Schmidt pass and normalisation in three launches: h2 = V w ; w -= V^T h2 (the norm of the result accumulated by the
+// same kernel) ; v = w/|w|, col[0..k) = h1 + h2, col[norm_slot] = |w|
+int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                                   const double* h1, double* h2, double* col, int norm_slot) {
+    if (!c || !V || !w || !v || !h1 || !h2 || !col || k <= 0 || n <= 0 || ldv < n || norm_slot < 0) return MIMSEM_ERR_ARG;
+    const unsigned gb = (unsigned)((n + 255)/256);
+    int nb = 0;
+    int rc = c->ensure_kry((long long)RD_BLOCKS*k + gb);
+    if (rc) return rc;
+    if ((rc = rowdot_partials(c, k, n, V, ldv, w, 0, &nb))) return rc;
+    double* npart = c->d_kry + (size_t)RD_BLOCKS*k;
+    hipLaunchKernelGGL(k_maxpy_reduce, dim3(gb), dim3(256), (size_t)k*sizeof(double), c->stream, k, nb, n, V, ldv, c->d_kry, -1.0, w, h2, npart);
+    hipLaunchKernelGGL(k_normalize, dim3(gb), dim3(256), 0, c->stream, (int)gb, n, npart, w, v, k, h1, h2, col, norm_slot);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

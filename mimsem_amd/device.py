@@ -16,6 +16,23 @@ def _ptr(t):
     return t.data_ptr()
 
 
+class no_gc:
+    """Python's cyclic garbage collector must not run inside a stream capture: a collected device tensor is freed by the caching
+    allocator with calls that are illegal on a capturing stream, the error is raised inside a destructor and the process aborts
+    (seen as 'Fatal Python error: Aborted ... Garbage-collecting' in the middle of a GraphedGMRES capture)."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()                     # (torch.cuda.graph collects once on entry by itself)
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class DeviceMesh:
     """Flattens any set of patches (Topo+Geom pairs) into the element->slot tables of mimsem_mesh_desc.
 
@@ -132,7 +149,7 @@ class Engine:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), self.on_current_stream():
+        with no_gc(), torch.cuda.graph(g), self.on_current_stream():
             out = fn()
         torch.cuda.synchronize(dev)
         return g, out
@@ -345,6 +362,19 @@ class Engine:
                                               x2.data_ptr(), x2.stride(0), y2.data_ptr(), y2.stride(0)), "sw_operator")
         return y if (x.dim() == 2 or out is not None) else y[0]
 
+    def sw_operator_precond(self, a, grav, H, f0, blocks, x, out=None):
+        """z = P (A x) in three launches (mimsem_sw_operator_precond_apply): the Krylov body of the shallow-water solve"""
+        nd = 2 * self.n1e + self.n2e
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        assert x2.shape[1] == self.sizes[1] + self.sizes[2] and x2.stride(1) == 1 and blocks.shape == (self.nEl, nd, nd)
+        f2 = f0 if f0.dim() == 2 else f0.unsqueeze(0)
+        assert f2.shape[1] == self.sizes[0] and f2.shape[0] in (1, x2.shape[0])
+        z = out if out is not None else torch.empty(x2.shape[0], x2.shape[1], dtype=torch.float64, device=self.device)
+        z2 = z if z.dim() == 2 else z.unsqueeze(0)
+        check(self.L.mimsem_sw_operator_precond_apply(self.ctx, x2.shape[0], a, grav, H, f2.data_ptr(), 0 if f2.shape[0] == 1 else f2.stride(0),
+                                                      _ptr(blocks), x2.data_ptr(), x2.stride(0), z2.data_ptr(), z2.stride(0)), "sw_operator_precond")
+        return z if (x.dim() == 2 or out is not None) else z[0]
+
     def sw_blocks_apply(self, blocks, x, out=None):
         """z = sum_e R_e^T B_e R_e x on packed rows [u | h]; blocks [nEl, ND, ND] stored column-major per element (mimsem_sw_blocks_apply)"""
         nd = 2 * self.n1e + self.n2e
@@ -469,6 +499,16 @@ class Engine:
         k = V.shape[0] if k is None else k
         check(self.L.mimsem_krylov_orthogonalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), alpha, _ptr(w), _ptr(h)), "krylov_orthogonalize")
         return w
+
+    def reorthonormalize(self, V, w, v, k, h1, h2, col, norm_slot):
+        """second Gram-Schmidt pass + normalisation in three launches: h2[:k] = V[:k] w; w -= V[:k]^T h2; v = w/|w|;
+        col[:k] = h1 + h2; col[norm_slot] = |w| (col: device or pinned host tensor)"""
+        assert w.numel() == v.numel() and v.is_contiguous() and col.dtype == torch.float64 and col.is_contiguous()
+        assert col.is_cuda or col.is_pinned(), "col must be device or pinned host memory"
+        assert col.numel() > max(k - 1, norm_slot)
+        check(self.L.mimsem_krylov_reorthonormalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(w), _ptr(v), _ptr(h1), _ptr(h2),
+                                                    col.data_ptr(), norm_slot), "krylov_reorthonormalize")
+        return v
 
     def normalize(self, w, v, k, h1, h2, col, norm_slot):
         """v = w/|w|; col[:k] = h1 + h2; col[norm_slot] = |w|.  col: device tensor or PINNED host tensor (written by the kernel)"""

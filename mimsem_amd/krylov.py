@@ -10,6 +10,8 @@ import os
 
 import torch
 
+from .device import no_gc
+
 
 def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, allreduce=None, precond=None):
     """Solve A x = b for a batch of systems (rows of b).  apply_A(x)->A x on [nlev, n] tensors.
@@ -304,8 +306,8 @@ class GraphedGMRES:
         if not w.is_contiguous():
             w = w.contiguous()
         eng.orthogonalize(V, w, self.h, k=k)
-        eng.orthogonalize(V, w, self.h2, k=k)                                            # re-orthogonalisation
-        eng.normalize(w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1)      # Hessenberg column straight to pinned memory
+        # re-orthogonalisation + normalisation in three launches; the Hessenberg column goes straight to pinned memory
+        eng.reorthonormalize(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1)
 
     def _graph(self, j):
         if self.graphs[j] is None:
@@ -318,7 +320,7 @@ class GraphedGMRES:
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool), self.eng.on_current_stream():
+            with no_gc(), torch.cuda.graph(g, pool=self.pool), self.eng.on_current_stream():
                 self._step(j)
             if self.pool is None:
                 self.pool = g.pool()
@@ -392,6 +394,11 @@ class GraphedGMRES:
             self.eng.maxpy(self.V, torch.tensor(y, dtype=bf.dtype, device=bf.device), x, alpha=1.0, k=k)
             if res <= tol:
                 break
+        # capture ahead: the look-ahead replays run up to `lookahead` steps past the one that converges, and the count moves by a
+        # step or two from solve to solve -- a capture (tens of ms) must not land in somebody's time step later
+        for j in range(min(m, k + self.lookahead + 2)):
+            if self.graphs[j] is None:
+                self._graph(j)
         return x.view(shape), its, res / bnorm
 
 

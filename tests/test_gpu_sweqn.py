@@ -204,3 +204,29 @@ def test_richardson_sweeps_match_composition(sw):
     eng.richardson_sweep("PHMAT_UP", q1, bq, dinv, f=h0, u=u0, tau=tau, upd=updq)
     assert rel_l2(updq.cpu().numpy(), refq.cpu().numpy()) < 1e-13
     assert torch.equal(q1, q + updq)
+
+
+def test_sw_fused_krylov_body_and_reorthonormalize(sw):
+    """mimsem_sw_operator_precond_apply == precond(apply) to round-off; mimsem_krylov_reorthonormalize == orthogonalize + normalize"""
+    import torch
+    cs, eng, O, S, uq, hq = sw
+    r = np.random.default_rng(21)
+    dm = eng.mesh
+    x = _t(eng, np.concatenate([r.standard_normal(dm.n1), 20.0 * r.standard_normal(dm.n2)]))
+    dt = 360.0
+    ref = S.precond_A(S.apply_A(x, dt), dt)
+    got = S._krylov_body(dt)(x)
+    assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    n, m = dm.n1 + dm.n2, 12
+    V = eng.tensor(r.standard_normal((m, n))); w0 = eng.tensor(r.standard_normal(n))
+    h1 = eng.tensor(r.standard_normal(m))
+    for k in (1, 5, m):
+        wa, wb = w0.clone(), w0.clone()
+        h2a = torch.zeros(m, dtype=torch.float64, device=eng.device); h2b = torch.zeros_like(h2a)
+        cola = torch.zeros(m + 2, dtype=torch.float64, device=eng.device); colb = torch.zeros_like(cola)
+        va, vb = torch.empty_like(w0), torch.empty_like(w0)
+        eng.orthogonalize(V, wa, h2a, k=k); eng.normalize(wa, va, k, h1, h2a, cola, m + 1)
+        eng.reorthonormalize(V, wb, vb, k, h1, h2b, colb, m + 1)
+        assert torch.equal(wa, wb) and torch.equal(h2a, h2b) and torch.equal(cola[:k], colb[:k])
+        assert abs(float(cola[m + 1] - colb[m + 1])) < 1e-13 * float(cola[m + 1])
+        assert float((va - vb).abs().max()) < 1e-14 * float(va.abs().max())
