@@ -1092,12 +1092,13 @@ template <int N> __device__ __forceinline__ double row_ror(double v) {
 // pivot search = 4 butterfly rounds, pivot row = N2 broadcasts.  Rows are never swapped -- the lane chosen at step c keeps the
 // row and remembers c; the in-place inverse T then satisfies  D^-1[c_l][p_c] = T[l][c]  (c_l: step at which lane l was the pivot,
 // p_c: pivot lane of step c), which is how it is scattered into LDS.  LDS only carries the operands of the two block products.
-template <int N2>
+template <int N2, int GW = 16>
 __global__ __launch_bounds__(64) void k_block_thomas_rows(int nEl, int nk, const double* __restrict__ L, const double* __restrict__ f,
                                                           double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws,
                                                           double* __restrict__ Dinv) {
-    constexpr int nn = N2*N2, GW = 16, CPW = 64/GW;
-    static_assert(N2 <= GW, "one lane per block row");
+    constexpr int nn = N2*N2, CPW = 64/GW;
+    static_assert(N2 <= GW && (GW == 16 || GW == 32), "one lane per block row; 16 or 32 lanes per column");
+    constexpr bool PIPE = N2 <= 9;        // prefetch + deferred stores cost 8 N2 VGPRs: only while the rows are short
     __shared__ double sG[CPW][nn], sU[CPW][nn], sI[CPW][nn], sy[CPW][N2], sv[CPW][N2];
     const int lane = threadIdx.x, g = lane/GW, r = lane%GW;
     const int e0 = blockIdx.x*CPW + g;
@@ -1126,13 +1127,16 @@ __global__ __launch_bounds__(64) void k_block_thomas_rows(int nEl, int nk, const
             for (int m = 0; m < N2; m++) Dinv[((size_t)e*nk + k)*nn + r*N2 + m] = Ist[m];
         }
     };
-    fetch(0);
+    if (PIPE) fetch(0);
     for (int k = 0; k < nk; k++) {
+        if (!PIPE) fetch(k);
 #pragma unroll
         for (int j = 0; j < N2; j++) { S[j] = Sn[j]; T[j] = Tn[j]; U[j] = Un[j]; }
         double vv = fn;
-        if (k > 0) flush(k - 1);
-        if (k + 1 < nk) fetch(k + 1);
+        if (PIPE) {
+            if (k > 0) flush(k - 1);
+            if (k + 1 < nk) fetch(k + 1);
+        }
         if (k > 0) {
 #pragma unroll
             for (int m = 0; m < N2; m++) {
@@ -1154,6 +1158,10 @@ __global__ __launch_bounds__(64) void k_block_thomas_rows(int nEl, int nk, const
                                  if (oc > cand || (oc == cand && ol < bl)) { cand = oc; bl = ol; } }
             MIMSEM_ARGMAX_ROUND(1) MIMSEM_ARGMAX_ROUND(2) MIMSEM_ARGMAX_ROUND(4) MIMSEM_ARGMAX_ROUND(8)
 #undef MIMSEM_ARGMAX_ROUND
+            if constexpr (GW == 32) {            // the two 16-lane rows of the column compare notes
+                const double oc = __shfl_xor(cand, 16, 32); const int ol = __shfl_xor(bl, 16, 32);
+                if (oc > cand || (oc == cand && ol < bl)) { cand = oc; bl = ol; }
+            }
             piv[c] = bl;
             double pr[N2];
 #pragma unroll
@@ -1200,9 +1208,10 @@ __global__ __launch_bounds__(64) void k_block_thomas_rows(int nEl, int nk, const
 #pragma unroll
         for (int j = 0; j < N2; j++) { Gst[j] = Gr[j]; Ist[j] = Ir[j]; }
         yst = y;
+        if (!PIPE) flush(k);
         wsync_lds();
     }
-    flush(nk - 1);
+    if (PIPE) flush(nk - 1);
     // back substitution d_k = y_k - G_k d_{k+1}: each lane re-reads its own row of G_k (its own stores)
     for (int k = nk - 1; k >= 0; k--) {
         double s = 0.0;
