@@ -107,6 +107,11 @@ def column_extras(eng, dm, rng, torch):
     t = timeit(lambda: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F]), 5)
     res["schur_column_solves_per_s"] = nEl / t
     res["schur_ms_all_columns"] = t * 1e3
+    thetaI, rt = lev(nk + 1, 280, 320), lev(nk, 150, 350)            # solve_schur_column_3: theta on the nk+1 interfaces
+    velz = eng.tensor(rng.standard_normal((nEl, (nk - 1) * n2)) * 0.1 * area)
+    t = timeit(lambda: eng.solve_schur_3(75.0, thetaI, velz, rho, rt, pi, *[f.clone() for f in F]), 3)
+    res["schur3_column_solves_per_s"] = nEl / t
+    res["schur3_ms_all_columns"] = t * 1e3
     t = timeit(lambda: eng.colop_apply("CONST_RHO", theta, f1=rho, nout_slots=nk), 20)
     res["vertops_assemble_apply_columns_per_s"] = nEl / t
     vh = eng.tensor(rng.standard_normal((nk, dm.n2)))
