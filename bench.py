@@ -7,7 +7,8 @@ the p=3, 24x24x6 cubed sphere with 30 levels (BASELINE config 4 grid, 103 680 pa
 N>1: the 24 patches (12x12 elements) are dealt to the ranks (strong scaling) and each step ends with the
 halo reduce (RCCL send/recv over xGMI) that replaces the reference's VecScatter REVERSE/ADD.
 
-At N = 1 the same line also carries "sw": shallow-water time steps/s (the second half of BASELINE's metric; --no-sw skips it).
+At N = 1 the same line also carries "sw": shallow-water time steps/s (the second half of BASELINE's metric; --no-sw skips it)
+and "column": HEVI column Schur solves/s on the same grid (--no-column skips it).
 Prints ONE JSON line (rank 0).  roofline: dominant kernel k_elem_apply<3,UMAT>, HIP-event timed inside the
 timed region.  cpu_baseline: the oracle's reference-structure (assemble CSR + SpMV) path on host cores.
 """
@@ -220,6 +221,7 @@ def main():
                                                         "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
     ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
     ap.add_argument("--sweep", action="store_true", help="extra: SURVEY 8(d) batch-size sweep of six operator families (384 ... 1e6 element-level pairs)")
+    ap.add_argument("--no-column", action="store_true", help="skip the column-solves/s extra (reported by default at N = 1, ~3 s)")
     ap.add_argument("--no-sw", action="store_true", help="skip the shallow-water time-steps/s extra (reported by default at N = 1, ~20 s)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
     ap.add_argument("--cold", type=int, default=0, metavar="R",
@@ -380,7 +382,7 @@ def main():
                          "k_elem_apply_us": b1 / bn * 1e3, "k_gather_sum_us": b2 / bn * 1e3, "bytes_per_unit_op": 2320,
                          "op_GBs": ub * 2320 / ((b1 + b2) / bn * 1e-3) / 1e9}
         del engb
-    if a.column and rank == 0 and world == 1:
+    if (a.column or not a.no_column) and rank == 0 and world == 1:     # the column half of the hot path: on by default at N = 1 (~3 s)
         out["column"] = column_extras(eng, dm, rng, torch)
     if a.pcie and rank == 0 and world == 1:
         import ctypes as C

@@ -2,7 +2,7 @@ python -m pytest tests -m gpu -q -x > gpurun_out/t16.log 2>&1; tail -3 gpurun_ou
 for v in 1 0; do
   echo "FUSE=$v"
   if [ $v = 1 ]; then export MIMSEM_FUSE=1; else unset MIMSEM_FUSE; fi
-  python bench.py --no-cpu --no-sw --steps 400 --warmup 40 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print(d['value']/1e9, d['ms_per_step']*1e3, d['roofline']['avg_kernel_us'], d['roofline_op']['avg_us'])"
+  python bench.py --no-cpu --no-sw --no-column --steps 400 --warmup 40 2>/dev/null | python -c "import sys,json; d=json.load(sys.stdin); print(d['value']/1e9, d['ms_per_step']*1e3, d['roofline']['avg_kernel_us'], d['roofline_op']['avg_us'])"
 done
 unset MIMSEM_FUSE
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fuse -o r01 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu --no-sw > /dev/null 2>&1; grep -E "k_elem|k_gather" $R/gpurun_out/prof_fuse/r01_kernel_stats.csv
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fuse -o r01 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu --no-sw --no-column > /dev/null 2>&1; grep -E "k_elem|k_gather" $R/gpurun_out/prof_fuse/r01_kernel_stats.csv
