@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_block_thomas_resolve(int nEl, int nk, co
 
 int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* Dinv = nullptr) {
     const int n2 = c->es.n2e, nn = n2*n2;
-    static const bool rows = !getenv("MIMSEM_THOMAS_WAVE");          // row-per-lane kernel (4 columns per wavefront); the wave-per-column one stays selectable
+    const bool rows = !getenv("MIMSEM_THOMAS_WAVE");          // row-per-lane kernel (4 columns per wavefront); the wave-per-column one stays selectable
     if (rows && !getenv("MIMSEM_THOMAS_WG") && (n2 == 4 || n2 == 9 || n2 == 16)) {
         const unsigned grid = (unsigned)((c->nEl + 3)/4);
         switch (n2) {

@@ -319,3 +319,26 @@ def test_fused_schur_assembly_matches_default(setup, monkeypatch, mode):
     assert rel_l2(L1.cpu().numpy(), L0.cpu().numpy()) < 1e-9
     for a, b in zip(alt, base):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8
+
+
+@pytest.mark.parametrize("var", ["MIMSEM_THOMAS_WAVE", "MIMSEM_THOMAS_WG", "MIMSEM_EOS_WIDE", "MIMSEM_BAND_NAIVE"])
+def test_selectable_kernel_variants_agree(setup, monkeypatch, var):
+    """every kernel alternative behind an environment switch gives the default result: block-Thomas per wave / per
+    workgroup, the wide EOS pipeline, the entry-per-thread band product"""
+    eng, P = setup
+    if P.nk < 4:
+        pytest.skip("solve_schur_column_3 needs nk >= 4")
+    F = _col_fields(P)
+    r = np.random.default_rng(19)
+    nEl, N, Nm = P.nEl, P.nk * P.n2e, (P.nk - 1) * P.n2e
+    Fs = [r.standard_normal((nEl, n)) * 1e8 for n in (Nm, N, N, N)]
+    t = eng.tensor
+    a_eta = (75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]))
+    a_3 = (75.0, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]))
+    base_eta = eng.solve_schur_eta(*a_eta, *[t(f) for f in Fs])
+    base_3 = eng.solve_schur_3(*a_3, *[t(f) for f in Fs])
+    monkeypatch.setenv(var, "1")
+    alt_eta = eng.solve_schur_eta(*a_eta, *[t(f) for f in Fs])
+    alt_3 = eng.solve_schur_3(*a_3, *[t(f) for f in Fs])
+    for a, b in list(zip(alt_eta, base_eta)) + list(zip(alt_3, base_3)):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8, var
