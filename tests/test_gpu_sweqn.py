@@ -230,3 +230,19 @@ def test_sw_fused_krylov_body_and_reorthonormalize(sw):
         assert torch.equal(wa, wb) and torch.equal(h2a, h2b) and torch.equal(cola[:k], colb[:k])
         assert abs(float(cola[m + 1] - colb[m + 1])) < 1e-13 * float(cola[m + 1])
         assert float((va - vb).abs().max()) < 1e-14 * float(va.abs().max())
+
+
+@pytest.mark.parametrize("env", [{"MIMSEM_SW_PC": "diag"}, {"MIMSEM_SW_RICHARDSON": "0"}, {"MIMSEM_SW_FUSED_SWEEPS": "0"},
+                                 {"MIMSEM_SW_WARM_START": "0", "MIMSEM_SW_CHUNK": "6"}, {"MIMSEM_GMRES_LOOKAHEAD": "1"}],
+                         ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_sw_solver_switches_agree(sw, monkeypatch, env):
+    """the solver alternatives behind environment switches change how the linear systems are solved, not the step"""
+    from mimsem_amd.sweqn import SWEqn
+    cs, eng, O, S, uq, hq = sw
+    u0, h0 = _t(eng, O.init1(uq)), _t(eng, O.init2(hq))
+    ud, hd = S.solve(u0, h0, 360.0, nits=2, q_exact=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    S2 = SWEqn(eng, O.xq[eng.mesh.gidq])
+    ua, ha = S2.solve(u0, h0, 360.0, nits=2, q_exact=False)
+    assert rel_l2(ua[0].cpu().numpy(), ud[0].cpu().numpy()) < 1e-9 and rel_l2(ha[0].cpu().numpy(), hd[0].cpu().numpy()) < 1e-10
