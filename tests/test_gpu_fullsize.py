@@ -120,6 +120,31 @@ def test_column_solve_satisfies_its_block_tridiagonal_system(full):
     assert all(bool(torch.isfinite(v).all()) for v in (d_u, d_rho, d_eta, d_pi))
 
 
+def test_column_solve_3_satisfies_its_block_pentadiagonal_system(full):
+    """solve_schur_column_3 at full size (row-per-lane 18x18 super-block sweep + refinement): L d_rt = F_rt with the
+    block-pentadiagonal L the call itself returns ([nEl, nk, 5, n2, n2], block column = row - 2 + b); F_rt is the updated
+    right-hand side the reference leaves behind"""
+    import torch
+    cs, dm, eng, rng = full
+    nEl, n2, nk = dm.nEl, eng.n2e, NK
+    area = float(dm.det.mean()) * 4.0 / n2
+    dz = float(dm.thick.mean())
+    lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+    theta, rho, rt, pi = lev(nk + 1, 280, 320) / dz, lev(nk, 0.5, 1.2), lev(nk, 250, 400), lev(nk, 700, 1000)
+    velz = lev(nk - 1, -1.0, 1.0) / dz
+    F = [eng.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (nk - 1, nk, nk, nk)]
+    d_u, d_rho, d_rt, d_pi, L = eng.solve_schur_3(75.0, theta, velz, rho, rt, pi, *F, want_L=True)
+    d = d_rt.view(nEl, nk, n2)
+    Ld = torch.zeros_like(d)
+    for b in range(5):
+        off = b - 2
+        lo, hi = max(0, -off), min(nk, nk - off)
+        Ld[:, lo:hi] += torch.einsum("ekij,ekj->eki", L[:, lo:hi, b], d[:, lo + off:hi + off])
+    f = F[2].view(nEl, nk, n2)
+    res = torch.linalg.vector_norm((Ld - f).reshape(nEl, -1), dim=1) / torch.linalg.vector_norm(f.reshape(nEl, -1), dim=1)
+    assert float(res.max()) < 1e-9, float(res.max())
+
+
 def test_shallow_water_step_conserves_mass_exactly():
     """config 3 (24x24x6, Galewsky-style step): h DoFs are face integrals and the continuity row is M2 (dh + dt E21 F) = 0, so the
     total mass sum(h) is conserved to round-off by every Picard iteration; the vorticity integral sum(M0 w) vanishes on the sphere"""
