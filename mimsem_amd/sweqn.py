@@ -412,3 +412,36 @@ def williamson2(xq, alpha=0.25 * math.pi):
     b = -torch.cos(lam) * torch.cos(theta) * math.sin(alpha) + torch.sin(theta) * math.cos(alpha)
     h = H0 - (RAD_SPHERE * OMEGA * U0 + 0.5 * U0 * U0) * b * b / GRAV
     return torch.stack([u, v], dim=1), h
+
+
+def galewsky(xq):
+    """src/Galewsky.cpp:24-82 evaluated at points xq [n,3]: (u, v), h -- the barotropically unstable mid-latitude jet of Galewsky,
+    Scott & Polvani (2004) with its balanced depth (the reference's 1000-step rectangle rule from the equator, the latitude
+    advanced BEFORE each evaluation) and the localised depth perturbation."""
+    eps, umax = 1.0e-8, 80.0 * (RAD_SPHERE / RAD_EARTH)
+    phi0 = math.pi / 7.0
+    phi1 = math.pi / 2.0 - phi0
+    en = math.exp(-4.0 / ((phi1 - phi0) * (phi1 - phi0)))
+
+    def jet(phi):
+        inside = (phi > phi0 + eps) & (phi < phi1 - eps)
+        arg = torch.where(inside, (phi - phi0) * (phi - phi1), torch.full_like(phi, -1.0))
+        return torch.where(inside, (umax / en) * torch.exp(1.0 / arg), torch.zeros_like(phi))
+
+    phi = torch.asin(xq[:, 2] / RAD_SPHERE)
+    lam = torch.atan2(xq[:, 1], xq[:, 0])
+    ni = 1000
+    dphi = (phi / ni).abs()
+    sgn = torch.where(phi > 0, torch.ones_like(phi), -torch.ones_like(phi))
+    h = torch.full_like(phi, 10000.0 * (RAD_SPHERE / RAD_EARTH))
+    grav, omega = 9.80616 * (RAD_SPHERE / RAD_EARTH), 7.292e-5
+    pp = torch.zeros_like(phi)
+    for _ in range(ni):
+        pp = pp + sgn * dphi
+        # the reference evaluates u_init at x2 = (x, y, R sin(phiPrime)): its latitude is asin(sin(phiPrime)) = phiPrime
+        u = jet(pp)
+        f = 2.0 * omega * torch.sin(pp)
+        h = h - RAD_SPHERE * u * (f + torch.tan(pp) * u / RAD_SPHERE) * dphi / grav
+    hHat, alpha, beta, phi2 = 120.0 * (RAD_SPHERE / RAD_EARTH), 1.0 / 3.0, 1.0 / 15.0, math.pi / 4.0
+    h = h + hHat * torch.cos(phi) * torch.exp(-1.0 * (lam / alpha) ** 2) * torch.exp(-1.0 * ((phi2 - phi) / beta) ** 2)
+    return torch.stack([jet(phi), torch.zeros_like(phi)], dim=1), h
