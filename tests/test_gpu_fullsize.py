@@ -184,6 +184,40 @@ def test_shallow_water_step_conserves_mass_exactly():
     assert float(torch.linalg.vector_norm(h1 - h0) / torch.linalg.vector_norm(h0)) < 2e-5
 
 
+def test_galewsky_quarter_day_conserves():
+    """config 3 as the reference driver runs it (src/Galewsky.cpp: jet + perturbation, dt = 360 s, 2 Picard iterations, upwinded q)
+    for 60 steps = 6 h: mass to round-off, energy and potential enstrophy drifts of the size the reference prints to
+    output/conservation.dat, the zonal jet still at 80 m/s, nothing blown up"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.sweqn import SWEqn, galewsky
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(PN, NE, 6); coords = sphere_coords(PN, NE)
+    topos = [Topo(cs, p, 1) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+    for g in geoms:
+        g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+    dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+    eng = Engine(dm)
+    xq = np.zeros((dm.nq, 3))
+    for g in geoms:
+        xq[g.loc0] = coords[g.loc0]
+    S = SWEqn(eng, xq[dm.gidq])
+    uq, hq = galewsky(torch.as_tensor(xq[dm.gidq], device=eng.device))
+    u, h = S.init1(uq), S.init2(hq)
+    c0 = S.conservation(u, h)
+    for _ in range(60):
+        u, h = S.solve(u, h, 360.0, nits=2, q_exact=False)
+    c1 = S.conservation(u, h)
+    assert abs(c1["mass"] - c0["mass"]) < 1e-12 * abs(c0["mass"])
+    assert abs(c1["energy"] - c0["energy"]) < 1e-6 * abs(c0["energy"])
+    assert abs(c1["enstrophy"] - c0["enstrophy"]) < 1e-3 * abs(c0["enstrophy"])
+    un = eng.interp_quad(1, u)[0]                              # (zonal, meridional) at every quadrature point
+    assert bool(torch.isfinite(un).all()) and 70.0 < float(un[..., 0].max()) < 90.0 and float(un[..., 1].abs().max()) < 10.0
+
+
 def test_config5_periodic_box_p4_full_size():
     """config 5 grid: p=4, 32x32 elements, 64 levels, doubly periodic box (1024 columns of 16x16 blocks): area known answer,
     symmetry, batched-level equality, and the residual of the column Schur solve"""
