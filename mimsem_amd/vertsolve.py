@@ -67,3 +67,76 @@ class VertSolve:
         f_theta_corr = 0.5 * dt * self._mv("CONST_RHO", self.V10(F), f1=theta, rows=nk)
         f_theta_corr += 0.5 * dt * self._mv("CONLIN_W", F, f1=tA2, rows=nk)
         return fw, F, G, f_theta_corr
+
+    def init_gz(self, levs, gravity=9.80616):
+        """VertSolve::initGZ (eul/VertSolve.cpp:89-175): zv_k = W^T diag(SCALE w_q / 2) (g z_k + g z_{k+1}), the weak-form geopotential
+        of every level from the interface heights on the quadrature grid (Geom::levs [nk+1, nq]); returned in the vertical layout"""
+        eng = self.eng
+        gz = gravity * torch.as_tensor(levs, dtype=torch.float64, device=eng.device)
+        zh = (0.5 * SCALE) * eng.apply("WTQ", (gz[:-1] + gz[1:]).contiguous())
+        return eng.l2_horiz_to_vert(zh)
+
+    # ---- the vertical implicit solve: the caller of the column path (SURVEY 3.2 step 6) ---------------------------------------
+    def solve_schur_eta(self, velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing=None, udwdx=None, hs_lat=None, maxit=20, tol=1.0e-12,
+                        verbose=False):
+        """VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) for EVERY column at once: Newton iterations on (w, rho, eta, Pi)
+        with solve_schur_column_eta as the linear solve, all state in the "vertical" layout [nEl][slots*n2e] (L2Vecs::vz).
+
+        horiz_forcing(rho_i, rho_j, theta_l2_h) -> (dFx, dGx): the horizontal transport tendencies of advection_rhs_ec in the
+        vertical layout ([nEl][nk*n2e]); None = no horizontal wind.  udwdx: optional [nEl][(nk-1)*n2e].  hs_lat: latitude of the
+        quadrature points [nEl][mp12] switches the Held-Suarez temperature forcing on.
+        Returns (velz, rho, rt, exner) at the new time level and leaves theta_h / theta_l2_h / exner_h (the time-centred fields
+        the horizontal corrector reads) and the per-iteration max-norms in self.*"""
+        eng, nk, dt = self.eng, self.nk, self.dt
+        mv = self._mv
+        velz_j, rho_j, rt_j, exner_j = velz_i.clone(), rho_i.clone(), rt_i.clone(), exner_i.clone()
+        theta_i = eng.diag_theta(1, rho_i, rt_i)                          # diagTheta2 :1766
+        theta_h = theta_i.clone()
+        theta_l2_i = eng.diag_theta(0, rho_i, rt_i)                       # diagTheta_L2 :1773
+        theta_l2_h = theta_l2_i.clone()
+        exner_h, velz_h, rho_h, rt_h = exner_i.clone(), velz_i.clone(), rho_i.clone(), rt_i.clone()
+        self.history = []
+        for itt in range(1, maxit + 1):
+            self.k2i_z = 0.0
+            dFx, dGx = horiz_forcing(rho_i, rho_j, theta_l2_h) if horiz_forcing is not None else (None, None)
+            F_w, F_z, G_z, ftc = self.assemble_residual_ec(theta_l2_h, exner_h, velz_i, velz_j, rho_i, rho_j, zv)     # :1806
+            if udwdx is not None:
+                F_w = F_w + dt * udwdx
+            F_exner = eng.column_eos(0, rt_j, exner_j)                    # Assemble_EOS_Residual :1810
+            dF_z = rho_j + dt * self.V10(F_z) - rho_i                     # VecAYPX / VecAXPY :1815-1819
+            dG_z = rt_j + 0.5 * dt * self.V10(G_z) - rt_i
+            F_rho = mv("CONST", dF_z, rows=nk)
+            F_rt = mv("CONST", dG_z, rows=nk) + ftc
+            if dFx is not None:
+                F_rho = F_rho + dt * dFx
+                F_rt = F_rt + dt * dGx
+            if hs_lat is not None:
+                F_rt = F_rt + dt * eng.temp_forcing_hs(hs_lat, exner_h, theta_h, rho_h)                               # :1831-1834
+            # entropy residual from the (rho theta) and rho residuals :1836-1842
+            t1 = mv("CONST_RHO_INV", F_rt, f1=rt_h, rows=nk) - mv("CONST_RHO_INV", F_rho, f1=rho_h, rows=nk)
+            F_eta = mv("CONST", t1, rows=nk)
+            # theta_h in W3 and eta_h :1844-1851
+            th_w3 = mv("CONST_RHO_INV", mv("CONST", rt_h, rows=nk), f1=rho_h, rows=nk)
+            eta = mv("CONST_INV", eng.column_eos(2, th_w3, None), rows=nk)
+            d_w, d_rho, d_eta, d_exner = eng.solve_schur_eta(dt, th_w3, rho_h, eta, exner_h, F_w, F_rho, F_eta, F_exner)   # :1855
+            # theta_j (before the update) and eta_j :1858-1865
+            th_w3 = mv("CONST_RHO_INV", mv("CONST", rt_j, rows=nk), f1=rho_j, rows=nk)
+            eta = mv("CONST_INV", eng.column_eos(2, th_w3, d_eta), rows=nk)
+            velz_j = velz_j + d_w; rho_j = rho_j + d_rho; exner_j = exner_j + d_exner
+            rt_j = mv("CONST_INV", eng.column_eos(3, rho_j, eta), rows=nk)                                            # :1871-1872
+            col = lambda dx, x: float((torch.linalg.vector_norm(dx, dim=1) / torch.linalg.vector_norm(x, dim=1)).max())   # MaxNorm :228
+            nv = torch.tensor([col(d_exner, exner_j), col(d_w, velz_j), col(d_rho, rho_j), col(d_eta, eta)], dtype=torch.float64, device=eng.device)
+            nv = eng.allreduce(nv, op="max").tolist()                    # MPI_Allreduce(MAX) :1915-1918
+            norms = dict(exner=nv[0], w=nv[1], rho=nv[2], eta=nv[3])
+            self.history.append(norms)
+            exner_h = 0.5 * exner_i + 0.5 * exner_j; velz_h = 0.5 * velz_i + 0.5 * velz_j
+            rho_h = 0.5 * rho_i + 0.5 * rho_j; rt_h = 0.5 * rt_i + 0.5 * rt_j
+            theta_h = 0.5 * eng.diag_theta(1, rho_j, rt_j) + 0.5 * theta_i                                            # :1896-1903
+            theta_l2_h = 0.5 * eng.diag_theta(0, rho_j, rt_j) + 0.5 * theta_l2_i                                      # :1905-1912
+            if verbose:
+                print("\t%d:\t|d_exner|/|exner|: %.6e\t|d_w|/|w|: %.6e\t|d_rho|/|rho|: %.6e\t|d_eta|/|eta|: %.6e"
+                      % (itt, norms["exner"], norms["w"], norms["rho"], norms["eta"]))
+            if norms["exner"] < tol and norms["rho"] < tol:               # :1922
+                break
+        self.theta_h, self.theta_l2_h, self.exner_h = theta_h, theta_l2_h, exner_h
+        return velz_j, rho_j, rt_j, exner_j

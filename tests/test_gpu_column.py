@@ -342,3 +342,55 @@ def test_selectable_kernel_variants_agree(setup, monkeypatch, var):
     alt_3 = eng.solve_schur_3(*a_3, *[t(f) for f in Fs])
     for a, b in list(zip(alt_eta, base_eta)) + list(zip(alt_3, base_3)):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8, var
+
+
+def test_vertical_newton_loop_matches_oracle(setup):
+    """the caller of the column path: VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) for all columns at once
+    (mimsem_amd/vertsolve.py) against the column-by-column numpy restatement oracle/vert_oracle.py -- three Newton iterations,
+    no horizontal wind; state and max-norm history.  Also VertSolve::initGZ (:89-175) against its formula."""
+    from mimsem_amd.vertsolve import SCALE as VSCALE, VertSolve
+    from oracle import vert_oracle
+    eng, P = setup
+    if P.nk < 4:
+        pytest.skip("Rayleigh layer needs nk >= 4")
+    r = np.random.default_rng(29)
+    nEl, nk, n2 = P.nEl, P.nk, P.n2e
+    dt = 0.5
+    t = eng.tensor
+    vs = VertSolve(eng, dt)
+    levs = eng.mesh.geoms[0].levs
+    zv_d = vs.init_gz(levs)
+    W, Q = P.arr("W", (P.mp12, n2)), P.arr("Q", (P.mp12,))
+    inds0 = eng.mesh.geoms[0].all_inds0_l()
+    zv = np.zeros((nEl, nk * n2))
+    for e in range(nEl):
+        for k in range(nk):
+            gz = 9.80616 * (levs[k, inds0[e]] + levs[k + 1, inds0[e]])
+            zv[e, k * n2:(k + 1) * n2] = W.T @ (VSCALE * 0.5 * Q * gz)
+    assert rel_l2(zv_d.cpu().numpy(), zv) < 1e-13
+    # an EOS-consistent column at rest plus small perturbations: Newton steps stay in the physical range of log / exp / pow.  A
+    # constant value v is the 2-form with DoF_j = v * (area of sub-cell j) * det * thickness (the edge functions histopolate)
+    wd = np.diff(P.arr("qx", (P.mp1,)))
+    wj = np.outer(wd, wd).ravel()
+    detm = P.det.mean(axis=1)
+    thm = np.stack([[P.thick[k, inds0[e]].mean() for k in range(nk)] for e in range(nEl)])
+    rho_v, th_v = np.linspace(1.2, 0.5, nk), np.linspace(290.0, 330.0, nk)
+    pi_v = 1004.5 * (287.0 * rho_v * th_v / 1.0e5) ** (287.0 / 717.5)
+
+    def col(v):
+        out = np.zeros((nEl, nk * n2))
+        for e in range(nEl):
+            for k in range(nk):
+                out[e, k * n2:(k + 1) * n2] = v[k] * wj * detm[e] * thm[e, k]
+        return out
+    pert = lambda: 1.0 + 1e-4 * r.standard_normal((nEl, nk * n2))
+    rho, rt, exner = col(rho_v) * pert(), col(rho_v * th_v) * pert(), col(pi_v) * pert()
+    velz = np.zeros((nEl, (nk - 1) * n2))
+    got = vs.solve_schur_eta(t(velz), t(rho), t(rt), t(exner), zv_d, maxit=3, tol=0.0)
+    want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, 3)
+    for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
+        assert np.all(np.isfinite(b)), name
+        assert rel_l2(a.cpu().numpy(), b) < 1e-8, name
+    for hd, ho in zip(vs.history, want[4]):
+        for k in ("exner", "w", "rho", "eta"):
+            assert abs(hd[k] - ho[k]) <= 1e-5 * ho[k] + 1e-15, (k, hd[k], ho[k])
