@@ -113,6 +113,30 @@ def column_extras(eng, dm, rng, torch):
     t = timeit(lambda: eng.solve_schur_3(75.0, thetaI, velz, rho, rt, pi, *[f.clone() for f in F]), 3)
     res["schur3_column_solves_per_s"] = nEl / t
     res["schur3_ms_all_columns"] = t * 1e3
+    # the caller of the column solve: one Newton iteration of VertSolve::solve_schur_eta (residual assembly, EOS residual, entropy
+    # diagnostics, the Schur solve, the updates and both theta diagnoses) for every column, from an EOS-consistent state at rest
+    from mimsem_amd.geom import gll_points
+    from mimsem_amd.vertsolve import VertSolve
+    wd = np.diff(gll_points(PN)); wj = np.outer(wd, wd).ravel()
+    cell = dm.det.mean(axis=1)[:, None, None] * dm.thick.mean(axis=2).T[:, :, None] * wj[None, None, :]       # [nEl, nk, n2]
+    zl = np.mean([g.levs.mean(axis=1) for g in dm.geoms], axis=0)               # mean interface heights -> level mid-heights
+    zm = 0.5 * (zl[:-1] + zl[1:])
+    th_v = 300.0 + 0.004 * zm                                                    # hydrostatic column: dPi/dz = -g/theta, EOS for rho theta
+    pi_v = 1004.5 - (9.80616 / 0.004) * np.log(th_v / 300.0)
+    rho_v = (1.0e5 / 287.0) * (pi_v / 1004.5) ** (717.5 / 287.0) / th_v
+    colv = lambda v: eng.tensor((cell * v[None, :, None]).reshape(nEl, nk * n2) * (1.0 + 1e-4 * rng.standard_normal((nEl, nk * n2))))
+    vs = VertSolve(eng, 75.0)
+    levs = np.zeros((nk + 1, dm.nq))
+    for g in dm.geoms:
+        levs[:, np.searchsorted(dm.gidq, g.loc0[np.arange(g.n0)])] = g.levs
+    zv = vs.init_gz(levs)
+    st = (eng.zeros(nEl, (nk - 1) * n2), colv(rho_v), colv(rho_v * th_v), colv(pi_v))
+    vs.solve_schur_eta(*st, zv, maxit=2, tol=0.0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    vs.solve_schur_eta(*st, zv, maxit=4, tol=0.0)
+    torch.cuda.synchronize(); tn = (time.perf_counter() - t0) / 4
+    res["vertical_newton_iteration_ms"] = tn * 1e3
+    res["vertical_newton_norms_last"] = vs.history[-1]
     t = timeit(lambda: eng.colop_apply("CONST_RHO", theta, f1=rho, nout_slots=nk), 20)
     res["vertops_assemble_apply_columns_per_s"] = nEl / t
     vh = eng.tensor(rng.standard_normal((nk, dm.n2)))
