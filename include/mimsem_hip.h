@@ -278,6 +278,10 @@ int mimsem_colop_blocks(mimsem_ctx* ctx, int colop, unsigned flags,
  * transpose != 0 applies A^T (MatMultTranspose, eul/VertSolve.cpp:486)                           */
 int mimsem_colop_apply(mimsem_ctx* ctx, int colop, unsigned flags, int transpose,
                        const double* f1, const double* f2, const double* x, double* y);
+/* MatMult(M, x, y) with blocks obtained earlier from mimsem_colop_blocks(_ex) -- for the operators that depend on the geometry
+ * only (AssembleConst, AssembleConstInv, AssembleLinear, AssembleLinearInv, AssembleRayleigh: eul/VertOps.cpp:184-1013), which the
+ * reference re-assembles before every MatMult */
+int mimsem_colop_apply_blocks(mimsem_ctx* ctx, int colop, int transpose, const double* blocks, const double* x, double* y);
 
 /* EOS / log / exp column vectors (C7), eul/VertOps.cpp:732-787, :987-1047, :1204-1305.
  * which: 0 = Assemble_EOS_Residual(rt=a, exner=b) ; 1 = Assemble_EOS_RHS(rt=a, factor=p0, exponent=p1) ;

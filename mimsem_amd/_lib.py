@@ -63,6 +63,7 @@ _SIGS = {
                                                c_dp, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_precond_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_krylov_reorthonormalize": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),
+    "mimsem_colop_apply_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_colop_nblocks": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_colop_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, c_dp, c_dp, c_dp]),

@@ -658,6 +658,13 @@ int mimsem_colop_apply(mimsem_ctx* c, int colop, unsigned flags, int transpose,
     return stored_apply(c, colop, transpose, M, x, y);
 }
 
+// MatMult with blocks the caller already holds (mimsem_colop_blocks output): the operators that depend on the geometry only
+// (AssembleConst, AssembleConstInv, AssembleLinear, AssembleLinearInv, AssembleRayleigh) need not be re-assembled per use
+int mimsem_colop_apply_blocks(mimsem_ctx* c, int colop, int transpose, const double* blocks, const double* x, double* y) {
+    if (!c || !blocks || !x || !y || colop < 0 || colop >= MIMSEM_V_COUNT) return MIMSEM_ERR_ARG;
+    return stored_apply(c, colop, transpose, blocks, x, y);
+}
+
 // L2Vecs::HorizToVert / VertToHoriz, eul/L2Vecs.cpp:55-101 ([k][e][i] <-> [e][k][i], faces element-contiguous)
 int mimsem_l2_transpose(mimsem_ctx* c, int dir, int nkv, double* vh, long long hs, double* vz) {
     if (!c || !vh || !vz || nkv < 0) return MIMSEM_ERR_ARG;

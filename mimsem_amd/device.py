@@ -410,6 +410,13 @@ class Engine:
               "colop_apply(%s)" % colop)
         return y
 
+    def colop_apply_blocks(self, colop, blocks, x, nout_slots, transpose=False):
+        """MatMult with blocks from colop_blocks (geometry-only operators assembled once)"""
+        y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_colop_apply_blocks(self.ctx, COLOPS[colop], int(transpose), _ptr(blocks), _ptr(x), _ptr(y)),
+              "colop_apply_blocks(%s)" % colop)
+        return y
+
     def colop_blocks_ex(self, colop, param=0.0, f1=None, f2=None, uh=None, flags=0):
         """the Strang / Held-Suarez colops: param = dt_fric or dt, uh = [nk, n1] horizontal velocity (local 1-forms)"""
         nb = self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])

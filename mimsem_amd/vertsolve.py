@@ -13,9 +13,17 @@ class VertSolve:
         self.eng, self.dt, self.rayleigh = eng, dt, rayleigh
         self.nk, self.n2e = eng.nk, eng.n2e
         self.k2i_z = 0.0
+        self._blocks = {}
 
     # thin wrappers: vo->AssembleX(ex,ey,...,M); MatMult(M, x, y) for every column
+    _GEOMETRY_ONLY = ("CONST", "CONST_INV", "LINEAR", "LINEAR_INV", "RAYLEIGH")
+
     def _mv(self, colop, x, f1=None, f2=None, flags=0, rows=None, transpose=False):
+        if colop in self._GEOMETRY_ONLY and f1 is None and f2 is None and flags == 0:
+            # assembled once per VertSolve (the reference re-assembles before every MatMult; the blocks only depend on the mesh)
+            if colop not in self._blocks:
+                self._blocks[colop] = self.eng.colop_blocks(colop)
+            return self.eng.colop_apply_blocks(colop, self._blocks[colop], x, rows, transpose=transpose)
         return self.eng.colop_apply(colop, x, f1=f1, f2=f2, flags=flags, transpose=transpose, nout_slots=rows)
 
     def V10(self, x):
