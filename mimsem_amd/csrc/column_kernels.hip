@@ -540,6 +540,11 @@ bool colop_is_inverse(int colop) {
 
 int up_blocks_into(mimsem_ctx* c, int colop, const double* rho, double* M, double* tmpM);   // below (needs the velocity set in the ctx)
 
+// matrix-free MatMult for the operators whose stored block is W^T diag(c) W itself (no inverse, no product): defined with the row
+// kernels below.  Returns MIMSEM_ERR_UNSUPPORTED when the operator needs its blocks.
+int launch_colop_apply_mf(mimsem_ctx* c, int colop, unsigned flags, int transpose, const double* f1, const double* f2,
+                          const double* x, double* y);
+
 // blocks of a column operator into M ([nEl][nr][nw][n2][n2]); cq scratch [nEl][nr][nw][mp12] (x2 for EOS)
 int colop_blocks_into(mimsem_ctx* c, int colop, unsigned flags, const double* f1, const double* f2,
                       double* M, double* cq, double* tmpM, const double* Bconst = nullptr /* CONST blocks if the caller has them */) {
@@ -649,8 +654,9 @@ int mimsem_colop_blocks(mimsem_ctx* c, int colop, unsigned flags, const double* 
 int mimsem_colop_apply(mimsem_ctx* c, int colop, unsigned flags, int transpose,
                        const double* f1, const double* f2, const double* x, double* y) {
     if (!c || !x || !y || colop < 0 || colop >= MIMSEM_V_COUNT) return MIMSEM_ERR_ARG;
-    int rc = c->ensure_col(colop_ws_doubles(c));
-    if (rc) return rc;
+    int rc = launch_colop_apply_mf(c, colop, flags, transpose, f1, f2, x, y);
+    if (rc != MIMSEM_ERR_UNSUPPORTED) return rc;
+    if ((rc = c->ensure_col(colop_ws_doubles(c)))) return rc;
     const long long nbmax = (long long)c->nEl*(c->nk + 1)*2;
     const int nn = c->es.n2e*c->es.n2e;
     double* cq = c->d_col; double* tmpM = cq + nbmax*c->es.mp12; double* M = tmpM + 2*nbmax*nn;
@@ -971,6 +977,78 @@ __device__ __forceinline__ void wsync_lds() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// y = M x (or M^T x) WITHOUT the blocks, for the operators whose block (r, w) is W^T diag(c_{r,w}) W: one group of lanes per (column,
+// output slot) task, lane q owns quadrature point q -- it evaluates the coefficient (the same colop_coef the block assembly
+// uses), interpolates the input there and scales; lanes a < n2 project back.  Replaces k_coef_block (53 us) + the stored apply
+// (33 us) of mimsem_colop_apply by one launch.
+template <int N>
+__global__ __launch_bounds__(256) void k_colop_apply_mf(CG g, int colop, unsigned flags, const double* __restrict__ f1,
+        const double* __restrict__ f2, int transpose, int nr, int nw, int nxx, int nyy, int off,
+        const double* __restrict__ x, double* __restrict__ y) {
+    constexpr int N2 = N*N, MP1 = N + 1, MP12 = MP1*MP1;
+    constexpr int GW = MP12 <= 16 ? 16 : (MP12 <= 32 ? 32 : 64), TPB = 256/GW;
+    __shared__ double sE[MP1*N], sw[MP1], sW[MP12*N2], sx[TPB][N2], sv[TPB][MP12];
+    const int tid = threadIdx.x, t = tid/GW, r = tid%GW;
+    if (tid < MP1*N) sE[tid] = g.E[tid];
+    if (tid < MP1) sw[tid] = g.w[tid];
+    __syncthreads();
+    for (int i = tid; i < MP12*N2; i += 256) { const int q = i/N2, j = i%N2; sW[i] = sE[(q%MP1)*N + j%N]*sE[(q/MP1)*N + j/N]; }
+    __syncthreads();
+    const long long task0 = (long long)blockIdx.x*TPB + t, ntask = (long long)g.nEl*nyy;
+    const bool live = task0 < ntask;
+    const long long task = live ? task0 : ntask - 1;
+    const int ry = (int)(task%nyy), e = (int)(task/nyy);
+    CG gl = g; gl.E = sE; gl.w = sw;
+    double acc = 0.0;
+    for (int w = 0; w < nw; w++) {
+        int rb, cx;                       // stored block row, input slot (as in stored_apply)
+        if (nw == 1)         { rb = ry; cx = ry; }
+        else if (!transpose) { rb = ry; cx = ry + off + w; }
+        else                 { rb = ry - off - w; cx = rb; }
+        const bool ok = rb >= 0 && rb < nr && cx >= 0 && cx < nxx;
+        wsync_lds();
+        if (r < N2) sx[t][r] = ok ? x[((size_t)e*nxx + cx)*N2 + r] : 0.0;
+        wsync_lds();
+        if (r < MP12) {
+            double u = 0.0;
+#pragma unroll
+            for (int j = 0; j < N2; j++) u += sW[r*N2 + j]*sx[t][j];
+            sv[t][r] = ok ? colop_coef(gl, colop, flags, e, rb, w, r, f1, f2)*u : 0.0;
+        }
+        wsync_lds();
+        if (r < N2) {
+#pragma unroll
+            for (int q = 0; q < MP12; q++) acc += sW[q*N2 + r]*sv[t][q];
+        }
+    }
+    if (live && r < N2) y[(size_t)task*N2 + r] = acc;
+}
+
+int launch_colop_apply_mf(mimsem_ctx* c, int colop, unsigned flags, int transpose, const double* f1, const double* f2,
+                          const double* x, double* y) {
+    if (colop_is_inverse(colop) || colop == MIMSEM_V_EOS_BLOCK || colop == MIMSEM_V_EOS_BLOCK_INV ||
+        colop == MIMSEM_V_LINEAR_RHO2_UP || colop == MIMSEM_V_LINCON2_UP || getenv("MIMSEM_COLOP_BLOCKS"))
+        return MIMSEM_ERR_UNSUPPORTED;
+    int nr, nw, nx, ny;
+    colop_shape(colop, c->nk, &nr, &nw, &nx, &ny);
+    const int off = (colop == MIMSEM_V_LINCON) ? 0 : -1;
+    const int nyy = transpose ? nx : ny, nxx = transpose ? ny : nx;
+    const long long ntask = (long long)c->nEl*nyy;
+    if (ntask == 0) return MIMSEM_OK;
+    const CG g = make_cg(c);
+    const int mp12 = c->es.mp12, gw = mp12 <= 16 ? 16 : (mp12 <= 32 ? 32 : 64), tpb = 256/gw;
+    const unsigned grid = (unsigned)((ntask + tpb - 1)/tpb);
+    switch (c->es.n) {
+#define MIMSEM_MF(N) case N: hipLaunchKernelGGL((k_colop_apply_mf<N>), dim3(grid), dim3(256), 0, c->stream, g, colop, flags, f1, f2, transpose, \
+                                                nr, nw, nxx, nyy, off, x, y); break;
+    MIMSEM_MF(1) MIMSEM_MF(2) MIMSEM_MF(3) MIMSEM_MF(4) MIMSEM_MF(5) MIMSEM_MF(6) MIMSEM_MF(7)
+#undef MIMSEM_MF
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 template <int N2>
 __global__ __launch_bounds__(64) void k_block_thomas_wave(int nk, const double* __restrict__ L, const double* __restrict__ f,
                                                           double* __restrict__ d, double* __restrict__ Gws, double* __restrict__ yws,
