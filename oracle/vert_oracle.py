@@ -41,15 +41,17 @@ def assemble_residual_ec(P, ex, ey, dt, theta, Pi, velz1, velz2, rho1, rho2, zv,
     return fw, F, G, ftc
 
 
-def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits):
+def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits, hs_forcing=False, udwdx=None):
     """`nits` Newton iterations of :1721-1973 for every column of the patch; arrays [nEl][slots*n2e]; returns the new state and
-    the max-norm history"""
+    the max-norm history.  hs_forcing: the Held-Suarez temperature forcing of :1831-1834; udwdx: the optional F_w term of :1809"""
     nEl, nk, n2 = P.nEl, P.nk, P.n2e
     V10 = _v10(nk, n2)
     velz_j, rho_j, rt_j, exner_j = velz_i.copy(), rho_i.copy(), rt_i.copy(), exner_i.copy()
     col = lambda f: np.stack([f(e % P.nElsX, e // P.nElsX, e) for e in range(nEl)])
     theta_l2_i = col(lambda ex, ey, e: P.diag_theta_L2(ex, ey, rho_i[e], rt_i[e]))
     theta_l2_h = theta_l2_i.copy()
+    theta_i = col(lambda ex, ey, e: P.diag_theta2(ex, ey, rho_i[e], rt_i[e]))
+    theta_h = theta_i.copy()
     exner_h, velz_h, rho_h, rt_h = exner_i.copy(), velz_i.copy(), rho_i.copy(), rt_i.copy()
     hist = []
     for _ in range(nits):
@@ -58,12 +60,16 @@ def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits):
             ex, ey = e % P.nElsX, e // P.nElsX
             D = lambda op, **kw: P.colop_dense(op, ex, ey, **kw)
             F_w, F_z, G_z, ftc = assemble_residual_ec(P, ex, ey, dt, theta_l2_h[e], exner_h[e], velz_i[e], velz_j[e], rho_i[e], rho_j[e], zv[e], V10)
+            if udwdx is not None:
+                F_w = F_w + dt * udwdx[e]
             F_exner = P.eos_residual(ex, ey, rt_j[e], exner_j[e])
             VB = D("CONST")
             dF_z = rho_j[e] + dt * (V10 @ F_z) - rho_i[e]
             dG_z = rt_j[e] + 0.5 * dt * (V10 @ G_z) - rt_i[e]
             F_rho = VB @ dF_z
             F_rt = VB @ dG_z + ftc
+            if hs_forcing:
+                F_rt = F_rt + dt * P.temp_forcing_hs(ex, ey, exner_h[e], theta_h[e], rho_h[e])
             t1 = D("CONST_RHO_INV", f1=rt_h[e]) @ F_rt - D("CONST_RHO_INV", f1=rho_h[e]) @ F_rho
             F_eta = VB @ t1
             th_w3 = D("CONST_RHO_INV", f1=rho_h[e]) @ (VB @ rt_h[e])
@@ -79,6 +85,7 @@ def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits):
                 mx[k] = max(mx[k], np.linalg.norm(dx) / np.linalg.norm(x))
             exner_h[e] = 0.5 * exner_i[e] + 0.5 * exner_j[e]; velz_h[e] = 0.5 * velz_i[e] + 0.5 * velz_j[e]
             rho_h[e] = 0.5 * rho_i[e] + 0.5 * rho_j[e]; rt_h[e] = 0.5 * rt_i[e] + 0.5 * rt_j[e]
+        theta_h = 0.5 * col(lambda ex, ey, e: P.diag_theta2(ex, ey, rho_j[e], rt_j[e])) + 0.5 * theta_i
         theta_l2_j = col(lambda ex, ey, e: P.diag_theta_L2(ex, ey, rho_j[e], rt_j[e]))
         theta_l2_h = 0.5 * theta_l2_j + 0.5 * theta_l2_i
         hist.append(mx)

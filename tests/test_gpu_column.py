@@ -394,3 +394,10 @@ def test_vertical_newton_loop_matches_oracle(setup):
     for hd, ho in zip(vs.history, want[4]):
         for k in ("exner", "w", "rho", "eta"):
             assert abs(hd[k] - ho[k]) <= 1e-5 * ho[k] + 1e-15, (k, hd[k], ho[k])
+    # with the Held-Suarez temperature forcing and the u dw/dx term switched on
+    lat = P.sq[:, 1][P.elinds("q")]                                    # Geom::s[elInds0_l][1]: latitude of the quadrature points
+    udwdx = 1e-3 * r.standard_normal((nEl, (nk - 1) * n2)) * float(np.abs(zv).mean()) / 9.80616 / 1.5e4
+    got = vs.solve_schur_eta(t(velz), t(rho), t(rt), t(exner), zv_d, maxit=2, tol=0.0, hs_lat=t(np.ascontiguousarray(lat)), udwdx=t(udwdx))
+    want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, 2, hs_forcing=True, udwdx=udwdx)
+    for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
+        assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < 1e-8, name
