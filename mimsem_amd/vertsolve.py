@@ -84,6 +84,17 @@ class VertSolve:
         zh = (0.5 * SCALE) * eng.apply("WTQ", (gz[:-1] + gz[1:]).contiguous())
         return eng.l2_horiz_to_vert(zh)
 
+    def horiz_forcing_from(self, hs, velx1, velx2):
+        """the horizontal transport tendencies the Newton loop adds (eul/VertSolve.cpp:1799): HorizSolve::advection_rhs_ec on the
+        horizontal layout, transposed into the vertical one (L2Vecs::HorizToVert)"""
+        eng, nk = self.eng, self.nk
+
+        def forcing(rho_i, rho_j, theta_l2_h):
+            dF, dG, _, _ = hs.advection_rhs_ec(velx1, velx2, eng.l2_vert_to_horiz(rho_i, nk), eng.l2_vert_to_horiz(rho_j, nk),
+                                                eng.l2_vert_to_horiz(theta_l2_h, nk))
+            return eng.l2_horiz_to_vert(dF), eng.l2_horiz_to_vert(dG)
+        return forcing
+
     # ---- the vertical implicit solve: the caller of the column path (SURVEY 3.2 step 6) ---------------------------------------
     def solve_schur_eta(self, velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing=None, udwdx=None, hs_lat=None, maxit=20, tol=1.0e-12,
                         verbose=False):

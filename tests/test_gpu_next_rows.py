@@ -252,3 +252,55 @@ def test_krylov_batched_cg_kernels(sphere):
     z = eng.tensor(rng.standard_normal((nr, n))); p2 = p.clone()
     eng.cg_direction(num, den, z, p2)
     assert torch.allclose(p2, z + al * p, rtol=1e-13, atol=1e-13)
+
+
+def test_vertical_newton_loop_with_horizontal_transport():
+    """VertSolve::solve_schur_eta with HorizSolve::advection_rhs_ec re-evaluated in every Newton iteration (eul/VertSolve.cpp:1798-1799)
+    on a whole (small) sphere: a hydrostatic column state plus a weak horizontal wind -- the iteration contracts and stays finite;
+    without wind the horizontal tendencies vanish identically"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom, gll_points
+    from mimsem_amd.horizsolve import HorizSolve
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from mimsem_amd.vertsolve import VertSolve
+    pn, ne, nk = 3, 3, 8
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    topos = [Topo(cs, p, nk) for p in range(6)]
+    geoms = [Geom(t, cs, coords, nk) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(nk, g.n0))
+    dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+    eng = Engine(dm)
+    rng = np.random.default_rng(41)
+    nEl, n2 = dm.nEl, eng.n2e
+    wd = np.diff(gll_points(pn)); wj = np.outer(wd, wd).ravel()
+    cell = dm.det.mean(axis=1)[:, None, None] * dm.thick.mean(axis=2).T[:, :, None] * wj[None, None, :]
+    zl = np.mean([g.levs.mean(axis=1) for g in geoms], axis=0); zm = 0.5 * (zl[:-1] + zl[1:])
+    th_v = 300.0 + 0.004 * zm
+    pi_v = 1004.5 - (9.80616 / 0.004) * np.log(th_v / 300.0)
+    rho_v = (1.0e5 / 287.0) * (pi_v / 1004.5) ** (717.5 / 287.0) / th_v
+    colv = lambda v: eng.tensor((cell * v[None, :, None]).reshape(nEl, nk * n2))
+    vs = VertSolve(eng, 30.0)
+    levs = np.zeros((nk + 1, dm.nq))
+    for g in geoms:
+        levs[:, np.searchsorted(dm.gidq, g.loc0[np.arange(g.n0)])] = g.levs
+    zv = vs.init_gz(levs)
+    st = (eng.zeros(nEl, (nk - 1) * n2), colv(rho_v), colv(rho_v * th_v), colv(pi_v))
+    hs = HorizSolve(eng)
+    zero = eng.zeros(nk, dm.n1)
+    f0 = vs.horiz_forcing_from(hs, zero, zero)(st[1], st[1], eng.diag_theta(0, st[1], st[2]))
+    assert float(f0[0].abs().max()) == 0.0 and float(f0[1].abs().max()) == 0.0
+    # a weak wind: a smooth 1-form = weak gradient of a smooth scalar, ~1 m/s
+    xq = np.zeros((dm.nq, 3))
+    for g in geoms:
+        xq[g.loc0] = coords[g.loc0]
+    phi_q = torch.as_tensor(xq[dm.gidq][:, 2] / 6371220.0, device=eng.device).repeat(nk, 1).contiguous()
+    phi = eng.apply("WTQ", phi_q)                                     # sin(latitude), as a weak 2-form on every level
+    velx = hs.grad(phi / float(phi.abs().max()) * float(st[1].abs().mean()) * 1e-6)
+    forcing = vs.horiz_forcing_from(hs, velx, velx)
+    out = vs.solve_schur_eta(*st, zv, horiz_forcing=forcing, maxit=4, tol=0.0)
+    assert all(bool(torch.isfinite(o).all()) for o in out)
+    h = vs.history
+    assert h[-1]["exner"] < 0.2 * h[0]["exner"] and h[-1]["rho"] < h[0]["rho"] and h[-1]["exner"] < 1e-3, h
