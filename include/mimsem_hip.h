@@ -83,7 +83,7 @@ enum mimsem_op {
      * mimsem_op_apply_up: f = the op's field, u = local 1-form velocity that defines the departure points */
     MIMSEM_OP_PHMAT_UP = 14, /* Phmat::assemble_up(ul,hl,fac,dt)  src/Assembly.cpp:499-567   f=hl (2-form)  0 -> 0 */
     MIMSEM_OP_ROTMAT_UP = 15,/* RotMat_up::assemble(q0,ul,fac,dt) src/Assembly.cpp:1784-1853 f=q0 (0-form)  1 -> 1 */
-    /* eul-flavour operators whose TEST functions are evaluated at departure points (mimsem_op_apply_up; p <= 6) */
+    /* eul-flavour operators whose TEST functions are evaluated at departure points (mimsem_op_apply_up) */
     MIMSEM_OP_UMAT_UP = 19,   /* Umat::assemble_up(lev,scale,tau,ui,uj)      Assembly.cpp:156-279  f=ui, u=uj (local 1-forms) 1 -> 1 */
     MIMSEM_OP_UHMAT_UP = 20,  /* Uhmat::assemble_up(h2,lev,scale,dt,u1)      :477-560              f=h2, u=u1, tau=dt        1 -> 1 */
     MIMSEM_OP_UVEC_HU_UP = 21,/* Uvec::assemble_hu_up(lev,scale,vel,rho,fac,tau,vel2) :2281-2373   x=vel, f=rho, u=vel2, alpha=fac */

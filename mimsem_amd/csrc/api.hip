@@ -409,7 +409,6 @@ int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double sc
                        const double* x, long long xs, double* y, long long ys, double alpha) {
     if (!is_up_op(op) || !u) return MIMSEM_ERR_ARG;
     if ((flags & MIMSEM_FLAG_TRANSPOSE) && op != MIMSEM_OP_UMAT_UP && op != MIMSEM_OP_UHMAT_UP) return MIMSEM_ERR_ARG;
-    if (c && c->es.n > 6 && op >= MIMSEM_OP_UMAT_UP && op <= MIMSEM_OP_UVEC_HU_UP) return MIMSEM_ERR_UNSUPPORTED;    // LDS budget of the test-upwind kernels
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, y, ys, alpha);
 }
 

@@ -287,7 +287,8 @@ template <int N, int OP, bool FUSED>
 __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     using D = Dims<N>;
     using T = OpTraits<OP>;
-    constexpr int LPE = D::LPE, EPB = D::EPB;
+    // the test-upwind operators keep per-point basis tables in LDS: at p = 7 two elements per workgroup (128 threads) fit in 64 KB
+    constexpr int LPE = D::LPE, EPB = (T::tup != 0 && N == 7) ? 2 : D::EPB;
     static_assert(!FUSED || T::out == S1, "the fused scatter-add exists for 1-form results only");
     __shared__ double s_acc[FUSED ? 2 : 1][FUSED ? EPB*2*D::n1e : 1];   // the group's element-local results, double-buffered by level parity
     __shared__ double sE[D::mp1*N];
@@ -1248,7 +1249,15 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         MIMSEM_CASE(MIMSEM_OP_WTQ) MIMSEM_CASE(MIMSEM_OP_PTQ) MIMSEM_CASE(MIMSEM_OP_UTQ)
         case MIMSEM_OP_UMAT_UP: case MIMSEM_OP_UHMAT_UP: case MIMSEM_OP_UVEC_HU_UP:
             if constexpr (N <= 6) { switch (op) { MIMSEM_CASE(MIMSEM_OP_UMAT_UP) MIMSEM_CASE(MIMSEM_OP_UHMAT_UP) MIMSEM_CASE(MIMSEM_OP_UVEC_HU_UP) } break; }
-            else return MIMSEM_ERR_UNSUPPORTED;
+            else {                           // p = 7: two elements per workgroup of 128 threads (LDS budget, see k_elem_apply)
+                const unsigned g2 = (unsigned)((items + 1)/2);
+                switch (op) {
+                case MIMSEM_OP_UMAT_UP:    hipLaunchKernelGGL((k_elem_apply<N, MIMSEM_OP_UMAT_UP, false>), dim3(g2), dim3(128), 0, c->stream, a); break;
+                case MIMSEM_OP_UHMAT_UP:   hipLaunchKernelGGL((k_elem_apply<N, MIMSEM_OP_UHMAT_UP, false>), dim3(g2), dim3(128), 0, c->stream, a); break;
+                default:                   hipLaunchKernelGGL((k_elem_apply<N, MIMSEM_OP_UVEC_HU_UP, false>), dim3(g2), dim3(128), 0, c->stream, a); break;
+                }
+                break;
+            }
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_CASE

@@ -154,8 +154,6 @@ def test_quad_grid_projections(setup, which, op):
 def test_eul_upwinded_test_functions(setup, which):
     """B2 Umat::assemble_up, B4 Uhmat::assemble_up, B17 Uvec::assemble_hu_up (eul/Assembly.cpp:156-279, 477-560, 2281-2373)"""
     eng, P, rng = setup
-    if P.n > 6:
-        pytest.skip("test-upwind kernels are built for p <= 6")
     r = np.random.default_rng(41)
     lev, tau = 1, 75.0
     vscale = P.det.mean() / P.thickInv[lev].mean() * 0.3 / tau        # shift ~ 0.3 of the reference element
