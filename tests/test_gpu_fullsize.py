@@ -184,6 +184,34 @@ def test_shallow_water_step_conserves_mass_exactly():
     assert float(torch.linalg.vector_norm(h1 - h0) / torch.linalg.vector_norm(h0)) < 2e-5
 
 
+def test_vertical_newton_loop_converges_on_a_hydrostatic_column(full):
+    """config 4 size: VertSolve::solve_schur_eta from a hydrostatic, EOS-consistent column at rest -- the Newton iteration contracts
+    to the reference's stopping level (|d_exner|/|exner|, |d_rho|/|rho| < 1e-12) and the column stays at rest to truncation error"""
+    import torch
+    from mimsem_amd.geom import gll_points
+    from mimsem_amd.vertsolve import VertSolve
+    cs, dm, eng, rng = full
+    nEl, n2, nk = dm.nEl, eng.n2e, NK
+    wd = np.diff(gll_points(PN)); wj = np.outer(wd, wd).ravel()
+    cell = dm.det.mean(axis=1)[:, None, None] * dm.thick.mean(axis=2).T[:, :, None] * wj[None, None, :]
+    zl = np.mean([g.levs.mean(axis=1) for g in dm.geoms], axis=0); zm = 0.5 * (zl[:-1] + zl[1:])
+    th_v = 300.0 + 0.004 * zm
+    pi_v = 1004.5 - (9.80616 / 0.004) * np.log(th_v / 300.0)
+    rho_v = (1.0e5 / 287.0) * (pi_v / 1004.5) ** (717.5 / 287.0) / th_v
+    colv = lambda v: eng.tensor((cell * v[None, :, None]).reshape(nEl, nk * n2))
+    vs = VertSolve(eng, 75.0)
+    levs = np.zeros((nk + 1, dm.nq))
+    for g in dm.geoms:
+        levs[:, np.searchsorted(dm.gidq, g.loc0[np.arange(g.n0)])] = g.levs
+    zv = vs.init_gz(levs)
+    st = (eng.zeros(nEl, (nk - 1) * n2), colv(rho_v), colv(rho_v * th_v), colv(pi_v))
+    velz, rho, rt, exner = vs.solve_schur_eta(*st, zv, maxit=30)
+    h = vs.history
+    assert h[-1]["exner"] < 1e-12 and h[-1]["rho"] < 1e-12 and len(h) < 30, (len(h), h[-1])
+    assert all(bool(torch.isfinite(v).all()) for v in (velz, rho, rt, exner))
+    assert float(torch.linalg.vector_norm(rho - st[1]) / torch.linalg.vector_norm(st[1])) < 1e-2      # discrete balance ~ continuous balance
+
+
 def test_galewsky_quarter_day_conserves():
     """config 3 as the reference driver runs it (src/Galewsky.cpp: jet + perturbation, dt = 360 s, 2 Picard iterations, upwinded q)
     for 60 steps = 6 h: mass to round-off, energy and potential enstrophy drifts of the size the reference prints to
