@@ -121,6 +121,10 @@ int  mimsem_ctx_sync(mimsem_ctx* ctx);
 int  mimsem_ctx_set_levels(mimsem_ctx* ctx, const double* thick, const double* thickInv);
 /* bytes of device workspace the context currently holds */
 long long mimsem_ctx_workspace_bytes(const mimsem_ctx* ctx);
+/* Levels one work item of the element kernel (pass 1 of mimsem_op_apply) keeps its level-invariant data (metric, determinant,
+ * gather slots) in registers for, at a call over nlev levels: the byte model of bench.py's roofline needs it (the metric of an
+ * element is re-read once per chunk, not once per level). */
+int  mimsem_op_level_chunk(const mimsem_ctx* ctx, int nlev);
 /* Measurement hook (bench.py): when on = n > 0, every n-th mimsem_op_apply brackets its element kernel (pass 1) and its
  * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
  * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */

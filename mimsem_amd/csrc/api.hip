@@ -106,6 +106,19 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
     return MIMSEM_OK;
 }
 
+// levels per work item of the element kernel: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible
+int level_chunk(const mimsem_ctx* c, int nlev) {
+    const ElemSizes& es = c->es;
+    const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
+    const long long blocks1 = ((long long)c->nEl + epb - 1)/epb;          // workgroups per single level
+    long long lch = (blocks1*nlev)/(256*6);
+    if (lch < 1) lch = 1;
+    if (lch > nlev) lch = nlev;
+    if (lch > 8) lch = 8;
+    if (c->lch_override > 0) lch = std::min(c->lch_override, nlev);
+    return (int)std::max(1LL, lch);
+}
+
 int op_spaces(int op, int* in, int* cf, int* out) {
     switch (op) {
     case MIMSEM_OP_UMAT: case MIMSEM_OP_UTMAT:   *in = 1; *cf = -1; *out = 1; return 0;
@@ -132,8 +145,14 @@ int op_spaces(int op, int* in, int* cf, int* out) {
 
 // Workspaces only ever grow, and an outgrown buffer is RETIRED, not freed: a hipGraph captured earlier (Krylov / Richardson steps)
 // has the old address baked into its kernel arguments and must keep working on it; retired buffers go with the context.
+bool mimsem_ctx::is_capturing() const {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) return false;
+    return st != hipStreamCaptureStatusNone;
+}
 int mimsem_ctx::ensure_ye(long long doubles) {
     if (doubles <= ye_doubles) return MIMSEM_OK;
+    if (is_capturing()) return MIMSEM_ERR_STATE;
     if (d_ye) { retired.push_back(d_ye); d_ye = nullptr; ye_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_ye, (size_t)doubles*sizeof(double)));
     ye_doubles = doubles; bytes += doubles*8;
@@ -141,6 +160,7 @@ int mimsem_ctx::ensure_ye(long long doubles) {
 }
 int mimsem_ctx::ensure_kry(long long doubles) {
     if (doubles <= kry_doubles) return MIMSEM_OK;
+    if (is_capturing()) return MIMSEM_ERR_STATE;
     if (d_kry) { retired.push_back(d_kry); d_kry = nullptr; kry_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_kry, (size_t)doubles*sizeof(double)));
     kry_doubles = doubles; bytes += doubles*8;
@@ -148,7 +168,9 @@ int mimsem_ctx::ensure_kry(long long doubles) {
 }
 int mimsem_ctx::ensure_col(long long doubles) {
     if (doubles <= col_doubles) return MIMSEM_OK;
-    if (d_col) { MIMSEM_HIP_TRY(hipFree(d_col)); bytes -= col_doubles*8; d_col = nullptr; col_doubles = 0; }
+    // retired like d_ye / d_kry: a graph captured around a column call (Engine.capture accepts any fn) keeps the old address
+    if (is_capturing()) return MIMSEM_ERR_STATE;          // growing = hipMalloc, illegal on a capturing stream: warm up outside the capture
+    if (d_col) { retired.push_back(d_col); d_col = nullptr; col_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_col, (size_t)doubles*sizeof(double)));
     col_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
@@ -319,8 +341,9 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     }
     {
         const size_t cnt = (size_t)d->nk*d->nEl*es.mp12;
-        MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double)));
-        MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_tI, std::max<size_t>(cnt, 1)*sizeof(double)));
+        hipError_t he = hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double));
+        if (he == hipSuccess) he = hipMalloc((void**)&c->d_tI, std::max<size_t>(cnt, 1)*sizeof(double));
+        if (he != hipSuccess) return fail(mimsem::hip_fail(he, "hipMalloc(thickness)"));
         c->bytes += 2*(long long)cnt*8;
     }
     if ((rc = mimsem_ctx_set_levels(c, d->thick, d->thickInv))) return fail(rc);
@@ -345,6 +368,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
 int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) { if (!c) return MIMSEM_ERR_ARG; c->stream = (hipStream_t)s; return MIMSEM_OK; }
 int mimsem_ctx_sync(mimsem_ctx* c) { if (!c) return MIMSEM_ERR_ARG; MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream)); return MIMSEM_OK; }
 long long mimsem_ctx_workspace_bytes(const mimsem_ctx* c) { return c ? c->bytes : 0; }
+int mimsem_op_level_chunk(const mimsem_ctx* c, int nlev) { return (c && nlev > 0) ? level_chunk(c, nlev) : MIMSEM_ERR_ARG; }
 
 int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thickInv) {
     if (!c) return MIMSEM_ERR_ARG;
@@ -439,15 +463,8 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     if (in == 3 && !c->d_iq) return MIMSEM_ERR_STATE;     // projection operators need mimsem_mesh_desc::indsq
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;
     a.f2 = f2; a.f2s = f2s; a.param = param; a.xn = c->d_xn;
-    {   // levels per work item: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible
-        const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
-        const long long blocks1 = ((long long)c->nEl + epb - 1)/epb;          // workgroups per single level
-        long long lch = (blocks1*nlev)/(256*6);
-        if (lch < 1) lch = 1;
-        if (lch > nlev) lch = nlev;
-        if (lch > 8) lch = 8;
-        if (c->lch_override > 0) lch = std::min(c->lch_override, nlev);
-        a.lch = (int)lch;
+    {
+        a.lch = level_chunk(c, nlev);
         a.swz = 0;   // pass 1: the natural order already keeps all level-chunks of an element on one XCD (profiles/r01_swizzle_ab.txt)
     }
     int rc;

@@ -87,6 +87,7 @@ struct mimsem_ctx {
     hipEvent_t ev_k2[2] = {nullptr, nullptr};   // ... of the next gather-sum kernel
 
     std::vector<void*> retired;          // outgrown workspaces (still referenced by captured graphs), freed with the context
+    bool is_capturing() const;           // the context's stream is inside a hipGraph capture (workspaces must not grow there)
     int ensure_ye(long long doubles);
     int ensure_col(long long doubles);
     double* d_kry = nullptr;            // partial sums of the Krylov multi-dot

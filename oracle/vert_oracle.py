@@ -41,13 +41,21 @@ def assemble_residual_ec(P, ex, ey, dt, theta, Pi, velz1, velz2, rho1, rho2, zv,
     return fw, F, G, ftc
 
 
-def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits, hs_forcing=False, udwdx=None):
+def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits, hs_forcing=False, udwdx=None, columns=None):
     """`nits` Newton iterations of :1721-1973 for every column of the patch; arrays [nEl][slots*n2e]; returns the new state and
-    the max-norm history.  hs_forcing: the Held-Suarez temperature forcing of :1831-1834; udwdx: the optional F_w term of :1809"""
+    the max-norm history.  hs_forcing: the Held-Suarez temperature forcing of :1831-1834; udwdx: the optional F_w term of :1809.
+    columns: optional list of element indices -- only those columns are advanced (the others keep their input state and the
+    max-norms run over the subset): columns are independent, which is what makes a sampled full-size comparison possible."""
     nEl, nk, n2 = P.nEl, P.nk, P.n2e
+    cols = list(range(nEl)) if columns is None else [int(c) for c in columns]
     V10 = _v10(nk, n2)
     velz_j, rho_j, rt_j, exner_j = velz_i.copy(), rho_i.copy(), rt_i.copy(), exner_i.copy()
-    col = lambda f: np.stack([f(e % P.nElsX, e // P.nElsX, e) for e in range(nEl)])
+    def col(f):
+        first = f(cols[0] % P.nElsX, cols[0] // P.nElsX, cols[0])
+        out = np.zeros((nEl, first.size))
+        for e in cols:
+            out[e] = f(e % P.nElsX, e // P.nElsX, e)
+        return out
     theta_l2_i = col(lambda ex, ey, e: P.diag_theta_L2(ex, ey, rho_i[e], rt_i[e]))
     theta_l2_h = theta_l2_i.copy()
     theta_i = col(lambda ex, ey, e: P.diag_theta2(ex, ey, rho_i[e], rt_i[e]))
@@ -56,7 +64,7 @@ def solve_schur_eta(P, dt, velz_i, rho_i, rt_i, exner_i, zv, nits, hs_forcing=Fa
     hist = []
     for _ in range(nits):
         mx = dict(exner=0.0, w=0.0, rho=0.0, eta=0.0)
-        for e in range(nEl):
+        for e in cols:
             ex, ey = e % P.nElsX, e // P.nElsX
             D = lambda op, **kw: P.colop_dense(op, ex, ey, **kw)
             F_w, F_z, G_z, ftc = assemble_residual_ec(P, ex, ey, dt, theta_l2_h[e], exner_h[e], velz_i[e], velz_j[e], rho_i[e], rho_j[e], zv[e], V10)
