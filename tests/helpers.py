@@ -36,3 +36,60 @@ def make_patch(oracle, pn=3, ne=4, nprocs=6, pi=0, nk=3, seed=0):
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+# ---- extended-precision reference for the column Schur solves (round-1 VERDICT "What's weak" 2) -------------------------------
+def dense_from_band(blocks, nk, n2, lo):
+    """[nk][2*lo+1][n2][n2] block bands (block column = row - lo + b) -> dense (nk*n2)^2"""
+    N = nk * n2
+    M = np.zeros((N, N))
+    for k in range(nk):
+        for b in range(2 * lo + 1):
+            c = k - lo + b
+            if 0 <= c < nk:
+                M[k*n2:(k+1)*n2, c*n2:(c+1)*n2] = blocks[k, b]
+    return M
+
+
+def _ld_lu_solve(A, b, bw):
+    LU = np.array(A, dtype=np.longdouble); x = np.array(b, dtype=np.longdouble)
+    N = LU.shape[0]
+    for i in range(N):
+        r1 = min(N, i + 1 + bw); c1 = min(N, i + 1 + 2 * bw)
+        p = i + int(np.argmax(np.abs(LU[i:r1, i])))
+        if p != i:
+            LU[[i, p]] = LU[[p, i]]; x[[i, p]] = x[[p, i]]
+        f = LU[i+1:r1, i] / LU[i, i]
+        LU[i+1:r1, i+1:c1] -= np.outer(f, LU[i, i+1:c1])
+        x[i+1:r1] -= f * x[i]
+    for i in range(N - 1, -1, -1):
+        c1 = min(N, i + 1 + 2 * bw)
+        x[i] = (x[i] - LU[i, i+1:c1] @ x[i+1:c1]) / LU[i, i]
+    return x
+
+
+def ld_solve(A, b):
+    """A x = b by banded LU with partial pivoting in numpy.longdouble (x87 80-bit on the x86 hosts: eps 1.1e-19) plus one
+    refinement step -- the 'exact' solution of a system whose entries are given in double"""
+    A = np.asarray(A, dtype=np.float64)
+    nz = np.nonzero(A)
+    bw = int(np.abs(nz[0] - nz[1]).max()) if nz[0].size else 0
+    Al = A.astype(np.longdouble); bl = np.asarray(b, dtype=np.longdouble)
+    x = _ld_lu_solve(A, b, bw)
+    x = x + _ld_lu_solve(A, bl - Al @ x, bw)
+    return x
+
+
+def _rel_ld(a, b):
+    a = np.asarray(a, dtype=np.longdouble); b = np.asarray(b, dtype=np.longdouble)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), np.longdouble(1e-300)))
+
+
+def solve_error_budget(L_hip, rhs_hip, d_hip, L_orc, rhs_orc, d_orc):
+    """Where does |d_hip - d_orc| come from?  Each side is compared with the extended-precision solution of ITS OWN system
+    (solver error: block-Thomas + refinement on the device, dense LU in the oracle); the two extended-precision solutions differ
+    by what cond(L) makes of the round-off difference between the two assembled operators / right-hand sides.  All relative L2."""
+    x_h, x_o = ld_solve(L_hip, rhs_hip), ld_solve(L_orc, rhs_orc)
+    return {"rel_L": rel_l2(L_hip, L_orc), "rel_rhs": rel_l2(rhs_hip, rhs_orc), "cond": float(np.linalg.cond(L_orc)),
+            "hip_vs_own_system": _rel_ld(d_hip, x_h), "oracle_vs_own_system": _rel_ld(d_orc, x_o),
+            "diff_of_exact_solutions": _rel_ld(x_h, x_o), "diff": rel_l2(d_hip, d_orc)}

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import make_patch, rel_l2
+from tests.helpers import dense_from_band, make_patch, rel_l2, solve_error_budget
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -109,8 +109,8 @@ def test_diag_theta(setup):
     th1 = eng.diag_theta(1, eng.tensor(F["rho"]), eng.tensor(F["rt"])).cpu().numpy()
     for e in (0, P.nEl - 1):
         ex, ey = e % P.nElsX, e // P.nElsX
-        assert rel_l2(th0[e], P.diag_theta_L2(ex, ey, F["rho"][e], F["rt"][e])) < 1e-9
-        assert rel_l2(th1[e], P.diag_theta2(ex, ey, F["rho"][e], F["rt"][e])) < 1e-9
+        assert rel_l2(th0[e], P.diag_theta_L2(ex, ey, F["rho"][e], F["rt"][e])) < TOL
+        assert rel_l2(th1[e], P.diag_theta2(ex, ey, F["rho"][e], F["rt"][e])) < TOL
 
 
 def test_schur_column_solve(setup):
@@ -130,16 +130,17 @@ def test_schur_column_solve(setup):
     for e in (0, nEl - 1):
         ex, ey = e % P.nElsX, e // P.nElsX
         ref = P.solve_schur_column_eta(ex, ey, dt, F["thetaL"][e], F["rho"][e], F["eta"][e], F["pi"][e], Fu[e], Frho[e], Feta[e], Fpi[e])
-        Ld = np.zeros((N, N))
-        for k in range(nk):
-            for w, c in ((0, k - 1), (1, k), (2, k + 1)):
-                if 0 <= c < nk:
-                    Ld[k*n2:(k+1)*n2, c*n2:(c+1)*n2] = L[e, k, w]
+        Ld = dense_from_band(L[e], nk, n2, lo=1)
         # the operator itself (incl. exact zeros outside the three block diagonals of the reference's product)
-        assert rel_l2(Ld, ref["L_pi"]) < 1e-9
-        for name, got in (("d_pi", d_pi), ("d_u", d_u), ("d_eta", d_eta), ("d_rho", d_rho),
-                          ("F_u", dFu), ("F_rho", dFrho), ("F_eta", dFeta), ("F_pi", dFpi)):
-            assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name
+        assert rel_l2(Ld, ref["L_pi"]) < TOL
+        # error budget against an extended-precision solve of each side's own system (tests/helpers.py): the device sweep is held
+        # to 1e-10 on ITS system; the two solutions may differ by cond(L_pi) x the round-off difference of the two operators
+        b = solve_error_budget(Ld, dFpi[e].cpu().numpy(), d_pi[e].cpu().numpy(), ref["L_pi"], ref["F_pi"], ref["d_pi"])
+        assert b["hip_vs_own_system"] < TOL, b
+        bound = max(TOL, 4.0 * b["diff_of_exact_solutions"] + b["hip_vs_own_system"] + b["oracle_vs_own_system"])
+        assert b["diff"] < bound, b
+        for name, got in (("d_u", d_u), ("d_eta", d_eta), ("d_rho", d_rho), ("F_u", dFu), ("F_rho", dFrho), ("F_eta", dFeta), ("F_pi", dFpi)):
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < max(TOL, 50.0 * bound), (name, b)
 
 
 def test_residual_compositions(setup):
@@ -188,10 +189,10 @@ def test_residual_compositions(setup):
         VBr = D("CONST_RHO", f1=theta[e]); VBA = D("CONLIN_W", f1=tA2)
         fw_ref += 0.5 * dt * V01 @ (VBr @ Pi[e]) - 0.5 * dt * VBA.T @ Pi[e]
         ftc_ref = 0.5 * dt * VBr @ (V10 @ F_ref) + 0.5 * dt * VBA @ F_ref
-        assert rel_l2(Fz[e].cpu().numpy(), F_ref) < 1e-9
-        assert rel_l2(G[e].cpu().numpy(), G_ref) < 1e-9
-        assert rel_l2(fw[e].cpu().numpy(), fw_ref) < 1e-9
-        assert rel_l2(ftc[e].cpu().numpy(), ftc_ref) < 1e-9
+        assert rel_l2(Fz[e].cpu().numpy(), F_ref) < TOL
+        assert rel_l2(G[e].cpu().numpy(), G_ref) < TOL
+        assert rel_l2(fw[e].cpu().numpy(), fw_ref) < TOL
+        assert rel_l2(ftc[e].cpu().numpy(), ftc_ref) < TOL
 
 
 def _uh(P, r, dt):
@@ -223,8 +224,8 @@ def test_hs_colops(setup, colop, k1, k2, param, up):
         ex, ey = e % P.nElsX, e // P.nElsX
         want = P.colop_dense_ex(colop, ex, ey, param=param, f1=None if f1 is None else f1[e], f2=None if f2 is None else f2[e], uh=uh)
         got = _dense_from_blocks(P, colop, blk[e])
-        assert rel_l2(got, want) < 1e-9, colop
-        assert rel_l2(y[e], want @ x[e]) < 1e-9, colop
+        assert rel_l2(got, want) < TOL, colop
+        assert rel_l2(y[e], want @ x[e]) < TOL, colop
 
 
 def test_diag_theta_up_and_temp_forcing(setup):
@@ -245,8 +246,8 @@ def test_diag_theta_up_and_temp_forcing(setup):
     got = eng.temp_forcing_hs(t(lat), t(exner), t(F["theta"]), t(F["rho"])).cpu().numpy()
     for e in (0, P.nEl - 1):
         ex, ey = e % P.nElsX, e // P.nElsX
-        assert rel_l2(th[e], P.diag_theta_up(ex, ey, dt, F["rho"][e], F["rt"][e], uh)) < 1e-9
-        assert rel_l2(got[e], P.temp_forcing_hs(ex, ey, exner[e], F["theta"][e], F["rho"][e])) < 1e-9
+        assert rel_l2(th[e], P.diag_theta_up(ex, ey, dt, F["rho"][e], F["rt"][e], uh)) < TOL
+        assert rel_l2(got[e], P.temp_forcing_hs(ex, ey, exner[e], F["theta"][e], F["rho"][e])) < TOL
 
 
 @pytest.mark.parametrize("flags", [0, 3], ids=["eul", "box"])
@@ -269,16 +270,14 @@ def test_schur_column_3_pentadiagonal(setup, flags):
         ex, ey = e % P.nElsX, e // P.nElsX
         ref = P.solve_schur_column_3(ex, ey, dt, F["theta"][e], F["velz"][e], F["rho"][e], F["rt"][e], F["pi"][e],
                                      Fu[e], Frho[e], Frt[e], Fpi[e], flags=flags)
-        Ld = np.zeros((N, N))
-        for k in range(nk):
-            for b in range(5):
-                c = k - 2 + b
-                if 0 <= c < nk:
-                    Ld[k*n2:(k+1)*n2, c*n2:(c+1)*n2] = L[e, k, b]
-        assert rel_l2(Ld, ref["L"]) < 1e-9                      # incl. exact zeros outside the five block diagonals
-        for name, got in (("d_rt", d_rt), ("d_u", d_u), ("d_pi", d_pi), ("d_rho", d_rho),
-                          ("F_u", dFu), ("F_rho", dFrho), ("F_rt", dFrt), ("F_pi", dFpi)):
-            assert rel_l2(got[e].cpu().numpy(), ref[name]) < 1e-8, name
+        Ld = dense_from_band(L[e], nk, n2, lo=2)
+        assert rel_l2(Ld, ref["L"]) < TOL                       # incl. exact zeros outside the five block diagonals
+        b = solve_error_budget(Ld, dFrt[e].cpu().numpy(), d_rt[e].cpu().numpy(), ref["L"], ref["F_rt"], ref["d_rt"])
+        assert b["hip_vs_own_system"] < TOL, b
+        bound = max(TOL, 4.0 * b["diff_of_exact_solutions"] + b["hip_vs_own_system"] + b["oracle_vs_own_system"])
+        assert b["diff"] < bound, b
+        for name, got in (("d_u", d_u), ("d_pi", d_pi), ("d_rho", d_rho), ("F_u", dFu), ("F_rho", dFrho), ("F_rt", dFrt), ("F_pi", dFpi)):
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < max(TOL, 50.0 * bound), (name, b)
 
 
 def test_vertical_incidence(setup):
@@ -316,9 +315,9 @@ def test_fused_schur_assembly_matches_default(setup, monkeypatch, mode):
     monkeypatch.setenv("MIMSEM_SCHUR_FUSED", mode)
     alt = eng.solve_schur_eta(*args, *[t(f) for f in Fs])
     L1 = eng.helmholtz_blocks(*args)
-    assert rel_l2(L1.cpu().numpy(), L0.cpu().numpy()) < 1e-9
+    assert rel_l2(L1.cpu().numpy(), L0.cpu().numpy()) < TOL
     for a, b in zip(alt, base):
-        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL
 
 
 @pytest.mark.parametrize("var", ["MIMSEM_THOMAS_WAVE", "MIMSEM_THOMAS_WG", "MIMSEM_EOS_WIDE", "MIMSEM_BAND_NAIVE"])
@@ -341,7 +340,7 @@ def test_selectable_kernel_variants_agree(setup, monkeypatch, var):
     alt_eta = eng.solve_schur_eta(*a_eta, *[t(f) for f in Fs])
     alt_3 = eng.solve_schur_3(*a_3, *[t(f) for f in Fs])
     for a, b in list(zip(alt_eta, base_eta)) + list(zip(alt_3, base_3)):
-        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-8, var
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, var
 
 
 def test_vertical_newton_loop_matches_oracle(setup):
@@ -390,7 +389,7 @@ def test_vertical_newton_loop_matches_oracle(setup):
     want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, 3)
     for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
         assert np.all(np.isfinite(b)), name
-        assert rel_l2(a.cpu().numpy(), b) < 1e-8, name
+        assert rel_l2(a.cpu().numpy(), b) < TOL, name
     for hd, ho in zip(vs.history, want[4]):
         for k in ("exner", "w", "rho", "eta"):
             assert abs(hd[k] - ho[k]) <= 1e-5 * ho[k] + 1e-15, (k, hd[k], ho[k])
@@ -400,4 +399,4 @@ def test_vertical_newton_loop_matches_oracle(setup):
     got = vs.solve_schur_eta(t(velz), t(rho), t(rt), t(exner), zv_d, maxit=2, tol=0.0, hs_lat=t(np.ascontiguousarray(lat)), udwdx=t(udwdx))
     want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, 2, hs_forcing=True, udwdx=udwdx)
     for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
-        assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < 1e-8, name
+        assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < TOL, name

@@ -14,16 +14,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, form, q):
+def _worker(rank, world, port, form, q, pn=2, ne=2, npatch=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mimsem_amd.mesh import CubedSphere
         from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
         from mimsem_amd.topo import Topo
-        cs = CubedSphere(2, 2, 6)
+        cs = CubedSphere(pn, ne, npatch)
         nG = cs.nDofs0G if form == 0 else cs.nDofs1G
-        pids = patches_of_rank(6, world, rank)
+        pids = patches_of_rank(npatch, world, rank)
         topos = [Topo(cs, p) for p in pids]
         if form == 0:
             touched = np.unique(np.concatenate([t.loc0 for t in topos]))
@@ -45,7 +45,7 @@ def _worker(rank, world, port, form, q):
         assert torch.equal(v, v2) and ex.pairwise == (form == 1)
         # expected: the all-patch sum at every slot I hold
         want = np.zeros((2, nG))
-        for p in range(6):
+        for p in range(npatch):
             t = Topo(cs, p); g = t.loc0 if form == 0 else t.loc1
             np.add.at(want[0], g, (p + 1.0) * (g + 1.0)); np.add.at(want[1], g, (p + 2.0) * (g + 1.0))
         ok = np.array_equal(v.numpy(), want[:, touched])
@@ -65,6 +65,21 @@ def test_sharded_halo_matches_global(world, form):
     for p in procs: p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert sum(ng for _, _, ng in res) > 0          # the test really exchanged ghosts
+
+
+@pytest.mark.parametrize("form", [0, 1])
+def test_config1_six_ranks_halo(form):
+    """BASELINE config 1: p=3, 8x8 elements per face, 6 MPI ranks = one patch per rank -- the reference's own decomposition
+    (scr/Setup.py pn=3 ne=8 6 procs); the 6-rank halo reduce / ghost fill equals the global sums on every rank"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 6, port, form, q, 3, 8, 6)) for r in range(6)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(ng > 0 for _, _, ng in res)          # every rank holds ghosts on this decomposition
 
 
 def test_ownership_tables_partition_all_ids():
