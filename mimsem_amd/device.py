@@ -12,8 +12,16 @@ from ._lib import COLOPS, FLAG_ACCUM, FLAG_VERT, OPS, MeshDesc, check
 def _ptr(t):
     if t is None:
         return None
-    assert t.dtype in (torch.float64, torch.int32) and t.is_contiguous() and t.is_cuda, "device float64/int32 contiguous tensor required"
+    if not (t.dtype in (torch.float64, torch.int32) and t.is_contiguous() and t.is_cuda):
+        raise _lib.MimsemError("device float64/int32 contiguous tensor required, got %s %s contiguous=%s" % (t.device, t.dtype, t.is_contiguous()))
     return t.data_ptr()
+
+
+def _need(cond, what):
+    """argument validation that survives python -O: the C ABI takes raw pointers, a wrong-sized tensor would be an out-of-bounds
+    device access (a GPU memory fault), so sizes are checked here and reported as MimsemError"""
+    if not cond:
+        raise _lib.MimsemError("invalid argument: " + what)
 
 
 class no_gc:
@@ -387,24 +395,67 @@ class Engine:
         return y if (x.dim() == 2 or out is not None) else y[0]
 
     # ---- column operators -------------------------------------------------------------------
+    def _col(self, t, slots, name, optional=False):
+        """a "vertical" array [nEl, slots*n2e] (L2Vecs::vz of every column)"""
+        if t is None:
+            _need(optional, name + " is required")
+            return
+        _need(t.dim() == 2 and t.shape[0] == self.nEl and t.shape[1] == slots * self.n2e,
+              "%s must be [nEl=%d, %d*n2e=%d], got %s" % (name, self.nEl, slots, slots * self.n2e, tuple(t.shape)))
+
+    def _colop_slots(self, colop, transpose=False):
+        """(input slots, output slots) of a column operator in units of n2e (eul/VertOps.cpp: rows x cols of each Assemble*)"""
+        nk = self.nk
+        rc = dict(CONST=(nk, nk), CONST_INV=(nk, nk), CONST_RHO=(nk, nk), CONST_RHO_INV=(nk, nk), CONST_THETA=(nk, nk), EOS_BLOCK=(nk, nk),
+                  EOS_BLOCK_INV=(nk, nk), LINEAR=(nk - 1, nk - 1), LINEAR_INV=(nk - 1, nk - 1), LINEAR_RT=(nk - 1, nk - 1),
+                  LINEAR_THETA=(nk - 1, nk - 1), RAYLEIGH=(nk - 1, nk - 1), LINEAR_RAYLEIGH_INV=(nk - 1, nk - 1),
+                  LINEAR_RHO2=(nk + 1, nk + 1), LINEAR_RHO2_UP=(nk + 1, nk + 1), LINCON=(nk - 1, nk), LINCON2=(nk + 1, nk), LINCON2_UP=(nk + 1, nk),
+                  CONLIN=(nk, nk - 1), CONLIN_W=(nk, nk - 1), CONLIN_RHODPI=(nk, nk - 1))[colop]
+        rows, cols = rc
+        return (rows, cols) if transpose else (cols, rows)
+
+    _COLOP_F1 = dict(CONST_RHO="nk", CONST_RHO_INV="nk", CONST_THETA="nk+1", EOS_BLOCK="nk", EOS_BLOCK_INV="nk", LINEAR_RT="nk", LINEAR_THETA="nk+1",
+                     LINEAR_RHO2="nk", LINEAR_RHO2_UP="nk", CONLIN_W="nk-1", CONLIN_RHODPI="nk")
+
+    def _check_colop(self, colop, f1, f2, x=None, nout_slots=None, transpose=False, uh=None):
+        _need(colop in COLOPS, "unknown column operator %r" % (colop,))
+        nk = self.nk
+        if colop in self._COLOP_F1:
+            self._col(f1, eval(self._COLOP_F1[colop], {"nk": nk}), "f1 of " + colop)
+        if colop == "CONLIN_RHODPI":
+            self._col(f2, nk - 1, "f2 of CONLIN_RHODPI")
+        if colop == "EOS_BLOCK_INV" and f2 is not None:
+            self._col(f2, nk + 1, "f2 (theta) of EOS_BLOCK_INV")
+        if colop in ("LINEAR_RHO2_UP", "LINCON2_UP"):
+            _need(uh is not None and uh.dim() == 2 and uh.shape == (nk, self.sizes[1]), "uh of %s must be [nk, n1]" % colop)
+        if x is not None:
+            sin, sout = self._colop_slots(colop, transpose)
+            self._col(x, sin, "x of " + colop)
+            _need(nout_slots == sout, "%s%s maps %d -> %d slots; nout_slots=%r" % (colop, "^T" if transpose else "", sin, sout, nout_slots))
+
     def l2_horiz_to_vert(self, vh):
+        _need(vh.dim() == 2 and vh.shape[1] == self.sizes[2] and vh.shape[0] in (self.nk - 1, self.nk, self.nk + 1), "vh must be [nk-1|nk|nk+1, n2], got %s" % (tuple(vh.shape),))
         nkv = vh.shape[0]
         vz = torch.empty(self.nEl, nkv * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_l2_transpose(self.ctx, 0, nkv, _ptr(vh), vh.stride(0), _ptr(vz)), "l2_transpose")
         return vz
 
     def l2_vert_to_horiz(self, vz, nkv):
+        self._col(vz, nkv, "vz")
         vh = torch.empty(nkv, self.sizes[2], dtype=torch.float64, device=self.device)
         check(self.L.mimsem_l2_transpose(self.ctx, 1, nkv, _ptr(vh), vh.stride(0), _ptr(vz)), "l2_transpose")
         return vh
 
     def colop_blocks(self, colop, f1=None, f2=None, flags=0):
+        self._check_colop(colop, f1, f2)
         nb = self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])
         out = torch.empty(self.nEl, nb, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_colop_blocks(self.ctx, COLOPS[colop], flags, _ptr(f1), _ptr(f2), _ptr(out)), "colop_blocks(%s)" % colop)
         return out
 
     def colop_apply(self, colop, x, f1=None, f2=None, flags=0, transpose=False, nout_slots=None):
+        """nout_slots: rows of the operator in units of n2e (required; checked against the operator's shape)"""
+        self._check_colop(colop, f1, f2, x, nout_slots, transpose)
         y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_colop_apply(self.ctx, COLOPS[colop], flags, int(transpose), _ptr(f1), _ptr(f2), _ptr(x), _ptr(y)),
               "colop_apply(%s)" % colop)
@@ -412,6 +463,9 @@ class Engine:
 
     def colop_apply_blocks(self, colop, blocks, x, nout_slots, transpose=False):
         """MatMult with blocks from colop_blocks (geometry-only operators assembled once)"""
+        self._check_colop(colop, None, None, x, nout_slots, transpose)
+        _need(blocks.dim() == 4 and blocks.shape[0] == self.nEl and blocks.shape[1] == self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])
+              and blocks.shape[2:] == (self.n2e, self.n2e), "blocks of %s have shape %s" % (colop, tuple(blocks.shape)))
         y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_colop_apply_blocks(self.ctx, COLOPS[colop], int(transpose), _ptr(blocks), _ptr(x), _ptr(y)),
               "colop_apply_blocks(%s)" % colop)
@@ -419,6 +473,7 @@ class Engine:
 
     def colop_blocks_ex(self, colop, param=0.0, f1=None, f2=None, uh=None, flags=0):
         """the Strang / Held-Suarez colops: param = dt_fric or dt, uh = [nk, n1] horizontal velocity (local 1-forms)"""
+        self._check_colop(colop, f1, f2, uh=uh)
         nb = self.L.mimsem_colop_nblocks(self.ctx, COLOPS[colop])
         out = torch.empty(self.nEl, nb, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_colop_blocks_ex(self.ctx, COLOPS[colop], flags, param, _ptr(f1), _ptr(f2), _ptr(uh),
@@ -426,6 +481,7 @@ class Engine:
         return out
 
     def colop_apply_ex(self, colop, x, nout_slots, param=0.0, f1=None, f2=None, uh=None, flags=0, transpose=False):
+        self._check_colop(colop, f1, f2, x, nout_slots, transpose, uh=uh)
         y = torch.empty(self.nEl, nout_slots * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_colop_apply_ex(self.ctx, COLOPS[colop], flags, int(transpose), param, _ptr(f1), _ptr(f2), _ptr(uh),
                                            uh.stride(0) if uh is not None else 0, _ptr(x), _ptr(y)), "colop_apply_ex(%s)" % colop)
@@ -434,17 +490,22 @@ class Engine:
     def column_incidence(self, which, x):
         """'V10' | 'V01' | 'V10_full' applied to every column (VertOps::vertOps)"""
         w = dict(V10=0, V01=1, V10_full=2)[which]
+        self._col(x, (self.nk - 1, self.nk, self.nk + 1)[w], "x of " + which)
         ny = self.nk - 1 if w == 1 else self.nk
         y = torch.empty(self.nEl, ny * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_incidence(self.ctx, w, _ptr(x), _ptr(y)), "column_incidence")
         return y
 
     def diag_theta_up(self, dt, rho, rt, uh):
+        self._col(rho, self.nk, "rho"); self._col(rt, self.nk, "rt")
+        _need(uh.dim() == 2 and uh.shape == (self.nk, self.sizes[1]), "uh must be [nk, n1]")
         th = torch.empty(self.nEl, (self.nk + 1) * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_diag_theta_up(self.ctx, dt, _ptr(rho), _ptr(rt), _ptr(uh), uh.stride(0), _ptr(th)), "diag_theta_up")
         return th
 
     def temp_forcing_hs(self, lat, exner, theta, rho):
+        _need(lat.dim() == 2 and lat.shape == (self.nEl, self.mp12), "lat must be [nEl, mp12] (latitude of the quadrature points)")
+        self._col(exner, self.nk, "exner"); self._col(theta, self.nk + 1, "theta"); self._col(rho, self.nk, "rho")
         out = torch.empty(self.nEl, self.nk * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_temp_forcing_hs(self.ctx, _ptr(lat), _ptr(exner), _ptr(theta), _ptr(rho), _ptr(out)), "temp_forcing_hs")
         return out
@@ -452,6 +513,10 @@ class Engine:
     def solve_schur_3(self, dt, theta, velz, rho, rt, pi, F_u, F_rho, F_rt, F_pi, want_L=False, flags=0):
         """solve_schur_column_3 for every column; F_* updated in place; returns d_u, d_rho, d_rt, d_pi (, L [nEl,nk,5,n2e,n2e]);
         flags = 3 reproduces the box twin (box/VertSolve.cpp:879-1058)"""
+        nk = self.nk
+        for a, sl, nm in ((theta, nk + 1, "theta"), (velz, nk - 1, "velz"), (rho, nk, "rho"), (rt, nk, "rt"), (pi, nk, "pi"),
+                          (F_u, nk - 1, "F_u"), (F_rho, nk, "F_rho"), (F_rt, nk, "F_rt"), (F_pi, nk, "F_pi")):
+            self._col(a, sl, nm)
         N, Nm = self.nk * self.n2e, (self.nk - 1) * self.n2e
         mk = lambda n: torch.empty(self.nEl, n, dtype=torch.float64, device=self.device)
         d_u, d_rho, d_rt, d_pi = mk(Nm), mk(N), mk(N), mk(N)
@@ -462,23 +527,33 @@ class Engine:
         return (d_u, d_rho, d_rt, d_pi, L) if want_L else (d_u, d_rho, d_rt, d_pi)
 
     def column_eos(self, which, a, b=None, p0=0.0, p1=0.0):
+        _need(which in (0, 1, 2, 3), "column_eos which = 0..3")
+        self._col(a, self.nk, "a"); self._col(b, self.nk, "b", optional=which in (1, 2))
         out = torch.empty(self.nEl, self.nk * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_eos(self.ctx, which, _ptr(a), _ptr(b), p0, p1, _ptr(out)), "column_eos")
         return out
 
     def diag_theta(self, which, rho, rt):
+        _need(which in (0, 1), "diag_theta which = 0 (diagTheta_L2) | 1 (diagTheta2)")
+        self._col(rho, self.nk, "rho"); self._col(rt, self.nk, "rt")
         nl = self.nk + (1 if which == 1 else 0)
         th = torch.empty(self.nEl, nl * self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_diag_theta(self.ctx, which, _ptr(rho), _ptr(rt), _ptr(th)), "diag_theta")
         return th
 
     def helmholtz_blocks(self, dt, theta, rho, eta, pi):
+        for a, nm in ((theta, "theta"), (rho, "rho"), (eta, "eta"), (pi, "pi")):
+            self._col(a, self.nk, nm)
         out = torch.empty(self.nEl, self.nk, 3, self.n2e, self.n2e, dtype=torch.float64, device=self.device)
         check(self.L.mimsem_column_helmholtz_blocks(self.ctx, dt, _ptr(theta), _ptr(rho), _ptr(eta), _ptr(pi), _ptr(out)), "helmholtz_blocks")
         return out
 
     def solve_schur_eta(self, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi):
         """F_* are updated in place (as the reference does); returns d_u, d_rho, d_eta, d_pi"""
+        nk = self.nk
+        for a, sl, nm in ((theta, nk, "theta"), (rho, nk, "rho"), (eta, nk, "eta"), (pi, nk, "pi"),
+                          (F_u, nk - 1, "F_u"), (F_rho, nk, "F_rho"), (F_eta, nk, "F_eta"), (F_pi, nk, "F_pi")):
+            self._col(a, sl, nm)
         N, Nm = self.nk * self.n2e, (self.nk - 1) * self.n2e
         mk = lambda n: torch.empty(self.nEl, n, dtype=torch.float64, device=self.device)
         d_u, d_rho, d_eta, d_pi = mk(Nm), mk(N), mk(N), mk(N)

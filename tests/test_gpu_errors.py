@@ -105,3 +105,36 @@ def test_empty_inputs_are_no_ops(small):
     assert torch.equal(y1, keep)
     assert eng.L.mimsem_incidence_apply(eng.ctx, 1, 0, y1.data_ptr(), dm.n1, y1.data_ptr(), dm.n1) == 0
     assert eng.L.mimsem_krylov_mdot(eng.ctx, 0, dm.n1, y1.data_ptr(), dm.n1, y1.data_ptr(), y1.data_ptr()) == 0
+
+
+def test_column_wrappers_reject_wrong_shapes(small):
+    """the column entry points take raw pointers: the host mirror checks every array length and raises MimsemError (also under
+    python -O: no assert) instead of letting a short tensor become an out-of-bounds device access"""
+    import torch
+    from mimsem_amd._lib import MimsemError
+    eng, dm, P = small
+    nk, n2, nEl = 4, eng.n2e, dm.nEl
+    col = lambda sl: eng.zeros(nEl, sl * n2) + 1.0
+    bad = [lambda: eng.colop_apply("CONST_RHO", col(nk), f1=col(nk)),                       # nout_slots missing (was a TypeError)
+           lambda: eng.colop_apply("CONST_RHO", col(nk), f1=col(nk - 1), nout_slots=nk),      # short coefficient field
+           lambda: eng.colop_apply("CONLIN_W", col(nk), f1=col(nk - 1), nout_slots=nk),       # x must have nk-1 slots
+           lambda: eng.colop_apply("CONLIN_W", col(nk - 1), f1=col(nk - 1), nout_slots=nk - 1),   # rows are nk
+           lambda: eng.colop_apply("LINEAR", col(nk - 1)[:-1], nout_slots=nk - 1),            # a column missing
+           lambda: eng.colop_blocks("LINEAR_THETA", f1=col(nk)),                            # theta lives on nk+1 interfaces
+           lambda: eng.column_eos(0, col(nk), None),                                        # exner missing
+           lambda: eng.column_eos(7, col(nk), col(nk)),
+           lambda: eng.diag_theta(0, col(nk), col(nk + 1)),
+           lambda: eng.column_incidence("V01", col(nk - 1)),
+           lambda: eng.solve_schur_eta(75.0, col(nk), col(nk), col(nk), col(nk), col(nk), col(nk), col(nk), col(nk)),      # F_u has nk-1 slots
+           lambda: eng.solve_schur_3(75.0, col(nk), col(nk - 1), col(nk), col(nk), col(nk), col(nk - 1), col(nk), col(nk), col(nk)),   # theta on nk+1
+           lambda: eng.l2_vert_to_horiz(col(nk), nk + 1),
+           lambda: eng.temp_forcing_hs(eng.zeros(nEl, 3), col(nk), col(nk + 1), col(nk)),
+           lambda: eng.colop_apply("CONST", col(nk).cpu(), nout_slots=nk),                    # host tensor
+           lambda: eng.colop_apply("CONST", col(nk).float(), nout_slots=nk)]                  # wrong dtype
+    for i, fn in enumerate(bad):
+        with pytest.raises(MimsemError):
+            fn()
+    # and the well-formed calls still work
+    y = eng.colop_apply("CONLIN_W", col(nk - 1), f1=col(nk - 1), nout_slots=nk)
+    yt = eng.colop_apply("CONLIN_W", col(nk), f1=col(nk - 1), nout_slots=nk - 1, transpose=True)
+    assert y.shape == (nEl, nk * n2) and yt.shape == (nEl, (nk - 1) * n2) and bool(torch.isfinite(y).all())
