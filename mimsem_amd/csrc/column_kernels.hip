@@ -14,6 +14,7 @@
 // sparse mat-mat products, no symbolic phases, no per-column PETSc objects.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "ctx.hpp"
 
 #define RD 287.0
@@ -2508,10 +2509,22 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
 }
 
 }  // namespace
+
+#include "column_dpp.inc"
+
+namespace {
+// default for orders 1..3: the LDS-free fused path of column_dpp.inc; MIMSEM_SCHUR_FUSED=rows|wave|0 selects the round-1 kernels
+bool use_sweep(const mimsem_ctx* c) {
+    const char* fmode = getenv("MIMSEM_SCHUR_FUSED");
+    return sweep_supported(c) && (!fmode || strcmp(fmode, "sweep") == 0);
+}
+}  // namespace
+
 extern "C" {
 int mimsem_column_helmholtz_blocks(mimsem_ctx* c, double dt, const double* theta, const double* rho,
                                    const double* eta, const double* pi, double* out) {
     if (!c || !theta || !rho || !eta || !pi || !out || c->nk < 2) return MIMSEM_ERR_ARG;
+    if (use_sweep(c)) return sweep_helmholtz(c, dt, theta, rho, eta, pi, out);
     Schur S;
     int rc = schur_operator(c, dt, theta, rho, eta, pi, S);
     if (rc) return rc;
@@ -2527,6 +2540,7 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
     if (!c || !theta || !rho || !eta || !pi || !F_u || !F_rho || !F_eta || !F_pi || !d_u || !d_rho || !d_eta || !d_pi)
         return MIMSEM_ERR_ARG;
     if (c->nk < 2) return MIMSEM_ERR_ARG;
+    if (use_sweep(c)) return sweep_solve_eta(c, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi, d_u, d_rho, d_eta, d_pi);
     const int nk = c->nk, nm = nk - 1, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
     const double hdt = 0.5*dt, gam = RD/CV;
     Schur S;
