@@ -310,6 +310,35 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
 int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
         const double* theta, const double* rho, const double* eta, const double* pi, double* out);
 
+/* ---- row C8 fused: the residual assembly and update of the vertical Newton loop ------------------------------- */
+/* VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) is a Newton loop around solve_schur_column_eta; per iteration and column the
+ * reference runs assemble_residual_ec with diagnose_F_z / diagnose_Phi_z (:237-286, :432-502: ~12 VertOps assemblies, ~25 MatMult), the
+ * EOS residual, the entropy residual and the entropy variables (:1806-1851), and after the solve the update and the EOS (:1858-1912).
+ * The three entry points below do that for EVERY column in four launches (orders 1..3; MIMSEM_ERR_UNSUPPORTED above).  All arrays are
+ * "vertical" vectors [nEl][slots*n2e]: velz*, F_w, d_w, add_w on the nk-1 interfaces, theta2 / blend2 on nk+1, the rest on the nk levels.
+ *
+ * mimsem_column_newton_residual: theta = theta_l2_h, Pi = exner_h (the time-centred fields), velz / rho / rt at times i and j, zv from
+ *   VertSolve::initGZ, the half-time rho_h / rt_h, exner_j.  add_w / add_rho / add_rt (nullable) are added times dt to F_w / F_rho / F_rt:
+ *   the u dw/dx term (:1809), the horizontal transport tendencies (:1799, :1822-1826), the Held-Suarez forcing (:1831-1834).
+ *   Out: the four right-hand sides of solve_schur_column_eta (F_w, F_rho, F_eta, F_exner), theta_h in W3 and eta_h (its theta, eta
+ *   arguments), and k2i [nEl][(nk-1)*n2e] = F_z . (VA(theta) grad Pi) entry by entry (its sum / SCALE is VertSolve::k2i_z). */
+int mimsem_column_newton_residual(mimsem_ctx* ctx, double dt, double rayleigh,
+        const double* theta, const double* Pi, const double* velz_i, const double* velz_j, const double* rho_i, const double* rho_j,
+        const double* zv, const double* rt_i, const double* rt_j, const double* rho_h, const double* rt_h, const double* exner_j,
+        const double* add_w, const double* add_rho, const double* add_rt,
+        double* F_w, double* F_rho, double* F_eta, double* F_exner, double* th_w3, double* eta, double* k2i);
+/* after the solve (:1858-1912): eta_j from the iterate BEFORE the update, velz_j += d_w, rho_j += d_rho, exner_j += d_exner,
+ * rt_j = VB^-1 W^T Q (rho_j exp(eta_j)); x_h = 0.5 x_i + 0.5 x_j; norm_squares [8][nEl][nk*n2e] = squares of (d_exner, exner_j, d_w, velz_j,
+ * d_rho, rho_j, d_eta, eta_j): summed per column they give the ratios of VertSolve::MaxNorm (:228). */
+int mimsem_column_newton_update(mimsem_ctx* ctx, const double* d_w, const double* d_rho, const double* d_eta, const double* d_exner,
+        const double* velz_i, const double* rho_i, const double* rt_i, const double* exner_i,
+        double* velz_j, double* rho_j, double* rt_j, double* exner_j,
+        double* velz_h, double* rho_h, double* rt_h, double* exner_h, double* norm_squares);
+/* diagTheta2 and / or diagTheta_L2 (:289-352) in one launch, optionally blended: out = wa * theta(rho, rt) + wb * blend
+ * (the half-time averages theta_h = 0.5 theta_j + 0.5 theta_i of :1896-1912).  theta2 / thetaL: either may be null. */
+int mimsem_column_diag_theta_blend(mimsem_ctx* ctx, const double* rho, const double* rt, double* theta2, const double* blend2,
+                                   double* thetaL, const double* blendL, double wa, double wb);
+
 /* ---- Strang / Held-Suarez column rows --------------------------------------------------------- */
 /* mimsem_colop_blocks / mimsem_colop_apply with the extra arguments of the *_ex operators: param (dt_fric or dt)
  * and uh = the horizontal velocity as local 1-forms, one row per level ([nk][uh_stride], the reference's Vec* uhl). */

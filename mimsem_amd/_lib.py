@@ -71,6 +71,9 @@ _SIGS = {
     "mimsem_colop_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, c_dp, c_dp, c_dp, c_dp]),
     "mimsem_column_eos": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, C.c_double, C.c_double, c_dp]),
     "mimsem_column_diag_theta": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]),
+    "mimsem_column_newton_residual": (C.c_int, [C.c_void_p, C.c_double, C.c_double] + [c_dp]*22),
+    "mimsem_column_newton_update": (C.c_int, [C.c_void_p] + [c_dp]*17),
+    "mimsem_column_diag_theta_blend": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double]),
     "mimsem_column_solve_schur_eta": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*12),
     "mimsem_column_helmholtz_blocks": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*5),
     "mimsem_colop_blocks_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_double, c_dp, c_dp, c_dp, c_ll, c_dp]),

@@ -2393,10 +2393,16 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
 
 }  // namespace
 
+namespace { bool diag_theta_fused_supported(const mimsem_ctx* c) { return c->es.n >= 1 && c->es.n <= 3 && c->nk >= 2; } }
 extern "C" {
+int mimsem_column_diag_theta_blend(mimsem_ctx* c, const double* rho, const double* rt, double* theta2, const double* blend2,
+                                   double* thetaL, const double* blendL, double wa, double wb);
 
 int mimsem_column_diag_theta(mimsem_ctx* c, int which, const double* rho, const double* rt, double* theta) {
     if (!c || !rho || !rt || !theta || which < 0 || which > 1) return MIMSEM_ERR_ARG;
+    if (diag_theta_fused_supported(c) && !getenv("MIMSEM_DIAG_THETA_WIDE"))      // orders 1..3: one launch on the DPP row algebra (column_newton.inc)
+        return which == 0 ? mimsem_column_diag_theta_blend(c, rho, rt, nullptr, nullptr, theta, nullptr, 1.0, 0.0)
+                          : mimsem_column_diag_theta_blend(c, rho, rt, theta, nullptr, nullptr, nullptr, 1.0, 0.0);
     const int nk = c->nk, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
     int rc = c->ensure_col(colop_ws_doubles(c) + (long long)nEl*(nk + 1)*(3LL*nn + 2LL*n2));
     if (rc) return rc;
@@ -2511,6 +2517,7 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
 }  // namespace
 
 #include "column_dpp.inc"
+#include "column_newton.inc"
 
 namespace {
 // default for orders 1..3: the LDS-free fused path of column_dpp.inc; MIMSEM_SCHUR_FUSED=rows|wave|0 selects the round-1 kernels

@@ -541,6 +541,51 @@ class Engine:
         check(self.L.mimsem_column_diag_theta(self.ctx, which, _ptr(rho), _ptr(rt), _ptr(th)), "diag_theta")
         return th
 
+    def diag_theta_blend(self, rho, rt, blend2=None, blendL=None, wa=1.0, wb=0.0, want2=True, wantL=True):
+        """diagTheta2 and diagTheta_L2 in ONE launch, optionally blended with earlier fields: wa * theta(rho, rt) + wb * blend
+        (mimsem_column_diag_theta_blend).  Returns (theta2 [nEl, (nk+1) n2e] | None, thetaL [nEl, nk n2e] | None)."""
+        self._col(rho, self.nk, "rho"); self._col(rt, self.nk, "rt")
+        self._col(blend2, self.nk + 1, "blend2", optional=True); self._col(blendL, self.nk, "blendL", optional=True)
+        mk = lambda n: torch.empty(self.nEl, n * self.n2e, dtype=torch.float64, device=self.device)
+        th2 = mk(self.nk + 1) if want2 else None
+        thL = mk(self.nk) if wantL else None
+        check(self.L.mimsem_column_diag_theta_blend(self.ctx, _ptr(rho), _ptr(rt), _ptr(th2), _ptr(blend2), _ptr(thL), _ptr(blendL), wa, wb),
+              "diag_theta_blend")
+        return th2, thL
+
+    def newton_residual(self, dt, rayleigh, theta, Pi, velz_i, velz_j, rho_i, rho_j, zv, rt_i, rt_j, rho_h, rt_h, exner_j,
+                        add_w=None, add_rho=None, add_rt=None):
+        """mimsem_column_newton_residual: (F_w, F_rho, F_eta, F_exner, th_w3, eta, k2i) for every column (VertSolve.cpp:1806-1851)"""
+        nk = self.nk
+        for a, sl, nm in ((theta, nk, "theta"), (Pi, nk, "Pi"), (velz_i, nk - 1, "velz_i"), (velz_j, nk - 1, "velz_j"), (rho_i, nk, "rho_i"),
+                          (rho_j, nk, "rho_j"), (zv, nk, "zv"), (rt_i, nk, "rt_i"), (rt_j, nk, "rt_j"), (rho_h, nk, "rho_h"), (rt_h, nk, "rt_h"),
+                          (exner_j, nk, "exner_j")):
+            self._col(a, sl, nm)
+        self._col(add_w, nk - 1, "add_w", optional=True); self._col(add_rho, nk, "add_rho", optional=True); self._col(add_rt, nk, "add_rt", optional=True)
+        mk = lambda n: torch.empty(self.nEl, n * self.n2e, dtype=torch.float64, device=self.device)
+        F_w, F_rho, F_eta, F_ex, th_w3, eta, k2i = mk(nk - 1), mk(nk), mk(nk), mk(nk), mk(nk), mk(nk), mk(nk - 1)
+        check(self.L.mimsem_column_newton_residual(self.ctx, dt, rayleigh, _ptr(theta), _ptr(Pi), _ptr(velz_i), _ptr(velz_j), _ptr(rho_i), _ptr(rho_j),
+                                                   _ptr(zv), _ptr(rt_i), _ptr(rt_j), _ptr(rho_h), _ptr(rt_h), _ptr(exner_j),
+                                                   _ptr(add_w), _ptr(add_rho), _ptr(add_rt),
+                                                   _ptr(F_w), _ptr(F_rho), _ptr(F_eta), _ptr(F_ex), _ptr(th_w3), _ptr(eta), _ptr(k2i)), "newton_residual")
+        return F_w, F_rho, F_eta, F_ex, th_w3, eta, k2i
+
+    def newton_update(self, d_w, d_rho, d_eta, d_exner, velz_i, rho_i, rt_i, exner_i, velz_j, rho_j, rt_j, exner_j):
+        """mimsem_column_newton_update: velz_j / rho_j / rt_j / exner_j are updated IN PLACE; returns (velz_h, rho_h, rt_h, exner_h, norm_squares
+        [8, nEl, nk n2e]) (VertSolve.cpp:1858-1912)"""
+        nk = self.nk
+        for a, sl, nm in ((d_w, nk - 1, "d_w"), (d_rho, nk, "d_rho"), (d_eta, nk, "d_eta"), (d_exner, nk, "d_exner"), (velz_i, nk - 1, "velz_i"),
+                          (rho_i, nk, "rho_i"), (rt_i, nk, "rt_i"), (exner_i, nk, "exner_i"), (velz_j, nk - 1, "velz_j"), (rho_j, nk, "rho_j"),
+                          (rt_j, nk, "rt_j"), (exner_j, nk, "exner_j")):
+            self._col(a, sl, nm)
+        mk = lambda n: torch.empty(self.nEl, n * self.n2e, dtype=torch.float64, device=self.device)
+        velz_h, rho_h, rt_h, exner_h = mk(nk - 1), mk(nk), mk(nk), mk(nk)
+        nrm = torch.empty(8, self.nEl, nk * self.n2e, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_newton_update(self.ctx, _ptr(d_w), _ptr(d_rho), _ptr(d_eta), _ptr(d_exner), _ptr(velz_i), _ptr(rho_i), _ptr(rt_i),
+                                                 _ptr(exner_i), _ptr(velz_j), _ptr(rho_j), _ptr(rt_j), _ptr(exner_j),
+                                                 _ptr(velz_h), _ptr(rho_h), _ptr(rt_h), _ptr(exner_h), _ptr(nrm)), "newton_update")
+        return velz_h, rho_h, rt_h, exner_h, nrm
+
     def helmholtz_blocks(self, dt, theta, rho, eta, pi):
         for a, nm in ((theta, "theta"), (rho, "rho"), (eta, "eta"), (pi, "pi")):
             self._col(a, self.nk, nm)

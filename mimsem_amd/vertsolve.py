@@ -1,6 +1,8 @@
 """Host-side mirror of the per-column residual assembly of the reference's VertSolve (eul/VertSolve.cpp:237-286,
 432-502): compositions of VertOps operators and mat-vecs, here issued for ALL columns at once through the C ABI
 (mimsem_colop_apply) on "vertical" device arrays [nEl][nslots*n2e] (L2Vecs::vz concatenated)."""
+import os
+
 import torch
 
 SCALE = 1.0e8          # eul/VertOps.cpp:21
@@ -14,6 +16,9 @@ class VertSolve:
         self.nk, self.n2e = eng.nk, eng.n2e
         self.k2i_z = 0.0
         self._blocks = {}
+        # orders 1..3: residual assembly / update of the Newton loop through the fused entry points (mimsem_column_newton_*: four
+        # launches per iteration instead of ~150 single-operator calls); MIMSEM_NEWTON_FUSED=0 keeps the composed form below
+        self.fused = os.environ.get("MIMSEM_NEWTON_FUSED", "1") != "0"
 
     # thin wrappers: vo->AssembleX(ex,ey,...,M); MatMult(M, x, y) for every column
     _GEOMETRY_ONLY = ("CONST", "CONST_INV", "LINEAR", "LINEAR_INV", "RAYLEIGH")
@@ -107,6 +112,8 @@ class VertSolve:
         Returns (velz, rho, rt, exner) at the new time level and leaves theta_h / theta_l2_h / exner_h (the time-centred fields
         the horizontal corrector reads) and the per-iteration max-norms in self.*"""
         eng, nk, dt = self.eng, self.nk, self.dt
+        if self.fused and eng.mesh.n <= 3:
+            return self._solve_schur_eta_fused(velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing, udwdx, hs_lat, maxit, tol, verbose)
         mv = self._mv
         velz_j, rho_j, rt_j, exner_j = velz_i.clone(), rho_i.clone(), rt_i.clone(), exner_i.clone()
         theta_i = eng.diag_theta(1, rho_i, rt_i)                          # diagTheta2 :1766
@@ -157,5 +164,45 @@ class VertSolve:
                       % (itt, norms["exner"], norms["w"], norms["rho"], norms["eta"]))
             if norms["exner"] < tol and norms["rho"] < tol:               # :1922
                 break
+        self.theta_h, self.theta_l2_h, self.exner_h = theta_h, theta_l2_h, exner_h
+        return velz_j, rho_j, rt_j, exner_j
+
+    def _solve_schur_eta_fused(self, velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing, udwdx, hs_lat, maxit, tol, verbose):
+        """the same Newton loop on the fused entry points (orders 1..3): per iteration mimsem_column_newton_residual (2 launches),
+        mimsem_column_solve_schur_eta (3), mimsem_column_newton_update (1), mimsem_column_diag_theta_blend (1) and one reduction of
+        the norm partials; every statement of the composed loop above has its counterpart inside those kernels"""
+        eng, dt = self.eng, self.dt
+        velz_j, rho_j, rt_j, exner_j = velz_i.clone(), rho_i.clone(), rt_i.clone(), exner_i.clone()
+        theta_i, theta_l2_i = eng.diag_theta_blend(rho_i, rt_i)                    # diagTheta2 :1766, diagTheta_L2 :1773
+        theta_h, theta_l2_h = theta_i, theta_l2_i
+        exner_h, velz_h, rho_h, rt_h = exner_i, velz_i, rho_i, rt_i
+        self.history = []
+        self._k2i = None
+        for itt in range(1, maxit + 1):
+            add_rho = add_rt = None
+            if horiz_forcing is not None:
+                add_rho, add_rt = horiz_forcing(rho_i, rho_j, theta_l2_h)
+            if hs_lat is not None:
+                hs = eng.temp_forcing_hs(hs_lat, exner_h, theta_h, rho_h)                                            # :1831-1834
+                add_rt = hs if add_rt is None else add_rt + hs
+            F_w, F_rho, F_eta, F_exner, th_w3, eta, k2i = eng.newton_residual(
+                dt, self.rayleigh or 0.0, theta_l2_h, exner_h, velz_i, velz_j, rho_i, rho_j, zv, rt_i, rt_j, rho_h, rt_h, exner_j,
+                add_w=udwdx, add_rho=add_rho, add_rt=add_rt)
+            self._k2i = k2i
+            d_w, d_rho, d_eta, d_exner = eng.solve_schur_eta(dt, th_w3, rho_h, eta, exner_h, F_w, F_rho, F_eta, F_exner)   # :1855
+            velz_h, rho_h, rt_h, exner_h, nrm = eng.newton_update(d_w, d_rho, d_eta, d_exner, velz_i, rho_i, rt_i, exner_i,
+                                                                  velz_j, rho_j, rt_j, exner_j)
+            cs = nrm.sum(dim=2)                                                     # [8, nEl]: column sums of squares
+            nv = torch.sqrt(cs[0::2] / cs[1::2]).amax(dim=1)                        # MaxNorm :228 for exner, w, rho, eta
+            nv = eng.allreduce(nv, op="max").tolist()                               # MPI_Allreduce(MAX) :1915-1918
+            norms = dict(exner=nv[0], w=nv[1], rho=nv[2], eta=nv[3])
+            self.history.append(norms)
+            theta_h, theta_l2_h = eng.diag_theta_blend(rho_j, rt_j, blend2=theta_i, blendL=theta_l2_i, wa=0.5, wb=0.5)     # :1896-1912
+            if verbose:
+                print("\t%d:\t|d_exner|/|exner|: %.6e\t|d_w|/|w|: %.6e\t|d_rho|/|rho|: %.6e\t|d_eta|/|eta|: %.6e"
+                      % (itt, norms["exner"], norms["w"], norms["rho"], norms["eta"]))
+            if norms["exner"] < tol and norms["rho"] < tol:
+                break
+        self.k2i_z = float(self._k2i.sum()) / SCALE if self._k2i is not None else 0.0
         self.theta_h, self.theta_l2_h, self.exner_h = theta_h, theta_l2_h, exner_h
         return velz_j, rho_j, rt_j, exner_j
