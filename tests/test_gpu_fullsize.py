@@ -115,8 +115,22 @@ def test_column_solve_satisfies_its_block_tridiagonal_system(full):
     Ld = torch.einsum("ekij,ekj->eki", L[:, :, 1], d)
     Ld[:, 1:] += torch.einsum("ekij,ekj->eki", L[:, 1:, 0], d[:, :-1])
     Ld[:, :-1] += torch.einsum("ekij,ekj->eki", L[:, :-1, 2], d[:, 1:])
-    res = torch.linalg.vector_norm(Ld - rhs, dim=(1, 2)) / torch.linalg.vector_norm(rhs, dim=(1, 2))
-    assert float(res.max()) < 1e-9, float(res.max())
+    # normwise backward error |L d - f| / (|L| |d| + |f|): what a solver can be held to.  (Relative to |f| alone the floor is
+    # eps |L| |d| / |f|, which on the worst of these rough random columns -- cond(L) up to 3e10 -- is ~1e-8 for LAPACK's pivoted LU too:
+    # scripts/diag_thomas_residual.py prints both.)
+    Lnorm = torch.sqrt((L * L).sum(dim=(1, 2, 3, 4)))
+    res = torch.linalg.vector_norm(Ld - rhs, dim=(1, 2))
+    bwd = res / (Lnorm * torch.linalg.vector_norm(d, dim=(1, 2)) + torch.linalg.vector_norm(rhs, dim=(1, 2)))
+    assert float(bwd.max()) < 1e-13, float(bwd.max())
+    rel = res / torch.linalg.vector_norm(rhs, dim=(1, 2))
+    assert float(rel.median()) < 1e-12 and float(rel.max()) < 1e-7, (float(rel.median()), float(rel.max()))
+    # the worst column against LAPACK's banded-blind pivoted LU on the same dense system: same order of residual
+    w = int(rel.argmax())
+    from tests.helpers import dense_from_band
+    Ldense = dense_from_band(L[w].cpu().numpy(), NK, n2, lo=1); f = rhs[w].cpu().numpy().ravel()
+    x = np.linalg.solve(Ldense, f)
+    lap = np.linalg.norm(Ldense @ x - f) / np.linalg.norm(f)
+    assert float(rel[w]) < 20.0 * lap + 1e-12, (float(rel[w]), lap)
     assert all(bool(torch.isfinite(v).all()) for v in (d_u, d_rho, d_eta, d_pi))
 
 
