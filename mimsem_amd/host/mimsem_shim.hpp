@@ -1,16 +1,22 @@
 // mimsem_amd/host/mimsem_shim.hpp -- header-only C++ host layer over the C ABI (include/mimsem_hip.h).
 //
-// The reference's operator classes (eul/Assembly.h:1-384) are constructed from (Topo*, Geom*, LagrangeNode*,
-// LagrangeEdge*) and expose  assemble(...)  + a public PETSc  Mat M  that callers feed to MatMult.  PETSc is not in
-// this image, so this shim keeps the reference's class NAMES, constructor shape and assemble() signatures but
-// works on raw device pointers (what VecGetArray + a device mirror gives): `mult(x, y)` stands where the reference
-// has  MatMult(X->M, x, y).  INTEGRATION.md shows the same code wrapped in a MATSHELL inside eul/Assembly.cpp.
+// The reference's operator classes (eul/Assembly.h:1-384, src/Assembly.h:1-278) are constructed from (Topo*, Geom*,
+// LagrangeNode*, LagrangeEdge*) and expose  assemble(...)  + a public PETSc  Mat M  (and MT) that callers feed to MatMult.
+// PETSc is not in this image, so this shim keeps the reference's class NAMES, CONSTRUCTOR SIGNATURES and assemble() /
+// assemble_up() signatures but works on raw device pointers (what VecGetArray + a device mirror gives): `mult(x, y)` stands
+// where the reference has  MatMult(X->M, x, y),  `mult_MT(x, y)`  for MatMult(X->MT, ...).  namespace mimsem_host holds the
+// eul/ flavour, mimsem_host::src the src/ flavour (no lev / scale arguments).  The device context of a
+// (Topo, Geom) pair is created on first use and shared by every operator built from that pair (Mesh::of).
+// INTEGRATION.md shows the same code wrapped in a MATSHELL inside eul/Assembly.cpp.
 //
 // Topo / Geom here are minimal stand-ins exposing exactly the public members the operator classes read
 // (eul/Topo.h:5-51, eul/Geom.h:8-36); a maintainer passes the real objects instead.
 #pragma once
 #include <cstddef>
+#include <map>
+#include <memory>
 #include <stdexcept>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../include/mimsem_hip.h"
@@ -93,6 +99,20 @@ public:
         check(mimsem_ctx_create(&d, device, &ctx), "mimsem_ctx_create");
     }
     ~Mesh() { mimsem_ctx_destroy(ctx); }
+    // the context of a (Topo, Geom) pair: built on first use, shared by every operator object constructed from the pair (the
+    // reference's objects each keep the two pointers; a process holds one pair per rank).  release_all() before the GPU goes away.
+    static Mesh* of(const Topo* t, const Geom* g, int device = 0) {
+        auto& reg = registry();
+        auto it = reg.find({t, g});
+        if (it == reg.end()) it = reg.emplace(std::make_pair(t, g), std::unique_ptr<Mesh>(new Mesh(t, g, device))).first;
+        return it->second.get();
+    }
+    // classes the reference constructs from the Topo alone (E10mat, E21mat): the context some Geom-carrying object registered for it
+    static Mesh* of_topo(const Topo* t) {
+        for (auto& kv : registry()) if (kv.first.first == t) return kv.second.get();
+        throw std::runtime_error("mimsem_host: no device context yet for this Topo (construct an operator with (Topo*, Geom*, ...) first)");
+    }
+    static void release_all() { registry().clear(); }
     Mesh(const Mesh&) = delete;
     Mesh& operator=(const Mesh&) = delete;
     double* to_device(const double* host, size_t n) {
@@ -116,18 +136,30 @@ public:
     void interp2_g(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 2, MIMSEM_INTERP_GLOBAL, 1, x, 0, out, 0), "interp2_g"); }
     const Topo* topo; const Geom* geom; mimsem_ctx* ctx = nullptr;
     int nEl_ = 0, n2e = 0;
+private:
+    static std::map<std::pair<const Topo*, const Geom*>, std::unique_ptr<Mesh>>& registry() {
+        static std::map<std::pair<const Topo*, const Geom*>, std::unique_ptr<Mesh>> r;
+        return r;
+    }
 };
 
 // common part of every operator class: remembers what assemble() was given, mult() issues the fused launch
 class OperatorBase {
 protected:
     OperatorBase(Mesh* m, int op_) : mesh(m), op(op_) {}
+    OperatorBase(Topo* t, Geom* g, int op_) : mesh(Mesh::of(t, g)), op(op_) {}
     Mesh* mesh; int op; int lev = 0; double scale = 1.0; unsigned flags = 0; const double* field = nullptr;
-public:
-    // MatMult(X->M, x, y) on device vectors (single level, like the reference)
-    void mult(const double* x, double* y) const {
-        check(mimsem_op_apply(mesh->ctx, op, lev, 1, scale, flags, field, 0, x, 0, y, 0, 1.0), "mimsem_op_apply");
+    const double* field2 = nullptr; double tau = 0.0; bool up = false;      // the assemble_up variants (second field, departure time)
+    void apply(const double* x, double* y, unsigned extra) const {
+        if (up) check(mimsem_op_apply_up(mesh->ctx, op, lev, 1, scale, tau, flags | extra, field, 0, field2, 0, x, 0, y, 0, 1.0), "mimsem_op_apply_up");
+        else check(mimsem_op_apply(mesh->ctx, op, lev, 1, scale, flags | extra, field, 0, x, 0, y, 0, 1.0), "mimsem_op_apply");
     }
+public:
+    Mesh* device_mesh() const { return mesh; }
+    // MatMult(X->M, x, y) on device vectors (single level, like the reference)
+    void mult(const double* x, double* y) const { apply(x, y, 0u); }
+    // MatMult(X->MT, x, y): the transpose the assemble_up variants build with MatTranspose (eul/Assembly.cpp:261)
+    void mult_MT(const double* x, double* y) const { apply(x, y, MIMSEM_FLAG_TRANSPOSE); }
     // the dense element blocks the reference hands to MatSetValues (device, [nEl][esz])
     void element_matrices(double* out) const {
         check(mimsem_op_element_matrices(mesh->ctx, op, lev, scale, flags, field, out), "mimsem_op_element_matrices");
@@ -137,58 +169,82 @@ public:
 
 // ---- eul/Assembly.h classes (same names, same assemble() argument order) ---------------------------
 struct Umat : OperatorBase {     // eul/Assembly.h:1-16
+    Umat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UMAT) {}
     Umat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_UMAT) {}
-    void assemble(int lev_, double scale_, bool vert_scale) { lev = lev_; scale = scale_; flags = vert_scale ? MIMSEM_FLAG_VERT : 0; }
+    void assemble(int lev_, double scale_, bool vert_scale) { op = MIMSEM_OP_UMAT; up = false; field = nullptr; lev = lev_; scale = scale_; flags = vert_scale ? MIMSEM_FLAG_VERT : 0; }
+    // test functions evaluated at x_q + 0.5 tau (ui + uj); M and MT both available afterwards (eul/Assembly.cpp:156-279)
+    void assemble_up(int lev_, double scale_, double tau_, const double* ui, const double* uj) {
+        op = MIMSEM_OP_UMAT_UP; up = true; field = ui; field2 = uj; tau = tau_; lev = lev_; scale = scale_; flags = 0;
+    }
 };
 struct Wmat : OperatorBase {     // :18-30
+    Wmat(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WMAT) {}
     Wmat(Mesh* m, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WMAT) {}
     void assemble(int lev_, double scale_, bool vert_scale) { lev = lev_; scale = scale_; flags = vert_scale ? MIMSEM_FLAG_VERT : 0; }
 };
 struct Uhmat : OperatorBase {    // :32-60
+    Uhmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UHMAT) {}
     Uhmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_UHMAT) {}
-    void assemble(const double* h2, int lev_, bool const_vert, double scale_) { field = h2; lev = lev_; scale = scale_; flags = const_vert ? MIMSEM_FLAG_VERT : 0; }
+    void assemble(const double* h2, int lev_, bool const_vert, double scale_) { op = MIMSEM_OP_UHMAT; up = false; field = h2; lev = lev_; scale = scale_; flags = const_vert ? MIMSEM_FLAG_VERT : 0; }
+    void assemble_up(const double* h2, int lev_, double scale_, double dt, const double* u1) {       // eul/Assembly.cpp:477-560
+        op = MIMSEM_OP_UHMAT_UP; up = true; field = h2; field2 = u1; tau = dt; lev = lev_; scale = scale_; flags = 0;
+    }
 };
 struct Pmat : OperatorBase {
+    Pmat(Topo* t, Geom* g, LagrangeNode*) : OperatorBase(t, g, MIMSEM_OP_PMAT) {}
     Pmat(Mesh* m, LagrangeNode*) : OperatorBase(m, MIMSEM_OP_PMAT) {}
     void assemble(int lev_, double scale_) { op = MIMSEM_OP_PMAT; field = nullptr; lev = lev_; scale = scale_; }
     void assemble_h(int lev_, double scale_, const double* h2) { op = MIMSEM_OP_PHMAT; field = h2; lev = lev_; scale = scale_; }
 };
 struct WtQUmat : OperatorBase {
+    WtQUmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WTQUMAT) {}
     WtQUmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WTQUMAT) {}
     void assemble(const double* u1, int lev_, double scale_) { field = u1; lev = lev_; scale = scale_; }
 };
 struct RotMat : OperatorBase {
+    RotMat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_ROTMAT) {}
     RotMat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_ROTMAT) {}
     void assemble(const double* q0, int lev_, double scale_) { field = q0; lev = lev_; scale = scale_; }
 };
 struct Whmat : OperatorBase {
+    Whmat(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WHMAT) {}
     Whmat(Mesh* m, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WHMAT) {}
     void assemble(const double* rho, int lev_, double scale_, bool vert_scale_rho) { field = rho; lev = lev_; scale = scale_; flags = vert_scale_rho ? MIMSEM_FLAG_VERT : 0; }
 };
 struct Ut_mat : OperatorBase {
+    Ut_mat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UTMAT) {}
     Ut_mat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_UTMAT) {}
     void assemble(int lev_, double scale_) { op = MIMSEM_OP_UTMAT; field = nullptr; lev = lev_; scale = scale_; }
     void assemble_h(int lev_, double scale_, const double* rho) { op = MIMSEM_OP_UTMAT_H; field = rho; lev = lev_; scale = scale_; }
 };
 struct UtQWmat : OperatorBase {
+    UtQWmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UTQWMAT) {}
     UtQWmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_UTQWMAT) {}
     void assemble(const double* u1, double scale_) { field = u1; scale = scale_; }
 };
 struct WtQdUdz_mat : OperatorBase {
+    WtQdUdz_mat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WTQDUDZ) {}
     WtQdUdz_mat(Mesh* m, LagrangeNode*, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WTQDUDZ) {}
     void assemble(const double* u1, double scale_) { field = u1; scale = scale_; }
 };
 struct WmatInv : OperatorBase {
+    WmatInv(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WMATINV) {}
     WmatInv(Mesh* m, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WMATINV) {}
     void assemble(int lev_, double scale_) { lev = lev_; scale = scale_; }
 };
 struct WhmatInv : OperatorBase {
+    WhmatInv(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WHMATINV) {}
     WhmatInv(Mesh* m, LagrangeEdge*) : OperatorBase(m, MIMSEM_OP_WHMATINV) {}
     void assemble(const double* rho, int lev_, double scale_) { field = rho; lev = lev_; scale = scale_; }
 };
 // Uvec (eul/Assembly.h, Assembly.cpp:2124-2430): the matrix-free vectors are the same kernels applied to `vel`
 struct Uvec {
+    Uvec(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : mesh(Mesh::of(t, g)) {}
     Uvec(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
+    // Uvec::assemble_hu_up (eul/Assembly.cpp:2281-2373): accumulates fac * (upwinded-test-function flux of vel weighted by rho) into vl
+    void assemble_hu_up(int lev, double scale, const double* vel, const double* rho, double fac, double tau, const double* vel2, double* vl) {
+        check(mimsem_op_apply_up(mesh->ctx, MIMSEM_OP_UVEC_HU_UP, lev, 1, scale, tau, MIMSEM_FLAG_ACCUM, rho, 0, vel2, 0, vel, 0, vl, 0, fac), "Uvec::assemble_hu_up");
+    }
     void assemble(int lev, double scale, bool /*vert_scale: ignored by the reference too*/, const double* vel, double* vl) {
         check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UMAT, lev, 1, scale, MIMSEM_FLAG_VERT, nullptr, 0, vel, 0, vl, 0, 1.0), "Uvec::assemble");
     }
@@ -204,6 +260,7 @@ struct Uvec {
 
 // Umat_ray (eul/Assembly.h; Assembly.cpp:1858-1979): Held-Suarez friction, same assemble() argument order
 struct Umat_ray {
+    Umat_ray(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : mesh(Mesh::of(t, g)) {}
     Umat_ray(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
     void assemble(int lev_, double scale_, double dt_, const double* exner_k_, const double* exner_s_) {
         lev = lev_; scale = scale_; dt = dt_; exner_k = exner_k_; exner_s = exner_s_;
@@ -220,30 +277,32 @@ struct Umat_ray {
 
 // Pvec / Phvec (Assembly.cpp:585-689): lumped 0-form mass as a vector
 struct Pvec {
+    Pvec(Topo* t, Geom* g, LagrangeNode*) : mesh(Mesh::of(t, g)) {}
     Pvec(Mesh* m, LagrangeNode*) : mesh(m) {}
     void assemble(int lev, double scale, double* vl) { check(mimsem_pvec(mesh->ctx, lev, 1, scale, nullptr, 0, vl, 0), "Pvec"); }
     Mesh* mesh;
 };
 struct Phvec {
+    Phvec(Topo* t, Geom* g, LagrangeNode*) : mesh(Mesh::of(t, g)) {}
     Phvec(Mesh* m, LagrangeNode*) : mesh(m) {}
     void assemble(const double* h2, int lev, double scale, double* vl) { check(mimsem_pvec(mesh->ctx, lev, 1, scale, h2, 0, vl, 0), "Phvec"); }
     Mesh* mesh;
 };
 
 // projections from the quadrature-point grid (Assembly.cpp:691-902); x indexed like Geom's quad grid
-struct WtQmat { WtQmat(Mesh* m, LagrangeEdge*) : mesh(m) {}
+struct WtQmat { WtQmat(Topo* t, Geom* g, LagrangeEdge*) : mesh(Mesh::of(t, g)) {} WtQmat(Mesh* m, LagrangeEdge*) : mesh(m) {}
     void mult(const double* xq, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_WTQ, 0, 1, 1.0, 0, nullptr, 0, xq, 0, y, 0, 1.0), "WtQmat"); } Mesh* mesh; };
-struct PtQmat { PtQmat(Mesh* m, LagrangeNode*) : mesh(m) {}
+struct PtQmat { PtQmat(Topo* t, Geom* g, LagrangeNode*) : mesh(Mesh::of(t, g)) {} PtQmat(Mesh* m, LagrangeNode*) : mesh(m) {}
     void mult(const double* xq, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_PTQ, 0, 1, 1.0, 0, nullptr, 0, xq, 0, y, 0, 1.0), "PtQmat"); } Mesh* mesh; };
-struct UtQmat { UtQmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
+struct UtQmat { UtQmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : mesh(Mesh::of(t, g)) {} UtQmat(Mesh* m, LagrangeNode*, LagrangeEdge*) : mesh(m) {}
     void mult(const double* xq2, double* y) const { check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UTQ, 0, 1, 1.0, 0, nullptr, 0, xq2, 0, y, 0, 1.0), "UtQmat"); } Mesh* mesh; };
 
 // E10mat / E21mat (Assembly.cpp:1102-1220): public members E10, E01 / E21, E12 become mult functions
-struct E10mat { E10mat(Mesh* m) : mesh(m) {}
+struct E10mat { explicit E10mat(Topo* t) : mesh(Mesh::of_topo(t)) {} explicit E10mat(Mesh* m) : mesh(m) {}
     void mult_E10(const double* x0, double* y1) const { check(mimsem_incidence_apply(mesh->ctx, 0, 1, x0, 0, y1, 0), "E10"); }
     void mult_E01(const double* x1, double* y0) const { check(mimsem_incidence_apply(mesh->ctx, 3, 1, x1, 0, y0, 0), "E01"); }
     Mesh* mesh; };
-struct E21mat { E21mat(Mesh* m) : mesh(m) {}
+struct E21mat { explicit E21mat(Topo* t) : mesh(Mesh::of_topo(t)) {} explicit E21mat(Mesh* m) : mesh(m) {}
     void mult_E21(const double* x1, double* y2) const { check(mimsem_incidence_apply(mesh->ctx, 1, 1, x1, 0, y2, 0), "E21"); }
     void mult_E12(const double* x2, double* y1) const { check(mimsem_incidence_apply(mesh->ctx, 2, 1, x2, 0, y1, 0), "E12"); }
     Mesh* mesh; };
@@ -251,6 +310,7 @@ struct E21mat { E21mat(Mesh* m) : mesh(m) {}
 // L2Vecs (eul/L2Vecs.h:1-25): vh[k] = level k's horizontal 2-form vector, vz[e] = column e's vertical vector.
 // Device storage: vh [nk][n2] contiguous, vz [nEl][nk*n2e] contiguous (the per-element Vecs of the reference, concatenated).
 struct L2Vecs {
+    L2Vecs(int nk_, Topo* t, Geom* g) : L2Vecs(nk_, Mesh::of(t, g)) {}              // eul/L2Vecs.h: L2Vecs(int _nk, Topo*, Geom*)
     L2Vecs(int nk_, Mesh* m) : nk(nk_), mesh(m) {
         n2 = m->topo->n2; nEl = m->nEl_; n2e = m->n2e;
         vh = m->device_alloc((size_t)nk*n2); vz = m->device_alloc((size_t)nEl*nk*n2e);
@@ -271,6 +331,7 @@ struct L2Vecs {
 // columns (`for(ii...) { vo->AssembleX(ex, ey, ..., vo->VB); MatMult(vo->VB, a, b); }`); here Assemble* records the operator for
 // ALL columns (fields are the concatenated vz arrays) and mult() is that loop's body for every column in one launch.
 struct VertOps {
+    VertOps(Topo* t, Geom* g) : mesh(Mesh::of(t, g)) {}                              // eul/VertOps.h: VertOps(Topo*, Geom*)
     explicit VertOps(Mesh* m) : mesh(m) {}
     void AssembleConst()                                  { set(MIMSEM_V_CONST); }
     void AssembleConstInv()                               { set(MIMSEM_V_CONST_INV); }
@@ -319,6 +380,7 @@ private:
 
 // VertSolve (eul/VertSolve.h): the column solves, every column at once (the reference loops over ex, ey)
 struct VertSolve {
+    VertSolve(Topo* t, Geom* g, double dt_) : mesh(Mesh::of(t, g)), dt(dt_) {}        // eul/VertSolve.h: VertSolve(Topo*, Geom*, double dt)
     VertSolve(Mesh* m, double dt_) : mesh(m), dt(dt_) {}
     void solve_schur_column_eta(const double* theta, const double* /*velz: unused by the reference*/, const double* rho, const double* eta, const double* pi,
                                 double* F_u, double* F_rho, double* F_eta, double* F_pi, double* d_u, double* d_rho, double* d_eta, double* d_pi) {
@@ -335,5 +397,49 @@ struct VertSolve {
         check(mimsem_column_diag_theta_up(mesh->ctx, dt, rho, rt, ul, ul_stride, theta), "diagTheta_up"); }
     Mesh* mesh; double dt;
 };
+
+// ---- src/ flavour (shallow water, src/Assembly.h:1-278): no lev / scale arguments, no layer thickness ------------------------------
+namespace src {
+struct Umat : OperatorBase {      // src/Assembly.h:1-13
+    Umat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UMAT) {}
+    void assemble() { op = MIMSEM_OP_UMAT; up = false; field = nullptr; }
+};
+struct Wmat : OperatorBase {      // :15-24
+    Wmat(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WMAT) {}
+    void assemble() {}
+};
+struct Pmat : OperatorBase {      // :26-35
+    Pmat(Topo* t, Geom* g, LagrangeNode*) : OperatorBase(t, g, MIMSEM_OP_PMAT) {}
+    void assemble() {}
+};
+struct Phmat : OperatorBase {     // :37-49
+    Phmat(Topo* t, Geom* g, LagrangeNode*) : OperatorBase(t, g, MIMSEM_OP_PHMAT) {}
+    void assemble(const double* h2) { op = MIMSEM_OP_PHMAT; up = false; field = h2; }
+    // trial functions at the departure points x_q - tau u, tau = 1/(1/(fac dt))  (src/Assembly.cpp:499-567)
+    void assemble_up(const double* ul, const double* hl, double fac, double dt) {
+        op = MIMSEM_OP_PHMAT_UP; up = true; field = hl; field2 = ul; tau = 1.0/(1.0/(fac*dt));
+    }
+};
+struct Uhmat : OperatorBase {     // :51-79
+    Uhmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_UHMAT) {}
+    void assemble(const double* h2) { field = h2; }
+};
+struct WtQUmat : OperatorBase {   // :131-155
+    WtQUmat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WTQUMAT) {}
+    void assemble(const double* u1) { field = u1; }
+};
+struct RotMat : OperatorBase {    // :157-179
+    RotMat(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_ROTMAT) {}
+    void assemble(const double* q0) { field = q0; }
+};
+struct Whmat : OperatorBase {     // :199-208
+    Whmat(Topo* t, Geom* g, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_WHMAT) {}
+    void assemble(const double* h2) { field = h2; }
+};
+struct RotMat_up : OperatorBase { // :227-250; assemble(q0, ul, tau, dt): the vorticity at x_q - (tau dt) u  (src/Assembly.cpp:1784-1853)
+    RotMat_up(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : OperatorBase(t, g, MIMSEM_OP_ROTMAT_UP) { up = true; }
+    void assemble(const double* q0, const double* ul, double tau_, double dt) { field = q0; field2 = ul; tau = 1.0/(1.0/(tau_*dt)); }
+};
+}  // namespace src
 
 }  // namespace mimsem_host

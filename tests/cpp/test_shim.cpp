@@ -30,7 +30,7 @@ int main() {
     geom.thick.assign(P->thick, P->thick + (size_t)nk*P->n0q);
     geom.thickInv.assign(P->thickInv, P->thickInv + (size_t)nk*P->n0q);
     GaussLobatto quad{n}; LagrangeNode node{n, &quad}; LagrangeEdge edge{n, &node};
-    Mesh mesh(&topo, &geom, 0);
+    Mesh& mesh = *Mesh::of(&topo, &geom);          // what every (Topo*, Geom*, ...) constructor below resolves to
 
     std::vector<double> u(P->n1), h(P->n2), Mu(P->n1), want(P->n1, 0.0);
     for (auto& v : u) v = S(rng);
@@ -51,7 +51,7 @@ int main() {
     std::vector<double> em((size_t)nEl*orc_op_elmat_size(P, ORC_UMAT));
 
     // M1->assemble(lev, SCALE, true); MatMult(M1->M, u, Mu);
-    Umat M1(&mesh, &node, &edge);
+    Umat M1(&topo, &geom, &node, &edge);                  // the reference's constructor signature (eul/Assembly.h:3)
     M1.assemble(1, SCALE, true);
     M1.mult(d_u, d_y);
     orc_op_elmats(P, ORC_UMAT, 1, SCALE, 1, nullptr, em.data());
@@ -60,7 +60,7 @@ int main() {
     compare("Umat");
 
     // F->assemble(h, lev, true, SCALE); MatMult(F->M, u, hu);
-    Uhmat F(&mesh, &node, &edge);
+    Uhmat F(&topo, &geom, &node, &edge);
     F.assemble(d_h, 0, true, SCALE);
     F.mult(d_u, d_y);
     orc_op_elmats(P, ORC_UHMAT, 0, SCALE, 1, h.data(), em.data());
@@ -68,25 +68,101 @@ int main() {
     orc_op_apply(P, ORC_UHMAT, em.data(), u.data(), want.data());
     compare("Uhmat");
 
+
+    // ---- upwinded test functions: M1->assemble_up(lev, SCALE, tau, ui, uj); MatMult(M1->M, ..) and MatMult(M1->MT, ..)  (eul/Assembly.cpp:156-279)
+    {
+        double tI = 0.0; for (int j = 0; j < P->n0q; j++) tI += P->thickInv[(size_t)1*P->n0q + j]; tI /= P->n0q;
+        double dm = 0.0; for (double v : det) dm += v; dm /= det.size();
+        const double tau = 75.0, vs = dm/tI*0.3/tau;                    // departure shift ~0.3 of the reference element
+        std::vector<double> ui(P->n1), uj(P->n1);
+        for (auto& v : ui) v = S(rng)*vs;
+        for (auto& v : uj) v = S(rng)*vs;
+        double *d_ui = mesh.to_device(ui.data(), ui.size()), *d_uj = mesh.to_device(uj.data(), uj.size());
+        M1.assemble_up(1, SCALE, tau, d_ui, d_uj);
+        M1.mult(d_u, d_y);
+        orc_op_elmats_testup(P, 0, 1, SCALE, tau, ui.data(), uj.data(), em.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_UMAT, em.data(), u.data(), want.data());
+        compare("Umat_up");
+        M1.mult_MT(d_u, d_y);
+        {   // MT: transpose every element's 2x2 block matrix [UU UV; VU VV]
+            const int n1e = P->n1e; std::vector<double> et(em.size());
+            for (int e = 0; e < nEl; e++) for (int b = 0; b < 4; b++) for (int i = 0; i < n1e; i++) for (int j = 0; j < n1e; j++) {
+                const int bt = (b == 1) ? 2 : (b == 2 ? 1 : b);
+                et[((size_t)e*4 + bt)*n1e*n1e + (size_t)j*n1e + i] = em[((size_t)e*4 + b)*n1e*n1e + (size_t)i*n1e + j];
+            }
+            std::fill(want.begin(), want.end(), 0.0);
+            orc_op_apply(P, ORC_UMAT, et.data(), u.data(), want.data());
+        }
+        compare("Umat MT");
+        F.assemble_up(d_h, 1, SCALE, tau, d_ui);
+        F.mult(d_u, d_y);
+        orc_op_elmats_testup(P, 1, 1, SCALE, tau, h.data(), ui.data(), em.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_UMAT, em.data(), u.data(), want.data());
+        compare("Uhmat_up");
+        // Uvec::assemble_hu_up(lev, scale, vel, rho, fac, tau, vel2)  (eul/Assembly.cpp:2281-2373; accumulates into vl)
+        Uvec uv(&topo, &geom, &node, &edge);
+        std::fill(want.begin(), want.end(), 0.0);
+        check(mimsem_memset(mesh.ctx, d_y, 0, (long long)(Mu.size()*sizeof(double))), "memset");
+        uv.assemble_hu_up(1, SCALE, d_u, d_h, 1.0/3.0, tau, d_uj, d_y);
+        orc_uvec_hu_up(P, 1, SCALE, u.data(), h.data(), 1.0/3.0, tau, uj.data(), want.data());
+        compare("hu_up");
+        M1.assemble(1, SCALE, true);                                    // back to the plain operator for what follows
+        mimsem_free(d_ui); mimsem_free(d_uj);
+    }
+    // ---- src/ flavour (src/Assembly.h): no lev / scale; Phmat::assemble_up, RotMat_up::assemble  (src/Assembly.cpp:499-567, 1784-1853)
+    {
+        double dm = 0.0; for (double v : det) dm += v; dm /= det.size();
+        const double fac = 0.5, dts = 600.0;
+        std::vector<double> ul(P->n1), x0(P->n0), q0(P->n0), y0(P->n0), w0(P->n0, 0.0), e0((size_t)nEl*orc_op_elmat_size(P, ORC_PMAT)), e1((size_t)nEl*orc_op_elmat_size(P, ORC_ROTMAT));
+        for (auto& v : ul) v = S(rng)*dm*0.2/(fac*dts);
+        for (auto& v : x0) v = S(rng);
+        for (auto& v : q0) v = S(rng)*1e-4;
+        double *d_ul = mesh.to_device(ul.data(), ul.size()), *d_x0 = mesh.to_device(x0.data(), x0.size()), *d_q0 = mesh.to_device(q0.data(), q0.size());
+        double* d_y0 = mesh.device_alloc(P->n0);
+        src::Phmat M0h(&topo, &geom, &node);
+        M0h.assemble_up(d_ul, d_h, fac, dts);
+        M0h.mult(d_x0, d_y0); mesh.to_host(y0.data(), d_y0, y0.size());
+        orc_op_elmats_up(P, 0, fac, dts, h.data(), ul.data(), e0.data());
+        orc_op_apply(P, ORC_PMAT, e0.data(), x0.data(), w0.data());
+        double num = 0, den = 0; for (size_t i = 0; i < y0.size(); i++) { num += (y0[i] - w0[i])*(y0[i] - w0[i]); den += w0[i]*w0[i]; }
+        std::printf("%-8s rel L2 = %.3e\n", "Phmat_up", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
+        src::RotMat_up R(&topo, &geom, &node, &edge);
+        R.assemble(d_q0, d_ul, fac, dts);
+        R.mult(d_u, d_y);
+        orc_op_elmats_up(P, 1, fac, dts, q0.data(), ul.data(), e1.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_ROTMAT, e1.data(), u.data(), want.data());
+        compare("RotMat_up");
+        src::Umat M1s(&topo, &geom, &node, &edge);
+        M1s.assemble();
+        M1s.mult(d_u, d_y);
+        orc_op_elmats(P, ORC_UMAT, 0, 1.0, 0, nullptr, em.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_UMAT, em.data(), u.data(), want.data());
+        compare("src Umat");
+        mimsem_free(d_ul); mimsem_free(d_x0); mimsem_free(d_q0); mimsem_free(d_y0);
+    }
     // ---- incidence, Pvec, projections -------------------------------------------------------------------
     {
         std::vector<double> x0(P->n0), y1(P->n1), w1(P->n1, 0.0), y2(P->n2), w2(P->n2, 0.0), pv(P->n0), wp(P->n0, 0.0);
         for (auto& v : x0) v = S(rng);
         double *d_x0 = mesh.to_device(x0.data(), x0.size()), *d_y1 = mesh.device_alloc(P->n1), *d_y2 = mesh.device_alloc(P->n2), *d_p = mesh.device_alloc(P->n0);
-        E10mat NtoE(&mesh); E21mat EtoF(&mesh);
+        E10mat NtoE(&topo); E21mat EtoF(&topo);
         NtoE.mult_E10(d_x0, d_y1); mesh.to_host(y1.data(), d_y1, y1.size()); orc_e10_apply(P, x0.data(), w1.data());
         EtoF.mult_E21(d_u, d_y2);  mesh.to_host(y2.data(), d_y2, y2.size()); orc_e21_apply(P, u.data(), w2.data());
         bool same = true;
         for (size_t i = 0; i < y1.size(); i++) same = same && y1[i] == w1[i];
         for (size_t i = 0; i < y2.size(); i++) same = same && y2[i] == w2[i];
         std::printf("%-8s %s\n", "E10/E21", same ? "bit-exact" : "MISMATCH"); if (!same) fails++;
-        Pvec m0(&mesh, &node); m0.assemble(1, SCALE, d_p); mesh.to_host(pv.data(), d_p, pv.size()); orc_pvec(P, 1, SCALE, wp.data());
+        Pvec m0(&topo, &geom, &node); m0.assemble(1, SCALE, d_p); mesh.to_host(pv.data(), d_p, pv.size()); orc_pvec(P, 1, SCALE, wp.data());
         double num = 0, den = 0; for (size_t i = 0; i < pv.size(); i++) { num += (pv[i] - wp[i])*(pv[i] - wp[i]); den += wp[i]*wp[i]; }
         std::printf("%-8s rel L2 = %.3e\n", "Pvec", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
         std::vector<double> xq(P->n0q), pq(P->n0), wq(P->n0, 0.0);
         for (auto& v : xq) v = S(rng);
         double* d_xq = mesh.to_device(xq.data(), xq.size());
-        PtQmat PtQ(&mesh, &node); PtQ.mult(d_xq, d_p); mesh.to_host(pq.data(), d_p, pq.size()); orc_project_from_quad(P, 1, xq.data(), wq.data());
+        PtQmat PtQ(&topo, &geom, &node); PtQ.mult(d_xq, d_p); mesh.to_host(pq.data(), d_p, pq.size()); orc_project_from_quad(P, 1, xq.data(), wq.data());
         num = den = 0; for (size_t i = 0; i < pq.size(); i++) { num += (pq[i] - wq[i])*(pq[i] - wq[i]); den += wq[i]*wq[i]; }
         std::printf("%-8s rel L2 = %.3e\n", "PtQmat", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
         mimsem_free(d_x0); mimsem_free(d_y1); mimsem_free(d_y2); mimsem_free(d_p); mimsem_free(d_xq);
@@ -113,7 +189,7 @@ int main() {
     // ---- L2Vecs, VertOps, VertSolve: the column path as eul/VertSolve.cpp drives it ---------------------------
     {
         const int n2e = P->n2e, N = nk*n2e;
-        L2Vecs rho(nk, &mesh);
+        L2Vecs rho(nk, &topo, &geom);
         std::vector<double> vh((size_t)nk*P->n2), vz((size_t)nEl*N), wz((size_t)nEl*N);
         for (auto& v : vh) v = U(rng)*1e9;
         rho.CopyFromHoriz(vh.data()); rho.HorizToVert();
@@ -122,7 +198,7 @@ int main() {
         std::printf("%-8s %s\n", "L2Vecs", same ? "bit-exact" : "MISMATCH"); if (!same) fails++;
 
         // vo->AssembleConstWithRho(ex, ey, rho, vo->VB); MatMult(vo->VB, a, b);   (every column at once)
-        VertOps vo(&mesh);
+        VertOps vo(&topo, &geom);
         std::vector<double> a((size_t)nEl*N), b((size_t)nEl*N), dense((size_t)N*N);
         for (auto& v : a) v = S(rng);
         double *d_a = mesh.to_device(a.data(), a.size()), *d_b = mesh.device_alloc(a.size());
@@ -150,7 +226,7 @@ int main() {
         std::vector<double*> dv;
         for (auto* f : {&th, &rh, &et, &pi, &Fu, &Fr, &Fe, &Fp}) dv.push_back(mesh.to_device(f->data(), f->size()));
         double *d_du = mesh.device_alloc((size_t)nEl*Nm), *d_dr = mesh.device_alloc((size_t)nEl*N), *d_de = mesh.device_alloc((size_t)nEl*N), *d_dp = mesh.device_alloc((size_t)nEl*N);
-        VertSolve vert(&mesh, 75.0);
+        VertSolve vert(&topo, &geom, 75.0);
         vert.solve_schur_column_eta(dv[0], nullptr, dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7], d_du, d_dr, d_de, d_dp);
         std::vector<double> gp((size_t)nEl*N), gu((size_t)nEl*Nm);
         mesh.to_host(gp.data(), d_dp, gp.size()); mesh.to_host(gu.data(), d_du, gu.size());
@@ -166,12 +242,31 @@ int main() {
             for (int i = 0; i < Nm; i++) { num += (gu[(size_t)e*Nm + i] - wu[i])*(gu[(size_t)e*Nm + i] - wu[i]); den += wu[i]*wu[i]; }
             worst = std::max(worst, std::sqrt(num/den));
         }
-        std::printf("%-8s rel L2 = %.3e\n", "Schur", worst); if (!(worst < 1e-8)) fails++;
+        std::printf("%-8s rel L2 = %.3e\n", "Schur", worst); if (!(worst < 1e-10)) fails++;
+        // vert->diagTheta2(rho, rt, theta) / diagTheta_L2  (eul/VertSolve.cpp:289-352), every column
+        {
+            std::vector<double> rt = field(nk, 250, 400), t2((size_t)nEl*(nk + 1)*n2e), tl((size_t)nEl*N), w2((nk + 1)*n2e), wl(N);
+            double *d_rt = mesh.to_device(rt.data(), rt.size()), *d_t2 = mesh.device_alloc(t2.size()), *d_tl = mesh.device_alloc(tl.size());
+            vert.diagTheta2(dv[1], d_rt, d_t2); vert.diagTheta_L2(dv[1], d_rt, d_tl);
+            mesh.to_host(t2.data(), d_t2, t2.size()); mesh.to_host(tl.data(), d_tl, tl.size());
+            worst = 0.0;
+            for (int e : {0, nEl - 1}) {
+                orc_diag_theta2(P, e%nels, e/nels, &rh[(size_t)e*N], &rt[(size_t)e*N], w2.data());
+                orc_diag_theta_L2(P, e%nels, e/nels, &rh[(size_t)e*N], &rt[(size_t)e*N], wl.data());
+                double num = 0, den = 0;
+                for (int i = 0; i < (nk + 1)*n2e; i++) { const double g = t2[(size_t)e*(nk + 1)*n2e + i]; num += (g - w2[i])*(g - w2[i]); den += w2[i]*w2[i]; }
+                for (int i = 0; i < N; i++) { const double g = tl[(size_t)e*N + i]; num += (g - wl[i])*(g - wl[i]); den += wl[i]*wl[i]; }
+                worst = std::max(worst, std::sqrt(num/den));
+            }
+            std::printf("%-8s rel L2 = %.3e\n", "diagTheta", worst); if (!(worst < 1e-10)) fails++;
+            mimsem_free(d_rt); mimsem_free(d_t2); mimsem_free(d_tl);
+        }
         for (double* q : dv) mimsem_free(q);
         mimsem_free(d_du); mimsem_free(d_dr); mimsem_free(d_de); mimsem_free(d_dp);
     }
     mimsem_free(d_u); mimsem_free(d_h); mimsem_free(d_y);
     orc_patch_destroy(P);
+    Mesh::release_all();
     std::printf(fails ? "FAILED\n" : "OK\n");
     return fails;
 }
