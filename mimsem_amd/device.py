@@ -329,6 +329,17 @@ class Engine:
                                               _ptr(y2), y2.stride(0), alpha), "mimsem_elem_blocks_apply")
         return y if x.dim() == 2 else y2[0]
 
+    def wvec(self, rho, lev0=0, scale=1.0, vert_scale=True, out=None):
+        """Wvec::assemble(lev, scale, vert_scale, rho) (eul/Assembly.cpp:2457-2495; row B18): the matrix-free 2-form right-hand side
+        W^T diag(w s/det [thickInv]) W rho -- Wmat applied to rho.  (The reference leaves its Wt table unfilled and has every call
+        commented out; this is the evident intent, see oracle/o_assembly.c.)"""
+        return self.apply("WMAT", rho, lev0=lev0, scale=scale, flags=FLAG_VERT if vert_scale else 0, out=out)
+
+    def wvec_K(self, vel1, vel2, lev0=0, scale=1.0, out=None):
+        """Wvec::assemble_K(lev, scale, vel1, vel2) (eul/Assembly.cpp:2497-2545): the kinetic-energy 2-form 1/2 <vel2, vel1> as a
+        vector -- WtQUmat(vel2) applied to vel1"""
+        return self.apply("WTQUMAT", vel1, f=vel2, lev0=lev0, scale=scale, out=out)
+
     def pvec(self, lev0=0, nlev=1, scale=1.0, h2=None):
         y = torch.empty(nlev, self.sizes[0], dtype=torch.float64, device=self.device)
         check(self.L.mimsem_pvec(self.ctx, lev0, nlev, scale, _ptr(h2), h2.stride(0) if h2 is not None else 0,

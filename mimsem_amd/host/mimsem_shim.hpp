@@ -258,6 +258,20 @@ struct Uvec {
     Mesh* mesh;
 };
 
+// Wvec (eul/Assembly.h:371-384, Assembly.cpp:2443-2552; row B18).  The reference's Wvec never fills its transpose table Wt and all
+// its call sites are commented out (eul/HorizSolve.cpp:222-223, 441-448); what the loops compute with Wt = W^T is Wmat x rho and
+// WtQUmat(vel2) x vel1, which is what these two issue.
+struct Wvec {
+    Wvec(Topo* t, Geom* g, LagrangeEdge*) : mesh(Mesh::of(t, g)) {}
+    void assemble(int lev, double scale, bool vert_scale, const double* rho, double* vg) {
+        check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_WMAT, lev, 1, scale, vert_scale ? MIMSEM_FLAG_VERT : 0u, nullptr, 0, rho, 0, vg, 0, 1.0), "Wvec::assemble");
+    }
+    void assemble_K(int lev, double scale, const double* vel1, const double* vel2, double* vg) {
+        check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_WTQUMAT, lev, 1, scale, 0u, vel2, 0, vel1, 0, vg, 0, 1.0), "Wvec::assemble_K");
+    }
+    Mesh* mesh;
+};
+
 // Umat_ray (eul/Assembly.h; Assembly.cpp:1858-1979): Held-Suarez friction, same assemble() argument order
 struct Umat_ray {
     Umat_ray(Topo* t, Geom* g, LagrangeNode*, LagrangeEdge*) : mesh(Mesh::of(t, g)) {}

@@ -325,6 +325,55 @@ void orc_uvec_wxu(const orc_patch* p, int lev, double scale, const double* vel, 
     uvec_core(p, 2, lev, scale, vel, vort, 1.0, vl);
 }
 
+/* B18  Wvec::assemble :2457-2495 and Wvec::assemble_K :2497-2545 -- CORRECTED restatement.  The reference allocates Wt in the
+ * constructor (:2452) and never fills it (every other class calls Tran_IP right after Alloc2D), and all its live uses are
+ * commented out (eul/HorizSolve.cpp:222-223, 441-448): as written it projects with an uninitialised table.  Here Wt = W^T, the
+ * evident intent; everything else follows the reference's loops line by line.  These two are therefore NOT pinned to reference
+ * behaviour -- they pin that  Wvec::assemble == Wmat x rho  and  Wvec::assemble_K == WtQUmat(vel2) x vel1. */
+void orc_wvec(const orc_patch* p, int lev, double scale, int vert_scale, const double* rho, double* vg) {
+    int ex, ey, ei, ii, k, mp1 = p->mp1, mp12 = p->mp12, n2e = p->n2e, i2[128], iq[128];
+    double Qaa[128], rhs[128], r;
+    memset(vg, 0, sizeof(double)*p->n2);
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        ei = ey*p->nElsX + ex;
+        orc_elinds2_l(p, ex, ey, i2); orc_elindsq_l(p, ex, ey, iq);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            Qaa[ii] = p->Q[ii]*(scale/det);
+            if (vert_scale) Qaa[ii] *= p->thickInv[(size_t)lev*p->n0q + iq[ii]];
+            orc_interp2_l(p, ex, ey, ii%mp1, ii/mp1, rho, &r);
+            Qaa[ii] *= r;
+        }
+        orc_la->axb(n2e, mp12, p->Wt, Qaa, rhs);
+        for (k = 0; k < n2e; k++) vg[i2[k]] += rhs[k];
+    }
+}
+void orc_wvec_K(const orc_patch* p, int lev, double scale, const double* vel1, const double* vel2, double* vg) {
+    int ex, ey, ei, ii, k, mp1 = p->mp1, mp12 = p->mp12, n2e = p->n2e, i2[128], iq[128];
+    double Qaa[128], Qab[128], rhs_a[128], rhs_b[128], uxg[2], uxl[2];
+    const double* tI = p->thickInv + (size_t)lev*p->n0q;
+    memset(vg, 0, sizeof(double)*p->n2);
+    for (ey = 0; ey < p->nElsX; ey++) for (ex = 0; ex < p->nElsX; ex++) {
+        ei = ey*p->nElsX + ex;
+        orc_elinds2_l(p, ex, ey, i2); orc_elindsq_l(p, ex, ey, iq);
+        for (ii = 0; ii < mp12; ii++) {
+            double det = p->det[(size_t)ei*mp12 + ii];
+            const double* jac = &p->J[((size_t)ei*mp12 + ii)*4];
+            orc_interp1_l(p, ex, ey, ii%mp1, ii/mp1, vel1, uxl);
+            orc_interp1_g(p, ex, ey, ii%mp1, ii/mp1, vel2, uxg);
+            uxg[0] *= tI[iq[ii]];
+            uxg[1] *= tI[iq[ii]];
+            Qaa[ii] = 0.5*(uxg[0]*J00 + uxg[1]*J10)*p->Q[ii]*(scale/det);
+            Qab[ii] = 0.5*(uxg[0]*J01 + uxg[1]*J11)*p->Q[ii]*(scale/det);
+            Qaa[ii] *= (uxl[0]*tI[iq[ii]]);
+            Qab[ii] *= (uxl[1]*tI[iq[ii]]);
+        }
+        orc_la->axb(n2e, mp12, p->Wt, Qaa, rhs_a);
+        orc_la->axb(n2e, mp12, p->Wt, Qab, rhs_b);
+        for (k = 0; k < n2e; k++) vg[i2[k]] += (rhs_a[k] + rhs_b[k]);
+    }
+}
+
 /* E10mat ctor :1118-1147 -- rows of the element's own (west/south) edges, INSERT semantics */
 void orc_e10_apply(const orc_patch* p, const double* x0, double* y1) {
     int ex, ey, ii, jj, kk, ll, nn = p->n, np1 = p->np1, i0[128], ix[128], iy[128];

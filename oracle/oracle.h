@@ -153,6 +153,9 @@ void orc_phvec(const orc_patch* p, int lev, double scale, const double* h2, doub
 void orc_uvec(const orc_patch* p, int lev, double scale, int vert_scale, const double* vel, double* vl);            /* B17 :2124-2196 (pre-scatter) */
 void orc_uvec_hu(const orc_patch* p, int lev, double scale, const double* vel, const double* rho, double fac, double* vl); /* :2198-2279 */
 void orc_uvec_wxu(const orc_patch* p, int lev, double scale, const double* vel, const double* vort, double* vl);    /* :2375-2430 */
+/* B18 Wvec::assemble :2457-2495 / assemble_K :2497-2545 with Wt = W^T (the reference never fills Wt: corrected restatement, see o_assembly.c) */
+void orc_wvec(const orc_patch* p, int lev, double scale, int vert_scale, const double* rho, double* vg);
+void orc_wvec_K(const orc_patch* p, int lev, double scale, const double* vel1, const double* vel2, double* vg);
 /* incidence applies on local vectors (E10mat :1102-1162, E21mat :1170-1220): signs only */
 void orc_e10_apply(const orc_patch* p, const double* x0, double* y1);  /* owned (non E/N boundary) edges */
 void orc_e21_apply(const orc_patch* p, const double* x1, double* y2);

@@ -285,6 +285,14 @@ class Patch:
     def uvec_wxu(self, lev, scale, vel, vort):
         v = np.zeros(self.n1); self.L.orc_uvec_wxu(self.p, lev, C.c_double(scale), _dp(vel), _dp(vort), _dp(v)); return v
 
+    def wvec(self, lev, scale, vert_scale, rho):
+        """Wvec::assemble with Wt = W^T (corrected restatement of eul/Assembly.cpp:2457-2495)"""
+        v = np.zeros(self.n2); self.L.orc_wvec(self.p, lev, C.c_double(scale), int(vert_scale), _dp(rho), _dp(v)); return v
+
+    def wvec_K(self, lev, scale, vel1, vel2):
+        """Wvec::assemble_K with Wt = W^T (eul/Assembly.cpp:2497-2545)"""
+        v = np.zeros(self.n2); self.L.orc_wvec_K(self.p, lev, C.c_double(scale), _dp(vel1), _dp(vel2), _dp(v)); return v
+
     def e10(self, x0):
         y = np.zeros(self.n1); self.L.orc_e10_apply(self.p, _dp(x0), _dp(y)); return y
 

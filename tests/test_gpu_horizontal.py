@@ -97,6 +97,22 @@ def test_uvec_family_and_accumulate(setup):
     assert rel_l2(y.cpu().numpy(), want) < TOL
 
 
+def test_wvec_family(setup):
+    """B18 Wvec::assemble / assemble_K (eul/Assembly.cpp:2457-2545) against the restatement of the reference's loops with the
+    transpose table filled (the reference leaves Wt uninitialised; its call sites are commented out) -- and that restatement
+    against Wmat / WtQUmat, which is what the two methods compute"""
+    eng, P, rng = setup
+    r = np.random.default_rng(12)
+    rho = r.uniform(1, 2, P.n2) * 1e6; vel1, vel2 = r.standard_normal(P.n1) * 10.0, r.standard_normal(P.n1) * 10.0
+    for vs in (True, False):
+        want = P.wvec(1, SCALE, vs, rho)
+        assert rel_l2(eng.wvec(eng.tensor(rho), lev0=1, scale=SCALE, vert_scale=vs).cpu().numpy(), want) < TOL
+        assert rel_l2(P.apply("WMAT", rho, lev=1, scale=SCALE, flag=int(vs)), want) < 1e-13
+    want = P.wvec_K(2, SCALE, vel1, vel2)
+    assert rel_l2(eng.wvec_K(eng.tensor(vel1), eng.tensor(vel2), lev0=2, scale=SCALE).cpu().numpy(), want) < TOL
+    assert rel_l2(P.apply("WTQUMAT", vel1, lev=2, scale=SCALE, f1=vel2), want) < 1e-13
+
+
 def test_pvec_phvec(setup):
     eng, P, rng = setup
     h = np.random.default_rng(9).uniform(1, 2, P.n2) * 1e6
