@@ -63,8 +63,8 @@ class HorizSolve:
     def laplacian(self, u):
         """del2 * (grad(E21 u) + E10 curl(u))   (:256-283)"""
         ddu = self.grad(self.eng.incidence("E21", u))
-        ddu = ddu + self.eng.incidence("E10", self.curl(u))
-        return self.del2 * ddu
+        ddu.add_(self.eng.incidence("E10", self.curl(u)))
+        return ddu.mul_(self.del2)
 
     def _uvec_hu4(self, ua, ub, ha, hb):
         """the four m1->assemble_hu(level, SCALE, u, h, false, fac) calls + gtol_1 reverse-add (:300-305, :675-682)"""
@@ -87,9 +87,10 @@ class HorizSolve:
         Fk, Gk = self.diagnose_fluxes(u1, u2, h1, h2, theta)
         dFk = eng.incidence("E21", Fk)
         dF = self._ap("WMAT", dFk, flags=VERT)
+        # (sums of operator results are accumulated by the operator kernels themselves: MIMSEM_FLAG_ACCUM + alpha, no elementwise passes)
         dG = self._ap("WMAT", eng.incidence("E21", Gk), flags=VERT, alpha=0.5)
-        dG += 0.5 * self._ap("WHMAT", dFk, f=theta, flags=VERT)
-        dG += self._ap("WTQUMAT", Fk, f=self.grad(theta))                       # K incl. its 0.5 factor
+        self._ap("WHMAT", dFk, f=theta, flags=VERT | ACCUM, alpha=0.5, out=dG)
+        self._ap("WTQUMAT", Fk, f=self.grad(theta), flags=ACCUM, out=dG)        # K incl. its 0.5 factor
         self.Fk, self.Gk = Fk, Gk
         return dF, dG, Fk, Gk
 
@@ -97,19 +98,19 @@ class HorizSolve:
     def _to_levels(self, a):
         """0.5*(interface k-1) + 0.5*(interface k) with the missing boundary interfaces left out (:451-459)"""
         out = torch.zeros(self.nk, a.shape[1], dtype=a.dtype, device=a.device)
-        out[1:] += 0.5 * a
-        out[:-1] += 0.5 * a
+        out[1:].add_(a, alpha=0.5)
+        out[:-1].add_(a, alpha=0.5)
         return out
 
     def diagnose_Phi(self, u1, u2, velz1, velz2):
         """:419-470"""
-        Phi = (1.0 / 3.0) * self._ap("WTQUMAT", u1, f=u1)
-        Phi += (1.0 / 3.0) * self._ap("WTQUMAT", u2, f=u1)
-        Phi += (1.0 / 3.0) * self._ap("WTQUMAT", u2, f=u2)
+        Phi = self._ap("WTQUMAT", u1, f=u1, alpha=1.0 / 3.0)
+        self._ap("WTQUMAT", u2, f=u1, flags=ACCUM, alpha=1.0 / 3.0, out=Phi)
+        self._ap("WTQUMAT", u2, f=u2, flags=ACCUM, alpha=1.0 / 3.0, out=Phi)
         z1, z2 = self._to_levels(velz1), self._to_levels(velz2)
-        Phi += (1.0 / 6.0) * self._ap("WHMAT", z1, f=z1)
-        Phi += (1.0 / 6.0) * self._ap("WHMAT", z2, f=z1)
-        Phi += (1.0 / 6.0) * self._ap("WHMAT", z2, f=z2)
+        self._ap("WHMAT", z1, f=z1, flags=ACCUM, alpha=1.0 / 6.0, out=Phi)
+        self._ap("WHMAT", z2, f=z1, flags=ACCUM, alpha=1.0 / 6.0, out=Phi)
+        self._ap("WHMAT", z2, f=z2, flags=ACCUM, alpha=1.0 / 6.0, out=Phi)
         return Phi
 
     def diagnose_q(self, rho, u):
@@ -125,25 +126,25 @@ class HorizSolve:
         dPi = self.grad(Pi)
         dTheta = self.grad(theta)
         fu = eng.incidence("E12", Phi)
-        uh = 0.5 * velx1 + 0.5 * velx2
-        q = self.diagnose_q(0.5 * rho1 + 0.5 * rho2, uh)
+        uh = (velx1 + velx2).mul_(0.5)
+        q = self.diagnose_q((rho1 + rho2).mul_(0.5), uh)
         if Fx is None:
             Fx, _ = self.m1.solve(self._uvec_hu4(velx1, velx2, rho1, rho2))
-        fu += self._ap("ROTMAT", Fx, f=q)
-        fu += 0.5 * self._ap("UHMAT", dPi, f=theta, flags=VERT)                 # pressure gradient force
-        fu -= 0.5 * self._ap("UHMAT", dTheta, f=Pi, flags=VERT)
+        self._ap("ROTMAT", Fx, f=q, flags=ACCUM, out=fu)
+        self._ap("UHMAT", dPi, f=theta, flags=VERT | ACCUM, alpha=0.5, out=fu)  # pressure gradient force
+        self._ap("UHMAT", dTheta, f=Pi, flags=VERT | ACCUM, alpha=-0.5, out=fu)
         dp = eng.incidence("E12", self._ap("WHMAT", theta, f=Pi, flags=VERT))
-        fu += 0.5 * dp
+        fu.add_(dp, alpha=0.5)
         if Fk is not None:
             self.k2i_dev = self.eng.wsum(1, Fk * dp) / SCALE       # stays on the device (no host sync: the call is hipGraph-capturable)
         # second vorticity term: interface i feeds levels i and i+1 (:704-746)
-        dz = 0.5 * dudz1 + 0.5 * dudz2
+        dz = (dudz1 + dudz2).mul_(0.5)
         if dwdx1 is not None:
-            dz = dz - 0.5 * dwdx1 - 0.5 * dwdx2
-        v = Fz if Fz is not None else 0.5 * velz1 + 0.5 * velz2
+            dz.sub_(dwdx1 + dwdx2, alpha=0.5)
+        v = Fz if Fz is not None else (velz1 + velz2).mul_(0.5)
         t = eng.apply("UTQWMAT", v, f=dz, lev0=0, scale=SCALE)                  # UtQWmat::assemble(u1, scale): no thickness
-        fu[1:] += 0.5 * t
-        fu[:-1] += 0.5 * t
+        fu[1:].add_(t, alpha=0.5)
+        fu[:-1].add_(t, alpha=0.5)
         if self.do_visc:
-            fu += self.m1.apply(self.laplacian(self.laplacian(uh)))
+            self._ap("UMAT", self.laplacian(self.laplacian(uh)), flags=VERT | ACCUM, out=fu)
         return fu
