@@ -543,6 +543,50 @@ def main():
     if rank == 0 and world == 1 and a.cold != 0:
         # the HBM number: on by default (--cold 0 skips it), R = 8 spheres = 829 440 units per launch
         extra("roofline_cold", lambda: cold_workload(dm, a.cold, local_rank, rng, torch))
+    if world > 1 and not a.no_column:
+        # the column half of the hot path sharded: all nk levels of an element live on one GPU, so the Schur solves and the Newton loop
+        # need no halo at all -- only the MPI_Allreduce(MAX) of the four norms per iteration.  Aggregate = all columns / slowest rank.
+        def column_sharded():
+            from mimsem_amd.distributed import DistEngine
+            from mimsem_amd.geom import gll_points
+            from mimsem_amd.vertsolve import VertSolve
+            nEl, nk, n2 = dm.nEl, NK, eng.n2e
+            area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+            lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+            theta, rho, eta, pi = lev(nk, 280, 320), lev(nk, 0.5, 1.2), lev(nk, 5, 6), lev(nk, 700, 1000)
+            F = [eng.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (nk - 1, nk, nk, nk)]
+            for _ in range(2):
+                eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F])
+            fence(); t1 = time.perf_counter()
+            for _ in range(5):
+                eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F])
+            fence(); ts = (time.perf_counter() - t1) / 5
+            wd = np.diff(gll_points(PN)); wj = np.outer(wd, wd).ravel()
+            cell = dm.det.mean(axis=1)[:, None, None] * dm.thick.mean(axis=2).T[:, :, None] * wj[None, None, :]
+            zl = np.mean([g.levs.mean(axis=1) for g in geoms], axis=0); zm = 0.5 * (zl[:-1] + zl[1:])
+            th_v = 300.0 + 0.004 * zm
+            pi_v = 1004.5 - (9.80616 / 0.004) * np.log(th_v / 300.0)
+            rho_v = (1.0e5 / 287.0) * (pi_v / 1004.5) ** (717.5 / 287.0) / th_v
+            colv = lambda v: eng.tensor((cell * v[None, :, None]).reshape(nEl, nk * n2) * (1.0 + 1e-4 * rng.standard_normal((nEl, nk * n2))))
+            vs = VertSolve(DistEngine(eng, cs, world, rank), 75.0)
+            levs = np.zeros((nk + 1, dm.nq))
+            for g in geoms:
+                levs[:, np.searchsorted(dm.gidq, g.loc0[np.arange(g.n0)])] = g.levs
+            zv = vs.init_gz(levs)
+            st = (eng.zeros(nEl, (nk - 1) * n2), colv(rho_v), colv(rho_v * th_v), colv(pi_v))
+            vs.solve_schur_eta(*st, zv, maxit=2, tol=0.0)
+            fence(); t1 = time.perf_counter()
+            vs.solve_schur_eta(*st, zv, maxit=4, tol=0.0)
+            fence(); tn = (time.perf_counter() - t1) / 4
+            tt = torch.tensor([ts, tn], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ts, tn = tt.tolist()
+            ncol = cs.ne * cs.ne * 6
+            return {"workload": "solve_schur_column_eta and one Newton iteration of VertSolve::solve_schur_eta, 3 456 columns x 30 levels dealt "
+                                "to the ranks (no halo: columns are rank-local; one all-reduce of four norms per iteration)",
+                    "schur_column_solves_per_s": ncol / ts, "schur_ms": ts * 1e3, "newton_iteration_ms": tn * 1e3,
+                    "newton_column_iterations_per_s": ncol / tn, "columns_per_rank": nEl}
+        extra("column_sharded", column_sharded)
     if a.sw and world > 1:
         # the SW step on the ranks' shards (config 3: 24x24x6 sphere over N GPUs, halo over xGMI); latency-bound at this size
         from mimsem_amd.distributed import DistEngine
