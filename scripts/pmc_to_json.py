@@ -7,7 +7,7 @@ import csv, json, sys, collections
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 def load(d):
     rows = collections.defaultdict(list)
-    for r in csv.DictReader(open(f"{d}/r01_counter_collection.csv")):
+    for r in csv.DictReader(open(f"{d}/r02_counter_collection.csv")):
         rows[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in rows.items()}
 F, W = load(fetch_dir), load(write_dir)
