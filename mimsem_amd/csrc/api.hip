@@ -106,6 +106,96 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
     return MIMSEM_OK;
 }
 
+// Wave-groups of the wave-level fused kernel (k_apply_wave): G = 64/LPE elements grown over shared edge slots so that they form a
+// compact patch (2 x 2 at p <= 3: the candidate sharing the most slots with the group wins, ties go to a neighbour of the SEED, which
+// turns the third pick perpendicular to the second and lets the fourth close the square), and per group the write-out table:
+// its distinct slots in ascending order, each with the one or two element-local positions that feed it; a slot whose contributors
+// all sit in the group goes straight to y, the others (the group's perimeter) leave one partial sum each.
+struct WavePlan {
+    int ngroups = 0, rounds = 0, nps = 0, npart = 0;
+    std::vector<int> perm, pslot, ppart;
+    std::vector<int2> plan;
+    std::vector<int4> lane;
+};
+int build_wave_plan(int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, WavePlan& P) {
+    const int nd = 2*n1e;
+    if (G*nd > 0xFFFE) return MIMSEM_ERR_UNSUPPORTED;
+    auto slot_of = [&](int e, int j) { return j < n1e ? ix[(size_t)e*n1e + j] : iy[(size_t)e*n1e + j - n1e]; };
+    std::vector<int> own((size_t)n1*2, -1), cnt(n1, 0);
+    for (int e = 0; e < nEl; e++) for (int j = 0; j < nd; j++) {
+        const int s = slot_of(e, j);
+        if (s < 0 || s >= n1) return MIMSEM_ERR_ARG;
+        if (cnt[s] >= 2) return MIMSEM_ERR_UNSUPPORTED;
+        own[(size_t)s*2 + cnt[s]++] = e;
+    }
+    P.ngroups = (nEl + G - 1)/G; P.rounds = (G*nd + 63)/64;
+    P.perm.assign((size_t)P.ngroups*G, -1);
+    std::vector<char> assigned(nEl, 0), seedn(nEl, 0);
+    std::vector<int> score(nEl, 0), touched;
+    int next_seed = 0;
+    for (int g = 0; g < P.ngroups; g++) {
+        for (int t : touched) { score[t] = 0; seedn[t] = 0; }
+        touched.clear();
+        for (int k = 0; k < G; k++) {
+            int best = -1;
+            auto better = [&](int t, int b) {
+                if (score[t] != score[b]) return score[t] > score[b];
+                if (seedn[t] != seedn[b]) return seedn[t] > seedn[b];
+                return t < b; };
+            for (int t : touched) if (!assigned[t] && (best < 0 || better(t, best))) best = t;
+            if (best < 0) { while (next_seed < nEl && assigned[next_seed]) next_seed++; if (next_seed >= nEl) break; best = next_seed; }
+            assigned[best] = 1; P.perm[(size_t)g*G + k] = best;
+            for (int j = 0; j < nd; j++) {
+                const int s = slot_of(best, j);
+                for (int w = 0; w < 2; w++) {
+                    const int o = own[(size_t)s*2 + w];
+                    if (o >= 0 && o != best && !assigned[o]) { if (!score[o]) touched.push_back(o); score[o]++; if (k == 0) seedn[o] = 1; }
+                }
+            }
+        }
+    }
+    // lane tables: lane = element-in-group * LPE + q
+    const int lpe = 64/G;
+    P.lane.resize((size_t)P.ngroups*64);
+    for (int g = 0; g < P.ngroups; g++)
+        for (int l = 0; l < 64; l++) {
+            const int pe = P.perm[(size_t)g*G + l/lpe], e = pe >= 0 ? pe : 0, q = l%lpe;
+            const int qd = std::min(q, n1e - 1), qn = std::min(q, n0e - 1);
+            P.lane[(size_t)g*64 + l] = int4{e, ix[(size_t)e*n1e + qd], iy[(size_t)e*n1e + qd], i0[(size_t)e*n0e + qn]};
+        }
+    std::vector<int> part((size_t)n1*2, -1), ingroup(n1, 0);
+    const unsigned zero = (unsigned)(G*nd + 128);                      // the wave strip's zero entry (k_apply_wave: ZERO)
+    std::vector<std::vector<int2>> entries(P.ngroups);
+    for (int g = 0; g < P.ngroups; g++) {
+        std::vector<std::pair<int, int>> contrib;                      // (slot, position in group)
+        for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
+            for (int j = 0; j < nd; j++) { const int s = slot_of(e, j); ingroup[s]++; contrib.push_back({s, k*nd + j}); } }
+        std::sort(contrib.begin(), contrib.end());
+        for (size_t i = 0; i < contrib.size(); ) {
+            const int s = contrib[i].first;
+            size_t j = i; while (j < contrib.size() && contrib[j].first == s) j++;
+            const unsigned p0 = (unsigned)contrib[i].second, p1 = (j - i > 1) ? (unsigned)contrib[i + 1].second : zero;
+            int dst;
+            if (ingroup[s] == cnt[s]) dst = s;
+            else { const int pi = P.npart++; dst = -(pi + 2);
+                   if (part[(size_t)s*2] < 0) part[(size_t)s*2] = pi; else part[(size_t)s*2 + 1] = pi; }
+            entries[g].push_back(int2{dst, (int)(p0 | (p1 << 16))});
+            i = j;
+        }
+        for (auto& c2 : contrib) ingroup[c2.first] = 0;
+    }
+    // unused entries store (a defined value) into the dump tail of the partial-sum row: [npart, npart + 64)
+    P.plan.resize((size_t)P.ngroups*P.rounds*64);
+    for (int g = 0; g < P.ngroups; g++)
+        for (int t = 0; t < P.rounds*64; t++)
+            P.plan[(size_t)g*P.rounds*64 + t] = t < (int)entries[g].size() ? entries[g][t]
+                                                                           : int2{-(P.npart + t%64 + 2), (int)(0u | (zero << 16))};
+    for (int s = 0; s < n1; s++)
+        if (part[(size_t)s*2] >= 0 || cnt[s] == 0) { P.pslot.push_back(s); P.ppart.push_back(part[(size_t)s*2]); P.ppart.push_back(part[(size_t)s*2 + 1]); }
+    P.nps = (int)P.pslot.size();
+    return MIMSEM_OK;
+}
+
 // levels per work item of the element kernel: keep >= ~6 workgroups per CU in flight, otherwise amortise as much as possible
 int level_chunk(const mimsem_ctx* c, int nlev) {
     const ElemSizes& es = c->es;
@@ -117,6 +207,20 @@ int level_chunk(const mimsem_ctx* c, int nlev) {
     if (lch > 8) lch = 8;
     if (c->lch_override > 0) lch = std::min(c->lch_override, nlev);
     return (int)std::max(1LL, lch);
+}
+
+// levels per work item of the wave-level kernel (<= 6, its compile-time bound WLC): as many as possible while the launch still has
+// about four wavefronts per SIMD (256 CUs x 4 SIMDs)
+int wave_level_chunk(const mimsem_ctx* c, int nlev) {
+    if (c->wave_lch > 0) return std::max(1, std::min(std::min(c->wave_lch, 6), nlev));
+    int best = 1;
+    for (int lch = 1; lch <= std::min(6, nlev); lch++) {
+        const long long waves = (long long)c->w_ngroups*((nlev + lch - 1)/lch);
+        if (waves >= 4096 || lch == 1) best = lch;
+    }
+    // prefer a chunk that divides the levels evenly when it costs at most one level of amortisation
+    for (int lch = best; lch >= std::max(1, best - 1); lch--) if (nlev%lch == 0) return lch;
+    return best;
 }
 
 int op_spaces(int op, int* in, int* cf, int* out) {
@@ -339,6 +443,27 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
             }
         }
     }
+    // Wave-level fused scatter-add of the 1-form -> 1-form operators (k_apply_wave): the default since round 2
+    // (MIMSEM_WAVE=0 selects the two-pass form for every operator)
+    if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0) {
+        WavePlan P;
+        const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
+        rc = es.n <= 4 ? build_wave_plan(d->n1, d->nEl, es.n1e, es.n0e, 64/lpe, d->inds1x, d->inds1y, d->inds0, P) : MIMSEM_ERR_UNSUPPORTED;
+        if (rc == MIMSEM_ERR_ARG) return fail(rc);
+        if (rc == MIMSEM_OK) {
+            if ((rc = upload(&c->d_wlane, P.lane.data(), P.lane.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_wplan, P.plan.data(), P.plan.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_wpslot, P.pslot.data(), P.pslot.size(), c))) return fail(rc);
+            if ((rc = upload(&c->d_wppart, P.ppart.data(), P.ppart.size(), c))) return fail(rc);
+            c->w_ngroups = P.ngroups; c->w_rounds = P.rounds; c->w_nps = P.nps; c->w_npart = P.npart; c->wave1 = true;
+            if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
+            if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
+            if (getenv("MIMSEM_VERBOSE"))
+                fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements, %d perimeter slots (%d partials) of %d\n",
+                        P.ngroups, 64/lpe, P.nps, P.npart, d->n1);
+        }
+        rc = MIMSEM_OK;
+    }
     {
         const size_t cnt = (size_t)d->nk*d->nEl*es.mp12;
         hipError_t he = hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double));
@@ -357,7 +482,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wpslot, c->d_wppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -503,6 +628,20 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         a.flags = flags & ~MIMSEM_FLAG_ACCUM;
         rc = launch_elem_apply(c, op, a);
         if (!rc) rc = launch_gather_perim(c, nlev, c->d_ye, c->f_npart, a.accum, y, ys);
+        c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+        return rc;
+    }
+    if (c->wave1 && (op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H)) {
+        // wave-level fused path: complete slots straight into y, one partial per perimeter slot into the workspace, perimeter pass
+        const long long prow = (long long)c->w_npart + 64;               // partial sums of a level + the dump tail
+        if ((rc = c->ensure_ye(prow*nlev))) return rc;
+        a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = c->w_ngroups; a.wdump = c->w_npart;
+        a.lch = wave_level_chunk(c, nlev);
+        a.swz = c->wave_order;
+        a.y = y; a.ys = ys; a.out = c->d_ye; a.os = prow;
+        a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+        rc = launch_apply_wave(c, op, a);
+        if (!rc) rc = launch_gather_perim(c, nlev, c->d_ye, prow, a.accum, y, ys, c->d_wpslot, c->d_wppart, c->w_nps);
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }

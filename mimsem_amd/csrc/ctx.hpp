@@ -63,6 +63,18 @@ struct mimsem_ctx {
     int* d_fcnt = nullptr;              // [ngroups] local ids in use
     int* d_pslot = nullptr;             // [nps] perimeter slots
     int* d_ppart = nullptr;             // [nps][2] their partial-sum indices (-1 = none)
+    // wave-level fused scatter-add (k_apply_wave, elem_wave.inc): wave-groups of 64/LPE neighbouring elements
+    bool wave1 = false;
+    int wave_order = 3;                 // bit 0: XCD-contiguous block order, bit 1: group-major items (MIMSEM_WAVE_ORDER)
+    int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per work item
+    int w_ngroups = 0, w_rounds = 0, w_nps = 0, w_npart = 0;
+    int4* d_wlane = nullptr;            // [w_ngroups][64] per lane {element, x-edge slot, y-edge slot, node slot}: always valid addresses
+                                        //   (padding elements and lanes without a DoF repeat a neighbour's: their results are never stored)
+    int2* d_wplan = nullptr;            // [w_ngroups][w_rounds][64] {dst, p0 | p1 << 16}: dst >= 0 vector slot (complete in the group),
+                                        //   <= -2 partial sum -(dst+2) (unused entries: the dump tail w_npart + lane of the partial row);
+                                        //   p0/p1 positions el*2*n1e + dof in the wave's LDS strip (single contributor: p1 = the zero)
+    int* d_wpslot = nullptr;            // [w_nps] perimeter slots (and slots no element touches: both partials -1)
+    int* d_wppart = nullptr;            // [w_nps][2]
     // workspace
     double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
     long long ye_doubles = 0;
@@ -113,6 +125,8 @@ struct ElemArgs {
     // fused 1-form scatter-add
     const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
     double* y; long long ys; int accum;
+    // wave-level fused scatter-add (k_apply_wave)
+    const int4* wlane; const int2* wplan; int wgroups; int wdump;
     // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)
     const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
 };
@@ -133,7 +147,9 @@ int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const doubl
                            const double* b, long long bs, double* ze, long long zes,
                            const double* escale = nullptr, long long ess = 0);
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
-int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
+int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
+                        const int* pslot = nullptr, const int* ppart = nullptr, int nps = -1);
+int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys, bool shared_only = false);
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,

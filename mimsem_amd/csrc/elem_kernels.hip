@@ -676,12 +676,15 @@ __global__ __launch_bounds__(256) void k_gather_perim(const double* __restrict__
     const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);
     for (int lev = l0; lev < l1; lev++) {
         const double* src = yp + (size_t)lev*yps;
-        double acc = src[p0];
+        double acc = 0.0;                    // a slot no element touches has no partial at all: written as 0 (as k_gather_sum does)
+        if (p0 >= 0) acc = src[p0];
         if (p1 >= 0) acc += src[p1];
         double* o = y + (size_t)lev*ys + s;
         if (accum) *o += acc; else *o = acc;
     }
 }
+
+#include "elem_wave.inc"
 
 // ---- dense element blocks for MatSetValues callers: out[e][blk][i][j] = sum_q Bt[i][q] c[q] B[q][j] ----
 // One 256-thread block per element.  Write-bound (4.6 KB/element for UMAT at p=3).
@@ -1392,14 +1395,49 @@ int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const
     return launch_gather_sum(c, form, nlev, c->d_ye, per, accum, y, ys);
 }
 
-int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys) {
-    if (c->f_nps == 0 || nlev == 0) return MIMSEM_OK;
-    const dim3 grid((unsigned)((c->f_nps + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
+int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
+                        const int* pslot, const int* ppart, int nps) {
+    if (nps < 0) { pslot = c->d_pslot; ppart = c->d_ppart; nps = c->f_nps; }
+    if (nps == 0 || nlev == 0) return MIMSEM_OK;
+    const dim3 grid((unsigned)((nps + 255)/256), (unsigned)((nlev + GS_LC - 1)/GS_LC));
     if (c->ev_k2[0]) hipExtLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0,
-                                           yp, yps, c->d_pslot, c->d_ppart, c->f_nps, nlev, accum, y, ys);
-    else hipLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, yp, yps, c->d_pslot, c->d_ppart, c->f_nps, nlev, accum, y, ys);
+                                           yp, yps, pslot, ppart, nps, nlev, accum, y, ys);
+    else hipLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, yp, yps, pslot, ppart, nps, nlev, accum, y, ys);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
+}
+
+// the wave-level fused form of the 1-form -> 1-form operators (elem_wave.inc): one wavefront per (wave-group, level chunk)
+template <int N>
+static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
+    const long long items = (long long)a.wgroups*((a.nlev + a.lch - 1)/a.lch);
+    if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((items + 3)/4);
+    if (grid == 0) return MIMSEM_OK;
+#define MIMSEM_WL(OPV, LCT, ACC) \
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(256), 0, c->stream, a)
+#define MIMSEM_WCASE(OPV) case OPV: \
+        if (a.lch == 1) { if (a.accum) { MIMSEM_WL(OPV, 1, true); } else { MIMSEM_WL(OPV, 1, false); } } \
+        else            { if (a.accum) { MIMSEM_WL(OPV, WLC, true); } else { MIMSEM_WL(OPV, WLC, false); } } \
+        break;
+    switch (op) {
+        MIMSEM_WCASE(MIMSEM_OP_UMAT) MIMSEM_WCASE(MIMSEM_OP_UHMAT) MIMSEM_WCASE(MIMSEM_OP_ROTMAT)
+        MIMSEM_WCASE(MIMSEM_OP_UTMAT) MIMSEM_WCASE(MIMSEM_OP_UTMAT_H)
+    default: return MIMSEM_ERR_ARG;
+    }
+#undef MIMSEM_WCASE
+#undef MIMSEM_WL
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
+    if (a.lch > WLC || a.lch < 1) return MIMSEM_ERR_ARG;
+    switch (c->es.n) {
+    case 1: return dispatch_apply_wave<1>(c, op, a); case 2: return dispatch_apply_wave<2>(c, op, a);
+    case 3: return dispatch_apply_wave<3>(c, op, a); case 4: return dispatch_apply_wave<4>(c, op, a);
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,

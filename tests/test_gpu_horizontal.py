@@ -293,23 +293,26 @@ def test_element_blocks_apply_level_sweep(setup):
                 assert rel_l2(got, ref) < 1e-12, (form, tr, scale is not None)
 
 
-@pytest.mark.parametrize("env", ["MIMSEM_DIRECT", "MIMSEM_FUSE"])
-def test_opt_in_scatter_variants_agree_with_default(setup, env, monkeypatch):
-    """the two alternative scatter-add organisations kept behind environment switches (direct single-contributor writes;
-    LDS group sums + perimeter pass) produce the default two-pass result"""
+@pytest.mark.parametrize("env,val", [("MIMSEM_DIRECT", "1"), ("MIMSEM_FUSE", "1"), ("MIMSEM_WAVE", "0"), ("MIMSEM_WAVE_ORDER", "0"),
+                                     ("MIMSEM_WAVE_LCH", "2")])
+def test_opt_in_scatter_variants_agree_with_default(setup, env, val, monkeypatch):
+    """the alternative scatter-add organisations kept behind environment switches (direct single-contributor writes; LDS group sums
+    per workgroup + perimeter pass; the two-pass form instead of the wave-level fused default; other work-item orders / level chunks
+    of the wave-level kernel) produce the default result"""
     import torch
     from mimsem_amd.device import Engine
     eng, P, rng = setup
-    monkeypatch.setenv(env, "1")
+    monkeypatch.setenv(env, val)
     alt = Engine(eng.mesh)                                  # the switches are read at context creation
     monkeypatch.delenv(env)
     r = np.random.default_rng(8)
     x1 = r.standard_normal((3, P.n1)); x0 = r.standard_normal((3, P.n0)); h = r.uniform(0.5, 1.5, (3, P.n2)) * 1e6
-    for op, x, f, fl in (("UMAT", x1, None, 1), ("UHMAT", x1, h, 1), ("PMAT", x0, None, 0)):
+    q0 = r.standard_normal((3, P.n0)) * 1e-4
+    for op, x, f, fl in (("UMAT", x1, None, 1), ("UHMAT", x1, h, 1), ("ROTMAT", x1, q0, 0), ("UTMAT_H", x1, h, 0), ("PMAT", x0, None, 0)):
         a = eng.apply(op, eng.tensor(x), f=None if f is None else eng.tensor(f), lev0=0, scale=SCALE, flags=fl)
         b = alt.apply(op, alt.tensor(x), f=None if f is None else alt.tensor(f), lev0=0, scale=SCALE, flags=fl)
-        if env == "MIMSEM_DIRECT":
-            assert torch.equal(a, b), op                    # same arithmetic, different store path
+        if env in ("MIMSEM_WAVE_ORDER", "MIMSEM_WAVE_LCH"):
+            assert torch.equal(a, b), op                    # same arithmetic, different work-item order / chunking
         else:
             assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-13, op
     base = eng.tensor(r.standard_normal((3, P.n1)))
