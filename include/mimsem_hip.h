@@ -125,6 +125,11 @@ long long mimsem_ctx_workspace_bytes(const mimsem_ctx* ctx);
  * gather slots) in registers for, at a call over nlev levels: the byte model of bench.py's roofline needs it (the metric of an
  * element is re-read once per chunk, not once per level). */
 int  mimsem_op_level_chunk(const mimsem_ctx* ctx, int nlev);
+/* The wave-level fused form of the 1-form -> 1-form operators (Umat, Uhmat, RotMat, Ut_mat; the default for orders <= 4 unless
+ * MIMSEM_WAVE=0): out[0] = wave-groups (wavefronts per level chunk), out[1] = vector slots the element kernel writes straight
+ * into y, out[2] = partial sums per level it leaves in the workspace, out[3] = slots the perimeter pass finishes,
+ * out[4] = levels per work item at a call over nlev levels.  Returns 0 when the form is off (all five are then 0). */
+int  mimsem_op_wave_stats(const mimsem_ctx* ctx, int nlev, int out[5]);
 /* Measurement hook (bench.py): when on = n > 0, every n-th mimsem_op_apply brackets its element kernel (pass 1) and its
  * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
  * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */

@@ -108,19 +108,30 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
 
 // Wave-groups of the wave-level fused kernel (k_apply_wave): G = 64/LPE elements grown over shared edge slots so that they form a
 // compact patch (2 x 2 at p <= 3: the candidate sharing the most slots with the group wins, ties go to a neighbour of the SEED, which
-// turns the third pick perpendicular to the second and lets the fourth close the square), and per group the write-out table:
-// its distinct slots in ascending order, each with the one or two element-local positions that feed it; a slot whose contributors
-// all sit in the group goes straight to y, the others (the group's perimeter) leave one partial sum each.
+// turns the third pick perpendicular to the second and lets the fourth close the square), and per group three lane tables.  The
+// element kernels are bound by the number of vector-memory instructions a wave issues (TA/TD busy 85 %, profiles/r02_umat_pmc.txt),
+// so both tables are built around 16-BYTE accesses:
+//   load pairs : the group's distinct slots covered by aligned pairs {2k, 2k+1} (the reference numbers an element's x- and y-edge
+//                DoFs alternately, so a pair is usually two wanted values): ONE dwordx4 load per level brings every DoF of the
+//                group; each loaded value is staged to the one or two elements that use it.
+//   store pairs: a pair of slots that are both COMPLETE in the group (every contributor inside it) is summed in LDS and written
+//                once, straight into y, as one 16-byte store; every other slot of the group (its perimeter, and complete slots
+//                without a complete partner) leaves a partial sum in a densely packed row of the workspace -- again in pairs --
+//                that k_gather_perim finishes.  With MIMSEM_WAVE_SINGLES=1 the unpaired complete slots get a second, 8-byte
+//                store round into y instead.
 struct WavePlan {
-    int ngroups = 0, rounds = 0, nps = 0, npart = 0;
-    std::vector<int> perm, pslot, ppart;
-    std::vector<int2> plan;
-    std::vector<int4> lane;
+    int ngroups = 0, nps = 0, npart = 0, nsing = 0, ndirect = 0;
+    std::vector<int> perm, pslot, ppart, node;
+    std::vector<int4> lane, plan;
+    std::vector<int2> sing;
 };
-int build_wave_plan(int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, WavePlan& P) {
-    const int nd = 2*n1e;
-    if (G*nd > 0xFFFE) return MIMSEM_ERR_UNSUPPORTED;
+int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles, WavePlan& P) {
+    const int nd = 2*n1e, lpe = 64/G, mp1 = order + 1;
+    const int RS = mp1 + (mp1 & 1), XT = n1e + mp1*RS, sxe0 = XT + 2*(lpe - n1e), SXE = sxe0 + (sxe0 & 1);     // as k_apply_wave
+    const unsigned NACC = (unsigned)(G*nd), ZERO = NACC + 128, DUMPX = (unsigned)XT;
+    if (G*SXE > 0xFFFE || n1 < 2) return MIMSEM_ERR_UNSUPPORTED;
     auto slot_of = [&](int e, int j) { return j < n1e ? ix[(size_t)e*n1e + j] : iy[(size_t)e*n1e + j - n1e]; };
+    auto xpos = [&](int k, int j) { return (unsigned)(k*SXE + (j < n1e ? j : n1e + ((j - n1e)/order)*RS + (j - n1e)%order)); };
     std::vector<int> own((size_t)n1*2, -1), cnt(n1, 0);
     for (int e = 0; e < nEl; e++) for (int j = 0; j < nd; j++) {
         const int s = slot_of(e, j);
@@ -128,7 +139,7 @@ int build_wave_plan(int n1, int nEl, int n1e, int n0e, int G, const int* ix, con
         if (cnt[s] >= 2) return MIMSEM_ERR_UNSUPPORTED;
         own[(size_t)s*2 + cnt[s]++] = e;
     }
-    P.ngroups = (nEl + G - 1)/G; P.rounds = (G*nd + 63)/64;
+    P.ngroups = (nEl + G - 1)/G;
     P.perm.assign((size_t)P.ngroups*G, -1);
     std::vector<char> assigned(nEl, 0), seedn(nEl, 0);
     std::vector<int> score(nEl, 0), touched;
@@ -154,42 +165,72 @@ int build_wave_plan(int n1, int nEl, int n1e, int n0e, int G, const int* ix, con
             }
         }
     }
-    // lane tables: lane = element-in-group * LPE + q
-    const int lpe = 64/G;
-    P.lane.resize((size_t)P.ngroups*64);
-    for (int g = 0; g < P.ngroups; g++)
+    P.lane.assign((size_t)P.ngroups*64, int4{0, 0, 0, 0});
+    P.plan.resize((size_t)P.ngroups*64);
+    P.node.resize((size_t)P.ngroups*64);
+    if (singles) P.sing.assign((size_t)P.ngroups*64, int2{-1, (int)(ZERO | (ZERO << 16))});
+    std::vector<int> part((size_t)n1*2, -1);
+    struct Use { int nx = 0; unsigned x[2] = {0, 0}; int na = 0; unsigned a[2] = {0, 0}; };      // staging / result positions of a slot in the group
+    std::vector<Use> use(n1);
+    std::vector<std::vector<int4>> entries(P.ngroups);
+    for (int g = 0; g < P.ngroups; g++) {
+        std::vector<int> slots;
+        for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
+            for (int j = 0; j < nd; j++) {
+                const int s = slot_of(e, j); Use& u = use[s];
+                if (!u.nx) slots.push_back(s);
+                u.x[u.nx++] = xpos(k, j); u.a[u.na++] = (unsigned)(k*nd + j);
+            } }
+        std::sort(slots.begin(), slots.end());
+        auto in_group = [&](int s) { return s >= 0 && s < n1 && use[s].nx > 0; };
+        auto complete = [&](int s) { return in_group(s) && use[s].nx == cnt[s]; };
+        auto xpack = [&](int s) { unsigned a0 = DUMPX, a1 = DUMPX; if (in_group(s)) { a0 = use[s].x[0]; if (use[s].nx > 1) a1 = use[s].x[1]; } return (int)(a0 | (a1 << 16)); };
+        auto apack = [&](int s) { unsigned a0 = ZERO, a1 = ZERO; if (in_group(s)) { a0 = use[s].a[0]; if (use[s].na > 1) a1 = use[s].a[1]; } return (int)(a0 | (a1 << 16)); };
+        // lane table: element + node slot of every lane, load pair of the first lanes
         for (int l = 0; l < 64; l++) {
             const int pe = P.perm[(size_t)g*G + l/lpe], e = pe >= 0 ? pe : 0, q = l%lpe;
-            const int qd = std::min(q, n1e - 1), qn = std::min(q, n0e - 1);
-            P.lane[(size_t)g*64 + l] = int4{e, ix[(size_t)e*n1e + qd], iy[(size_t)e*n1e + qd], i0[(size_t)e*n0e + qn]};
+            P.lane[(size_t)g*64 + l] = int4{e, 0, (int)(DUMPX | (DUMPX << 16)), (int)(DUMPX | (DUMPX << 16))};
+            P.node[(size_t)g*64 + l] = i0[(size_t)e*n0e + std::min(q, n0e - 1)];
         }
-    std::vector<int> part((size_t)n1*2, -1), ingroup(n1, 0);
-    const unsigned zero = (unsigned)(G*nd + 128);                      // the wave strip's zero entry (k_apply_wave: ZERO)
-    std::vector<std::vector<int2>> entries(P.ngroups);
-    for (int g = 0; g < P.ngroups; g++) {
-        std::vector<std::pair<int, int>> contrib;                      // (slot, position in group)
-        for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
-            for (int j = 0; j < nd; j++) { const int s = slot_of(e, j); ingroup[s]++; contrib.push_back({s, k*nd + j}); } }
-        std::sort(contrib.begin(), contrib.end());
-        for (size_t i = 0; i < contrib.size(); ) {
-            const int s = contrib[i].first;
-            size_t j = i; while (j < contrib.size() && contrib[j].first == s) j++;
-            const unsigned p0 = (unsigned)contrib[i].second, p1 = (j - i > 1) ? (unsigned)contrib[i + 1].second : zero;
-            int dst;
-            if (ingroup[s] == cnt[s]) dst = s;
-            else { const int pi = P.npart++; dst = -(pi + 2);
-                   if (part[(size_t)s*2] < 0) part[(size_t)s*2] = pi; else part[(size_t)s*2 + 1] = pi; }
-            entries[g].push_back(int2{dst, (int)(p0 | (p1 << 16))});
-            i = j;
+        int nload = 0; int last = -1;
+        for (int s : slots) {
+            if (s <= last) continue;                                  // covered by the previous pair
+            int b = s & ~1; if (b + 1 >= n1) b = n1 - 2;
+            if (nload >= 64) return MIMSEM_ERR_UNSUPPORTED;
+            int4& L = P.lane[(size_t)g*64 + nload++];
+            L.y = b; L.z = xpack(b); L.w = xpack(b + 1);
+            last = b + 1;
         }
-        for (auto& c2 : contrib) ingroup[c2.first] = 0;
+        // store pairs
+        std::vector<int> routed;
+        for (size_t i = 0; i < slots.size(); i++) {
+            const int s = slots[i];
+            if (!(s & 1) && s + 1 < n1 && complete(s) && complete(s + 1)) { entries[g].push_back(int4{s, apack(s), apack(s + 1), 0}); P.ndirect += 2; i++; continue; }
+            routed.push_back(s);
+        }
+        if (singles) {                                                 // complete slots without a complete partner: 8-byte stores
+            std::vector<int> keep; int ns = 0;
+            for (int s : routed) {
+                if (complete(s)) { if (ns >= 64) return MIMSEM_ERR_UNSUPPORTED; P.sing[(size_t)g*64 + ns++] = int2{s, apack(s)}; }
+                else keep.push_back(s);
+            }
+            routed.swap(keep); P.nsing += ns; P.ndirect += ns;
+        }
+        for (size_t i = 0; i < routed.size(); i += 2) {
+            const int s0 = routed[i], s1 = i + 1 < routed.size() ? routed[i + 1] : -1;
+            const int pi = P.npart; P.npart += 2;
+            auto reg = [&](int s, int idx) { if (s < 0) return; if (part[(size_t)s*2] < 0) part[(size_t)s*2] = idx; else part[(size_t)s*2 + 1] = idx; };
+            reg(s0, pi); reg(s1, pi + 1);
+            entries[g].push_back(int4{-(pi + 2), apack(s0), apack(s1), 0});
+        }
+        if (entries[g].size() > 64) return MIMSEM_ERR_UNSUPPORTED;
+        for (int s : slots) use[s] = Use();
     }
-    // unused entries store (a defined value) into the dump tail of the partial-sum row: [npart, npart + 64)
-    P.plan.resize((size_t)P.ngroups*P.rounds*64);
+    // unused lanes store (a defined value) into the dump tail of the partial-sum row: [npart, npart + 128)
     for (int g = 0; g < P.ngroups; g++)
-        for (int t = 0; t < P.rounds*64; t++)
-            P.plan[(size_t)g*P.rounds*64 + t] = t < (int)entries[g].size() ? entries[g][t]
-                                                                           : int2{-(P.npart + t%64 + 2), (int)(0u | (zero << 16))};
+        for (int t = 0; t < 64; t++)
+            P.plan[(size_t)g*64 + t] = t < (int)entries[g].size() ? entries[g][t]
+                                                                  : int4{-(P.npart + 2*t + 2), (int)(ZERO | (ZERO << 16)), (int)(ZERO | (ZERO << 16)), 0};
     for (int s = 0; s < n1; s++)
         if (part[(size_t)s*2] >= 0 || cnt[s] == 0) { P.pslot.push_back(s); P.ppart.push_back(part[(size_t)s*2]); P.ppart.push_back(part[(size_t)s*2 + 1]); }
     P.nps = (int)P.pslot.size();
@@ -209,18 +250,13 @@ int level_chunk(const mimsem_ctx* c, int nlev) {
     return (int)std::max(1LL, lch);
 }
 
-// levels per work item of the wave-level kernel (<= 6, its compile-time bound WLC): as many as possible while the launch still has
-// about four wavefronts per SIMD (256 CUs x 4 SIMDs)
+// levels per work item of the wave-level kernel: its compile-time bound WLC = 8 whenever the call has that many levels.  A wavefront's
+// fixed costs (kernel arguments, tables, metric, the dispatch of the wave itself: ~25 cycles per wave and XCD) are what the
+// 103 680-unit launch is made of (scripts/wave_size_sweep.py, s_memtime stamps of scripts/stamp_wave.sh), and the kernel computes
+// all WLC levels of a work item whether the chunk has them or not -- so: as many levels per wave as there are.
 int wave_level_chunk(const mimsem_ctx* c, int nlev) {
-    if (c->wave_lch > 0) return std::max(1, std::min(std::min(c->wave_lch, 6), nlev));
-    int best = 1;
-    for (int lch = 1; lch <= std::min(6, nlev); lch++) {
-        const long long waves = (long long)c->w_ngroups*((nlev + lch - 1)/lch);
-        if (waves >= 4096 || lch == 1) best = lch;
-    }
-    // prefer a chunk that divides the levels evenly when it costs at most one level of amortisation
-    for (int lch = best; lch >= std::max(1, best - 1); lch--) if (nlev%lch == 0) return lch;
-    return best;
+    if (c->wave_lch > 0) return std::max(1, std::min(std::min(c->wave_lch, 8), nlev));
+    return std::max(1, std::min(8, nlev));
 }
 
 int op_spaces(int op, int* in, int* cf, int* out) {
@@ -448,14 +484,40 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0) {
         WavePlan P;
         const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
-        rc = es.n <= 4 ? build_wave_plan(d->n1, d->nEl, es.n1e, es.n0e, 64/lpe, d->inds1x, d->inds1y, d->inds0, P) : MIMSEM_ERR_UNSUPPORTED;
+        const bool singles = getenv("MIMSEM_WAVE_SINGLES") && atoi(getenv("MIMSEM_WAVE_SINGLES")) != 0;
+        rc = es.n <= 4 ? build_wave_plan(es.n, d->n1, d->nEl, es.n1e, es.n0e, 64/lpe, d->inds1x, d->inds1y, d->inds0, singles, P) : MIMSEM_ERR_UNSUPPORTED;
         if (rc == MIMSEM_ERR_ARG) return fail(rc);
         if (rc == MIMSEM_OK) {
             if ((rc = upload(&c->d_wlane, P.lane.data(), P.lane.size(), c))) return fail(rc);
             if ((rc = upload(&c->d_wplan, P.plan.data(), P.plan.size(), c))) return fail(rc);
-            if ((rc = upload(&c->d_wpslot, P.pslot.data(), P.pslot.size(), c))) return fail(rc);
-            if ((rc = upload(&c->d_wppart, P.ppart.data(), P.ppart.size(), c))) return fail(rc);
-            c->w_ngroups = P.ngroups; c->w_rounds = P.rounds; c->w_nps = P.nps; c->w_npart = P.npart; c->wave1 = true;
+            {
+                std::vector<int4> rec(P.pslot.size());
+                for (size_t i = 0; i < rec.size(); i++) rec[i] = int4{P.pslot[i], P.ppart[2*i], P.ppart[2*i + 1], 0};
+                if ((rc = upload(&c->d_wprec, rec.data(), rec.size(), c))) return fail(rc);
+            }
+            if ((rc = upload(&c->d_wnode, P.node.data(), P.node.size(), c))) return fail(rc);
+            if (P.nsing && (rc = upload(&c->d_wsing, P.sing.data(), P.sing.size(), c))) return fail(rc);
+            // packed metric of the wave kernel: {gaa, gab, gbb, 1/det} = Q/det J^T J per quadrature point (16-byte loads) and the
+            // rotational factor (-J00 J11 + J01 J10) Q/det of RotMat
+            {
+                std::vector<double> G((size_t)P.ngroups*64*4, 0.0), Rv((size_t)P.ngroups*64, 0.0);
+                const int gsz = 64/lpe;
+                for (int g = 0; g < P.ngroups; g++)
+                    for (int l = 0; l < 64; l++) {
+                        const int e = P.perm[(size_t)g*gsz + l/lpe], q = l%lpe;
+                        if (e < 0 || q >= es.mp12) continue;                 // padding element / lane beyond the point grid: zeros
+                        const double* Jq = d->J + ((size_t)e*es.mp12 + q)*4;
+                        const double det = d->det[(size_t)e*es.mp12 + q];
+                        const double Q = c->tab.quad.w[q%es.mp1]*c->tab.quad.w[q/es.mp1];
+                        double* o = &G[((size_t)g*64 + l)*4];
+                        o[0] = (Jq[0]*Jq[0] + Jq[2]*Jq[2])*Q/det; o[1] = (Jq[0]*Jq[1] + Jq[2]*Jq[3])*Q/det;
+                        o[2] = (Jq[1]*Jq[1] + Jq[3]*Jq[3])*Q/det; o[3] = 1.0/det;
+                        Rv[(size_t)g*64 + l] = (-Jq[0]*Jq[3] + Jq[1]*Jq[2])*Q/det;
+                    }
+                if ((rc = upload(&c->d_wG, G.data(), G.size(), c))) return fail(rc);
+                if ((rc = upload(&c->d_wR, Rv.data(), Rv.size(), c))) return fail(rc);
+            }
+            c->w_ndirect = P.ndirect; c->w_ngroups = P.ngroups; c->w_nsing = P.nsing; c->w_nps = P.nps; c->w_npart = P.npart; c->wave1 = true;
             if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
             if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
             if (getenv("MIMSEM_VERBOSE"))
@@ -482,7 +544,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wpslot, c->d_wppart, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -494,6 +556,13 @@ int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) { if (!c) return MIMSEM_ERR_AR
 int mimsem_ctx_sync(mimsem_ctx* c) { if (!c) return MIMSEM_ERR_ARG; MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream)); return MIMSEM_OK; }
 long long mimsem_ctx_workspace_bytes(const mimsem_ctx* c) { return c ? c->bytes : 0; }
 int mimsem_op_level_chunk(const mimsem_ctx* c, int nlev) { return (c && nlev > 0) ? level_chunk(c, nlev) : MIMSEM_ERR_ARG; }
+int mimsem_op_wave_stats(const mimsem_ctx* c, int nlev, int out[5]) {
+    if (!c || !out || nlev < 1) return MIMSEM_ERR_ARG;
+    for (int i = 0; i < 5; i++) out[i] = 0;
+    if (!c->wave1) return 0;
+    out[0] = c->w_ngroups; out[1] = c->w_ndirect; out[2] = c->w_npart; out[3] = c->w_nps; out[4] = wave_level_chunk(c, nlev);
+    return 1;
+}
 
 int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thickInv) {
     if (!c) return MIMSEM_ERR_ARG;
@@ -633,15 +702,47 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     }
     if (c->wave1 && (op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H)) {
         // wave-level fused path: complete slots straight into y, one partial per perimeter slot into the workspace, perimeter pass
-        const long long prow = (long long)c->w_npart + 64;               // partial sums of a level + the dump tail
+        const long long prow = (long long)c->w_npart + 128;              // partial sums of a level + the dump tail (64 lanes x 16 bytes)
         if ((rc = c->ensure_ye(prow*nlev))) return rc;
         a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = c->w_ngroups; a.wdump = c->w_npart;
+        a.wsing = c->w_nsing ? c->d_wsing : nullptr; a.wnode = c->d_wnode; a.wG = c->d_wG; a.wR = c->d_wR;
         a.lch = wave_level_chunk(c, nlev);
         a.swz = c->wave_order;
         a.y = y; a.ys = ys; a.out = c->d_ye; a.os = prow;
         a.flags = flags & ~MIMSEM_FLAG_ACCUM;
+        a.wstamps = nullptr;
+        for (size_t k = 0; k < 20; k++) a.Etab[k] = k < c->tab.E.size() ? c->tab.E[k] : 0.0;
+#ifdef MIMSEM_STAMPS      // diagnostic build: per-phase s_memtime stamps of every work item of this launch, summarised on stderr
+        static long long* d_st = nullptr; static size_t st_items = 0;
+        const size_t items = (size_t)c->w_ngroups*((nlev + a.lch - 1)/a.lch);
+        if (getenv("MIMSEM_WAVE_STAMPS")) {
+            if (items > st_items) { if (d_st) (void)hipFree(d_st); (void)hipMalloc((void**)&d_st, items*16*8); st_items = items; }
+            (void)hipMemsetAsync(d_st, 0, items*16*8, c->stream);
+            a.wstamps = d_st;
+        }
+#endif
         rc = launch_apply_wave(c, op, a);
-        if (!rc) rc = launch_gather_perim(c, nlev, c->d_ye, prow, a.accum, y, ys, c->d_wpslot, c->d_wppart, c->w_nps);
+#ifdef MIMSEM_STAMPS
+        if (a.wstamps) {
+            (void)hipStreamSynchronize(c->stream);
+            std::vector<long long> h(items*16);
+            (void)hipMemcpy(h.data(), d_st, items*16*8, hipMemcpyDeviceToHost);
+            long long t0 = h[0], t1 = 0;
+            for (size_t i = 0; i < items; i++) { t0 = std::min(t0, h[i*16]); t1 = std::max(t1, h[i*16 + 15]); }
+            fprintf(stderr, "[stamps] items %zu lch %d  first entry -> last done: %lld ticks\n", items, a.lch, t1 - t0);
+            const char* names[16] = {"entry(rel. first)", "barrier", "tables requested", "level loads issued", "batch0", "batch1", "batch2", "batch3",
+                                     "b4", "b5", "b6", "b7", "", "", "", "stores acked"};
+            for (int k = 0; k < 16; k++) {
+                std::vector<long long> v;
+                for (size_t i = 0; i < items; i++) if (h[i*16 + k]) v.push_back(k == 0 ? h[i*16] - t0 : h[i*16 + k] - h[i*16]);
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "[stamps] %-20s min %8lld  p10 %8lld  median %8lld  p90 %8lld  max %8lld   (ticks since the wave's entry)\n", names[k],
+                        v.front(), v[v.size()/10], v[v.size()/2], v[v.size()*9/10], v.back());
+            }
+        }
+#endif
+        if (!rc) rc = launch_wave_perim(c, nlev, c->d_ye, prow, a.accum, y, ys);
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }

@@ -63,18 +63,22 @@ struct mimsem_ctx {
     int* d_fcnt = nullptr;              // [ngroups] local ids in use
     int* d_pslot = nullptr;             // [nps] perimeter slots
     int* d_ppart = nullptr;             // [nps][2] their partial-sum indices (-1 = none)
-    // wave-level fused scatter-add (k_apply_wave, elem_wave.inc): wave-groups of 64/LPE neighbouring elements
+    // wave-level fused scatter-add (k_apply_wave, elem_wave.inc): wave-groups of 64/LPE neighbouring elements; tables: build_wave_plan
     bool wave1 = false;
     int wave_order = 3;                 // bit 0: XCD-contiguous block order, bit 1: group-major items (MIMSEM_WAVE_ORDER)
     int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per work item
-    int w_ngroups = 0, w_rounds = 0, w_nps = 0, w_npart = 0;
-    int4* d_wlane = nullptr;            // [w_ngroups][64] per lane {element, x-edge slot, y-edge slot, node slot}: always valid addresses
-                                        //   (padding elements and lanes without a DoF repeat a neighbour's: their results are never stored)
-    int2* d_wplan = nullptr;            // [w_ngroups][w_rounds][64] {dst, p0 | p1 << 16}: dst >= 0 vector slot (complete in the group),
-                                        //   <= -2 partial sum -(dst+2) (unused entries: the dump tail w_npart + lane of the partial row);
-                                        //   p0/p1 positions el*2*n1e + dof in the wave's LDS strip (single contributor: p1 = the zero)
-    int* d_wpslot = nullptr;            // [w_nps] perimeter slots (and slots no element touches: both partials -1)
-    int* d_wppart = nullptr;            // [w_nps][2]
+    int w_ngroups = 0, w_nsing = 0, w_nps = 0, w_npart = 0, w_ndirect = 0;
+    int4* d_wlane = nullptr;            // [w_ngroups][64] {element of the lane, load pair: even slot b, staging positions of x[b] and of x[b+1]
+                                        //   (two 16-bit positions each; the dump position where nobody wants the value)}
+    int4* d_wplan = nullptr;            // [w_ngroups][64] store pair {dst, result positions of its first and second slot (2 x 16 bit, the
+                                        //   strip's zero for a missing contributor), 0}: dst >= 0: y[dst], y[dst+1]; dst <= -2: partial sums
+                                        //   -(dst+2), +1 of the workspace row (unused lanes: its dump tail)
+    int2* d_wsing = nullptr;            // [w_ngroups][64] optional 8-byte store round {slot or -1, positions} (MIMSEM_WAVE_SINGLES=1)
+    int* d_wnode = nullptr;             // [w_ngroups][64] node slot of the lane's quadrature point (RotMat's vorticity)
+    double* d_wG = nullptr;             // [w_ngroups][64][4] {gaa, gab, gbb, 1/det} of the lane's point: Q/det J^T J, in WAVE-GROUP order
+    double* d_wR = nullptr;             // [w_ngroups][64]    (-J00 J11 + J01 J10) Q/det: RotMat
+    int4* d_wprec = nullptr;            // [w_nps] {slot, partial 0, partial 1 (-1: none), 0}: slots finished by k_wave_perim (and slots no element
+                                        //   touches: no partial at all, written as 0)
     // workspace
     double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
     long long ye_doubles = 0;
@@ -126,7 +130,9 @@ struct ElemArgs {
     const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
     double* y; long long ys; int accum;
     // wave-level fused scatter-add (k_apply_wave)
-    const int4* wlane; const int2* wplan; int wgroups; int wdump;
+    const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wdump;
+    double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
+    long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null
     // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)
     const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
 };
@@ -150,6 +156,7 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
                         const int* pslot = nullptr, const int* ppart = nullptr, int nps = -1);
 int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a);
+int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys, bool shared_only = false);
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,

@@ -294,7 +294,7 @@ def test_element_blocks_apply_level_sweep(setup):
 
 
 @pytest.mark.parametrize("env,val", [("MIMSEM_DIRECT", "1"), ("MIMSEM_FUSE", "1"), ("MIMSEM_WAVE", "0"), ("MIMSEM_WAVE_ORDER", "0"),
-                                     ("MIMSEM_WAVE_LCH", "2")])
+                                     ("MIMSEM_WAVE_LCH", "2"), ("MIMSEM_WAVE_SINGLES", "1")])
 def test_opt_in_scatter_variants_agree_with_default(setup, env, val, monkeypatch):
     """the alternative scatter-add organisations kept behind environment switches (direct single-contributor writes; LDS group sums
     per workgroup + perimeter pass; the two-pass form instead of the wave-level fused default; other work-item orders / level chunks
