@@ -53,6 +53,37 @@ def b1_launch_bytes(nEl, n1, nlev, lch, pn=PN):
     return {"k1_compulsory": k1_c, "k1_requested": k1_r, "k2": k2, "units": units}
 
 
+def b1_wave_bytes(nEl, n1, nlev, st, pn=PN):
+    """Bytes of the B1 (Umat) apply in its wave-level fused form (k_apply_wave + k_wave_perim, the default for orders <= 4), from the
+    mesh sizes and the plan statistics `st` = mimsem_op_wave_stats: [wave-groups, slots written straight into y, partial sums per
+    level, slots of the perimeter pass, levels per work item].
+    k1_compulsory: what the element kernel MUST move: x once per level, thickInv per unit, the metric record (32 B per point) once per
+                element, its two lane tables once per wave-group, and the y slots it completes.  The partial sums it leaves for the
+                perimeter pass are this design's overhead, not compulsory: they only count under `requested`.
+    op_compulsory: the whole operator: every input once, every output once (x, thickInv, metric, y)."""
+    mp12 = (pn + 1)**2
+    ng, ndirect, npart, nps, lch = st
+    units, nchunk = nEl*nlev, -(-nlev//lch)
+    metric, tables = ng*64*32, ng*2*64*16
+    k1_c = nlev*n1*8 + units*mp12*8 + metric + tables + nlev*ndirect*8
+    k1_r = nlev*ng*64*16 + units*mp12*8 + nchunk*(metric + tables) + nlev*(ndirect + npart)*8
+    k2 = nlev*(npart*8 + nps*8) + nps*16                # partials read, y slots written, records
+    return {"k1_compulsory": k1_c, "k1_requested": k1_r, "k2": k2, "units": units,
+            "op_compulsory": nlev*n1*8*2 + units*mp12*8 + nEl*mp12*32}
+
+
+def launch_bytes(eng, dmesh, nlev):
+    """byte model of the B1 apply for whichever form the context runs, and the name of its dominant kernel"""
+    import ctypes as C
+    st = (C.c_int*5)()
+    if eng.L.mimsem_op_wave_stats(eng.ctx, nlev, st) == 1:
+        return b1_wave_bytes(dmesh.nEl, dmesh.n1, nlev, list(st)), "k_apply_wave<3,UMAT>", "k_wave_perim", int(st[4])
+    lch = eng.L.mimsem_op_level_chunk(eng.ctx, nlev)
+    bm = b1_launch_bytes(dmesh.nEl, dmesh.n1, nlev, lch)
+    bm["op_compulsory"] = bm["k1_compulsory"] + bm["k2"]
+    return bm, "k_elem_apply<3,UMAT>", "k_gather_sum<2>", lch
+
+
 def cpu_worker(args):
     """one host core: reference-structure assemble+MatMult on a 12x12-element patch for ~`budget` seconds"""
     budget, seed = args
@@ -258,27 +289,32 @@ def sw_extras(local_rank, torch):
     return res
 
 
-def roofline_entry(bm, k1, k12, cache_resident, note):
-    """roofline object of the dominant kernel k_elem_apply<3,UMAT> from in-run HIP-event durations (seconds) and the launch's
-    compulsory bytes; the whole operator (both kernels) and SURVEY 8(d)'s per-unit figures ride along as secondary entries"""
+def roofline_entry(bm, k1, k12, cache_resident, note, kname="k_elem_apply<3,UMAT>", k2name="k_gather_sum<2>"):
+    """roofline object of the dominant kernel from in-run HIP-event durations (seconds) and the launch's compulsory bytes; the
+    whole operator (both kernels) and SURVEY 8(d)'s per-unit figures ride along as secondary entries"""
     a1 = bm["k1_compulsory"] / k1 / 1e9
-    a12 = (bm["k1_compulsory"] + bm["k2"]) / k12 / 1e9
-    return {"bound": "hbm", "kernel": "k_elem_apply<3,UMAT>", "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    a12 = bm["op_compulsory"] / k12 / 1e9
+    return {"bound": "hbm", "kernel": kname, "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": a1 / HBM_PEAK_GBS, "traffic": None,
             "traffic_note": "PMC counters are not collected inside bench.py (they need rocprofv3 passes): null here; the same-round "
                             "profiles/ summaries hold the measured FETCH_SIZE/WRITE_SIZE of this launch",
             "cache_resident": cache_resident, "note": note,
             "avg_kernel_us": k1 * 1e6, "units_per_launch": bm["units"],
             "bytes_per_launch": bm["k1_compulsory"], "bytes_per_unit": bm["k1_compulsory"] / bm["units"],
-            "byte_model": "compulsory: x once per level (n1 doubles), thickInv + element-local result per unit, J/det/slots once per element",
+            "byte_model": ("compulsory: x once per level (n1 doubles), thickInv per unit, the metric record and lane tables once per "
+                           "element / wave-group, the y slots the kernel completes; its partial sums for the perimeter pass are overhead "
+                           "(under `requested` only)") if "wave" in kname else
+                          "compulsory: x once per level (n1 doubles), thickInv + element-local result per unit, J/det/slots once per element",
             "requested": {"bytes_per_launch": bm["k1_requested"], "GBs": bm["k1_requested"] / k1 / 1e9,
                           "note": "what the kernel's loads ask for (x gathered per element, metric re-read per level chunk): the part above "
                                   "`achieved` is served by L2 / Infinity Cache"},
             "algorithmic_reference": {"bytes_per_unit": BYTES_K1_B1, "GBs": bm["units"] * BYTES_K1_B1 / k1 / 1e9,
                                       "note": "SURVEY 8(d) figure (metric charged to every unit): exceeds what HBM delivers because one launch "
                                               "shares the metric between the levels of an element; NOT a roofline fraction"},
-            "whole_operator": {"kernels": "k_elem_apply<3,UMAT> + k_gather_sum<2>", "avg_us": k12 * 1e6,
-                               "bytes_per_launch": bm["k1_compulsory"] + bm["k2"], "achieved": a12, "frac": a12 / HBM_PEAK_GBS,
+            "whole_operator": {"kernels": kname + " + " + k2name, "avg_us": k12 * 1e6,
+                               "bytes_per_launch": bm["op_compulsory"], "achieved": a12, "frac": a12 / HBM_PEAK_GBS,
+                               "byte_model": "every input once (x, thickInv, metric), every output once (y)" if "wave" in kname else
+                                             "both passes' compulsory bytes (element-local results written and read)",
                                "algorithmic_reference_bytes_per_unit": BYTES_OP_B1}}
 
 
@@ -297,11 +333,10 @@ def cold_workload(dm, R, local_rank, rng, torch, steps=20):
         call()
     torch.cuda.synchronize(); dtc = time.perf_counter() - t1
     c1, c2, cn = engc.profile_read(); engc.set_profiling(0)
-    lch = engc.L.mimsem_op_level_chunk(engc.ctx, NK)
-    bm = b1_launch_bytes(dmc.nEl, dmc.n1, NK, lch)
+    bm, kname, k2name, lch = launch_bytes(engc, dmc, NK)
     ws = engc.L.mimsem_ctx_workspace_bytes(engc.ctx) / 1e6 + 2 * xc.numel() * 8 / 1e6
     r = roofline_entry(bm, c1 / cn * 1e-3, (c1 + c2) / cn * 1e-3, cache_resident=False,
-                       note="%d independent spheres in one launch, working set %.0f MB >> Infinity Cache" % (R, ws))
+                       note="%d independent spheres in one launch, context + vectors %.0f MB >> Infinity Cache" % (R, ws), kname=kname, k2name=k2name)
     r.update({"replicas": R, "level_chunk": lch, "working_set_MB": ws, "value": bm["units"] * steps / dtc,
               "value_unit": "element operator-applies/s (wall clock over %d back-to-back steps)" % steps})
     del engc
@@ -417,22 +452,22 @@ def main():
                    "order": PN, "elements": cs.ne * cs.ne * 6, "levels": NK, "units_per_step": units_total,
                    "patches": NPATCH, "patches_per_gpu": len(pids), "scale": SCALE, "level_chunk": None},
     }
-    lch = eng.L.mimsem_op_level_chunk(eng.ctx, NK)
+    bm, kname, k2name, lch = launch_bytes(eng, dm, NK)
     out["config"]["level_chunk"] = lch
+    out["config"]["form"] = "wave-level fused (k_apply_wave + k_wave_perim)" if "wave" in kname else "two-pass (k_elem_apply + k_gather_sum)"
     if nl:
         k1 = ms1 / nl * 1e-3
         k12 = (ms1 + ms2) / nl * 1e-3
-        bm = b1_launch_bytes(dm.nEl, dm.n1, NK, lch)
         out["roofline"] = roofline_entry(bm, k1, k12, cache_resident=True,
                                          note="working set (~35 MB fields + metric) sits inside the 256 MiB Infinity Cache and is re-read "
-                                              "every step: see roofline_cold for the HBM-resident workload")
+                                              "every step: see roofline_cold for the HBM-resident workload", kname=kname, k2name=k2name)
         if world == 1:
             # NOT measured in this run: the PMC passes need rocprofv3 (scripts/pmc_traffic.py); the committed summary of the
             # same 103 680-unit launch is quoted for orientation only
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 out["roofline"]["traffic_from_committed_profile"] = {
-                    "bytes_per_launch": min(pj["kernels"]["k_elem_apply<3,UMAT>"], key=lambda r: r["grid_threads"])["total_bytes"],
+                    "bytes_per_launch": min(pj["kernels"][kname], key=lambda r: r["grid_threads"])["total_bytes"],
                     "file": "profiles/pmc_traffic.json", "note": "rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE of an earlier run; a committed "
                     "constant, not an observation of this run"}
             except Exception:

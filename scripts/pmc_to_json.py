@@ -18,8 +18,9 @@ factor = true_read / cal[1]
 res = {"fetch_correction": round(factor, 4), "calibration": {"kernel": "k_halo_pack identity gather", "true_read_bytes": true_read,
        "FETCH_SIZE_bytes": cal[1], "true_write_bytes": n * 8, "WRITE_SIZE_bytes": W[cal[0]]}, "kernels": {}}
 for (k, g), v in F.items():
-    if "k_elem_apply" in k or "k_gather_sum" in k:
-        name = "k_elem_apply<3,UMAT>" if "k_elem_apply" in k else "k_gather_sum<2>"
+    if "k_elem_apply" in k or "k_gather_sum" in k or "k_apply_wave" in k or "k_wave_perim" in k:
+        name = ("k_apply_wave<3,UMAT>" if "k_apply_wave" in k else "k_wave_perim" if "k_wave_perim" in k else
+                "k_elem_apply<3,UMAT>" if "k_elem_apply" in k else "k_gather_sum<2>")
         res["kernels"].setdefault(name, []).append({"grid_threads": g, "read_bytes": v * 2.0 if abs(factor - 2) < 0.1 else v * factor,
                                                      "write_bytes": W.get((k, g)), "total_bytes": (v * factor) + W.get((k, g), 0.0)})
 json.dump(res, open(out, "w"), indent=1)
