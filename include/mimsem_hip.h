@@ -416,6 +416,37 @@ int mimsem_halo_pack(mimsem_ctx* ctx, const int* idx, int count, int nlev,
 int mimsem_halo_unpack(mimsem_ctx* ctx, const int* idx, int count, int nlev, int mode,
                        const double* buf, double* v, long long v_stride);
 
+/* ---- the whole exchange behind the ABI: VecScatterBegin / VecScatterEnd on gtol_0 / gtol_1 ---------------------------------
+ * (eul/Topo.cpp:145-155; REVERSE/ADD call sites eul/Assembly.cpp:2194-2195, FORWARD/INSERT eul/Euler_2.cpp:1455-1456).
+ * A plan holds, per neighbour rank i (at most MIMSEM_HALO_MAX_SEGMENTS), the local slots whose values are SENT to it
+ * (send_idx[send_off[i] .. send_off[i+1])) and the local slots that RECEIVE from it; slots are positions in a [level][nslots]
+ * vector of this context, all levels of a field travel in one message per neighbour ([level][slot] inside the message).
+ * For the reference's two scatters build two plans: REVERSE/ADD sends the ghost slots and receives into the owned mirrors,
+ * FORWARD/INSERT the other way round (mimsem_amd/partition.py::build_plans produces both lists).
+ *   mimsem_halo_begin packs on the context's stream and starts the transport on the plan's own communication stream;
+ *   work enqueued on the context's stream between begin and end (interior elements) overlaps the exchange;
+ *   mimsem_halo_end makes the context's stream wait for the transport and unpacks (ADD: in ranges of neighbours with
+ *   disjoint target slots, i.e. in a fixed order -- reproducible sums).  One exchange in flight per plan.
+ * Transports (choose one after create): RCCL point-to-point over xGMI on the HOST's communicator (librccl is resolved at run
+ * time, the process's already-loaded copy if there is one); a host callback (GPU-aware MPI, torch.distributed ...) that must
+ * leave the data in `recv` in stream order of `stream` (or synchronise it itself); loop-back (every neighbour is the rank itself).
+ * Errors: MIMSEM_ERR_ARG (bad lists / mode / level count), MIMSEM_ERR_STATE (no transport set, begin while in flight, end without
+ * begin, RCCL not loadable or failing, callback returned non-zero).                                                              */
+typedef struct mimsem_halo mimsem_halo;
+#define MIMSEM_HALO_INSERT 0     /* INSERT_VALUES (SCATTER_FORWARD ghost fill) */
+#define MIMSEM_HALO_ADD    1     /* ADD_VALUES (SCATTER_REVERSE reduce) */
+/* send / recv: device buffers, neighbour i's message at doubles [send_off[i], send_off[i+1]) / [recv_off[i], recv_off[i+1]) */
+typedef int (*mimsem_halo_transport_fn)(void* user, const double* send, const long long* send_off, double* recv,
+                                        const long long* recv_off, int nneigh, const int* ranks, void* stream);
+int  mimsem_halo_create(mimsem_ctx* ctx, int nneigh, const int* ranks, const int* send_idx, const int* send_off,
+                        const int* recv_idx, const int* recv_off, int nslots, int max_nlev, mimsem_halo** out);
+void mimsem_halo_destroy(mimsem_halo* plan);
+int  mimsem_halo_set_rccl(mimsem_halo* plan, void* nccl_comm);        /* ncclComm_t of the host, ranks as in that communicator */
+int  mimsem_halo_set_transport(mimsem_halo* plan, mimsem_halo_transport_fn fn, void* user);
+int  mimsem_halo_set_loopback(mimsem_halo* plan);
+int  mimsem_halo_begin(mimsem_halo* plan, int mode, int nlev, double* v, long long v_stride);
+int  mimsem_halo_end(mimsem_halo* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,7 +93,19 @@ _SIGS = {
     "mimsem_halo_segments": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
     "mimsem_halo_pack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_halo_unpack": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),
+    "mimsem_halo_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p)]),
+    "mimsem_halo_destroy": (None, [C.c_void_p]),
+    "mimsem_halo_set_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mimsem_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mimsem_halo_set_loopback": (C.c_int, [C.c_void_p]),
+    "mimsem_halo_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll]),
+    "mimsem_halo_end": (C.c_int, [C.c_void_p]),
 }
+
+# signature of the host transport of mimsem_halo_set_transport (include/mimsem_hip.h: mimsem_halo_transport_fn)
+HALO_TRANSPORT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p, C.POINTER(C.c_longlong), C.c_int,
+                             C.POINTER(C.c_int), C.c_void_p)
 
 OPS = dict(UMAT=0, WMAT=1, UHMAT=2, PMAT=3, PHMAT=4, WTQUMAT=5, ROTMAT=6, WHMAT=7, UTMAT=8,
            UTMAT_H=9, UTQWMAT=10, WTQDUDZ=11, WMATINV=12, WHMATINV=13, PHMAT_UP=14, ROTMAT_UP=15, WTQ=16, PTQ=17, UTQ=18, UMAT_UP=19, UHMAT_UP=20, UVEC_HU_UP=21, UMAT_RAY=22)

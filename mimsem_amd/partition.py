@@ -226,3 +226,92 @@ def rank_mesh(sphere, geoms_or_none, world, rank, nk, coords=None):
     topos = [Topo(sphere, p, nk) for p in pids]
     geoms = [Geom(t, sphere, coords, nk) for t in topos] if geoms_or_none is None else geoms_or_none
     return pids, topos, geoms
+
+
+class CHalo:
+    """The same exchanges through the C ABI (mimsem_halo_create / _begin / _end, include/mimsem_hip.h): what a C++ host binds instead
+    of VecScatterBegin/End.  Pack, transport and unpack are driven by the library; this class only builds the slot lists from a
+    HaloPlan and supplies a transport:
+      "dist"      a host callback over torch.distributed, staged through host memory (how a host with a plain MPI would do it;
+                  the test rehearsal of several ranks on one GPU over gloo uses it),
+      "loopback"  every neighbour is the rank itself (single-rank tests),
+      an int      an ncclComm_t of the caller: grouped ncclSend/ncclRecv on the plan's communication stream (xGMI).
+    begin()/end() are split so that interior work can be enqueued in between."""
+
+    def __init__(self, plan, engine, max_nlev, transport="dist"):
+        import ctypes as C
+        from ._lib import HALO_TRANSPORT, check
+        self.eng, self.L, self.C = engine, engine.L, C
+        self._check = check
+        nslots = len(plan.gids)
+        ranks = plan.neighbours()
+        empty = np.zeros(0, np.int32)
+
+        def lists(by_rank):
+            off = np.zeros(len(ranks) + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(by_rank.get(r, empty)) for r in ranks])
+            idx = np.concatenate([by_rank.get(r, empty) for r in ranks]).astype(np.int32) if ranks else empty
+            return np.ascontiguousarray(idx), off
+        gi, go = lists(plan.ghost_slots)
+        mi, mo = lists(plan.mirror_slots)
+        self.ranks = np.asarray(ranks, dtype=np.int32)
+        self._keep = (gi, go, mi, mo)
+        self.handles = {}
+        for name, (si, so, ri, ro) in (("reverse", (gi, go, mi, mo)), ("forward", (mi, mo, gi, go))):
+            h = C.c_void_p()
+            check(self.L.mimsem_halo_create(engine.ctx, len(ranks), self.ranks.ctypes.data, si.ctypes.data, so.ctypes.data,
+                                            ri.ctypes.data, ro.ctypes.data, nslots, max_nlev, C.byref(h)), "halo_create")
+            self.handles[name] = h
+        if transport == "loopback":
+            for h in self.handles.values():
+                check(self.L.mimsem_halo_set_loopback(h), "halo_set_loopback")
+        elif transport == "dist":
+            self._cb = HALO_TRANSPORT(self._dist_transport)          # keep the callback object alive
+            for h in self.handles.values():
+                check(self.L.mimsem_halo_set_transport(h, C.cast(self._cb, C.c_void_p), None), "halo_set_transport")
+        else:
+            for h in self.handles.values():
+                check(self.L.mimsem_halo_set_rccl(h, C.c_void_p(int(transport))), "halo_set_rccl")
+
+    def _dist_transport(self, user, send, send_off, recv, recv_off, nneigh, ranks, stream):
+        """host-staged exchange: wait for the pack, copy out, all_to_all over the process group, copy in"""
+        try:
+            C = self.C
+            torch.cuda.ExternalStream(stream).synchronize()
+            world = dist.get_world_size()
+            ns, nr = send_off[nneigh], recv_off[nneigh]
+            sh = np.empty(max(ns, 1)); rh = np.empty(max(nr, 1))
+            if ns:
+                self._check(self.L.mimsem_memcpy_d2h(self.eng.ctx, sh.ctypes.data, send, ns * 8), "memcpy_d2h")
+            ins, outs = [0] * world, [0] * world
+            for i in range(nneigh):
+                ins[ranks[i]] = send_off[i + 1] - send_off[i]
+                outs[ranks[i]] = recv_off[i + 1] - recv_off[i]
+            # neighbours are listed in rank order, so the segment order IS the all_to_all order
+            dist.all_to_all_single(torch.from_numpy(rh[:nr]), torch.from_numpy(sh[:ns]), output_split_sizes=outs, input_split_sizes=ins)
+            if nr:
+                self._check(self.L.mimsem_memcpy_h2d(self.eng.ctx, recv, rh.ctypes.data, nr * 8), "memcpy_h2d")
+            return 0
+        except Exception:                                            # noqa: BLE001 -- reported to the library as a failed transport
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def begin(self, name, v, add):
+        v2 = v if v.dim() == 2 else v.unsqueeze(0)
+        self._check(self.L.mimsem_halo_begin(self.handles[name], 1 if add else 0, v2.shape[0], v2.data_ptr(), v2.stride(0)), "halo_begin")
+        return name
+
+    def end(self, name):
+        self._check(self.L.mimsem_halo_end(self.handles[name]), "halo_end")
+
+    def reverse_add(self, v):
+        self.end(self.begin("reverse", v, True))
+
+    def forward_insert(self, v):
+        self.end(self.begin("forward", v, False))
+
+    def close(self):
+        for h in self.handles.values():
+            self.L.mimsem_halo_destroy(h)
+        self.handles = {}

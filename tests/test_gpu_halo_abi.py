@@ -1,0 +1,118 @@
+"""The halo exchange behind the C ABI (mimsem_halo_create / _begin / _end): loop-back transport in one process -- slot lists, both
+modes, the ordered ADD with repeated targets, begin/end split with work in between, error behaviour.  The several-rank form
+(host-callback transport over gloo) runs in tests/test_gpu_multiproc.py."""
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(oracle):
+    from mimsem_amd.device import DeviceMesh, Engine
+    from tests.helpers import make_patch
+    cs, topo, geom, P, rng = make_patch(oracle, 3, 4, 6, 2, nk=4, seed=5)
+    return Engine(DeviceMesh([topo], [geom], nk=4, numbering="local")), P
+
+
+def _plan(n, ghost, mirror):
+    p = types.SimpleNamespace(gids=np.arange(n), ghost_slots={0: np.asarray(ghost, np.int32)}, mirror_slots={0: np.asarray(mirror, np.int32)})
+    p.neighbours = lambda: [0]
+    return p
+
+
+def test_loopback_reverse_add_and_forward_insert(eng):
+    import torch
+    from mimsem_amd.partition import CHalo
+    e, P = eng
+    n = P.n1
+    rng = np.random.default_rng(3)
+    ghost = rng.choice(n, 40, replace=False).astype(np.int32)
+    mirror = rng.choice(np.setdiff1d(np.arange(n), ghost), 40, replace=False).astype(np.int32)
+    h = CHalo(_plan(n, ghost, mirror), e, max_nlev=4, transport="loopback")
+    for nlev in (4, 1, 3):
+        v0 = rng.standard_normal((nlev, n))
+        v = e.tensor(v0)
+        h.reverse_add(v)                                           # "owner" slots accumulate the "ghost" partial sums
+        want = v0.copy(); want[:, mirror] += v0[:, ghost]
+        assert np.array_equal(v.cpu().numpy(), want)
+        h.forward_insert(v)                                        # ghosts receive the owners' values
+        want[:, ghost] = want[:, mirror]
+        assert np.array_equal(v.cpu().numpy(), want)
+    # begin / end split: work enqueued in between runs while the exchange is in flight and does not disturb it
+    v0 = rng.standard_normal((4, n)); v = e.tensor(v0)
+    other = e.tensor(rng.standard_normal((4, n)))
+    tok = h.begin("reverse", v, True)
+    y = e.apply("UMAT", other, lev0=0, scale=1.0e8, flags=1)
+    h.end(tok)
+    want = v0.copy(); want[:, mirror] += v0[:, ghost]
+    assert np.array_equal(v.cpu().numpy(), want)
+    assert torch.isfinite(y).all()
+    h.close()
+
+
+def test_ordered_add_with_repeated_targets(eng):
+    """two neighbours' messages land on the same slots (cube-corner nodes): added in neighbour order, range by range"""
+    import ctypes as C
+    from mimsem_amd._lib import check
+    e, P = eng
+    n = P.n0
+    ranks = np.array([0, 0], np.int32)                                # the rank is its own neighbour twice
+    send_idx = np.array([1, 2, 3, 4, 5, 6], np.int32); send_off = np.array([0, 3, 6], np.int32)
+    recv_idx = np.array([10, 11, 12, 12, 11, 13], np.int32); recv_off = np.array([0, 3, 6], np.int32)     # 11 and 12 repeat
+    h = C.c_void_p()
+    check(e.L.mimsem_halo_create(e.ctx, 2, ranks.ctypes.data, send_idx.ctypes.data, send_off.ctypes.data, recv_idx.ctypes.data,
+                                 recv_off.ctypes.data, n, 2, C.byref(h)), "create")
+    check(e.L.mimsem_halo_set_loopback(h), "loopback")
+    v0 = np.random.default_rng(4).standard_normal((2, n)); v = e.tensor(v0)
+    check(e.L.mimsem_halo_begin(h, 1, 2, v.data_ptr(), v.stride(0)), "begin")
+    check(e.L.mimsem_halo_end(h), "end")
+    want = v0.copy()
+    for s, r in zip(send_idx, recv_idx):                               # neighbour 0 first, then neighbour 1
+        want[:, r] += v0[:, s]
+    assert np.array_equal(v.cpu().numpy(), want)
+    e.L.mimsem_halo_destroy(h)
+
+
+def test_halo_errors(eng):
+    import ctypes as C
+    from mimsem_amd._lib import MimsemError
+    from mimsem_amd.partition import CHalo
+    e, P = eng
+    n = P.n1
+    h = CHalo(_plan(n, [0, 1], [2, 3]), e, max_nlev=2, transport="loopback")
+    v = e.zeros(2, n)
+    tok = h.begin("reverse", v, True)
+    with pytest.raises(MimsemError):
+        h.begin("reverse", v, True)                                   # one exchange in flight per plan
+    h.end(tok)
+    with pytest.raises(MimsemError):
+        h.end(tok)                                                    # end without begin
+    with pytest.raises(MimsemError):
+        h.begin("reverse", e.zeros(3, n), True)                       # more levels than the plan was created for
+    h.close()
+    out = C.c_void_p()
+    bad = np.array([n + 5], np.int32); off = np.array([0, 1], np.int32); rk = np.array([0], np.int32)
+    assert e.L.mimsem_halo_create(e.ctx, 1, rk.ctypes.data, bad.ctypes.data, off.ctypes.data, bad.ctypes.data, off.ctypes.data, n, 1, C.byref(out)) == -1
+    # a plan without a transport refuses to start
+    ok = np.array([1], np.int32)
+    assert e.L.mimsem_halo_create(e.ctx, 1, rk.ctypes.data, ok.ctypes.data, off.ctypes.data, ok.ctypes.data, off.ctypes.data, n, 1, C.byref(out)) == 0
+    assert e.L.mimsem_halo_begin(out, 1, 1, v.data_ptr(), v.stride(0)) == -4
+    e.L.mimsem_halo_destroy(out)
+
+
+def test_rccl_transport_on_one_rank():
+    """mimsem_halo_set_rccl executed on hardware: a size-1 communicator and a plan whose neighbour is the rank itself (grouped
+    ncclSend/ncclRecv to self) -- all a one-GPU box can show of the xGMI transport; in its own process (it owns a process group)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "exp_rccl_self.py")], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rccl self exchange ok: True" in r.stdout and "forward ok: True" in r.stdout, r.stdout[-2000:]

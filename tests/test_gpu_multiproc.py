@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
         from mimsem_amd.device import DeviceMesh, Engine
         from mimsem_amd.geom import Geom
         from mimsem_amd.mesh import CubedSphere, sphere_coords
-        from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
+        from mimsem_amd.partition import CHalo, HaloExchanger, build_plans, patches_of_rank
         from mimsem_amd.topo import Topo
         from tests.helpers import SCALE, z_levels
         pn, ne, npatch, nk = 3, 4, 24, 3
@@ -49,6 +49,12 @@ def _worker(rank, world, port, q):
             halo.reverse_add(y)                    # owners hold the sums
             halo.forward_insert(y)                 # ghosts too
             halo.reverse_add(y.clone())            # second use of the cached buffers
+            # the same exchange through the C ABI (mimsem_halo_create/_begin/_end, host-callback transport): bit for bit
+            y2 = eng.apply(op, eng.tensor(xglob[:, gid]), lev0=0, scale=SCALE, flags=1 if form == 1 else 0)
+            ch = CHalo(plans[form], eng, max_nlev=nk, transport="dist")
+            ch.reverse_add(y2); ch.forward_insert(y2)
+            ok = ok and bool(torch.equal(y2, y))
+            ch.close()
             if rank == 0:
                 dm1, eng1 = build(list(range(npatch)))
                 want = eng1.apply(op, eng1.tensor(xglob), lev0=0, scale=SCALE, flags=1 if form == 1 else 0).cpu().numpy()
