@@ -359,6 +359,7 @@ def main():
     ap.add_argument("--no-column", action="store_true", help="skip the column-solves/s extra (reported by default at N = 1, ~3 s)")
     ap.add_argument("--no-sw", action="store_true", help="skip the shallow-water time-steps/s extra (reported by default at N = 1, ~20 s)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
+    ap.add_argument("--no-horiz-sharded", action="store_true", help="N > 1: skip the sharded HorizSolve right-hand-side extra (~10 s)")
     ap.add_argument("--cold", type=int, default=8, metavar="R",
                     help="roofline_cold (not the headline value): the same step on R independent copies of the sphere, "
                          "working set >> the 256 MiB Infinity Cache, i.e. genuinely HBM-resident; 0 skips it")
@@ -622,6 +623,40 @@ def main():
                     "schur_column_solves_per_s": ncol / ts, "schur_ms": ts * 1e3, "newton_iteration_ms": tn * 1e3,
                     "newton_column_iterations_per_s": ncol / tn, "columns_per_rank": nEl}
         extra("column_sharded", column_sharded)
+
+        # N2 sharded: HorizSolve's right-hand sides (advection_rhs_ec + momentum_rhs_ec, viscosity on: ~40 operator applies, 7 mass solves,
+        # every 0/1-form result completed over the halo) on the ranks' own patches x 30 levels -- milliseconds of work per rank, the
+        # workload on which sharding the config-4 grid can pay (the 21 us Umat step cannot: it is smaller than one exchange)
+        def horiz_sharded():
+            from mimsem_amd.distributed import DistEngine
+            from mimsem_amd.horizsolve import HorizSolve
+            xqg = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
+            for g in geoms:
+                xqg[g.loc0] = coords[g.loc0]
+            deng = DistEngine(eng, cs, world, rank)
+            hs = HorizSolve(deng, quad_coords=xqg[dm.gidq])
+            area = float(dm.det.mean()) * 4.0 / (PN * PN); dz = float(dm.thick.mean()); ln = area ** 0.5
+            rg = np.random.default_rng(777)                                   # the same global fields on every rank
+            U1 = rg.standard_normal((NK, cs.nDofs1G)) * 20.0 * ln * dz
+            H1 = rg.uniform(0.8, 1.2, (NK, cs.nDofs2G)) * area * dz
+            TH = rg.uniform(290, 310, (NK, cs.nDofs2G)) * area * dz; PI = rg.uniform(900, 1000, (NK, cs.nDofs2G)) * area * dz
+            VZ = rg.standard_normal((NK - 1, cs.nDofs2G)) * area; DU = rg.standard_normal((NK - 1, cs.nDofs1G)) * 1e-3 * ln
+            u1 = eng.tensor(U1[:, dm.gid1]); u2 = u1 * 1.01; h1 = eng.tensor(H1[:, dm.gid2]); h2 = h1 * 1.001
+            th = eng.tensor(TH[:, dm.gid2]); Pi = eng.tensor(PI[:, dm.gid2]); vz = eng.tensor(VZ[:, dm.gid2]); dudz = eng.tensor(DU[:, dm.gid1])
+
+            def rhs():
+                dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
+                return hs.momentum_rhs_ec(th, dudz, dudz, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk)
+            rhs(); fence(); t1 = time.perf_counter()
+            for _ in range(3):
+                rhs()
+            fence(); el = (time.perf_counter() - t1) / 3
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels dealt to the ranks, halo per operator",
+                    "ms_per_evaluation": 1e3 * tt.item(), "evaluations_per_s": 1.0 / tt.item(), "elements_per_rank": dm.nEl}
+        if not a.no_horiz_sharded:
+            extra("horiz_sharded", horiz_sharded)
     if a.sw and world > 1:
         # the SW step on the ranks' shards (config 3: 24x24x6 sphere over N GPUs, halo over xGMI); latency-bound at this size
         from mimsem_amd.distributed import DistEngine

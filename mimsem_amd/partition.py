@@ -10,10 +10,17 @@ Ownership follows the reference: a patch owns its west/south-inclusive nodes and
 east/north side (scr/Proc2.py:89-130); the two hanging nodes are owned by face 0's SE-corner patch and
 face 1's NW-corner patch.  2-forms never communicate.
 
-Transport: torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests).  Messages are kB-sized and latency bound, so all levels of a field travel in ONE message per
-neighbour rank.  Pack/unpack run on the device through the C ABI (mimsem_halo_pack / _unpack).
+Transport of HaloExchanger: ONE torch.distributed all_to_all_single per exchange (backend "nccl" = RCCL over xGMI on a GPU node: a
+grouped send/recv; "gloo" in the CPU tests and in the several-ranks-on-one-GPU rehearsals, staged through host memory).  Messages
+are kB-sized and latency bound, so all levels of a field travel in ONE message per neighbour rank.  Pack/unpack run on the device
+through the C ABI (mimsem_halo_segments).  The device-tensor RCCL branch of HaloExchanger has NOT run on hardware yet (no multi-GPU
+box in development; tests/test_gpu_nccl_world2.py runs it when two GPUs are visible).  CHalo is the same exchange driven entirely
+by the C ABI (mimsem_halo_create / _begin / _end) -- its RCCL transport has run on one rank (self send/recv), its host-callback
+transport on 2 and 3 ranks.
 """
+import functools
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -21,11 +28,58 @@ import torch.distributed as dist
 from .topo import Topo
 
 
-def patches_of_rank(n_patches, world, rank):
+def _cut(adj, part):
+    """number of patch adjacencies (weighted by shared edges) that cross parts"""
+    n = len(part)
+    return int(sum(adj[i, j] for i in range(n) for j in range(i + 1, n) if part[i] != part[j]))
+
+
+@functools.lru_cache(maxsize=None)
+def rank_of_patch(n_patches, world, layout=None):
+    """patch -> rank map (tuple of length n_patches), equal patch counts per rank.
+
+    "contiguous": ranges of patch ids (24 patches -> 24/12/6/3 per GPU) -- whole faces for 1/2/3/6 ranks, but for 4 and 8 ranks the
+    ranges straddle faces (8 ranks: patches {3, 4, 5} = one corner of face 0 and the bottom row of face 1).
+    "compact" (default): geometry-aware -- parts grown over the patch adjacency graph of the cubed sphere (a patch joins the part
+    it shares the most edges with), kept only when it cuts fewer patch adjacencies than the contiguous ranges, i.e. fewer halo
+    slots and fewer neighbour ranks per GPU.  MIMSEM_PATCH_MAP=contiguous selects the ranges."""
     if n_patches % world:
         raise ValueError(f"{n_patches} patches do not divide over {world} ranks")
     per = n_patches // world
-    return list(range(rank * per, (rank + 1) * per))
+    contiguous = tuple(p // per for p in range(n_patches))
+    layout = layout or os.environ.get("MIMSEM_PATCH_MAP", "compact")
+    npx = int(round((n_patches / 6.0) ** 0.5)) if n_patches % 6 == 0 else 0
+    if layout == "contiguous" or world == 1 or per == 1 or 6 * npx * npx != n_patches:
+        return contiguous
+    from .mesh import CubedSphere
+    cs = CubedSphere(1, npx, n_patches)                     # one element per patch: its four edges are the patch adjacencies
+    owners = {}
+    for p in cs.patches:
+        for g in np.unique(p.loc1):
+            owners.setdefault(int(g), []).append(p.pid)
+    adj = np.zeros((n_patches, n_patches), dtype=np.int64)
+    for ps in owners.values():
+        for a in ps:
+            for b in ps:
+                if a != b:
+                    adj[a, b] += 1
+    part = [-1] * n_patches
+    for r in range(world):
+        seed = min(p for p in range(n_patches) if part[p] < 0)
+        members = [seed]; part[seed] = r
+        while len(members) < per:
+            # the free patch sharing the most edges with the part; among equals the one with the fewest free neighbours (leaves
+            # no orphans behind), then the lowest id
+            cand = [(-int(adj[q, members].sum()), int(sum(1 for t in range(n_patches) if adj[q, t] and part[t] < 0)), q)
+                    for q in range(n_patches) if part[q] < 0]
+            q = min(cand)[2]
+            members.append(q); part[q] = r
+    return tuple(part) if _cut(adj, part) < _cut(adj, contiguous) else contiguous
+
+
+def patches_of_rank(n_patches, world, rank):
+    m = rank_of_patch(n_patches, world)
+    return [p for p in range(n_patches) if m[p] == rank]
 
 
 def owner_tables(sphere):
@@ -49,8 +103,8 @@ class HaloPlan:
     """send/recv slot lists of one form for one rank; both sides order every list by global id"""
 
     def __init__(self, gids, owner_patch, world, rank, n_patches):
-        per = n_patches // world
-        owner_rank = owner_patch[gids] // per
+        rmap = np.asarray(rank_of_patch(n_patches, world), dtype=np.int64)
+        owner_rank = rmap[owner_patch[gids]]
         self.rank, self.world = rank, world
         self.owned = owner_rank == rank
         # ghosts I hold, grouped by owning rank (gids are sorted, so each group is sorted by gid)
@@ -73,7 +127,7 @@ def build_plans(sphere, world, rank, gid0, gid1):
     for form, gids, owner in ((0, gid0, own0), (1, gid1, own1)):
         plan = HaloPlan(gids, owner, world, rank, n_patches)
         plan.form = form
-        per = n_patches // world
+        rmap = np.asarray(rank_of_patch(n_patches, world), dtype=np.int64)
         for r in range(world):
             if r == rank:
                 continue
@@ -83,7 +137,7 @@ def build_plans(sphere, world, rank, gid0, gid1):
                 touched = np.unique(np.concatenate([sphere.patches[p].loc0 for p in pids]))
             else:
                 touched = np.unique(np.concatenate([sphere.patches[p].loc1 for p in pids]))
-            mine = touched[owner[touched] // per == rank]           # sorted by gid
+            mine = touched[rmap[owner[touched]] == rank]            # sorted by gid
             if mine.size:
                 plan.mirror_slots[r] = np.searchsorted(gids, mine).astype(np.int32)
         plans.append(plan)

@@ -101,6 +101,8 @@ def test_bench_multi_rank_control_flow_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["patches_per_gpu"] == 12 and d["config"]["units_per_step"] == 103680
+    for key in ("column_sharded", "horiz_sharded"):                    # the N > 1 extras with real work per rank ran too
+        assert key in d and "error" not in d[key], d.get(key)
 
 
 def _sw_worker(rank, world, port, q):

@@ -1,0 +1,68 @@
+"""The device-tensor RCCL branch of HaloExchanger (all_to_all_single on GPU buffers over xGMI) and bench.py's N = 2 launch: needs TWO
+visible GPUs, so it is skipped on the one-GPU test box (where the same control flow runs over gloo, tests/test_gpu_multiproc.py) and
+runs wherever a multi-GPU node executes the suite."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from mimsem_amd.device import DeviceMesh, Engine
+        from mimsem_amd.geom import Geom
+        from mimsem_amd.mesh import CubedSphere, sphere_coords
+        from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
+        from mimsem_amd.topo import Topo
+        from tests.helpers import SCALE, z_levels
+        pn, ne, npatch, nk = 3, 4, 24, 3
+        cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+        xg = np.random.default_rng(123).standard_normal((nk, cs.nDofs1G))
+
+        def build(pids, dev):
+            topos = [Topo(cs, p, nk) for p in pids]
+            geoms = [Geom(t, cs, coords, nk) for t in topos]
+            for g in geoms:
+                g.set_levels(z_levels(nk, g.n0))
+            dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+            return dm, Engine(dm, device=dev)
+        dm, eng = build(patches_of_rank(npatch, world, rank), rank)
+        plan1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)[1]
+        y = eng.apply("UMAT", eng.tensor(xg[:, dm.gid1]), lev0=0, scale=SCALE, flags=1)
+        halo = HaloExchanger(plan1, engine=eng)
+        halo.reverse_add(y); halo.forward_insert(y)
+        dm1, eng1 = build(list(range(npatch)), rank)
+        want = eng1.apply("UMAT", eng1.tensor(xg), lev0=0, scale=SCALE, flags=1).cpu().numpy()
+        err = np.linalg.norm(y.cpu().numpy() - want[:, dm.gid1]) / np.linalg.norm(want)
+        q.put((rank, bool(err < 1e-12)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_halo_over_rccl_two_gpus():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
