@@ -393,6 +393,13 @@ int mimsem_krylov_reorthonormalize(mimsem_ctx* ctx, int k, long long n, const do
  * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
  * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */
 int mimsem_krylov_rowdot(mimsem_ctx* ctx, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out);
+/* Level-wise field algebra between the operator calls of HorizSolve (eul/HorizSolve.cpp: VecAXPY / VecAYPX / VecPointwiseDivide /
+ * VecScale chains, e.g. :246-254, :451-459, :472-493, :655-700): out[r][j] = alpha (a[r][j] op b[r][j]) + beta c[r][j] for nrows rows of n
+ * entries at their own strides; op 0: a alone (b ignored), 1: a*b, 2: a/b; c may be null (no second term) and may alias out.
+ * mimsem_interface_average: out[k] = (a[k-1] + a[k])/2 over nk levels from nk-1 interface rows, missing boundary interfaces left out. */
+int mimsem_vec_combine(mimsem_ctx* ctx, int nrows, long long n, double alpha, const double* a, long long a_stride, int op,
+                       const double* b, long long b_stride, double beta, const double* c, long long c_stride, double* out, long long out_stride);
+int mimsem_interface_average(mimsem_ctx* ctx, int nk, long long n, const double* a, long long a_stride, double* out, long long out_stride);
 int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
                             const double* p, long long ldp, const double* Ap, long long ldap,
                             double* x, long long ldx, double* r, long long ldr);

@@ -127,7 +127,55 @@ __global__ __launch_bounds__(256) void k_cg_direction(long long n, const double*
 
 }  // namespace
 
+// out[r][j] = alpha * (a[r][j] (op) b[r][j]) + beta * c[r][j]   (op 0: a alone, 1: a*b, 2: a/b); rows r at their own strides.
+// The level-wise field algebra between operator calls of HorizSolve (averages of two states, M0^-1 = 1/diagonal, accumulations)
+// as ONE library launch each instead of chains of framework elementwise kernels.
+__global__ __launch_bounds__(256) void k_vec_combine(int nrows, long long n, double alpha, const double* __restrict__ a, long long as_,
+                                                     int op, const double* __restrict__ b, long long bs, double beta,
+                                                     const double* c, long long cs, double* out, long long os) {
+    const long long j = (long long)blockIdx.x*256 + threadIdx.x;
+    if (j >= n) return;
+    for (int r = blockIdx.y; r < nrows; r += gridDim.y) {
+        double t = a[(size_t)r*as_ + j];
+        if (op == 1) t *= b[(size_t)r*bs + j];
+        else if (op == 2) t /= b[(size_t)r*bs + j];
+        t *= alpha;
+        if (c) t += beta*c[(size_t)r*cs + j];
+        out[(size_t)r*os + j] = t;
+    }
+}
+// out[k] = 0.5 a[k-1] + 0.5 a[k] over the nk levels of a field given on the nk-1 interfaces (the missing boundary interfaces left out):
+// HorizSolve::diagnose_Phi eul/HorizSolve.cpp:451-459
+__global__ __launch_bounds__(256) void k_interface_average(int nk, long long n, const double* __restrict__ a, long long as_, double* __restrict__ out, long long os) {
+    const long long j = (long long)blockIdx.x*256 + threadIdx.x;
+    if (j >= n) return;
+    for (int k = blockIdx.y; k < nk; k += gridDim.y) {
+        double t = 0.0;
+        if (k > 0) t += 0.5*a[(size_t)(k - 1)*as_ + j];
+        if (k < nk - 1) t += 0.5*a[(size_t)k*as_ + j];
+        out[(size_t)k*os + j] = t;
+    }
+}
+
 extern "C" {
+
+int mimsem_vec_combine(mimsem_ctx* c, int nrows, long long n, double alpha, const double* a, long long as_, int op, const double* b, long long bs,
+                       double beta, const double* cc, long long cs, double* out, long long os) {
+    if (!c || nrows < 0 || n < 0 || op < 0 || op > 2) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    if (!a || !out || (op && !b)) return MIMSEM_ERR_ARG;
+    hipLaunchKernelGGL(k_vec_combine, dim3((unsigned)((n + 255)/256), (unsigned)std::min(nrows, 64)), dim3(256), 0, c->stream,
+                       nrows, n, alpha, a, as_, op, b, bs, beta, cc, cs, out, os);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int mimsem_interface_average(mimsem_ctx* c, int nk, long long n, const double* a, long long as_, double* out, long long os) {
+    if (!c || nk < 1 || n < 0 || !out || (nk > 1 && !a)) return MIMSEM_ERR_ARG;
+    if (n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_interface_average, dim3((unsigned)((n + 255)/256), (unsigned)std::min(nk, 64)), dim3(256), 0, c->stream, nk, n, a, as_, out, os);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
 
 int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out) {
     if (!c || !A || !B || !out || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;

@@ -673,6 +673,33 @@ class Engine:
         check(self.L.mimsem_krylov_cg_direction(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(z), z.stride(0),
                                                 _ptr(p), p.stride(0)), "cg_direction")
 
+    def combine(self, a, alpha=1.0, op=None, b=None, beta=0.0, c=None, out=None):
+        """out = alpha * (a, a*b or a/b) + beta * c, row by row ([nrows, n] tensors whose rows are contiguous; slices along the first
+        dimension are fine); out may be a or c (mimsem_vec_combine)"""
+        a2 = a if a.dim() == 2 else a.unsqueeze(0)
+        out = torch.empty_like(a2) if out is None else out
+        o2 = out if out.dim() == 2 else out.unsqueeze(0)
+        opc = {None: 0, "mul": 1, "div": 2}[op]
+        ts = [a2, o2] + ([b] if b is not None else []) + ([c] if c is not None else [])
+        for t in ts:
+            t2 = t if t.dim() == 2 else t.unsqueeze(0)
+            if t2.shape != a2.shape or t2.stride(1) != 1 or t2.dtype != torch.float64 or t2.device != a2.device:
+                raise _lib.MimsemError("combine: operands must be float64 [nrows, n] with contiguous rows on one device, got %s vs %s" % (tuple(t2.shape), tuple(a2.shape)))
+        b2 = None if b is None else (b if b.dim() == 2 else b.unsqueeze(0))
+        c2 = None if c is None else (c if c.dim() == 2 else c.unsqueeze(0))
+        if opc and b2 is None:
+            raise _lib.MimsemError("combine: op needs b")
+        check(self.L.mimsem_vec_combine(self.ctx, a2.shape[0], a2.shape[1], float(alpha), a2.data_ptr(), a2.stride(0), opc,
+                                        None if b2 is None else b2.data_ptr(), 0 if b2 is None else b2.stride(0), float(beta),
+                                        None if c2 is None else c2.data_ptr(), 0 if c2 is None else c2.stride(0), o2.data_ptr(), o2.stride(0)), "vec_combine")
+        return out
+
+    def interface_average(self, a, nk):
+        """[nk-1, n] interface field -> [nk, n] level field, 0.5*(k-1) + 0.5*(k) with the missing boundary interfaces left out"""
+        out = torch.empty(nk, a.shape[1], dtype=torch.float64, device=a.device)
+        check(self.L.mimsem_interface_average(self.ctx, nk, a.shape[1], a.data_ptr(), a.stride(0), out.data_ptr(), out.stride(0)), "interface_average")
+        return out
+
     def norm(self, x):
         """2-norm of a whole (single-rank) vector; DistEngine overrides with the ownership-weighted, all-reduced version"""
         return float(torch.linalg.vector_norm(x))

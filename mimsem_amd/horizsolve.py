@@ -57,14 +57,13 @@ class HorizSolve:
 
     def curl(self, u, fg=None):
         """w = M0^-1 E01 M1 u (+ f)   (:233-254), u: [nk, n1]"""
-        w = self.eng.incidence("E01", self.m1.apply(u)) / self.m0
-        return w if fg is None else w + fg
+        t = self.eng.incidence("E01", self.m1.apply(u))
+        return self.eng.combine(t, 1.0, "div", self.m0, beta=0.0 if fg is None else 1.0, c=fg, out=t)
 
     def laplacian(self, u):
         """del2 * (grad(E21 u) + E10 curl(u))   (:256-283)"""
         ddu = self.grad(self.eng.incidence("E21", u))
-        ddu.add_(self.eng.incidence("E10", self.curl(u)))
-        return ddu.mul_(self.del2)
+        return self.eng.combine(ddu, self.del2, beta=self.del2, c=self.eng.incidence("E10", self.curl(u)), out=ddu)
 
     def _uvec_hu4(self, ua, ub, ha, hb):
         """the four m1->assemble_hu(level, SCALE, u, h, false, fac) calls + gtol_1 reverse-add (:300-305, :675-682)"""
@@ -97,10 +96,7 @@ class HorizSolve:
     # ---- momentum right-hand side ---------------------------------------------------------------------------------------
     def _to_levels(self, a):
         """0.5*(interface k-1) + 0.5*(interface k) with the missing boundary interfaces left out (:451-459)"""
-        out = torch.zeros(self.nk, a.shape[1], dtype=a.dtype, device=a.device)
-        out[1:].add_(a, alpha=0.5)
-        out[:-1].add_(a, alpha=0.5)
-        return out
+        return self.eng.interface_average(a, self.nk)
 
     def diagnose_Phi(self, u1, u2, velz1, velz2):
         """:419-470"""
@@ -115,8 +111,10 @@ class HorizSolve:
 
     def diagnose_q(self, rho, u):
         """:472-493: (M0h(rho)) q = E01 M1 u + M0 f ; M0h is diagonal"""
-        rhs = self.eng.incidence("E01", self.m1.apply(u)) + self.m0 * self.fg
-        return rhs / self.eng.pvec(0, self.nk, SCALE, h2=rho)
+        eng = self.eng
+        rhs = eng.incidence("E01", self.m1.apply(u))
+        eng.combine(self.m0, 1.0, "mul", self.fg.expand_as(self.m0) if self.fg.shape != self.m0.shape else self.fg, beta=1.0, c=rhs, out=rhs)
+        return eng.combine(rhs, 1.0, "div", eng.pvec(0, self.nk, SCALE, h2=rho), out=rhs)
 
     def momentum_rhs_ec(self, theta, dudz1, dudz2, velz1, velz2, Pi, velx1, velx2, rho1, rho2, Fx=None, Fz=None,
                         dwdx1=None, dwdx2=None, Fk=None):
@@ -126,25 +124,26 @@ class HorizSolve:
         dPi = self.grad(Pi)
         dTheta = self.grad(theta)
         fu = eng.incidence("E12", Phi)
-        uh = (velx1 + velx2).mul_(0.5)
-        q = self.diagnose_q((rho1 + rho2).mul_(0.5), uh)
+        uh = eng.combine(velx1, 0.5, beta=0.5, c=velx2)
+        q = self.diagnose_q(eng.combine(rho1, 0.5, beta=0.5, c=rho2), uh)
         if Fx is None:
             Fx, _ = self.m1.solve(self._uvec_hu4(velx1, velx2, rho1, rho2))
         self._ap("ROTMAT", Fx, f=q, flags=ACCUM, out=fu)
         self._ap("UHMAT", dPi, f=theta, flags=VERT | ACCUM, alpha=0.5, out=fu)  # pressure gradient force
         self._ap("UHMAT", dTheta, f=Pi, flags=VERT | ACCUM, alpha=-0.5, out=fu)
         dp = eng.incidence("E12", self._ap("WHMAT", theta, f=Pi, flags=VERT))
-        fu.add_(dp, alpha=0.5)
+        eng.combine(dp, 0.5, beta=1.0, c=fu, out=fu)
         if Fk is not None:
-            self.k2i_dev = self.eng.wsum(1, Fk * dp) / SCALE       # stays on the device (no host sync: the call is hipGraph-capturable)
+            self.k2i_dev = self.eng.wsum(1, eng.combine(Fk, 1.0, "mul", dp)) / SCALE   # stays on the device (no host sync: hipGraph-capturable)
         # second vorticity term: interface i feeds levels i and i+1 (:704-746)
-        dz = (dudz1 + dudz2).mul_(0.5)
+        dz = eng.combine(dudz1, 0.5, beta=0.5, c=dudz2)
         if dwdx1 is not None:
-            dz.sub_(dwdx1 + dwdx2, alpha=0.5)
-        v = Fz if Fz is not None else (velz1 + velz2).mul_(0.5)
+            eng.combine(dwdx1, -0.5, beta=1.0, c=dz, out=dz)
+            eng.combine(dwdx2, -0.5, beta=1.0, c=dz, out=dz)
+        v = Fz if Fz is not None else eng.combine(velz1, 0.5, beta=0.5, c=velz2)
         t = eng.apply("UTQWMAT", v, f=dz, lev0=0, scale=SCALE)                  # UtQWmat::assemble(u1, scale): no thickness
-        fu[1:].add_(t, alpha=0.5)
-        fu[:-1].add_(t, alpha=0.5)
+        eng.combine(t, 0.5, beta=1.0, c=fu[1:], out=fu[1:])
+        eng.combine(t, 0.5, beta=1.0, c=fu[:-1], out=fu[:-1])
         if self.do_visc:
             self._ap("UMAT", self.laplacian(self.laplacian(uh)), flags=VERT | ACCUM, out=fu)
         return fu
