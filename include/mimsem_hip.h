@@ -130,6 +130,22 @@ int  mimsem_op_level_chunk(const mimsem_ctx* ctx, int nlev);
  * into y, out[2] = partial sums per level it leaves in the workspace, out[3] = slots the perimeter pass finishes,
  * out[4] = levels per work item at a call over nlev levels.  Returns 0 when the form is off (all five are then 0). */
 int  mimsem_op_wave_stats(const mimsem_ctx* ctx, int nlev, int out[5]);
+/* Interior / boundary split of a 1-form operator apply, so that a halo exchange overlaps the interior work (the
+ * reference's MatMult + VecScatterBegin/End, eul/Assembly.cpp:2194-2195): tell the context once which 1-form slots take part in an
+ * exchange (ghosts and mirrors of mimsem_halo_create's lists) -- the element groups touching them are moved to the front of the
+ * plan -- then run   mimsem_op_apply_part(..., MIMSEM_PART_BOUNDARY);  mimsem_halo_begin(...);
+ *                    mimsem_op_apply_part(..., MIMSEM_PART_INTERIOR);  mimsem_halo_end(...).
+ * After the BOUNDARY part every marked slot of y holds its complete local sum; the INTERIOR part writes the remaining slots.
+ * Operators / orders without the wave-level form (and contexts without marked slots) run whole in the BOUNDARY part and do nothing
+ * in the INTERIOR part, so the sequence above is always valid.  MIMSEM_PART_ALL = mimsem_op_apply.  Set-up call: not inside a
+ * stream capture (MIMSEM_ERR_STATE), invalidates nothing a captured graph holds (old tables are retired, not freed).          */
+#define MIMSEM_PART_ALL      0
+#define MIMSEM_PART_BOUNDARY 1
+#define MIMSEM_PART_INTERIOR 2
+int  mimsem_ctx_set_halo_slots(mimsem_ctx* ctx, int form, const int* slots, int n);
+int  mimsem_op_apply_part(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                          const double* f, long long f_stride, const double* x, long long x_stride,
+                          double* y, long long y_stride, double alpha, int part);
 /* Measurement hook (bench.py): when on = n > 0, every n-th mimsem_op_apply brackets its element kernel (pass 1) and its
  * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
  * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */

@@ -37,6 +37,8 @@ _SIGS = {
     "mimsem_ctx_workspace_bytes": (c_ll, [C.c_void_p]),
     "mimsem_op_level_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_op_wave_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "mimsem_ctx_set_halo_slots": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "mimsem_op_apply_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double, C.c_int]),
     "mimsem_ctx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_ctx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_ll)]),
     "mimsem_malloc": (C.c_int, [C.POINTER(C.c_void_p), c_ll]),

@@ -120,12 +120,13 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
 //                that k_gather_perim finishes.  With MIMSEM_WAVE_SINGLES=1 the unpaired complete slots get a second, 8-byte
 //                store round into y instead.
 struct WavePlan {
-    int ngroups = 0, nps = 0, npart = 0, nsing = 0, ndirect = 0;
+    int ngroups = 0, nps = 0, npart = 0, nsing = 0, ndirect = 0, nbgroups = 0, nbrec = 0;
     std::vector<int> perm, pslot, ppart, node;
     std::vector<int4> lane, plan;
     std::vector<int2> sing;
 };
-int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles, WavePlan& P) {
+int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles,
+                    const char* marked /* [n1] halo slots or null */, WavePlan& P) {
     const int nd = 2*n1e, lpe = 64/G, mp1 = order + 1;
     const int RS = mp1 + (mp1 & 1), XT = n1e + mp1*RS, sxe0 = XT + 2*(lpe - n1e), SXE = sxe0 + (sxe0 & 1);     // as k_apply_wave
     const unsigned NACC = (unsigned)(G*nd), ZERO = NACC + 128, DUMPX = (unsigned)XT;
@@ -164,6 +165,22 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
                 }
             }
         }
+    }
+    // interior / boundary split (mimsem_ctx_set_halo_slots): groups that touch a slot taking part in a halo exchange come FIRST, so
+    // that "the boundary part" of an apply is a prefix of the launch (and a prefix of the perimeter records, below)
+    P.nbgroups = 0;
+    if (marked) {
+        std::vector<int> bnd, inn;
+        for (int g = 0; g < P.ngroups; g++) {
+            bool b = false;
+            for (int k = 0; k < G && !b; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
+                for (int j = 0; j < nd && !b; j++) b = marked[slot_of(e, j)] != 0; }
+            (b ? bnd : inn).push_back(g);
+        }
+        std::vector<int> perm2; perm2.reserve(P.perm.size());
+        for (int g : bnd) perm2.insert(perm2.end(), P.perm.begin() + (size_t)g*G, P.perm.begin() + (size_t)(g + 1)*G);
+        for (int g : inn) perm2.insert(perm2.end(), P.perm.begin() + (size_t)g*G, P.perm.begin() + (size_t)(g + 1)*G);
+        P.perm.swap(perm2); P.nbgroups = (int)bnd.size();
     }
     P.lane.assign((size_t)P.ngroups*64, int4{0, 0, 0, 0});
     P.plan.resize((size_t)P.ngroups*64);
@@ -231,8 +248,13 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         for (int t = 0; t < 64; t++)
             P.plan[(size_t)g*64 + t] = t < (int)entries[g].size() ? entries[g][t]
                                                                   : int4{-(P.npart + 2*t + 2), (int)(ZERO | (ZERO << 16)), (int)(ZERO | (ZERO << 16)), 0};
-    for (int s = 0; s < n1; s++)
-        if (part[(size_t)s*2] >= 0 || cnt[s] == 0) { P.pslot.push_back(s); P.ppart.push_back(part[(size_t)s*2]); P.ppart.push_back(part[(size_t)s*2 + 1]); }
+    P.nbrec = 0;
+    for (int pass = 0; pass < 2; pass++)                                // records of marked (halo) slots first
+        for (int s = 0; s < n1; s++) {
+            const bool m = marked && marked[s];
+            if ((pass == 0) != m) continue;
+            if (part[(size_t)s*2] >= 0 || cnt[s] == 0) { P.pslot.push_back(s); P.ppart.push_back(part[(size_t)s*2]); P.ppart.push_back(part[(size_t)s*2 + 1]); if (m) P.nbrec++; }
+        }
     P.nps = (int)P.pslot.size();
     return MIMSEM_OK;
 }
@@ -319,6 +341,58 @@ int mimsem_ctx::ensure_col(long long doubles) {
 hipEvent_t mimsem_ctx::next_event() {
     if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
     return ev_pool[ev_used++];
+}
+
+// (re)build the wave-level plan of a context from its host copies of the mesh; `marked` [n1] flags the 1-form slots that take part
+// in a halo exchange (null: none).  Old device tables are retired, not freed (a captured graph may still hold them).
+static int setup_wave(mimsem_ctx* c, const char* marked) {
+    const ElemSizes& es = c->es;
+    WavePlan P;
+    const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
+    const bool singles = getenv("MIMSEM_WAVE_SINGLES") && atoi(getenv("MIMSEM_WAVE_SINGLES")) != 0;
+    int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, marked, P);
+    if (rc) return rc;
+    void* old[] = {c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR};
+    for (void* p : old) if (p) c->retired.push_back(p);
+    c->d_wlane = nullptr; c->d_wplan = nullptr; c->d_wprec = nullptr; c->d_wnode = nullptr; c->d_wsing = nullptr; c->d_wG = nullptr; c->d_wR = nullptr;
+    c->wave1 = false;
+    if ((rc = upload(&c->d_wlane, P.lane.data(), P.lane.size(), c))) return rc;
+    if ((rc = upload(&c->d_wplan, P.plan.data(), P.plan.size(), c))) return rc;
+    {
+        std::vector<int4> rec(P.pslot.size());
+        for (size_t i = 0; i < rec.size(); i++) rec[i] = int4{P.pslot[i], P.ppart[2*i], P.ppart[2*i + 1], 0};
+        if ((rc = upload(&c->d_wprec, rec.data(), rec.size(), c))) return rc;
+    }
+    if ((rc = upload(&c->d_wnode, P.node.data(), P.node.size(), c))) return rc;
+    if (P.nsing && (rc = upload(&c->d_wsing, P.sing.data(), P.sing.size(), c))) return rc;
+    // packed metric of the wave kernel: {gaa, gab, gbb, 1/det} = Q/det J^T J per quadrature point (16-byte loads) and the
+    // rotational factor (-J00 J11 + J01 J10) Q/det of RotMat, in wave-group order
+    {
+        std::vector<double> G((size_t)P.ngroups*64*4, 0.0), Rv((size_t)P.ngroups*64, 0.0);
+        const int gsz = 64/lpe;
+        for (int g = 0; g < P.ngroups; g++)
+            for (int l = 0; l < 64; l++) {
+                const int e = P.perm[(size_t)g*gsz + l/lpe], q = l%lpe;
+                if (e < 0 || q >= es.mp12) continue;                 // padding element / lane beyond the point grid: zeros
+                const double* Jq = c->h_J.data() + ((size_t)e*es.mp12 + q)*4;
+                const double det = c->h_det[(size_t)e*es.mp12 + q];
+                const double Q = c->tab.quad.w[q%es.mp1]*c->tab.quad.w[q/es.mp1];
+                double* o = &G[((size_t)g*64 + l)*4];
+                o[0] = (Jq[0]*Jq[0] + Jq[2]*Jq[2])*Q/det; o[1] = (Jq[0]*Jq[1] + Jq[2]*Jq[3])*Q/det;
+                o[2] = (Jq[1]*Jq[1] + Jq[3]*Jq[3])*Q/det; o[3] = 1.0/det;
+                Rv[(size_t)g*64 + l] = (-Jq[0]*Jq[3] + Jq[1]*Jq[2])*Q/det;
+            }
+        if ((rc = upload(&c->d_wG, G.data(), G.size(), c))) return rc;
+        if ((rc = upload(&c->d_wR, Rv.data(), Rv.size(), c))) return rc;
+    }
+    c->w_ndirect = P.ndirect; c->w_ngroups = P.ngroups; c->w_nsing = P.nsing; c->w_nps = P.nps; c->w_npart = P.npart;
+    c->w_nbgroups = P.nbgroups; c->w_nbrec = P.nbrec; c->w_split = marked != nullptr; c->wave1 = true;
+    if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
+    if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
+    if (getenv("MIMSEM_VERBOSE"))
+        fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials) of %d\n",
+                P.ngroups, 64/lpe, P.nbgroups, P.nps, P.npart, c->n1);
+    return MIMSEM_OK;
 }
 
 extern "C" {
@@ -480,50 +554,14 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         }
     }
     // Wave-level fused scatter-add of the 1-form -> 1-form operators (k_apply_wave): the default since round 2
-    // (MIMSEM_WAVE=0 selects the two-pass form for every operator)
-    if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0) {
-        WavePlan P;
-        const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
-        const bool singles = getenv("MIMSEM_WAVE_SINGLES") && atoi(getenv("MIMSEM_WAVE_SINGLES")) != 0;
-        rc = es.n <= 4 ? build_wave_plan(es.n, d->n1, d->nEl, es.n1e, es.n0e, 64/lpe, d->inds1x, d->inds1y, d->inds0, singles, P) : MIMSEM_ERR_UNSUPPORTED;
-        if (rc == MIMSEM_ERR_ARG) return fail(rc);
-        if (rc == MIMSEM_OK) {
-            if ((rc = upload(&c->d_wlane, P.lane.data(), P.lane.size(), c))) return fail(rc);
-            if ((rc = upload(&c->d_wplan, P.plan.data(), P.plan.size(), c))) return fail(rc);
-            {
-                std::vector<int4> rec(P.pslot.size());
-                for (size_t i = 0; i < rec.size(); i++) rec[i] = int4{P.pslot[i], P.ppart[2*i], P.ppart[2*i + 1], 0};
-                if ((rc = upload(&c->d_wprec, rec.data(), rec.size(), c))) return fail(rc);
-            }
-            if ((rc = upload(&c->d_wnode, P.node.data(), P.node.size(), c))) return fail(rc);
-            if (P.nsing && (rc = upload(&c->d_wsing, P.sing.data(), P.sing.size(), c))) return fail(rc);
-            // packed metric of the wave kernel: {gaa, gab, gbb, 1/det} = Q/det J^T J per quadrature point (16-byte loads) and the
-            // rotational factor (-J00 J11 + J01 J10) Q/det of RotMat
-            {
-                std::vector<double> G((size_t)P.ngroups*64*4, 0.0), Rv((size_t)P.ngroups*64, 0.0);
-                const int gsz = 64/lpe;
-                for (int g = 0; g < P.ngroups; g++)
-                    for (int l = 0; l < 64; l++) {
-                        const int e = P.perm[(size_t)g*gsz + l/lpe], q = l%lpe;
-                        if (e < 0 || q >= es.mp12) continue;                 // padding element / lane beyond the point grid: zeros
-                        const double* Jq = d->J + ((size_t)e*es.mp12 + q)*4;
-                        const double det = d->det[(size_t)e*es.mp12 + q];
-                        const double Q = c->tab.quad.w[q%es.mp1]*c->tab.quad.w[q/es.mp1];
-                        double* o = &G[((size_t)g*64 + l)*4];
-                        o[0] = (Jq[0]*Jq[0] + Jq[2]*Jq[2])*Q/det; o[1] = (Jq[0]*Jq[1] + Jq[2]*Jq[3])*Q/det;
-                        o[2] = (Jq[1]*Jq[1] + Jq[3]*Jq[3])*Q/det; o[3] = 1.0/det;
-                        Rv[(size_t)g*64 + l] = (-Jq[0]*Jq[3] + Jq[1]*Jq[2])*Q/det;
-                    }
-                if ((rc = upload(&c->d_wG, G.data(), G.size(), c))) return fail(rc);
-                if ((rc = upload(&c->d_wR, Rv.data(), Rv.size(), c))) return fail(rc);
-            }
-            c->w_ndirect = P.ndirect; c->w_ngroups = P.ngroups; c->w_nsing = P.nsing; c->w_nps = P.nps; c->w_npart = P.npart; c->wave1 = true;
-            if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
-            if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
-            if (getenv("MIMSEM_VERBOSE"))
-                fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements, %d perimeter slots (%d partials) of %d\n",
-                        P.ngroups, 64/lpe, P.nps, P.npart, d->n1);
-        }
+    // (MIMSEM_WAVE=0 selects the two-pass form for every operator).  Host copies of the index maps and the metric stay with the
+    // context: mimsem_ctx_set_halo_slots re-derives the plan with the boundary groups first.
+    if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
+        c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
+        c->h_i0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e);
+        c->h_J.assign(d->J, d->J + (size_t)d->nEl*es.mp12*4); c->h_det.assign(d->det, d->det + (size_t)d->nEl*es.mp12);
+        rc = setup_wave(c, nullptr);
+        if (rc == MIMSEM_ERR_ARG || rc == MIMSEM_ERR_HIP) return fail(rc);
         rc = MIMSEM_OK;
     }
     {
@@ -608,7 +646,7 @@ int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
                          const double* x, long long xs, double* y, long long ys, double alpha,
-                         const GatherEpilogue* epi = nullptr, const double* blocks = nullptr);
+                         const GatherEpilogue* epi = nullptr, const double* blocks = nullptr, int part = 0);
 static bool is_up_op(int op);
 
 int mimsem_op_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
@@ -622,6 +660,24 @@ static bool is_up_op(int op) {
     return op == MIMSEM_OP_PHMAT_UP || op == MIMSEM_OP_ROTMAT_UP || op == MIMSEM_OP_UMAT_UP || op == MIMSEM_OP_UHMAT_UP ||
            op == MIMSEM_OP_UVEC_HU_UP || op == MIMSEM_OP_UMAT_RAY;
 }
+int mimsem_ctx_set_halo_slots(mimsem_ctx* c, int form, const int* slots, int n) {
+    if (!c || form != 1 || n < 0 || (n && !slots)) return MIMSEM_ERR_ARG;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    if (!c->wave1 && c->h_i1x.empty()) return MIMSEM_OK;      // two-pass form: nothing to reorder (the split degenerates, see mimsem_op_apply_part)
+    std::vector<char> marked(std::max(c->n1, 1), 0);
+    for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= c->n1) return MIMSEM_ERR_ARG; marked[slots[i]] = 1; }
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = setup_wave(c, marked.data());
+    return rc == MIMSEM_ERR_UNSUPPORTED ? MIMSEM_OK : rc;      // numbering without a wave-level plan: the two-pass form stays, the split degenerates
+}
+
+int mimsem_op_apply_part(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                         const double* f, long long fs, const double* x, long long xs,
+                         double* y, long long ys, double alpha, int part) {
+    if (is_up_op(op) || part < MIMSEM_PART_ALL || part > MIMSEM_PART_INTERIOR) return MIMSEM_ERR_ARG;
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, y, ys, alpha, nullptr, nullptr, part);
+}
+
 int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
                        const double* f, long long fs, const double* u, long long us,
                        const double* x, long long xs, double* y, long long ys, double alpha) {
@@ -635,8 +691,13 @@ int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double sc
 static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                          const double* f, long long fs, const double* f2, long long f2s, double param,
                          const double* x, long long xs, double* y, long long ys, double alpha,
-                         const GatherEpilogue* epi, const double* blocks) {
+                         const GatherEpilogue* epi, const double* blocks, int part) {
     if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    // interior / boundary split: only the wave-level form with marked halo slots really splits; everything else runs whole as
+    // "the boundary part" and has nothing left for "the interior part", so callers can always issue both
+    const bool wave_op = op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H;
+    const bool splits = part != 0 && c->wave1 && c->w_split && wave_op && !epi;
+    if (part == MIMSEM_PART_INTERIOR && !splits) return MIMSEM_OK;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
     if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;       // empty batch: nothing to do (pointers of empty arrays may be null)
@@ -704,7 +765,10 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         // wave-level fused path: complete slots straight into y, one partial per perimeter slot into the workspace, perimeter pass
         const long long prow = (long long)c->w_npart + 128;              // partial sums of a level + the dump tail (64 lanes x 16 bytes)
         if ((rc = c->ensure_ye(prow*nlev))) return rc;
-        a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = c->w_ngroups; a.wdump = c->w_npart;
+        int g0 = 0, g1 = c->w_ngroups, r0 = 0, r1 = c->w_nps;
+        if (splits && part == MIMSEM_PART_BOUNDARY) { g1 = c->w_nbgroups; r1 = c->w_nbrec; }
+        if (splits && part == MIMSEM_PART_INTERIOR) { g0 = c->w_nbgroups; r0 = c->w_nbrec; }
+        a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = g1 - g0; a.wg0 = g0; a.wdump = c->w_npart;
         a.wsing = c->w_nsing ? c->d_wsing : nullptr; a.wnode = c->d_wnode; a.wG = c->d_wG; a.wR = c->d_wR;
         a.lch = wave_level_chunk(c, nlev);
         a.swz = c->wave_order;
@@ -721,7 +785,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
             a.wstamps = d_st;
         }
 #endif
-        rc = launch_apply_wave(c, op, a);
+        rc = a.wgroups > 0 ? launch_apply_wave(c, op, a) : MIMSEM_OK;
 #ifdef MIMSEM_STAMPS
         if (a.wstamps) {
             (void)hipStreamSynchronize(c->stream);
@@ -742,7 +806,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
             }
         }
 #endif
-        if (!rc) rc = launch_wave_perim(c, nlev, c->d_ye, prow, a.accum, y, ys);
+        if (!rc) rc = launch_wave_perim(c, nlev, c->d_ye, prow, a.accum, y, ys, r0, r1);
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }

@@ -68,6 +68,8 @@ struct mimsem_ctx {
     int wave_order = 3;                 // bit 0: XCD-contiguous block order, bit 1: group-major items (MIMSEM_WAVE_ORDER)
     int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per work item
     int w_ngroups = 0, w_nsing = 0, w_nps = 0, w_npart = 0, w_ndirect = 0;
+    int w_nbgroups = 0, w_nbrec = 0; bool w_split = false;     // interior / boundary split (mimsem_ctx_set_halo_slots): boundary prefix sizes
+    std::vector<int> h_i1x, h_i1y, h_i0; std::vector<double> h_J, h_det;      // host copies of the mesh for re-deriving the plan
     int4* d_wlane = nullptr;            // [w_ngroups][64] {element of the lane, load pair: even slot b, staging positions of x[b] and of x[b+1]
                                         //   (two 16-bit positions each; the dump position where nobody wants the value)}
     int4* d_wplan = nullptr;            // [w_ngroups][64] store pair {dst, result positions of its first and second slot (2 x 16 bit, the
@@ -130,7 +132,7 @@ struct ElemArgs {
     const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
     double* y; long long ys; int accum;
     // wave-level fused scatter-add (k_apply_wave)
-    const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wdump;
+    const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump;
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
     long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null
     // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)
@@ -156,7 +158,7 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
                         const int* pslot = nullptr, const int* ppart = nullptr, int nps = -1);
 int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a);
-int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys);
+int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys, int r0 = 0, int r1 = -1);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys, bool shared_only = false);
 int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const double* B, long long bstride_lev,

@@ -1431,13 +1431,15 @@ static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
-int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys) {
-    if (c->w_nps == 0 || nlev == 0) return MIMSEM_OK;
-    const dim3 grid((unsigned)((c->w_nps + 255)/256), (unsigned)((nlev + PLC - 1)/PLC));
-    const int4* rec = (const int4*)c->d_wprec;
+int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys, int r0, int r1) {
+    if (r1 < 0) r1 = c->w_nps;
+    const int nps = r1 - r0;
+    if (nps <= 0 || nlev == 0) return MIMSEM_OK;
+    const dim3 grid((unsigned)((nps + 255)/256), (unsigned)((nlev + PLC - 1)/PLC));
+    const int4* rec = (const int4*)c->d_wprec + r0;
 #define MIMSEM_WP(ACC) \
-    if (c->ev_k2[0]) hipExtLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0, yp, yps, rec, c->w_nps, nlev, y, ys); \
-    else hipLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, yp, yps, rec, c->w_nps, nlev, y, ys)
+    if (c->ev_k2[0]) hipExtLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0, yp, yps, rec, nps, nlev, y, ys); \
+    else hipLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, yp, yps, rec, nps, nlev, y, ys)
     if (accum) { MIMSEM_WP(true); } else { MIMSEM_WP(false); }
 #undef MIMSEM_WP
     MIMSEM_HIP_TRY(hipGetLastError());

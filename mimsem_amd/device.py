@@ -204,6 +204,30 @@ class Engine:
                                      _ptr(x2), x2.stride(0), _ptr(y2), y2.stride(0), alpha), "mimsem_op_apply(%s)" % op)
         return y if x.dim() == 2 else y2[0]
 
+    def set_halo_slots(self, form, slots):
+        """mark the 1-form slots that take part in a halo exchange: their element groups move to the front of the plan, so that
+        apply_part(..., "boundary") completes exactly those slots (mimsem_ctx_set_halo_slots)"""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        check(self.L.mimsem_ctx_set_halo_slots(self.ctx, form, sl.ctypes.data, sl.size), "ctx_set_halo_slots")
+
+    def apply_part(self, op, part, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
+        """the boundary or the interior part of apply(): part "boundary" first (all marked slots of `out` complete afterwards), then
+        "interior" into the SAME out, with no other operator call of this engine in between (the parts share the workspace)"""
+        sin, sf, sout = self._SPACES[op]
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        nlev = x2.shape[0]
+        if x2.shape[1] != self.sizes[sin] or out is None or out.shape != (nlev, self.sizes[sout]):
+            raise _lib.MimsemError("apply_part: x [nlev, n_in] and out [nlev, n_out] required")
+        f2 = None
+        if sf is not None:
+            f2 = f if f.dim() == 2 else f.unsqueeze(0)
+            if f2.shape != (nlev, self.sizes[sf]):
+                raise _lib.MimsemError("apply_part: coefficient field of the wrong shape")
+        check(self.L.mimsem_op_apply_part(self.ctx, OPS[op], lev0, nlev, scale, flags, _ptr(f2), f2.stride(0) if f2 is not None else 0,
+                                          _ptr(x2), x2.stride(0), _ptr(out), out.stride(0), alpha, {"all": 0, "boundary": 1, "interior": 2}[part]),
+              "mimsem_op_apply_part(%s)" % op)
+        return out
+
     def apply_up(self, op, x, f, u, fac=None, dt=None, lev0=0, alpha=1.0, flags=0, out=None, scale=1.0, tau=None):
         """upwinded operators: f = the op's field, u = second (velocity) field.  SW ops (PHMAT_UP / ROTMAT_UP) pass fac, dt
         (tau = 1/(1/(fac*dt)), src/Assembly.cpp:541); the eul ops (UMAT_UP / UHMAT_UP / UVEC_HU_UP) pass scale and tau."""

@@ -11,15 +11,22 @@ import torch
 import torch.distributed as dist
 
 from .device import Engine
-from .partition import HaloExchanger, build_plans
+from .partition import CHalo, HaloExchanger, build_plans
 
 
 class DistEngine:
-    def __init__(self, eng, sphere, world, rank):
+    def __init__(self, eng, sphere, world, rank, overlap=False, transport="dist"):
+        """overlap=True: 1-form operator results are completed through the C ABI's halo plan (CHalo) with the INTERIOR / BOUNDARY
+        split of the apply -- boundary element groups first, exchange started, interior groups while it travels
+        (mimsem_op_apply_part + mimsem_halo_begin/_end); transport: "dist" (host callback over the process group) or an ncclComm_t."""
         self.eng, self.world, self.rank = eng, world, rank
         dm = eng.mesh
         plans = build_plans(sphere, world, rank, dm.gid0, dm.gid1)
         self.halo = {0: HaloExchanger(plans[0], engine=eng), 1: HaloExchanger(plans[1], engine=eng)}
+        self.chalo = None
+        if overlap and world > 1:
+            self.chalo = CHalo(plans[1], eng, max_nlev=eng.nk, transport=transport)
+            eng.set_halo_slots(1, self.chalo.shared)
         f = lambda m: torch.as_tensor(m, dtype=torch.float64, device=eng.device)
         self.own = {0: f(plans[0].owned), 1: f(plans[1].owned), 2: torch.ones(dm.n2, dtype=torch.float64, device=eng.device)}
         self._spaces = {0: self.own[0], 1: self.own[1], 2: self.own[2], "uh": torch.cat([self.own[1], self.own[2]])}
@@ -81,7 +88,23 @@ class DistEngine:
         form = Engine._SPACES[op][2]
         if form == 2:
             return self.eng.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags, alpha=alpha, out=out)
-        tmp = self.eng.apply(op, x if x.dim() == 2 else x.unsqueeze(0), f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha)
+        x2 = x if x.dim() == 2 else x.unsqueeze(0)
+        if self.chalo is not None and form == 1 and Engine._SPACES[op][0] == 1 and op in ("UMAT", "UHMAT", "ROTMAT", "UTMAT", "UTMAT_H"):
+            # boundary groups -> exchange in flight -> interior groups -> unpack: the halo travels while the interior is computed
+            tmp = torch.empty(x2.shape[0], self.eng.sizes[1], dtype=torch.float64, device=x2.device)
+            self.eng.apply_part(op, "boundary", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
+            tok = self.chalo.begin("pair", tmp, True)
+            self.eng.apply_part(op, "interior", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
+            self.chalo.end(tok)
+            if out is None:
+                return tmp if x.dim() == 2 else tmp[0]
+            o = out if out.dim() == 2 else out.unsqueeze(0)
+            if flags & 2:
+                o += tmp
+            else:
+                o.copy_(tmp)
+            return out
+        tmp = self.eng.apply(op, x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha)
         r = self._finish(form, tmp, out, bool(flags & 2))
         return r if (out is not None or x.dim() == 2) else r[0]
 

@@ -309,9 +309,13 @@ class CHalo:
         gi, go = lists(plan.ghost_slots)
         mi, mo = lists(plan.mirror_slots)
         self.ranks = np.asarray(ranks, dtype=np.int32)
-        self._keep = (gi, go, mi, mo)
+        # the symmetric exchange of sum_all: every slot shared with a rank, in gid order on both sides (as HaloExchanger's "pair")
+        pair = {r: np.sort(np.concatenate([plan.ghost_slots.get(r, empty), plan.mirror_slots.get(r, empty)])).astype(np.int32) for r in ranks}
+        pi, po = lists(pair)
+        self.shared = np.unique(pi)
+        self._keep = (gi, go, mi, mo, pi, po)
         self.handles = {}
-        for name, (si, so, ri, ro) in (("reverse", (gi, go, mi, mo)), ("forward", (mi, mo, gi, go))):
+        for name, (si, so, ri, ro) in (("reverse", (gi, go, mi, mo)), ("forward", (mi, mo, gi, go)), ("pair", (pi, po, pi, po))):
             h = C.c_void_p()
             check(self.L.mimsem_halo_create(engine.ctx, len(ranks), self.ranks.ctypes.data, si.ctypes.data, so.ctypes.data,
                                             ri.ctypes.data, ro.ctypes.data, nslots, max_nlev, C.byref(h)), "halo_create")
@@ -364,6 +368,10 @@ class CHalo:
 
     def forward_insert(self, v):
         self.end(self.begin("forward", v, False))
+
+    def sum_all(self, v):
+        """1-forms: every sharer sends its partial sums to the other and adds what it receives (a + b = b + a bitwise)"""
+        self.end(self.begin("pair", v, True))
 
     def close(self):
         for h in self.handles.values():

@@ -116,3 +116,47 @@ def test_rccl_transport_on_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "exp_rccl_self.py")], env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rccl self exchange ok: True" in r.stdout and "forward ok: True" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("op,fl", [("UMAT", 1), ("UHMAT", 1), ("ROTMAT", 0)])
+def test_interior_boundary_split_of_an_apply(oracle, op, fl):
+    """mimsem_ctx_set_halo_slots + mimsem_op_apply_part: boundary part then interior part = the whole apply bit for bit, and the
+    marked (halo) slots are already final after the boundary part"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    import ctypes as C
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from tests.helpers import SCALE, z_levels
+    cs = CubedSphere(3, 4, 6); coords = sphere_coords(3, 4)
+    topos = [Topo(cs, p, 9) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 9) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(9, g.n0))
+    dm = DeviceMesh(topos, geoms, nk=9, numbering="global")
+    eng = Engine(dm)
+    st = (C.c_int * 5)()
+    assert eng.L.mimsem_op_wave_stats(eng.ctx, 9, st) == 1                   # the wave-level form is what runs here
+    P = dm
+    r = np.random.default_rng(2)
+    x = eng.tensor(r.standard_normal((9, P.n1)))
+    f = {"UMAT": None, "UHMAT": eng.tensor(r.uniform(0.5, 1.5, (9, P.n2)) * 1e6), "ROTMAT": eng.tensor(r.standard_normal((9, P.n0)) * 1e-4)}[op]
+    whole = eng.apply(op, x, f=f, lev0=0, scale=SCALE, flags=fl)
+    marked = np.sort(r.choice(P.n1, 60, replace=False)).astype(np.int32)
+    eng.set_halo_slots(1, marked)
+    again = eng.apply(op, x, f=f, lev0=0, scale=SCALE, flags=fl)            # the re-ordered plan computes the same thing
+    assert torch.equal(again, whole)
+    out = torch.full_like(whole, float("nan"))
+    eng.apply_part(op, "boundary", x, f=f, lev0=0, scale=SCALE, flags=fl, out=out)
+    assert torch.equal(out[:, marked.astype(np.int64)], whole[:, marked.astype(np.int64)])
+    assert torch.isnan(out).any()                                            # something is left for the interior part
+    eng.apply_part(op, "interior", x, f=f, lev0=0, scale=SCALE, flags=fl, out=out)
+    assert torch.equal(out, whole)
+    # accumulate form
+    base = eng.tensor(r.standard_normal((9, P.n1)))
+    want = base.clone(); eng.apply(op, x, f=f, lev0=0, scale=SCALE, flags=fl | 2, alpha=0.5, out=want)
+    got = base.clone()
+    eng.apply_part(op, "boundary", x, f=f, lev0=0, scale=SCALE, flags=fl | 2, alpha=0.5, out=got)
+    eng.apply_part(op, "interior", x, f=f, lev0=0, scale=SCALE, flags=fl | 2, alpha=0.5, out=got)
+    assert torch.equal(got, want)

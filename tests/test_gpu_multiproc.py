@@ -55,6 +55,13 @@ def _worker(rank, world, port, q):
             ch.reverse_add(y2); ch.forward_insert(y2)
             ok = ok and bool(torch.equal(y2, y))
             ch.close()
+            if form == 1:
+                # DistEngine with the interior / boundary split: boundary groups, exchange in flight, interior groups, unpack
+                from mimsem_amd.distributed import DistEngine
+                dm2, eng2 = build(patches_of_rank(npatch, world, rank))
+                de = DistEngine(eng2, cs, world, rank, overlap=True)
+                y3 = de.apply(op, eng2.tensor(xglob[:, gid]), lev0=0, scale=SCALE, flags=1)
+                ok = ok and bool(torch.equal(y3, y))
             if rank == 0:
                 dm1, eng1 = build(list(range(npatch)))
                 want = eng1.apply(op, eng1.tensor(xglob), lev0=0, scale=SCALE, flags=1 if form == 1 else 0).cpu().numpy()

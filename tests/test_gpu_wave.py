@@ -1,0 +1,97 @@
+"""The wave-level fused form of the 1-form -> 1-form operators (k_apply_wave + k_wave_perim, mimsem_amd/csrc/elem_wave.inc) on small
+spheres in the reference's global numbering (where its slot-pair plan exists): against the two-pass form of the same library
+(MIMSEM_WAVE=0, itself checked against the oracle operator by operator in test_gpu_horizontal.py) and, at p = 3, against the oracle
+directly.  The full-size oracle comparisons of test_gpu_fullsize_oracle.py run the wave form too (config 1, 3, 4, 5 grids)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import SCALE, rel_l2, z_levels
+
+pytestmark = pytest.mark.gpu
+NK = 11                                   # 8 + 3: a full chunk and a ragged one
+
+
+def _mesh(pn, ne):
+    from mimsem_amd.device import DeviceMesh
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    topos = [Topo(cs, p, NK) for p in range(6)]
+    geoms = [Geom(t, cs, coords, NK) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(NK, g.n0))
+    return cs, topos, geoms, DeviceMesh(topos, geoms, nk=NK, numbering="global")
+
+
+@pytest.fixture(scope="module", params=[(2, 4), (3, 4), (4, 2)], ids=lambda p: "p%d_ne%d" % p)
+def engines(request):
+    import os
+    from mimsem_amd.device import Engine
+    pn, ne = request.param
+    cs, topos, geoms, dm = _mesh(pn, ne)
+    wave = Engine(dm)
+    st = (C.c_int * 5)()
+    assert wave.L.mimsem_op_wave_stats(wave.ctx, NK, st) == 1 and st[0] > 0 and st[4] == 8, list(st)
+    os.environ["MIMSEM_WAVE"] = "0"
+    try:
+        two = Engine(dm)
+    finally:
+        del os.environ["MIMSEM_WAVE"]
+    assert two.L.mimsem_op_wave_stats(two.ctx, NK, st) == 0
+    return pn, dm, wave, two, (cs, topos, geoms)
+
+
+CASES = [("UMAT", 1), ("UMAT", 0), ("UHMAT", 1), ("UHMAT", 0), ("ROTMAT", 0), ("UTMAT", 0), ("UTMAT_H", 0)]
+
+
+@pytest.mark.parametrize("op,fl", CASES, ids=["%s_%d" % c for c in CASES])
+def test_wave_form_equals_two_pass_form(engines, op, fl):
+    import torch
+    pn, dm, wave, two, _ = engines
+    r = np.random.default_rng(17)
+    x = r.standard_normal((NK, dm.n1))
+    f = {"UHMAT": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6, "UTMAT_H": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6,
+         "ROTMAT": r.standard_normal((NK, dm.n0)) * 1e-4}.get(op)
+    nl = NK - 1 if op == "UTMAT" else NK
+    for lev0, nlev in ((0, nl), (2, 3), (5, 1)):
+        xs = x[:nlev]; fs = None if f is None else f[:nlev]
+        a = wave.apply(op, wave.tensor(xs), f=None if fs is None else wave.tensor(fs), lev0=lev0, scale=SCALE, flags=fl)
+        b = two.apply(op, two.tensor(xs), f=None if fs is None else two.tensor(fs), lev0=lev0, scale=SCALE, flags=fl)
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-13, (op, lev0, nlev)
+        for k in range(nlev):                                           # level by level too: a wrong level would hide in the norm
+            assert rel_l2(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-12, (op, lev0, k)
+    base = r.standard_normal((nl, dm.n1))
+    ya, yb = wave.tensor(base), two.tensor(base)
+    wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl | 2, alpha=-0.375, out=ya)
+    two.apply(op, two.tensor(x[:nl]), f=None if f is None else two.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl | 2, alpha=-0.375, out=yb)
+    assert rel_l2(ya.cpu().numpy(), yb.cpu().numpy()) < 1e-13, op
+    # run-to-run reproducible bit for bit (fixed summation order, no atomics)
+    a1 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
+    a2 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
+    assert torch.equal(a1, a2)
+
+
+def test_wave_form_against_the_oracle(engines, oracle):
+    """p = 3: every patch of the small sphere against oracle.Patch (eul/Assembly.cpp coefficient loops restated)"""
+    pn, dm, wave, two, (cs, topos, geoms) = engines
+    if pn != 3:
+        pytest.skip("oracle comparison at p = 3")
+    from mimsem_amd.mesh import sphere_coords
+    from tests.test_gpu_fullsize_oracle import PatchView, _oracle_patch
+    coords = sphere_coords(pn, cs.ne)
+    r = np.random.default_rng(5)
+    x = r.standard_normal((NK, dm.n1)); h = r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6; q = r.standard_normal((NK, dm.n0)) * 1e-4
+    got = {("UMAT", 1): wave.apply("UMAT", wave.tensor(x), lev0=0, scale=SCALE, flags=1).cpu().numpy(),
+           ("UHMAT", 1): wave.apply("UHMAT", wave.tensor(x), f=wave.tensor(h), lev0=0, scale=SCALE, flags=1).cpu().numpy(),
+           ("ROTMAT", 0): wave.apply("ROTMAT", wave.tensor(x), f=wave.tensor(q), lev0=0, scale=SCALE, flags=0).cpu().numpy()}
+    for pi in range(6):
+        v = PatchView(dm, topos, pi); v.pid = pi
+        P = _oracle_patch(oracle, cs, coords, geoms[pi], pi, NK)
+        for (op, fl), y in got.items():
+            for lev in (0, NK - 1):
+                f1 = {"UMAT": None, "UHMAT": h[lev][v.s2], "ROTMAT": q[lev][v.s0]}[op]
+                want = P.apply(op, x[lev][v.s1], lev=lev, scale=SCALE, flag=fl, f1=f1)
+                assert rel_l2(y[lev][v.s1][v.int1], want[v.int1]) < 1e-10, (op, lev, v.pid)
