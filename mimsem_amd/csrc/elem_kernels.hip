@@ -1412,11 +1412,11 @@ template <int N>
 static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     const long long items = (long long)a.wgroups*((a.nlev + a.lch - 1)/a.lch);
     if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
-    const unsigned grid = (unsigned)((items + 3)/4);
+    const unsigned grid = (unsigned)((items + WNW - 1)/WNW);
     if (grid == 0) return MIMSEM_OK;
 #define MIMSEM_WL(OPV, LCT, ACC) \
-        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
-        else hipLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(256), 0, c->stream, a)
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, a)
 #define MIMSEM_WCASE(OPV) case OPV: \
         if (a.lch == 1) { if (a.accum) { MIMSEM_WL(OPV, 1, true); } else { MIMSEM_WL(OPV, 1, false); } } \
         else            { if (a.accum) { MIMSEM_WL(OPV, WLC, true); } else { MIMSEM_WL(OPV, WLC, false); } } \

@@ -7,7 +7,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d['roofline_cold']
 print('value %.3e ms/step %.4f | hot k1 %.2f us op %.2f us | cold k1 %.2f us op %.2f us value %.3e' % (d['value'], d['ms_per_step'], r['avg_kernel_us'], r['whole_operator']['avg_us'], c['avg_kernel_us'], c['whole_operator']['avg_us'], c['value']))" >> $out; }
 run MIMSEM_WAVE=0
-for o in 3 1; do run MIMSEM_WAVE_ORDER=$o; done
-run MIMSEM_WAVE_LCH=6
+run MIMSEM_WAVE_ORDER=3
+
 
 cat $out

@@ -15,3 +15,10 @@ cd $R
 python3 scripts/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python3 scripts/pmc_summarise.py $O/pmc_fetch $O/pmc_write > $O/pmc_summary.txt 2>&1
 tail -c 1500 $O/bench_default.json
+# the other kernel-stats summaries of the round (column, column-3, Newton, HorizSolve, SW) and the PMC passes of the Umat step
+cd $R
+for s in prof_column_rocprof.sh prof_column3_rocprof.sh prof_newton_rocprof.sh prof_horiz_rocprof.sh prof_sw_rocprof.sh; do
+  [ -f scripts/$s ] && bash scripts/$s > $O/${s%.sh}.log 2>&1
+done
+MODES="wave twopass" bash scripts/prof_umat_pmc.sh > $O/umat_pmc.txt 2>&1
+echo final profiles done
