@@ -128,7 +128,7 @@ int  mimsem_op_level_chunk(const mimsem_ctx* ctx, int nlev);
 /* The wave-level fused form of the 1-form -> 1-form operators (Umat, Uhmat, RotMat, Ut_mat; the default for orders <= 4 unless
  * MIMSEM_WAVE=0): out[0] = wave-groups (wavefronts per level chunk), out[1] = vector slots the element kernel writes straight
  * into y, out[2] = partial sums per level it leaves in the workspace, out[3] = slots the perimeter pass finishes,
- * out[4] = levels per work item at a call over nlev levels.  Returns 0 when the form is off (all five are then 0). */
+ * out[4] = levels one wavefront works through at a call over nlev levels (chunks of 8, several per wavefront when the launch has wavefronts to spare).  Returns 0 when the form is off (all five are then 0). */
 int  mimsem_op_wave_stats(const mimsem_ctx* ctx, int nlev, int out[5]);
 /* Interior / boundary split of a 1-form operator apply, so that a halo exchange overlaps the interior work (the
  * reference's MatMult + VecScatterBegin/End, eul/Assembly.cpp:2194-2195): tell the context once which 1-form slots take part in an

@@ -292,6 +292,17 @@ int wave_level_chunk(const mimsem_ctx* c, int nlev) {
     return std::max(1, std::min(8, nlev));
 }
 
+// chunks of 8 levels one wavefront works through (tables and metric loaded once, the level pipeline running on across the chunk
+// boundary): as many as leave ~2 wavefronts per SIMD -- fewer, longer-lived waves cost less dispatch and set-up, which is what the
+// cache-resident launches are made of
+int wave_chunks_per_item(const mimsem_ctx* c, int nlev, int lch, int ngroups) {
+    const int nch = (nlev + lch - 1)/lch;
+    if (lch != 8 || nch <= 1) return 1;
+    if (c->wave_cpp > 0) return std::min(c->wave_cpp, nch);
+    const int nparts = std::min(nch, std::max(1, (1536 + ngroups - 1)/std::max(ngroups, 1)));      // balanced parts
+    return (nch + nparts - 1)/nparts;
+}
+
 int op_spaces(int op, int* in, int* cf, int* out) {
     switch (op) {
     case MIMSEM_OP_UMAT: case MIMSEM_OP_UTMAT:   *in = 1; *cf = -1; *out = 1; return 0;
@@ -609,7 +620,8 @@ int mimsem_op_wave_stats(const mimsem_ctx* c, int nlev, int out[5]) {
     if (!c || !out || nlev < 1) return MIMSEM_ERR_ARG;
     for (int i = 0; i < 5; i++) out[i] = 0;
     if (!c->wave1) return 0;
-    out[0] = c->w_ngroups; out[1] = c->w_ndirect; out[2] = c->w_npart; out[3] = c->w_nps; out[4] = wave_level_chunk(c, nlev);
+    out[0] = c->w_ngroups; out[1] = c->w_ndirect; out[2] = c->w_npart; out[3] = c->w_nps;
+    { const int lch = wave_level_chunk(c, nlev); out[4] = lch*wave_chunks_per_item(c, nlev, lch, c->w_ngroups); }
     return 1;
 }
 
@@ -782,6 +794,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = g1 - g0; a.wg0 = g0; a.wdump = c->w_npart;
         a.wsing = c->w_nsing ? c->d_wsing : nullptr; a.wnode = c->d_wnode; a.wG = c->d_wG; a.wR = c->d_wR;
         a.lch = wave_level_chunk(c, nlev);
+        a.wcpp = wave_chunks_per_item(c, nlev, a.lch, g1 - g0);
         a.swz = c->wave_order;
         a.y = y; a.ys = ys; a.out = c->d_ye; a.os = prow;
         a.flags = flags & ~MIMSEM_FLAG_ACCUM;

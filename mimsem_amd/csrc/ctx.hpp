@@ -66,7 +66,8 @@ struct mimsem_ctx {
     // wave-level fused scatter-add (k_apply_wave, elem_wave.inc): wave-groups of 64/LPE neighbouring elements; tables: build_wave_plan
     bool wave1 = false;
     int wave_order = 3;                 // bit 0: XCD-contiguous block order, bit 1: group-major items (MIMSEM_WAVE_ORDER)
-    int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per work item
+    int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per chunk
+    int wave_cpp = 0;                   // MIMSEM_WAVE_CPP override of the chunks per work item (0: heuristic)
     int w_ngroups = 0, w_nsing = 0, w_nps = 0, w_npart = 0, w_ndirect = 0;
     int w_nbgroups = 0, w_nbrec = 0; bool w_split = false;     // interior / boundary split (mimsem_ctx_set_halo_slots): boundary prefix sizes
     std::vector<int> h_i1x, h_i1y, h_i0; std::vector<double> h_J, h_det;      // host copies of the mesh for re-deriving the plan
@@ -132,7 +133,7 @@ struct ElemArgs {
     const int* fperm; const unsigned short* flid; const int* fslot; const int* fcnt; int ngroups, lmax;
     double* y; long long ys; int accum;
     // wave-level fused scatter-add (k_apply_wave)
-    const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump;
+    const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump; int wcpp;
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
     long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null
     // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)

@@ -1410,7 +1410,8 @@ int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps
 // the wave-level fused form of the 1-form -> 1-form operators (elem_wave.inc): one wavefront per (wave-group, level chunk)
 template <int N>
 static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
-    const long long items = (long long)a.wgroups*((a.nlev + a.lch - 1)/a.lch);
+    const int nch = (a.nlev + a.lch - 1)/a.lch;
+    const long long items = (long long)a.wgroups*((nch + a.wcpp - 1)/a.wcpp);
     if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)((items + WNW - 1)/WNW);
     if (grid == 0) return MIMSEM_OK;
@@ -1446,7 +1447,7 @@ int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, 
     return MIMSEM_OK;
 }
 int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
-    if (a.lch > WLC || a.lch < 1) return MIMSEM_ERR_ARG;
+    if (a.lch > WLC || a.lch < 1 || a.wcpp < 1 || (a.wcpp > 1 && a.lch != WLC)) return MIMSEM_ERR_ARG;
     switch (c->es.n) {
     case 1: return dispatch_apply_wave<1>(c, op, a); case 2: return dispatch_apply_wave<2>(c, op, a);
     case 3: return dispatch_apply_wave<3>(c, op, a); case 4: return dispatch_apply_wave<4>(c, op, a);
