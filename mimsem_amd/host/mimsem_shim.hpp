@@ -143,6 +143,41 @@ private:
     }
 };
 
+// VecScatterBegin / VecScatterEnd on Topo::gtol_0 / gtol_1 (eul/Topo.cpp:145-155) with device-resident vectors: the slot lists are
+// the ones VecScatterCreate is given there (per neighbour rank: my ghost slots owned by it, my owned slots it holds as ghosts).
+// reverse_add  = VecScatter(gtol, l, g, ADD_VALUES, SCATTER_REVERSE)  (eul/Assembly.cpp:2194-2195)
+// forward_insert = VecScatter(gtol, g, l, INSERT_VALUES, SCATTER_FORWARD) (eul/Euler_2.cpp:1455-1456)
+// begin_* / end_* are split so that the interior part of an operator (OperatorBase::mult_part) runs while the messages travel.
+class VecScatterHalo {
+public:
+    VecScatterHalo(Mesh* m, int form, const std::vector<int>& ranks, const std::vector<int>& ghost_idx, const std::vector<int>& ghost_off,
+                   const std::vector<int>& mirror_idx, const std::vector<int>& mirror_off) : mesh(m) {
+        const int nslots = form == 1 ? m->topo->n1 : m->topo->n0, nn = (int)ranks.size();
+        check(mimsem_halo_create(m->ctx, nn, ranks.data(), ghost_idx.data(), ghost_off.data(), mirror_idx.data(), mirror_off.data(),
+                                 nslots, m->geom->nk, &rev), "mimsem_halo_create(reverse)");
+        check(mimsem_halo_create(m->ctx, nn, ranks.data(), mirror_idx.data(), mirror_off.data(), ghost_idx.data(), ghost_off.data(),
+                                 nslots, m->geom->nk, &fwd), "mimsem_halo_create(forward)");
+        if (form == 1) {                       // the slots that travel: their element groups go first in the operators' plans
+            std::vector<int> shared(ghost_idx); shared.insert(shared.end(), mirror_idx.begin(), mirror_idx.end());
+            check(mimsem_ctx_set_halo_slots(m->ctx, 1, shared.data(), (int)shared.size()), "mimsem_ctx_set_halo_slots");
+        }
+    }
+    ~VecScatterHalo() { mimsem_halo_destroy(rev); mimsem_halo_destroy(fwd); }
+    VecScatterHalo(const VecScatterHalo&) = delete;
+    VecScatterHalo& operator=(const VecScatterHalo&) = delete;
+    void use_rccl(void* nccl_comm) { check(mimsem_halo_set_rccl(rev, nccl_comm), "set_rccl"); check(mimsem_halo_set_rccl(fwd, nccl_comm), "set_rccl"); }
+    void use_transport(mimsem_halo_transport_fn fn, void* user) { check(mimsem_halo_set_transport(rev, fn, user), "set_transport"); check(mimsem_halo_set_transport(fwd, fn, user), "set_transport"); }
+    void use_loopback() { check(mimsem_halo_set_loopback(rev), "set_loopback"); check(mimsem_halo_set_loopback(fwd), "set_loopback"); }
+    void begin_reverse_add(double* v, int nlev, long long stride) { check(mimsem_halo_begin(rev, MIMSEM_HALO_ADD, nlev, v, stride), "halo_begin"); }
+    void end_reverse_add() { check(mimsem_halo_end(rev), "halo_end"); }
+    void begin_forward_insert(double* v, int nlev, long long stride) { check(mimsem_halo_begin(fwd, MIMSEM_HALO_INSERT, nlev, v, stride), "halo_begin"); }
+    void end_forward_insert() { check(mimsem_halo_end(fwd), "halo_end"); }
+    void reverse_add(double* v, int nlev, long long stride) { begin_reverse_add(v, nlev, stride); end_reverse_add(); }
+    void forward_insert(double* v, int nlev, long long stride) { begin_forward_insert(v, nlev, stride); end_forward_insert(); }
+private:
+    Mesh* mesh; mimsem_halo *rev = nullptr, *fwd = nullptr;
+};
+
 // common part of every operator class: remembers what assemble() was given, mult() issues the fused launch
 class OperatorBase {
 protected:
@@ -158,6 +193,12 @@ public:
     Mesh* device_mesh() const { return mesh; }
     // MatMult(X->M, x, y) on device vectors (single level, like the reference)
     void mult(const double* x, double* y) const { apply(x, y, 0u); }
+    // the same MatMult in two parts around a halo exchange: mult_part(x, y, MIMSEM_PART_BOUNDARY); halo.begin_reverse_add(y, ...);
+    // mult_part(x, y, MIMSEM_PART_INTERIOR); halo.end_reverse_add()  -- no other operator of this Mesh between the two parts
+    void mult_part(const double* x, double* y, int part) const {
+        if (up) { if (part != MIMSEM_PART_INTERIOR) apply(x, y, 0u); return; }      // upwinded variants run whole in the boundary part
+        check(mimsem_op_apply_part(mesh->ctx, op, lev, 1, scale, flags, field, 0, x, 0, y, 0, 1.0, part), "mimsem_op_apply_part");
+    }
     // MatMult(X->MT, x, y): the transpose the assemble_up variants build with MatTranspose (eul/Assembly.cpp:261)
     void mult_MT(const double* x, double* y) const { apply(x, y, MIMSEM_FLAG_TRANSPOSE); }
     // the dense element blocks the reference hands to MatSetValues (device, [nEl][esz])

@@ -264,6 +264,29 @@ int main() {
         for (double* q : dv) mimsem_free(q);
         mimsem_free(d_du); mimsem_free(d_dr); mimsem_free(d_de); mimsem_free(d_dp);
     }
+    // VecScatterBegin/End behind the ABI (eul/Assembly.cpp:2194-2195), loop-back transport: the "ghost" edges of this single patch
+    // are sent to "mirror" edges of the same patch and added there, with the operator split around the exchange
+    {
+        M1.assemble(0, SCALE, true);
+        std::vector<int> ranks{0}, ghost, mirror, off;
+        for (int i = 0; i < 12; i++) { ghost.push_back(3*i + 1); mirror.push_back(P->n1 - 2 - 5*i); }
+        off = {0, 12};
+        VecScatterHalo halo(&mesh, 1, ranks, ghost, off, mirror, off);
+        halo.use_loopback();
+        std::vector<double> whole(P->n1), split(P->n1);
+        M1.mult(d_u, d_y); mesh.to_host(whole.data(), d_y, whole.size());
+        for (int i = 0; i < 12; i++) whole[mirror[i]] += whole[ghost[i]];          // what REVERSE / ADD does
+        for (int i = 0; i < 12; i++) whole[ghost[i]] = whole[mirror[i]];           // then FORWARD / INSERT
+        M1.mult_part(d_u, d_y, MIMSEM_PART_BOUNDARY);
+        halo.begin_reverse_add(d_y, 1, P->n1);
+        M1.mult_part(d_u, d_y, MIMSEM_PART_INTERIOR);
+        halo.end_reverse_add();
+        halo.forward_insert(d_y, 1, P->n1);
+        mesh.to_host(split.data(), d_y, split.size());
+        double worst = 0.0;
+        for (int i = 0; i < P->n1; i++) worst = std::max(worst, std::fabs(split[i] - whole[i]));
+        std::printf("%-8s max abs diff = %.3e\n", "Halo", worst); if (!(worst == 0.0)) fails++;
+    }
     mimsem_free(d_u); mimsem_free(d_h); mimsem_free(d_y);
     orc_patch_destroy(P);
     Mesh::release_all();
