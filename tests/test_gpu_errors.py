@@ -138,3 +138,62 @@ def test_column_wrappers_reject_wrong_shapes(small):
     y = eng.colop_apply("CONLIN_W", col(nk - 1), f1=col(nk - 1), nout_slots=nk)
     yt = eng.colop_apply("CONLIN_W", col(nk), f1=col(nk - 1), nout_slots=nk - 1, transpose=True)
     assert y.shape == (nEl, nk * n2) and yt.shape == (nEl, (nk - 1) * n2) and bool(torch.isfinite(y).all())
+
+
+def test_round2_entry_points_reject_bad_arguments(small):
+    """mimsem_op_apply_part, mimsem_ctx_set_halo_slots, mimsem_op_wave_stats, mimsem_vec_combine, mimsem_interface_average,
+    mimsem_halo_*: negative codes, never a launch"""
+    from mimsem_amd._lib import OPS
+    eng, dm, P = small
+    L, ctx = eng.L, eng.ctx
+    x = eng.tensor(np.ones((4, dm.n1))); y = eng.zeros(4, dm.n1)
+    px, py = x.data_ptr(), y.data_ptr()
+    part = lambda op, p: L.mimsem_op_apply_part(ctx, op, 0, 4, SCALE, 0, None, 0, px, dm.n1, py, dm.n1, 1.0, p)
+    assert part(OPS["UMAT"], 1) == 0 and part(OPS["UMAT"], 2) == 0       # always a valid sequence (here: whole op, then nothing)
+    assert part(OPS["UMAT"], 3) == ERR_ARG and part(OPS["UMAT"], -1) == ERR_ARG
+    assert part(OPS["UMAT_UP"], 1) == ERR_ARG                             # upwinded operators have their own entry point
+    bad = np.array([dm.n1], np.int32)
+    assert L.mimsem_ctx_set_halo_slots(ctx, 1, bad.ctypes.data, 1) == ERR_ARG
+    assert L.mimsem_ctx_set_halo_slots(ctx, 0, bad.ctypes.data, 0) == ERR_ARG      # 1-forms only
+    assert L.mimsem_ctx_set_halo_slots(None, 1, None, 0) == ERR_ARG
+    st = (C.c_int * 5)()
+    assert L.mimsem_op_wave_stats(ctx, 0, st) == ERR_ARG and L.mimsem_op_wave_stats(None, 4, st) == ERR_ARG
+    assert L.mimsem_vec_combine(ctx, 4, dm.n1, 1.0, px, dm.n1, 3, px, dm.n1, 0.0, None, 0, py, dm.n1) == ERR_ARG     # unknown op
+    assert L.mimsem_vec_combine(ctx, 4, dm.n1, 1.0, px, dm.n1, 1, None, 0, 0.0, None, 0, py, dm.n1) == ERR_ARG       # a*b without b
+    assert L.mimsem_vec_combine(ctx, 4, dm.n1, 1.0, None, 0, 0, None, 0, 0.0, None, 0, py, dm.n1) == ERR_ARG
+    assert L.mimsem_vec_combine(ctx, 0, dm.n1, 1.0, None, 0, 0, None, 0, 0.0, None, 0, None, 0) == 0                   # empty: no-op
+    assert L.mimsem_interface_average(ctx, 0, dm.n1, px, dm.n1, py, dm.n1) == ERR_ARG
+    out = C.c_void_p()
+    rk = np.array([0], np.int32); off_bad = np.array([3, 1], np.int32); idx = np.array([0, 1, 2], np.int32)
+    assert L.mimsem_halo_create(ctx, 1, rk.ctypes.data, idx.ctypes.data, off_bad.ctypes.data, idx.ctypes.data, off_bad.ctypes.data, dm.n1, 1, C.byref(out)) == ERR_ARG
+    assert L.mimsem_halo_create(ctx, 65, rk.ctypes.data, idx.ctypes.data, off_bad.ctypes.data, idx.ctypes.data, off_bad.ctypes.data, dm.n1, 1, C.byref(out)) == ERR_ARG
+    assert L.mimsem_halo_create(ctx, 0, None, None, None, None, None, dm.n1, 0, C.byref(out)) == ERR_ARG               # max_nlev >= 1
+    assert L.mimsem_halo_begin(None, 1, 1, py, dm.n1) == ERR_ARG and L.mimsem_halo_end(None) == ERR_ARG
+    # combine through the wrapper: shape mismatch is a MimsemError, not a launch
+    from mimsem_amd._lib import MimsemError
+    with pytest.raises(MimsemError):
+        eng.combine(x, 1.0, "mul", eng.zeros(3, dm.n1))
+    # and it computes what it says
+    import torch
+    b = eng.tensor(np.full((4, dm.n1), 2.0)); c = eng.tensor(np.full((4, dm.n1), 3.0))
+    assert torch.equal(eng.combine(x, 2.0, "div", b, beta=-1.0, c=c), torch.full_like(x, 2.0 * 0.5 - 3.0))
+    a = eng.tensor(np.arange(3 * 5, dtype=float).reshape(3, 5))
+    want = torch.stack([0.5 * a[0], 0.5 * (a[0] + a[1]), 0.5 * (a[1] + a[2]), 0.5 * a[2]])
+    assert torch.equal(eng.interface_average(a, 4), want)
+
+
+def test_set_halo_slots_refused_inside_a_capture(small):
+    """a set-up call that re-derives device tables must not run on a capturing stream (MIMSEM_ERR_STATE), and leaves the context usable"""
+    import torch
+    eng, dm, P = small
+    sl = np.array([0, 1], np.int32)
+    x = eng.tensor(np.ones((4, dm.n1))); y = eng.zeros(4, dm.n1)
+    rcs = []
+
+    def fn():
+        rcs.append(eng.L.mimsem_ctx_set_halo_slots(eng.ctx, 1, sl.ctypes.data, 2))
+        return eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)
+    g, out = eng.capture(fn)                       # runs fn once outside the capture (warm-up), once inside
+    assert rcs == [0, -4], rcs
+    g.replay(); torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1))
