@@ -115,10 +115,11 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
 //                DoFs alternately, so a pair is usually two wanted values): ONE dwordx4 load per level brings every DoF of the
 //                group; each loaded value is staged to the one or two elements that use it.
 //   store pairs: a pair of slots that are both COMPLETE in the group (every contributor inside it) is summed in LDS and written
-//                once, straight into y, as one 16-byte store; every other slot of the group (its perimeter, and complete slots
-//                without a complete partner) leaves a partial sum in a densely packed row of the workspace -- again in pairs --
-//                that k_gather_perim finishes.  With MIMSEM_WAVE_SINGLES=1 the unpaired complete slots get a second, 8-byte
-//                store round into y instead.
+//                once, straight into y, as one 16-byte store; so is a complete slot whose pair partner is a perimeter slot of the same
+//                group (the partner's half of the store carries 0 and is overwritten by the perimeter pass later in the stream);
+//                every other slot of the group (its perimeter, and complete slots whose partner is outside the group) leaves a
+//                partial sum in a densely packed row of the workspace -- again in pairs -- that k_wave_perim finishes.
+//                MIMSEM_WAVE_SINGLES=1: no mixed pairs, unpaired complete slots in a second, 8-byte store round instead.
 struct WavePlan {
     int ngroups = 0, nps = 0, npart = 0, nsing = 0, ndirect = 0, nbgroups = 0, nbrec = 0;
     std::vector<int> perm, pslot, ppart, node;
@@ -224,6 +225,18 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         for (size_t i = 0; i < slots.size(); i++) {
             const int s = slots[i];
             if (!(s & 1) && s + 1 < n1 && complete(s) && complete(s + 1)) { entries[g].push_back(int4{s, apack(s), apack(s + 1), 0}); P.ndirect += 2; i++; continue; }
+            if (!(s & 1) && in_group(s + 1) && complete(s) != complete(s + 1) && !singles) {
+                // MIXED pair, both slots in the group: the complete one is written in a full 16-byte store whose other half carries 0
+                // (accumulate form: adds 0).  That half belongs to a perimeter slot NO group writes directly -- its value comes from
+                // k_wave_perim, strictly later in the stream --, so the store clobbers nothing; the partial sum of the perimeter slot
+                // goes to the workspace as usual.  (A complete slot whose partner is not in the group at all stays routed: the
+                // partner may be written directly by its own group at the same time.)
+                const int zz = (int)(ZERO | (ZERO << 16));
+                entries[g].push_back(int4{s, complete(s) ? apack(s) : zz, complete(s + 1) ? apack(s + 1) : zz, 0});
+                P.ndirect += 1;
+                routed.push_back(complete(s) ? s + 1 : s);
+                i++; continue;
+            }
             routed.push_back(s);
         }
         if (singles) {                                                 // complete slots without a complete partner: 8-byte stores
