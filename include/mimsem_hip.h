@@ -201,6 +201,11 @@ int mimsem_op_element_matrices_ex(mimsem_ctx* ctx, int op, int geom_lev, double 
  * With blocks_level_stride = 0 the blocks stay in LDS while the kernel sweeps the levels, and elem_scale (nullable,
  * [nlev][elem_scale_stride >= nEl]) multiplies element e's result at level lev: B_e(lev) = elem_scale[lev][e] * B_e -- e.g. the
  * inverse 1-form mass blocks of all levels from ONE thickness-free inverse per element and 1/thickInv per (level, element). */
+/* In-place inverse of nblocks dense n x n blocks (row-major, contiguous): the batched Gauss-Jordan behind WmatInv / WhmatInv and the
+ * column operators (LinAlg::Inv, eul/LinAlg.cpp:186-269: natural-order sweep for the SPD mass blocks with the reference's full-pivoting
+ * algorithm as the fall-back) for the element-block preconditioners of the Krylov solves (PCBJACOBI blocks, eul/HorizSolve.cpp:88-90):
+ * one block per thread in LDS above n = 16; MIMSEM_ERR_UNSUPPORTED when a single block no longer fits 160 KB (n > ~140).                 */
+int mimsem_block_inverse(mimsem_ctx* ctx, long long nblocks, int n, double* blocks);
 int mimsem_elem_blocks_apply(mimsem_ctx* ctx, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
                              const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long x_stride, double* y, long long y_stride, double alpha);

@@ -901,6 +901,11 @@ int mimsem_op_element_matrices(mimsem_ctx* c, int op, int geom_lev, double scale
     return launch_elmats(c, op, geom_lev, scale, flags, f, out);
 }
 
+int mimsem_block_inverse(mimsem_ctx* c, long long nblocks, int n, double* blocks) {
+    if (!c || nblocks < 0 || n < 1 || (nblocks && !blocks)) return MIMSEM_ERR_ARG;
+    return mimsem_block_inverse_inplace(c, nblocks, n, blocks);      // MIMSEM_ERR_UNSUPPORTED when one block no longer fits a workgroup's LDS
+}
+
 int mimsem_elem_blocks_apply(mimsem_ctx* c, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
                              const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long xs, double* y, long long ys, double alpha) {

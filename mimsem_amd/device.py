@@ -724,9 +724,22 @@ class Engine:
         check(self.L.mimsem_interface_average(self.ctx, nk, a.shape[1], a.data_ptr(), a.stride(0), out.data_ptr(), out.stride(0)), "interface_average")
         return out
 
+    def block_inverse(self, blocks):
+        """inverse of every [n, n] block of a [nblocks, n, n] tensor by the library's batched Gauss-Jordan (mimsem_block_inverse);
+        returns a new tensor"""
+        if blocks.dim() != 3 or blocks.shape[1] != blocks.shape[2] or blocks.dtype != torch.float64:
+            raise _lib.MimsemError("block_inverse: [nblocks, n, n] float64 tensor required")
+        out = blocks.contiguous().clone()
+        check(self.L.mimsem_block_inverse(self.ctx, out.shape[0], out.shape[1], out.data_ptr()), "block_inverse")
+        return out
+
     def norm(self, x):
-        """2-norm of a whole (single-rank) vector; DistEngine overrides with the ownership-weighted, all-reduced version"""
-        return float(torch.linalg.vector_norm(x))
+        """2-norm of a whole (single-rank) vector by the library's two-stage row-dot; DistEngine overrides with the ownership-weighted,
+        all-reduced version"""
+        v = x.reshape(1, -1)
+        if not v.is_contiguous():
+            v = v.contiguous()
+        return float(torch.sqrt(self.rowdot(v, v))[0])
 
     def complete(self, form, y):
         """single rank: results are already complete (DistEngine reduces the halo here)"""

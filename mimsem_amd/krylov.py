@@ -158,7 +158,7 @@ class MassSolver:
             # LDS while the kernel sweeps the levels, times 1/tau per (level, element)
             em = eng.element_matrices("UMAT", lev=0, scale=scale, flags=0).view(eng.nEl, 2, 2, n1e, n1e)
             B = em.permute(0, 1, 3, 2, 4).reshape(eng.nEl, 2 * n1e, 2 * n1e)
-            self.blocks = (d[:, :, None] * torch.linalg.inv(B) * d[:, None, :]).contiguous()
+            self.blocks = (d[:, :, None] * getattr(eng, "eng", eng).block_inverse(B) * d[:, None, :]).contiguous()
             tau = torch.as_tensor(dm.thickInv, device=eng.device).mean(dim=2) if vert_scale else \
                 torch.ones(eng.nk, eng.nEl, dtype=torch.float64, device=eng.device)
             self.escale = (1.0 / tau).contiguous()

@@ -73,7 +73,7 @@ class SWEqn:
         mult[0].index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=eng.device))
         mult = eng.complete(1, mult)[0]                                          # sharded: count the sharers on other ranks too
         d = 1.0 / mult[idx]                                                      # [nEl, 2 n1e]
-        Binv = torch.linalg.inv(B)
+        Binv = getattr(eng, "eng", eng).block_inverse(B)      # the library's batched Gauss-Jordan (24 x 24 SPD blocks)
         return (d[:, :, None] * Binv * d[:, None, :]).contiguous()
 
     def precond_M1(self, r, out=None):
@@ -258,7 +258,7 @@ class SWEqn:
         mult[0].index_add_(0, idx.reshape(-1), torch.ones(idx.numel(), dtype=torch.float64, device=dev))
         mult = eng.complete(1, mult)[0]
         d = torch.cat([1.0 / mult[idx], torch.ones(nEl, n2e, dtype=torch.float64, device=dev)], dim=1)
-        C = d[:, :, None] * torch.linalg.inv(Ae) * d[:, None, :]
+        C = d[:, :, None] * getattr(self.eng, "eng", self.eng).block_inverse(Ae) * d[:, None, :]
         return C.transpose(1, 2).contiguous()                     # column-major per element
 
     def _krylov_body(self, dt):
