@@ -732,7 +732,8 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     // interior / boundary split: only the wave-level form with marked halo slots really splits; everything else runs whole as
     // "the boundary part" and has nothing left for "the interior part", so callers can always issue both
     const bool wave_op = op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H;
-    const bool splits = part != 0 && c->wave1 && c->w_split && wave_op && !epi;
+    const bool splits = part != 0 && c->wave1 && c->w_split && wave_op && !epi &&
+                        (long long)c->n1 < (1LL << 28) && (long long)c->n0 < (1LL << 28) && (long long)c->n2 < (1LL << 28) && (long long)c->nEl*c->es.mp12 < (1LL << 28);
     if (part == MIMSEM_PART_INTERIOR && !splits) return MIMSEM_OK;
     int in, cf, outsp;
     if (op_spaces(op, &in, &cf, &outsp)) return MIMSEM_ERR_ARG;
@@ -797,7 +798,10 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }
-    if (c->wave1 && (op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H)) {
+    // the wave kernel addresses its rows with 32-bit byte offsets: vectors / metric beyond 4 GB per level stay on the two-pass form
+    const bool wave_fits = (long long)c->n1 < (1LL << 28) && (long long)c->n0 < (1LL << 28) && (long long)c->n2 < (1LL << 28) &&
+                           (long long)c->nEl*es.mp12 < (1LL << 28);
+    if (c->wave1 && wave_fits && wave_op) {
         // wave-level fused path: complete slots straight into y, one partial per perimeter slot into the workspace, perimeter pass
         const long long prow = (long long)c->w_npart + 128;              // partial sums of a level + the dump tail (64 lanes x 16 bytes)
         if ((rc = c->ensure_ye(prow*nlev))) return rc;
