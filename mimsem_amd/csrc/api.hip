@@ -764,6 +764,23 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     if (c->profiling && (c->prof_count++ % c->prof_every) == 0) { c->ev_k1[0] = c->next_event(); c->ev_k1[1] = c->next_event(); c->ev_k2[0] = c->next_event(); c->ev_k2[1] = c->next_event(); }
     if (outsp == 2) {
         a.out = y; a.os = ys;
+        // Wmat itself stays on k_elem_apply by default: measured 9.3e9 applies/s there against 8.2e9 on the DPP kernel (its element algebra
+        // is four DPP stages for 9 values); Whmat +3 %, WtQUmat +14 % (profiles/r02_wave_ab.txt).  MIMSEM_WAVE2=2 includes Wmat, 0 none.
+        const bool wave2_op = (op == MIMSEM_OP_WMAT && c->wave2_mode == 2) || op == MIMSEM_OP_WHMAT || op == MIMSEM_OP_WTQUMAT || op == MIMSEM_OP_WTQDUDZ;
+        const bool fits = (long long)c->n1 < (1LL << 28) && (long long)c->n2 < (1LL << 28) && (long long)c->nEl*es.mp12 < (1LL << 28);
+        if (c->wave1 && es.n == 3 && wave2_op && fits && part == 0 && c->wave2_mode != 0) {
+            // p = 3: the wave-level kernel of the 2-form-valued operators (no scatter: one launch)
+            if ((rc = c->ensure_ye(64))) return rc;
+            a.wlane = c->d_wlane; a.wplan = nullptr; a.wgroups = c->w_ngroups; a.wg0 = 0; a.wdump = 0; a.wsing = nullptr; a.wnode = nullptr;
+            a.wG = c->d_wG; a.wR = c->d_wR; a.wstamps = nullptr;
+            a.lch = wave_level_chunk(c, nlev); a.wcpp = wave_chunks_per_item(c, nlev, a.lch, c->w_ngroups); a.swz = c->wave_order;
+            a.accum = (flags & MIMSEM_FLAG_ACCUM) ? 1 : 0; a.y = c->d_ye;       // a.y: the dump for idle lanes
+            for (size_t k = 0; k < 20; k++) a.Etab[k] = k < c->tab.E.size() ? c->tab.E[k] : 0.0;
+            for (size_t k = 0; k < 5; k++) a.Wq[k] = k < c->tab.quad.w.size() ? c->tab.quad.w[k] : 0.0;
+            rc = launch_apply_wave2(c, op, a);
+            c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+            return rc;
+        }
         rc = launch_elem_apply(c, op, a);
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;

@@ -67,6 +67,7 @@ struct mimsem_ctx {
     bool wave1 = false;
     int wave_order = 3;                 // bit 0: XCD-contiguous block order, bit 1: group-major items (MIMSEM_WAVE_ORDER)
     int wave_lch = 0;                   // MIMSEM_WAVE_LCH override of the levels per chunk
+    int wave2_mode = 1;                 // MIMSEM_WAVE2: 2-form-valued operators on k_apply_wave2 (p = 3): 0 none, 1 Whmat / WtQUmat / WtQdUdz, 2 also Wmat
     int wave_cpp = 0;                   // MIMSEM_WAVE_CPP override of the chunks per work item (0: heuristic)
     int w_ngroups = 0, w_nsing = 0, w_nps = 0, w_npart = 0, w_ndirect = 0;
     int w_nbgroups = 0, w_nbrec = 0; bool w_split = false;     // interior / boundary split (mimsem_ctx_set_halo_slots): boundary prefix sizes
@@ -135,6 +136,7 @@ struct ElemArgs {
     // wave-level fused scatter-add (k_apply_wave)
     const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump; int wcpp;
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
+    double Wq[5];                    // GLL weights by value (orders <= 4)
     long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null
     // direct path: DoFs touched by exactly ONE element are written straight into y (no ye round trip, no pass 2 for them)
     const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
@@ -159,6 +161,7 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
                         const int* pslot = nullptr, const int* ppart = nullptr, int nps = -1);
 int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a);
+int launch_apply_wave2(mimsem_ctx* c, int op, const ElemArgs& a);
 int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys, int r0 = 0, int r1 = -1);
 int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, int accum,
                       double* y, long long ys, bool shared_only = false);

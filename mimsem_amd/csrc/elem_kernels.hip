@@ -1432,6 +1432,30 @@ static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
+// the 2-form-valued operators at p = 3 on the wave-level footing (elem_wave.inc: k_apply_wave2): one launch, no second pass
+int launch_apply_wave2(mimsem_ctx* c, int op, const ElemArgs& a) {
+    if (c->es.n != 3 || a.lch > WLC || a.lch < 1 || a.wcpp < 1 || (a.wcpp > 1 && a.lch != WLC)) return MIMSEM_ERR_ARG;
+    const int nch = (a.nlev + a.lch - 1)/a.lch;
+    const long long items = (long long)a.wgroups*((nch + a.wcpp - 1)/a.wcpp);
+    if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)((items + WNW - 1)/WNW);
+    if (grid == 0) return MIMSEM_OK;
+#define MIMSEM_W2(OPV, LCT, ACC) \
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave2<OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_apply_wave2<OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, a)
+#define MIMSEM_W2CASE(OPV) case OPV: \
+        if (a.lch == 1) { if (a.accum) { MIMSEM_W2(OPV, 1, true); } else { MIMSEM_W2(OPV, 1, false); } } \
+        else            { if (a.accum) { MIMSEM_W2(OPV, WLC, true); } else { MIMSEM_W2(OPV, WLC, false); } } \
+        break;
+    switch (op) {
+        MIMSEM_W2CASE(MIMSEM_OP_WMAT) MIMSEM_W2CASE(MIMSEM_OP_WHMAT) MIMSEM_W2CASE(MIMSEM_OP_WTQUMAT) MIMSEM_W2CASE(MIMSEM_OP_WTQDUDZ)
+    default: return MIMSEM_ERR_ARG;
+    }
+#undef MIMSEM_W2CASE
+#undef MIMSEM_W2
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
 int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys, int r0, int r1) {
     if (r1 < 0) r1 = c->w_nps;
     const int nps = r1 - r0;

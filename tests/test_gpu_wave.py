@@ -40,6 +40,12 @@ def engines(request):
         two = Engine(dm)
     finally:
         del os.environ["MIMSEM_WAVE"]
+    os.environ["MIMSEM_WAVE2"] = "2"                     # Wmat too on the DPP kernel (off by default: slower there)
+    try:
+        wave_all = Engine(dm)
+    finally:
+        del os.environ["MIMSEM_WAVE2"]
+    wave.wave_all = wave_all
     assert two.L.mimsem_op_wave_stats(two.ctx, NK, st) == 0
     return pn, dm, wave, two, (cs, topos, geoms)
 
@@ -72,6 +78,40 @@ def test_wave_form_equals_two_pass_form(engines, op, fl):
     a1 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
     a2 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
     assert torch.equal(a1, a2)
+
+
+CASES2 = [("WMAT", 1), ("WMAT", 0), ("WHMAT", 1), ("WHMAT", 0), ("WTQUMAT", 0), ("WTQDUDZ", 0)]
+
+
+@pytest.mark.parametrize("op,fl", CASES2, ids=["%s_%d" % c for c in CASES2])
+def test_two_form_valued_operators_on_the_wave_kernel(engines, op, fl):
+    """p = 3: Wmat, Whmat, WtQUmat, WtQdUdz_mat through k_apply_wave2 (one launch, all of the element algebra through DPP) against the
+    k_elem_apply form of the same library (MIMSEM_WAVE=0)"""
+    import torch
+    pn, dm, wave, two, _ = engines
+    if pn != 3:
+        pytest.skip("k_apply_wave2 exists at p = 3")
+    if op == "WMAT":
+        wave = wave.wave_all
+    r = np.random.default_rng(23)
+    x = r.standard_normal((NK, dm.n2 if op in ("WMAT", "WHMAT") else dm.n1))
+    f = {"WHMAT": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6, "WTQUMAT": r.standard_normal((NK, dm.n1)) * 1e3, "WTQDUDZ": r.standard_normal((NK, dm.n1)) * 1e3}.get(op)
+    for lev0, nlev in ((0, NK), (3, 2), (6, 1)):
+        xs = x[:nlev]; fs = None if f is None else f[:nlev]
+        a = wave.apply(op, wave.tensor(xs), f=None if fs is None else wave.tensor(fs), lev0=lev0, scale=SCALE, flags=fl)
+        b = two.apply(op, two.tensor(xs), f=None if fs is None else two.tensor(fs), lev0=lev0, scale=SCALE, flags=fl)
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-13, (op, lev0, nlev)
+        for k in range(nlev):
+            assert rel_l2(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-12, (op, lev0, k)
+    base = r.standard_normal((NK, dm.n2))
+    ya, yb = wave.tensor(base), two.tensor(base)
+    wave.apply(op, wave.tensor(x), f=None if f is None else wave.tensor(f), lev0=0, scale=SCALE, flags=fl | 2, alpha=0.75, out=ya)
+    two.apply(op, two.tensor(x), f=None if f is None else two.tensor(f), lev0=0, scale=SCALE, flags=fl | 2, alpha=0.75, out=yb)
+    assert rel_l2(ya.cpu().numpy(), yb.cpu().numpy()) < 1e-13, op
+    a1 = wave.apply(op, wave.tensor(x), f=None if f is None else wave.tensor(f), lev0=0, scale=SCALE, flags=fl)
+    assert torch.equal(a1, wave.apply(op, wave.tensor(x), f=None if f is None else wave.tensor(f), lev0=0, scale=SCALE, flags=fl))
+    single = wave.apply(op, wave.tensor(x[4]), f=None if f is None else wave.tensor(f[4]), lev0=4, scale=SCALE, flags=fl)
+    assert torch.equal(single, a1[4])                                  # level batch == single level, bit for bit
 
 
 def test_wave_form_against_the_oracle(engines, oracle):
