@@ -424,6 +424,8 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     c->w_nbgroups = P.nbgroups; c->w_nbrec = P.nbrec; c->w_split = marked != nullptr; c->wave1 = true;
     if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
     if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
+    if (const char* ev = getenv("MIMSEM_WAVE_CPP")) c->wave_cpp = atoi(ev);
+    if (const char* ev = getenv("MIMSEM_WAVE2")) c->wave2_mode = atoi(ev);
     if (getenv("MIMSEM_VERBOSE"))
         fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials) of %d\n",
                 P.ngroups, 64/lpe, P.nbgroups, P.nps, P.npart, c->n1);
