@@ -84,6 +84,59 @@ def launch_bytes(eng, dmesh, nlev):
     return bm, "k_elem_apply<3,UMAT>", "k_gather_sum<2>", lch
 
 
+def measure_pmc_traffic(timeout=150):
+    """HBM-side bytes per launch of the step's kernels, measured IN THIS RUN: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE --
+    separately, with --kernel-trace only, the program itself after `--`, as MI355X_MICROARCH.md prescribes) over
+    scripts/pmc_traffic.py: a calibration launch of known byte count (k_halo_pack over an identity index list: pins the gfx950
+    FETCH_SIZE x2 correction) and the same Umat step, cache-resident and on 8 spheres.  The children are separate processes (this one
+    keeps its GPU context and is idle meanwhile).  Returns {kernel: [{grid_threads, read_bytes, write_bytes, total_bytes}, ...]} or
+    raises; ~25 s."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="mimsem_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic.py")],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                raise RuntimeError("rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:]))
+            rows = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter:
+                        rows[(row["Kernel_Name"], int(row["Grid_Size"]))].append(float(row["Counter_Value"]) * 1024.0)     # KiB -> bytes
+            vals[counter] = {k: sum(v) / len(v) for k, v in rows.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    F, W = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    cal = [(k, v) for k, v in F.items() if "k_halo_pack" in k[0]]
+    if not cal:
+        raise RuntimeError("calibration launch missing from the counter file")
+    n = cal[0][0][1]                                       # one thread per packed double: n*8 bytes of data + n*4 of indices read
+    factor = (n * 8 + n * 4) / cal[0][1]
+    out = {"fetch_correction": round(factor, 4), "kernels": {}}
+    names = (("k_apply_wave", "k_apply_wave<3,UMAT>"), ("k_wave_perim", "k_wave_perim"), ("k_elem_apply", "k_elem_apply<3,UMAT>"),
+             ("k_gather_sum", "k_gather_sum<2>"))
+    for (k, g), v in sorted(F.items(), key=lambda kv: kv[0][1]):
+        for key, name in names:
+            if key in k:
+                out["kernels"].setdefault(name, []).append({"grid_threads": g, "read_bytes": v * factor, "write_bytes": W.get((k, g), 0.0),
+                                                            "total_bytes": v * factor + W.get((k, g), 0.0)})
+                break
+    return out
+
+
 def cpu_worker(args):
     """one host core: reference-structure assemble+MatMult on a 12x12-element patch for ~`budget` seconds"""
     budget, seed = args
@@ -296,8 +349,7 @@ def roofline_entry(bm, k1, k12, cache_resident, note, kname="k_elem_apply<3,UMAT
     a12 = bm["op_compulsory"] / k12 / 1e9
     return {"bound": "hbm", "kernel": kname, "achieved": a1, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": a1 / HBM_PEAK_GBS, "traffic": None,
-            "traffic_note": "PMC counters are not collected inside bench.py (they need rocprofv3 passes): null here; the same-round "
-                            "profiles/ summaries hold the measured FETCH_SIZE/WRITE_SIZE of this launch",
+            "traffic_note": "filled by the child rocprofv3 --pmc passes at the end of the run (absent with --no-pmc / N > 1: null)",
             "cache_resident": cache_resident, "note": note,
             "avg_kernel_us": k1 * 1e6, "units_per_launch": bm["units"],
             "bytes_per_launch": bm["k1_compulsory"], "bytes_per_unit": bm["k1_compulsory"] / bm["units"],
@@ -359,6 +411,7 @@ def main():
     ap.add_argument("--no-column", action="store_true", help="skip the column-solves/s extra (reported by default at N = 1, ~3 s)")
     ap.add_argument("--no-sw", action="store_true", help="skip the shallow-water time-steps/s extra (reported by default at N = 1, ~20 s)")
     ap.add_argument("--sw", action="store_true", help="extra: shallow-water Picard time steps/s (BASELINE configs 2 and 3 grids)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two child rocprofv3 --pmc passes that fill roofline.traffic (~25 s)")
     ap.add_argument("--no-horiz-sharded", action="store_true", help="N > 1: skip the sharded HorizSolve right-hand-side extra (~10 s)")
     ap.add_argument("--cold", type=int, default=8, metavar="R",
                     help="roofline_cold (not the headline value): the same step on R independent copies of the sphere, "
@@ -681,6 +734,25 @@ def main():
         if rank == 0:
             out["sw_sharded"] = {"workload": "SWEqn::solve, Galewsky-style (2 Picard iterations), 24x24x6 sphere sharded over the ranks",
                                  "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "krylov_iterations_last": dict(S.its)}
+    if rank == 0 and world == 1 and not a.no_pmc and "roofline" in out:
+        # roofline.traffic: HBM-side bytes per launch of the dominant kernel from PMC counters collected in THIS run (child rocprofv3
+        # passes); traffic_frac = those bytes over the in-run kernel time, against the 8 TB/s peak
+        try:
+            pm = measure_pmc_traffic()
+            kn = out["roofline"]["kernel"]
+            launches = sorted(pm["kernels"].get(kn, []), key=lambda r: r["grid_threads"])
+            if launches:
+                for key, rec in (("roofline", launches[0]), ("roofline_cold", launches[-1])):
+                    if key in out and "avg_kernel_us" in out[key] and (key == "roofline" or len(launches) > 1):
+                        out[key]["traffic"] = rec["total_bytes"]
+                        out[key]["traffic_GBs"] = rec["total_bytes"] / (out[key]["avg_kernel_us"] * 1e-6) / 1e9
+                        out[key]["traffic_frac"] = out[key]["traffic_GBs"] / HBM_PEAK_GBS
+                        out[key]["traffic_note"] = ("FETCH_SIZE x %.2f (calibrated on a launch of known byte count) + WRITE_SIZE of this launch, "
+                                                    "child rocprofv3 --pmc passes of this run (scripts/pmc_traffic.py)" % pm["fetch_correction"])
+                out["roofline"].pop("traffic_from_committed_profile", None)
+                out["pmc_traffic"] = pm
+        except Exception as ex:          # noqa: BLE001 -- the headline line never depends on the profiler being usable
+            out["roofline"]["traffic_note"] = "PMC passes not available in this run (%s: %s): traffic stays null" % (type(ex).__name__, str(ex)[:200])
     if rank == 0 and world == 1 and not a.no_cpu:
         extra("cpu_baseline", cpu_baseline)
     if rank == 0:

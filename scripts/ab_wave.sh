@@ -3,7 +3,7 @@
 # MIMSEM_WAVE_CPP = chunks of 8 levels per wavefront (default: balanced parts leaving >= 1536 wavefronts), MIMSEM_WAVE_ORDER, MIMSEM_WAVE_LCH.
 # bench.py hot (103 680 units) and cold (829 440 units); all variants in ONE run (boxes of the pool differ by ~10 %).
 out=gpurun_out/ab_wave.log; : > $out
-run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-sw --no-column 2>>gpurun_out/ab_wave.err | python -c "
+run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_wave.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d['roofline_cold']
 print('value %.3e ms/step %.4f | hot k1 %.2f us op %.2f us | cold k1 %.2f us op %.2f us value %.3e' % (d['value'], d['ms_per_step'], r['avg_kernel_us'], r['whole_operator']['avg_us'], c['avg_kernel_us'], c['whole_operator']['avg_us'], c['value']))" >> $out; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B on the GPU box: wavefronts per workgroup of k_apply_wave (rebuilt in the box's ephemeral copy) and kernel arguments in device memory
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; env "$@" python bench.py --no-cpu --no-sw --no-column 2>/dev/null | python -c "
+run() { echo "== $*"; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d['roofline_cold']
 print('value %.3e ms/step %.4f | hot k1 %.2f us op %.2f us | cold k1 %.2f us op %.2f us value %.3e' % (d['value'], d['ms_per_step'], r['avg_kernel_us'], r['whole_operator']['avg_us'], c['avg_kernel_us'], c['whole_operator']['avg_us'], c['value']))"; }

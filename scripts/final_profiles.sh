@@ -6,9 +6,9 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 python bench.py --steps 300 --warmup 30 > $O/bench_default.json 2> $O/bench_default.err || exit 1
-python bench.py --no-cpu --families --column --box --sw --horiz --pcie > $O/bench_extras.json 2> $O/bench_extras.err || exit 1
+python bench.py --no-cpu --no-pmc --families --column --box --sw --horiz --pcie > $O/bench_extras.json 2> $O/bench_extras.err || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r02 -- python3 $R/bench.py --no-cpu --no-sw --no-column --steps 300 --warmup 30 > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r02 -- python3 $R/bench.py --no-cpu --no-pmc --no-sw --no-column --steps 300 --warmup 30 > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o r02 -- python3 $R/scripts/pmc_traffic.py > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o r02 -- python3 $R/scripts/pmc_traffic.py > $O/pmc_write.log 2>&1 || exit 1
 cd $R
