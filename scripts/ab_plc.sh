@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B on the GPU box: levels per thread of k_wave_perim (rebuilt in the box's ephemeral copy of the repo)
+cd $GRAFT_REPO_ROOT
+run() { echo "== $*"; python bench.py --no-cpu --no-pmc --no-sw --no-column 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d['roofline_cold']
+print('value %.3e ms/step %.4f | hot k1 %.2f us op %.2f us | cold k1 %.2f us op %.2f us value %.3e' % (d['value'], d['ms_per_step'], r['avg_kernel_us'], r['whole_operator']['avg_us'], c['avg_kernel_us'], c['whole_operator']['avg_us'], c['value']))"; }
+run PLC=8
+for n in 4 2 16; do
+  (cd mimsem_amd/csrc && rm -f elem_kernels.o && make CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMIMSEM_PLC=$n" > /tmp/b.log 2>&1) || { tail -3 /tmp/b.log; continue; }
+  run PLC=$n
+done
