@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
 
 // block-preconditioned Richardson, middle pass: r_e = (b - gather(ye)) restricted to the element (gathered on the fly through
 // the 1-form plan), z_e = B_e r_e with B_e stored column-major ([c][r]); z_e goes to the second element-local buffer.
-template <int N>
+template <int N, int LC>
 __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
@@ -638,32 +638,48 @@ __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int 
     double brow[ND];
     int slot = 0, p0 = -1, p1 = -1;
     if (act) {
+        slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
+        p0 = plan[(size_t)slot*2]; p1 = plan[(size_t)slot*2 + 1];
+    }
+    // (staging the block through LDS with nine 16-byte loads per lane instead of 24 eight-byte ones was measured: no change, 23.9 us --
+    // after the level prefetch the kernel is bound by its 12 broadcast ds_read_b128 + 24 FMAs per level, not by the addresser)
+    if (act) {
         const double* Be = B + (size_t)e*ND*ND + r;
 #pragma unroll
         for (int c = 0; c < ND; c++) brow[c] = Be[(size_t)c*ND];
-        slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
-        p0 = plan[(size_t)slot*2]; p1 = plan[(size_t)slot*2 + 1];
     } else {
 #pragma unroll
         for (int c = 0; c < ND; c++) brow[c] = 0.0;
     }
-    for (int lev = l0; lev < l1; lev++) {
-        double* sx = s_x[lev & 1][el];
-        if (act) {
-            const double* src = ye + (size_t)lev*yes;
-            double acc = 0.0;
-            if (p0 >= 0) acc += src[p0];
-            if (p1 >= 0) acc += src[p1];
-            sx[r] = b[(size_t)lev*bs + slot] - acc;
-        }
-        wave_lds_sync();
-        if (act) {
-            double s = 0.0;
+    // Every level of the chunk is requested before the first is used (round 2): with one level in flight at a time the kernel was a
+    // chain of lch memory latencies per wavefront (30.8 us for 103 680 units, 38 % of HorizSolve's right-hand sides).  Branch-free
+    // loads on clamped addresses (idle lanes re-read slot 0), so that the wait counts stay exact.
+    // LC: compile-time bound on lch (8, the launcher's cap; 1 for single-level calls, which would otherwise do eight levels' work)
+    const bool m0 = act && p0 >= 0, m1 = act && p1 >= 0;
+    const int q0 = m0 ? p0 : 0, q1 = m1 ? p1 : 0;
+    double a0[LC], a1[LC], bb[LC], es[LC];
 #pragma unroll
-            for (int c = 0; c < ND; c++) s += brow[c]*sx[c];
-            if (escale) s *= escale[(size_t)lev*ess + e];
-            ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
-        }
+    for (int l = 0; l < LC; l++) {
+        const int lev = min(l0 + l, max(nlev - 1, 0));
+        const double* src = ye + (size_t)lev*yes;
+        a0[l] = src[q0]; a1[l] = src[q1];
+        bb[l] = b[(size_t)lev*bs + slot];
+        es[l] = escale ? escale[(size_t)lev*ess + e] : 1.0;
+    }
+#pragma unroll
+    for (int l = 0; l < LC; l++) {
+        const int lev = l0 + l;
+        double* sx = s_x[l & 1][el];
+        double acc = 0.0;
+        if (m0) acc += a0[l];
+        if (m1) acc += a1[l];
+        sx[r] = bb[l] - acc;
+        wave_lds_sync();
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < ND; c++) s += brow[c]*sx[c];
+        s *= es[l];
+        if (act && lev < l1) ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
     }
 }
 
@@ -1516,11 +1532,12 @@ static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const dou
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
-    int lch = (int)(((long long)((c->nEl + EPB - 1)/EPB)*nlev)/(256*6));             // ~6 workgroups per CU, as k_elem_apply
-    lch = std::max(1, std::min(lch, 8)); lch = std::min(lch, std::max(nlev, 1));
+    const int lch = std::max(1, std::min(nlev, 8));       // the kernel works through 8 levels per item whether the chunk has them or not
     const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
-    hipLaunchKernelGGL((k_blocks_residual<N>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
-                       c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+    if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
+                                     c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+    else hipLaunchKernelGGL((k_blocks_residual<N, 8>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
+                            c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
