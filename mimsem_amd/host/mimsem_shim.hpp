@@ -36,7 +36,10 @@ struct LagrangeEdge { int n; LagrangeNode* l; };
 // the members of eul/Topo.h the hot path reads, with the element->local index formulas of eul/Topo.cpp:200-251
 struct Topo {
     int pi = 0, elOrd = 0, nElsX = 0, nDofsX = 0, n0 = 0, n1 = 0, n2 = 0, nk = 1;
-    Topo(int order, int nels, int nk_) : elOrd(order), nElsX(nels), nDofsX(order*nels), nk(nk_) {
+    // paired: the co-located local 1-form layout of INTEGRATION.md 2.1 (y-edge (r, c) in the odd slot beside x-edge (r, c)) for which
+    // the engine's wave-level plan exists; false = the reference's layout (eul/Topo.cpp:215-240), served by the two-pass kernels
+    bool paired = false;
+    Topo(int order, int nels, int nk_, bool paired_ = false) : elOrd(order), nElsX(nels), nDofsX(order*nels), nk(nk_), paired(paired_) {
         n0 = (nDofsX + 1)*(nDofsX + 1); n1 = 2*(nDofsX + 1)*nDofsX; n2 = nDofsX*nDofsX;
     }
     void elInds0_l(int ex, int ey, int* out) const {
@@ -51,8 +54,15 @@ struct Topo {
     }
     void elInds1y_l(int ex, int ey, int* out) const {
         int k = 0;
-        for (int iy = 0; iy <= elOrd; iy++) for (int ix = 0; ix < elOrd; ix++)
-            out[k++] = 2*((ey*elOrd + iy)*nDofsX + ex*elOrd + ix) + 1;
+        for (int iy = 0; iy <= elOrd; iy++) for (int ix = 0; ix < elOrd; ix++) {
+            const int r = ey*elOrd + iy, c = ex*elOrd + ix;
+            out[k++] = !paired ? 2*(r*nDofsX + c) + 1 : r < nDofsX ? 2*(r*(nDofsX + 1) + c) + 1 : 2*(c*(nDofsX + 1) + nDofsX) + 1;
+        }
+    }
+    // the slot of entry ii of input/edges_y_%.4u.txt (row-major y-edges) in the local vector: loc1[slot] = loc1y[ii]
+    int slot_of_edge_y(int ii) const {
+        const int r = ii/nDofsX, c = ii%nDofsX;
+        return !paired ? 2*ii + 1 : r < nDofsX ? 2*(r*(nDofsX + 1) + c) + 1 : 2*(c*(nDofsX + 1) + nDofsX) + 1;
     }
 };
 

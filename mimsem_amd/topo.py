@@ -6,8 +6,17 @@ import numpy as np
 
 
 class Topo:
-    def __init__(self, sphere, pi, nk=1):
+    """paired=False: the reference's local 1-form layout (eul/Topo.cpp:82-86, 215-240): x-edge (r, c) at slot 2(r(D+1) + c), y-edge
+    (r, c) at slot 2(rD + c) + 1 -- the two halves of an aligned slot pair {2k, 2k+1} drift apart by one column per row, so the
+    wave-level plan of the engine (one 16-byte access per slot pair) does not exist for it and the two-pass kernels run.
+    paired=True: the same slots handed out so that a pair is CO-LOCATED -- y-edge (r, c) at 2(r(D+1) + c) + 1 next to x-edge (r, c) for
+    r < D; the D y-edges of the patch's top row take the odd slots left over beside the right-hand column of x-edges,
+    2(c(D+1) + D) + 1.  It is a permutation of the local vector (loc1 and both element maps change together, nothing else in the
+    reference looks inside a local 1-form vector), shown as a patch to Topo.cpp in INTEGRATION.md."""
+
+    def __init__(self, sphere, pi, nk=1, paired=False):
         p = sphere.patches[pi]
+        self.paired = paired
         self.pi = pi
         self.nk = nk
         self.elOrd = sphere.pn
@@ -15,6 +24,14 @@ class Topo:
         self.nDofsX = sphere.D
         self.loc0, self.loc1x, self.loc1y, self.loc2 = p.loc0, p.loc1x, p.loc1y, p.loc2
         self.loc1 = p.loc1
+        if paired:
+            D = sphere.D
+            r, c = np.meshgrid(np.arange(D + 1), np.arange(D), indexing="ij")
+            self._yslot = np.where(r < D, 2 * (r * (D + 1) + c) + 1, 2 * (c * (D + 1) + D) + 1).astype(np.int32)     # [D+1][D]
+            loc1 = np.empty_like(self.loc1)
+            loc1[0::2] = p.loc1x
+            loc1[self._yslot.ravel()] = p.loc1y
+            self.loc1 = loc1
         self.n0, self.n1x, self.n1y, self.n2 = p.loc0.size, p.loc1x.size, p.loc1y.size, p.loc2.size
         self.n1 = self.n1x + self.n1y
         self.n0l, self.n1xl, self.n1yl, self.n2l = p.n0l, p.n1xl, p.n1yl, p.n2l
@@ -37,6 +54,8 @@ class Topo:
 
     def all_inds1y_l(self):
         r, c = self._grid(self.elOrd + 1, self.elOrd)
+        if self.paired:
+            return self._yslot[r, c]
         return (2 * (r * self.nDofsX + c) + 1).astype(np.int32)
 
     def all_inds2_l(self):
@@ -51,7 +70,7 @@ class Topo:
     # global variants (eul/Topo.cpp:253-305)
     def all_inds0_g(self): return self.loc0[self.all_inds0_l()]
     def all_inds1x_g(self): return self.loc1x[self.all_inds1x_l() // 2]
-    def all_inds1y_g(self): return self.loc1y[(self.all_inds1y_l() - 1) // 2]
+    def all_inds1y_g(self): return self.loc1[self.all_inds1y_l()]
     def all_inds2_g(self): return (self.all_inds2_l() + self.pi * self.n2).astype(np.int32)
     def elInds0_g(self, ex, ey): return self.all_inds0_g()[ey * self.nElsX + ex]
     def elInds1x_g(self, ex, ey): return self.all_inds1x_g()[ey * self.nElsX + ex]

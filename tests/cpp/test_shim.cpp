@@ -287,6 +287,34 @@ int main() {
         for (int i = 0; i < P->n1; i++) worst = std::max(worst, std::fabs(split[i] - whole[i]));
         std::printf("%-8s max abs diff = %.3e\n", "Halo", worst); if (!(worst == 0.0)) fails++;
     }
+    // the co-located local layout (Topo(..., paired = true)): the same operator on the permuted vector, now on the
+    // wave-level kernels (mimsem_op_wave_stats reports a plan), against the oracle's result in the reference's layout
+    {
+        Topo topo_p(n, nels, nk, true);
+        Mesh& mesh_p = *Mesh::of(&topo_p, &geom);
+        int st[5] = {0, 0, 0, 0, 0}, st0[5] = {0, 0, 0, 0, 0};
+        const int has_p = mimsem_op_wave_stats(mesh_p.ctx, nk, st), has_r = mimsem_op_wave_stats(mesh.ctx, nk, st0);
+        std::printf("wave plan: paired layout %d (%d groups), reference layout %d\n", has_p, st[0], has_r);
+        if (has_p != 1) fails++;            // (on a patch this small the reference layout can still have one; from 8 x 8 elements at p = 3 it has not)
+        std::vector<int> slot(P->n1);                                  // reference slot -> paired slot
+        const int D = n*nels;
+        for (int ii = 0; ii < D*(D + 1); ii++) { slot[2*ii] = 2*ii; slot[2*ii + 1] = topo_p.slot_of_edge_y(ii); }
+        std::vector<double> up(P->n1), yp(P->n1);
+        for (int i = 0; i < P->n1; i++) up[slot[i]] = u[i];
+        double* d_up = mesh_p.to_device(up.data(), up.size());
+        double* d_yp = mesh_p.to_device(yp.data(), yp.size());
+        Umat M1p(&topo_p, &geom, &node, &edge);
+        M1p.assemble(1, SCALE, true);
+        M1p.mult(d_up, d_yp);
+        mesh_p.to_host(yp.data(), d_yp, yp.size());
+        orc_op_elmats(P, ORC_UMAT, 1, SCALE, 1, nullptr, em.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_UMAT, em.data(), u.data(), want.data());
+        double num = 0, den = 0;
+        for (int i = 0; i < P->n1; i++) { num += (yp[slot[i]] - want[i])*(yp[slot[i]] - want[i]); den += want[i]*want[i]; }
+        std::printf("%-8s rel L2 = %.3e\n", "paired", std::sqrt(num/den)); if (!(std::sqrt(num/den) < 1e-10)) fails++;
+        mimsem_free(d_up); mimsem_free(d_yp);
+    }
     mimsem_free(d_u); mimsem_free(d_h); mimsem_free(d_y);
     orc_patch_destroy(P);
     Mesh::release_all();

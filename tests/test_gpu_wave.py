@@ -135,3 +135,38 @@ def test_wave_form_against_the_oracle(engines, oracle):
                 f1 = {"UMAT": None, "UHMAT": h[lev][v.s2], "ROTMAT": q[lev][v.s0]}[op]
                 want = P.apply(op, x[lev][v.s1], lev=lev, scale=SCALE, flag=fl, f1=f1)
                 assert rel_l2(y[lev][v.s1][v.int1], want[v.int1]) < 1e-10, (op, lev, v.pid)
+
+
+@pytest.mark.parametrize("pn,ne", [(3, 8), (2, 4)], ids=["p3", "p2"])
+def test_paired_local_layout_gets_the_wave_plan(pn, ne):
+    """One patch in a rank-LOCAL layout, as a reference rank holds it.  The reference's own local numbering (eul/Topo.cpp:215-240) has
+    no slot-pair plan (two-pass kernels); the co-located one, Topo(paired=True), has -- same operator, vectors permuted."""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    engs = []
+    for paired in (False, True):
+        t = Topo(cs, 2, NK, paired=paired)
+        g = Geom(t, cs, coords, NK); g.set_levels(z_levels(NK, g.n0))
+        engs.append((t, Engine(DeviceMesh([t], [g], nk=NK, numbering="local"))))
+    (tr, ref), (tp, par) = engs
+    st = (C.c_int * 5)()
+    assert pn < 3 or ref.L.mimsem_op_wave_stats(ref.ctx, NK, st) == 0        # (p = 2: few enough slots per group for a plan either way)
+    assert par.L.mimsem_op_wave_stats(par.ctx, NK, st) == 1 and st[0] > 0, list(st)
+    # slot of every reference-layout entry in the paired layout
+    slot = np.empty(tr.n1, dtype=np.int64); slot[0::2] = np.arange(0, tr.n1, 2); slot[1::2] = tp._yslot.ravel()
+    assert np.array_equal(tp.loc1[slot], tr.loc1)
+    r = np.random.default_rng(41)
+    x = r.standard_normal((NK, tr.n1)); xp = np.empty_like(x); xp[:, slot] = x
+    h = r.uniform(0.5, 1.5, (NK, tr.n2)) * 1e6; q = r.standard_normal((NK, tr.n0)) * 1e-4
+    for op, f, fl in (("UMAT", None, 1), ("UMAT", None, 0), ("UHMAT", h, 1), ("ROTMAT", q, 0), ("UTMAT_H", h, 0)):
+        a = ref.apply(op, ref.tensor(x), f=None if f is None else ref.tensor(f), lev0=0, scale=SCALE, flags=fl).cpu().numpy()
+        b = par.apply(op, par.tensor(xp), f=None if f is None else par.tensor(f), lev0=0, scale=SCALE, flags=fl).cpu().numpy()
+        assert rel_l2(b[:, slot], a) < 1e-13, op
+    if pn == 3:                                                        # 1-form in, 2-form out on the DPP kernel
+        u = r.standard_normal((NK, tr.n1)) * 1e3; up = np.empty_like(u); up[:, slot] = u
+        a = ref.apply("WTQUMAT", ref.tensor(x), f=ref.tensor(u), lev0=0, scale=SCALE, flags=0).cpu().numpy()
+        b = par.apply("WTQUMAT", par.tensor(xp), f=par.tensor(up), lev0=0, scale=SCALE, flags=0).cpu().numpy()
+        assert rel_l2(b, a) < 1e-13
