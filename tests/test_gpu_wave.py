@@ -26,7 +26,7 @@ def _mesh(pn, ne):
     return cs, topos, geoms, DeviceMesh(topos, geoms, nk=NK, numbering="global")
 
 
-@pytest.fixture(scope="module", params=[(2, 4), (3, 4), (4, 2)], ids=lambda p: "p%d_ne%d" % p)
+@pytest.fixture(scope="module", params=[(2, 4), (3, 4), (4, 2), (3, 3), (2, 5)], ids=lambda p: "p%d_ne%d" % p)
 def engines(request):
     import os
     from mimsem_amd.device import Engine
