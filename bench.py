@@ -565,6 +565,23 @@ def main():
                          "kernel1_us": b1 / bn * 1e3, "kernel2_us": b2 / bn * 1e3, "bytes_per_unit_op": 2320,
                          "op_GBs": ub * 2320 / ((b1 + b2) / bn * 1e-3) / 1e9}
         del engb
+    # N > 1: the extras below run collectives of paths that no multi-GPU hardware has executed yet.  A rank that fails alone leaves
+    # its peers waiting in a collective; the headline measured above must survive that: past the budget rank 0 prints the line
+    # with what is there and every rank leaves (os._exit: a blocked collective cannot be unwound).
+    import threading
+    printed = threading.Lock()
+
+    def bail():
+        if printed.acquire(blocking=False):
+            out["extras_watchdog"] = "extras did not finish within %d s: line printed without the unfinished ones" % budget
+            if rank == 0:
+                sys.stdout.write(json.dumps(out) + "\n"); sys.stdout.flush()
+            os._exit(0)
+    budget = int(os.environ.get("MIMSEM_BENCH_EXTRAS_BUDGET", "300"))
+    watchdog = None
+    if world > 1:
+        watchdog = threading.Timer(budget, bail); watchdog.daemon = True; watchdog.start()
+
     def extra(key, fn):
         """an extra must never cost the headline line: a failure is reported under its key instead of aborting the run"""
         try:
@@ -712,28 +729,29 @@ def main():
             extra("horiz_sharded", horiz_sharded)
     if a.sw and world > 1:
         # the SW step on the ranks' shards (config 3: 24x24x6 sphere over N GPUs, halo over xGMI); latency-bound at this size
-        from mimsem_amd.distributed import DistEngine
-        from mimsem_amd.sweqn import SWEqn, williamson2
-        t1s = [Topo(cs, p, 1) for p in pids]
-        g1s = [Geom(t, cs, coords, 1, signed_det=True) for t in t1s]
-        for g in g1s:
-            g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
-        dms = DeviceMesh(t1s, g1s, nk=1, numbering="global")
-        engs = Engine(dms, device=local_rank)
-        xqs = np.zeros((int(max(g.loc0.max() for g in g1s)) + 1, 3))
-        for g in g1s:
-            xqs[g.loc0] = coords[g.loc0]
-        S = SWEqn(DistEngine(engs, cs, world, rank), xqs[dms.gidq])
-        uq, hq = williamson2(torch.as_tensor(xqs[dms.gidq], device=engs.device), alpha=0.0)
-        us, hs_ = S.init1(uq), S.init2(hq)
-        us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
-        fence(); t1 = time.perf_counter()
-        for _ in range(3):
+        def sw_sharded():
+            from mimsem_amd.distributed import DistEngine
+            from mimsem_amd.sweqn import SWEqn, williamson2
+            t1s = [Topo(cs, p, 1) for p in pids]
+            g1s = [Geom(t, cs, coords, 1, signed_det=True) for t in t1s]
+            for g in g1s:
+                g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+            dms = DeviceMesh(t1s, g1s, nk=1, numbering="global")
+            engs = Engine(dms, device=local_rank)
+            xqs = np.zeros((int(max(g.loc0.max() for g in g1s)) + 1, 3))
+            for g in g1s:
+                xqs[g.loc0] = coords[g.loc0]
+            S = SWEqn(DistEngine(engs, cs, world, rank), xqs[dms.gidq])
+            uq, hq = williamson2(torch.as_tensor(xqs[dms.gidq], device=engs.device), alpha=0.0)
+            us, hs_ = S.init1(uq), S.init2(hq)
             us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
-        fence(); els = (time.perf_counter() - t1) / 3
-        if rank == 0:
-            out["sw_sharded"] = {"workload": "SWEqn::solve, Galewsky-style (2 Picard iterations), 24x24x6 sphere sharded over the ranks",
-                                 "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "krylov_iterations_last": dict(S.its)}
+            fence(); t1 = time.perf_counter()
+            for _ in range(3):
+                us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
+            fence(); els = (time.perf_counter() - t1) / 3
+            return {"workload": "SWEqn::solve, Galewsky-style (2 Picard iterations), 24x24x6 sphere sharded over the ranks",
+                    "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "krylov_iterations_last": dict(S.its)}
+        extra("sw_sharded", sw_sharded)
     if rank == 0 and world == 1 and not a.no_pmc and "roofline" in out:
         # roofline.traffic: HBM-side bytes per launch of the dominant kernel from PMC counters collected in THIS run (child rocprofv3
         # passes); traffic_frac = those bytes over the in-run kernel time, against the 8 TB/s peak
@@ -755,8 +773,12 @@ def main():
             out["roofline"]["traffic_note"] = "PMC passes not available in this run (%s: %s): traffic stays null" % (type(ex).__name__, str(ex)[:200])
     if rank == 0 and world == 1 and not a.no_cpu:
         extra("cpu_baseline", cpu_baseline)
+    if watchdog is not None:
+        watchdog.cancel()
+    if not printed.acquire(blocking=False):
+        time.sleep(60)                                   # the watchdog is printing: it ends the process
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

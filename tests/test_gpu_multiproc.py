@@ -112,6 +112,24 @@ def test_bench_multi_rank_control_flow_rehearsal():
         assert key in d and "error" not in d[key], d.get(key)
 
 
+def test_bench_extras_watchdog_keeps_the_headline_line():
+    """N > 1: an extra that does not come back (here: a budget of 0 s) must not cost the headline -- rank 0 prints the
+    line measured so far with `extras_watchdog` set and every rank leaves with exit code 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIMSEM_BENCH_REHEARSAL="1", MIMSEM_BENCH_EXTRAS_BUDGET="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "extras_watchdog" in d and "roofline" in d
+
+
 def _sw_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist

@@ -49,6 +49,9 @@ def _worker(rank, world, port, q):
         want = eng1.apply("UMAT", eng1.tensor(xg), lev0=0, scale=SCALE, flags=1).cpu().numpy()
         err = np.linalg.norm(y.cpu().numpy() - want[:, dm.gid1]) / np.linalg.norm(want)
         q.put((rank, bool(err < 1e-12)))
+    except Exception as exc:                            # report instead of leaving the parent to time out
+        q.put((rank, "%s: %s" % (type(exc).__name__, exc)))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -62,7 +65,14 @@ def test_halo_over_rccl_two_gpus():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert all(ok for _, ok in res), res
+    try:
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:                                            # a rank that raised leaves its peer waiting in a collective: end exactly these two
+        for p in procs:
+            if p.is_alive():
+                p.terminate(); p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    assert all(ok is True for _, ok in res), res
