@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmimsem_hip.so")
+LIB_PATH = os.environ.get("MIMSEM_LIB") or os.path.join(_HERE, "libmimsem_hip.so")      # MIMSEM_LIB: another build of the same library (A/B runs)
 
 c_dp = C.c_void_p          # device / host pointers travel as plain addresses
 c_ll = C.c_longlong

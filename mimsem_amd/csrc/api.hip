@@ -605,8 +605,10 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         const size_t cnt = (size_t)d->nk*d->nEl*es.mp12;
         hipError_t he = hipMalloc((void**)&c->d_th, std::max<size_t>(cnt, 1)*sizeof(double));
         if (he == hipSuccess) he = hipMalloc((void**)&c->d_tI, std::max<size_t>(cnt, 1)*sizeof(double));
+        const size_t cntp = 2*(size_t)(d->nk/2 + 1)*d->nEl*es.mp12*2;
+        if (he == hipSuccess && es.n <= 4) he = hipMalloc((void**)&c->d_tIp, std::max<size_t>(cntp, 1)*sizeof(double));
         if (he != hipSuccess) return fail(mimsem::hip_fail(he, "hipMalloc(thickness)"));
-        c->bytes += 2*(long long)cnt*8;
+        c->bytes += 2*(long long)cnt*8 + (es.n <= 4 ? (long long)cntp*8 : 0);
     }
     if ((rc = mimsem_ctx_set_levels(c, d->thick, d->thickInv))) return fail(rc);
     // two element-local buffers + one packed [1-form | 2-form] row per level: the largest request of any entry point at nlev <= nk
@@ -618,7 +620,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
 void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI,
+    void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp,
                     c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -651,6 +653,18 @@ int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thic
     if (cnt) {
         MIMSEM_HIP_TRY(hipMemcpy(c->d_th, th.data(), cnt*sizeof(double), hipMemcpyHostToDevice));
         MIMSEM_HIP_TRY(hipMemcpy(c->d_tI, ti.data(), cnt*sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (cnt && c->d_tIp) {
+        // level pairs for the wave-level kernels: entry (parity, m) holds levels L = 2m + parity and L + 1 (beyond the last level: the last again)
+        const size_t row = (size_t)c->nEl*c->es.mp12, np = (size_t)c->nk/2 + 1;
+        std::vector<double> tp(2*np*row*2);
+        for (int par = 0; par < 2; par++) for (size_t m = 0; m < np; m++) {
+            const size_t L0 = std::min<size_t>(2*m + par, c->nk - 1), L1 = std::min<size_t>(2*m + par + 1, c->nk - 1);
+            double* o = tp.data() + ((size_t)par*np + m)*row*2;
+            const double *a0 = ti.data() + L0*row, *a1 = ti.data() + L1*row;
+            for (size_t i = 0; i < row; i++) { o[2*i] = a0[i]; o[2*i + 1] = a1[i]; }
+        }
+        MIMSEM_HIP_TRY(hipMemcpy(c->d_tIp, tp.data(), tp.size()*sizeof(double), hipMemcpyHostToDevice));
     }
     c->have_levels = (thick != nullptr) || (thickInv != nullptr);
     return MIMSEM_OK;
@@ -752,7 +766,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     ElemArgs a;
     a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
     a.flags = flags; a.scale = scale; a.alpha = alpha;
-    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.E = c->d_E; a.w = c->d_w;
+    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.E = c->d_E; a.w = c->d_w;
     a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2; a.iq = c->d_iq;
     if (in == 3 && !c->d_iq) return MIMSEM_ERR_STATE;     // projection operators need mimsem_mesh_desc::indsq
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;

@@ -43,6 +43,7 @@ struct mimsem_ctx {
     double* d_det = nullptr;    // [nEl][mp12]
     double* d_th = nullptr;     // [nk][nEl][mp12] thickness at the element's own quad points
     double* d_tI = nullptr;     // [nk][nEl][mp12] inverse thickness
+    double* d_tIp = nullptr;    // [2][nk/2 + 1][nEl][mp12][2]: the same in level PAIRS {L, L+1}, first index = parity of L (k_apply_wave: one 16-byte load per two levels)
     bool have_levels = false;
     int* d_i0 = nullptr;        // [nEl][n0e]
     int* d_i1x = nullptr;       // [nEl][n1e]
@@ -123,6 +124,7 @@ struct ElemArgs {
     unsigned flags;
     double scale, alpha;
     const double *J, *det, *tI, *th, *E, *w;
+    const double* tIp; int tnp;          // level-pair copy of tI, pairs per parity
     const int *i0, *i1x, *i1y, *i2, *iq;
     const double* f; long long fs;
     const double* f2; long long f2s;   // second coefficient field (velocity of the upwinded operators)

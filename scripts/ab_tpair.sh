@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B: thickInv of a level pair in one 16-byte load (default) against one 8-byte load per level (build_ab/libmimsem_hip_notpair.so, built
+# with -DMIMSEM_NO_TPAIR); bench.py hot and cold, both variants twice in ONE run (boxes of the pool differ by ~10 %).
+out=gpurun_out/ab_tpair.log; : > $out
+run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_tpair.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d['roofline_cold']
+print('value %.3e ms/step %.4f | hot k1 %.2f us op %.2f us | cold k1 %.2f us op %.2f us value %.3e' % (d['value'], d['ms_per_step'], r['avg_kernel_us'], r['whole_operator']['avg_us'], c['avg_kernel_us'], c['whole_operator']['avg_us'], c['value']))" >> $out; }
+NT=$PWD/build_ab/libmimsem_hip_notpair.so
+run MIMSEM_LIB=$NT
+run DEFAULT=1
+run MIMSEM_LIB=$NT
+run DEFAULT=1
+cat $out
