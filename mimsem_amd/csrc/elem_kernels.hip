@@ -683,6 +683,89 @@ __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int 
     }
 }
 
+// The same middle pass on the matrix cores: over a chunk of 16 levels, z_e = B_e r_e is a dense (ND x ND) . (ND x 16) product -- the
+// "genuinely dense element mat-vec" of the path, batched over levels.  One wavefront = (element, 16 levels):
+//   A operand  = the element's block, kept in registers for the item        (v_mfma_f64_16x16x4: lane l holds A[i = l&15][k = l>>4])
+//   B operand  = the residuals r[k][level], gathered with a flat (level, DoF) lane mapping (coalesced per level as before), staged
+//                through LDS into the operand layout                         (lane l holds B[k = l>>4][j = l&15])
+//   C / D      = z[i][level], 4 per lane (row = (l>>4) + 4 reg, column = l&15), scaled, turned back through LDS and stored in runs
+//                of ND contiguous values per level.
+// Against k_blocks_residual: 2 x ND/4 MFMAs per 16 levels instead of 16 x ND FMAs fed by 16 x ND/2 broadcast ds_read_b128 per lane.
+// Measured: no gain (see the launcher) -- kept as an opt-in and as the record of the experiment.
+typedef double mimsem_v4d __attribute__((ext_vector_type(4)));
+template <int N>
+__global__ __launch_bounds__(256) void k_blocks_residual_mfma(int nEl, int nlev, const int* __restrict__ i1x, const int* __restrict__ i1y,
+        const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
+        const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
+        const double* __restrict__ escale, long long ess) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e, LV = 16;
+    static_assert(ND%4 == 0, "whole K steps");
+    constexpr int MT = (ND + 15)/16, KS = ND/4, NM = (LV*ND + 63)/64;
+    constexpr int RS = LV + 1, OS = ND + 1;                 // padded strides of the operand tile [k][level] and the result tile [level][i]
+    constexpr int TS = (ND*RS > LV*OS) ? ND*RS : LV*OS;
+    __shared__ double s_t[4][TS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunk = (nlev + LV - 1)/LV;
+    const long long item = (long long)blockIdx.x*4 + wv;
+    if (item >= (long long)nEl*nchunk) return;              // wave-uniform
+    const int e = (int)(item%nEl), l0 = (int)(item/nEl)*LV, nl = min(LV, nlev - l0);
+    const int li = lane & 15, lk = lane >> 4;
+    double* st = s_t[wv];
+    // residuals first (the longest chain: element map -> plan -> values), the block behind them
+    double r[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const int n = lane + 64*m, j = n/ND, k = n%ND;       // level j of the chunk, DoF k of the element
+        const bool in = n < LV*ND;
+        const int kk = in ? k : 0, lev = min(l0 + (in ? j : 0), nlev - 1);
+        const int slot = (kk < D::n1e) ? i1x[e*D::n1e + kk] : i1y[e*D::n1e + kk - D::n1e];
+        const int p0 = plan[(size_t)slot*2], p1 = plan[(size_t)slot*2 + 1];
+        const double* src = ye + (size_t)lev*yes;
+        const double a0 = src[p0 >= 0 ? p0 : 0], a1 = src[p1 >= 0 ? p1 : 0];
+        double acc = 0.0;
+        if (p0 >= 0) acc += a0;
+        if (p1 >= 0) acc += a1;
+        r[m] = b[(size_t)lev*bs + slot] - acc;
+    }
+    double A[MT][KS];
+    {
+        const double* Be = B + (size_t)e*ND*ND;              // column-major: element (row i, column k) at k*ND + i
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const int i = 16*t + li;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; s2++) { const double v = Be[(size_t)(4*s2 + lk)*ND + (i < ND ? i : 0)]; A[t][s2] = i < ND ? v : 0.0; }
+        }
+    }
+    const int levj = min(l0 + li, nlev - 1);
+    const double esv = escale ? escale[(size_t)levj*ess + e] : 1.0;
+#pragma unroll
+    for (int m = 0; m < NM; m++) { const int n = lane + 64*m; if (n < LV*ND) st[(n%ND)*RS + n/ND] = r[m]; }
+    wave_lds_sync();
+    double bv[KS];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; s2++) bv[s2] = st[(4*s2 + lk)*RS + li];
+    mimsem_v4d acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        acc[t] = (mimsem_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t][s2], bv[s2], acc[t], 0, 0, 0);
+    }
+    wave_lds_sync();                                         // every lane has its operands: the tile may take the results
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) { const int i = 16*t + lk + 4*v; if (i < ND) st[li*OS + i] = acc[t][v]*esv; }
+    wave_lds_sync();
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const int n = lane + 64*m, j = n/ND, i = n%ND;
+        if (n < LV*ND && j < nl) ze[(size_t)(l0 + j)*zes + (size_t)e*ND + i] = st[j*OS + i];
+    }
+}
+
 // perimeter pass of the fused scatter-add: slots shared by two element groups sum their two partials
 __global__ __launch_bounds__(256) void k_gather_perim(const double* __restrict__ yp, long long yps, const int* __restrict__ pslot,
         const int* __restrict__ ppart, int nps, int nlev, int accum, double* __restrict__ y, long long ys) {
@@ -1532,6 +1615,18 @@ static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const dou
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
+    if constexpr (N >= 2 && N <= 4) {
+        // matrix-core form from a handful of levels on: opt-in (MIMSEM_BLOCKS_MFMA=1).  Measured on HorizSolve's right-hand sides (3 456
+        // elements x 30 levels): 25.3 us per launch against 23.8 us for the register-row form below -- the pass is bound by its gathers
+        // (three 8-byte loads per DoF and level through the plan), not by the block product, on either kind of ALU
+        if (c->blocks_mfma && nlev >= 6) {
+            const long long witems = (long long)c->nEl*((nlev + 15)/16);
+            hipLaunchKernelGGL((k_blocks_residual_mfma<N>), dim3((unsigned)((witems + 3)/4)), dim3(256), 0, c->stream, c->nEl, nlev,
+                               c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+            MIMSEM_HIP_TRY(hipGetLastError());
+            return MIMSEM_OK;
+        }
+    }
     const int lch = std::max(1, std::min(nlev, 8));       // the kernel works through 8 levels per item whether the chunk has them or not
     const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
     if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
