@@ -35,6 +35,13 @@ SCALE = 1.0e8
 BYTES_OP_B1 = 1440          # whole B1 apply incl. y read-modify-write and 96 B of indices
 BYTES_K1_B1 = 1248          # the element kernel alone: 120 dbl in + 24 dbl out + 96 B indices
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: FP64 vector (= matrix) peak
+# executed FP64 work of the column solves per (column, level), p = 3, nk = 30: SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of every kernel of the
+# solve x 64 lanes (FMA = 2 flop), rocprofv3 --pmc over scripts/prof_column.py / prof_column3.py (profiles/r02_column_pmc.txt;
+# refreshed in profiles/r03_column_pmc.txt).  Padding lanes of the 16-lane DPP rows (9 of 16 rows carry data) are executed work and
+# count: the figure is what the ALUs did, not the algorithm's minimum (~3 700 flop per level).
+SCHUR_ETA_FLOP_PER_COLUMN_LEVEL = 1.54e5
+SCHUR_3_FLOP_PER_COLUMN_LEVEL = 4.3e5
 
 
 def b1_launch_bytes(nEl, n1, nlev, lch, pn=PN):
@@ -214,11 +221,23 @@ def column_extras(eng, dm, rng, torch):
     t = timeit(lambda: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F]), 5)
     res["schur_column_solves_per_s"] = nEl / t
     res["schur_ms_all_columns"] = t * 1e3
+    # what bounds it: FP64 work counted by the SQ counters (profiles/r03_column_pmc.txt: FMA = 2 flop, MUL / ADD = 1, x 64 lanes per wave
+    # instruction, all three kernels of the solve) against the 78.6 TFLOP/s vector FP64 peak, and the bytes the solve must move (the four
+    # fields and four right-hand sides in, the four updated right-hand sides out, det + thickness per quadrature point) against 8 TB/s
+    mp12 = (PN + 1) ** 2
+    fl = SCHUR_ETA_FLOP_PER_COLUMN_LEVEL * nEl * nk
+    by = nEl * 8 * (4 * nk * n2 + 2 * (4 * nk - 1) * n2 + mp12 * (1 + 2 * nk))
+    res["schur_roofline"] = {"bound": "fp64 valu (latency chain of the block-Thomas sweep)", "flop_per_solve_all_columns": fl, "TFLOPs": fl / t / 1e12,
+                             "flop_frac": fl / t / 1e12 / FP64_PEAK_TFLOPS, "compulsory_bytes": by, "GBs": by / t / 1e9, "hbm_frac": by / t / 1e9 / HBM_PEAK_GBS}
     thetaI, rt = lev(nk + 1, 280, 320), lev(nk, 150, 350)            # solve_schur_column_3: theta on the nk+1 interfaces
     velz = eng.tensor(rng.standard_normal((nEl, (nk - 1) * n2)) * 0.1 * area)
     t = timeit(lambda: eng.solve_schur_3(75.0, thetaI, velz, rho, rt, pi, *[f.clone() for f in F]), 3)
     res["schur3_column_solves_per_s"] = nEl / t
     res["schur3_ms_all_columns"] = t * 1e3
+    by3 = nEl * 8 * ((nk + 1) * n2 + (nk - 1) * n2 + 3 * nk * n2 + 2 * (4 * nk - 1) * n2 + mp12 * (1 + 2 * nk))
+    fl3 = SCHUR_3_FLOP_PER_COLUMN_LEVEL * nEl * nk
+    res["schur3_roofline"] = {"bound": "fp64 valu", "flop_per_solve_all_columns": fl3, "TFLOPs": fl3 / t / 1e12, "flop_frac": fl3 / t / 1e12 / FP64_PEAK_TFLOPS,
+                              "compulsory_bytes": by3, "GBs": by3 / t / 1e9, "hbm_frac": by3 / t / 1e9 / HBM_PEAK_GBS}
     # the caller of the column solve: one Newton iteration of VertSolve::solve_schur_eta (residual assembly, EOS residual, entropy
     # diagnostics, the Schur solve, the updates and both theta diagnoses) for every column, from an EOS-consistent state at rest
     from mimsem_amd.geom import gll_points
@@ -342,6 +361,87 @@ def sw_extras(local_rank, torch):
     return res
 
 
+FAMILIES = (("B1", "UMAT", 1, None, 1), ("B3", "WMAT", 2, None, 1), ("B4", "UHMAT", 1, 2, 1), ("B8", "WTQUMAT", 1, 1, 0),
+            ("B9", "ROTMAT", 1, 0, 0), ("B11", "WHMAT", 2, 2, 1))          # (op, input form, coefficient form, flags)
+
+
+def family_bytes(op, nEl, sizes, nlev, pn=PN):
+    """COMPULSORY bytes of one launch of an operator family over all (element, level) units: every input once, every output once
+    (DESIGN 4.4).  x and y per level in their spaces, the coefficient field per level, thickInv per unit, and the metric once per
+    element: {gaa, gab, gbb, 1/det} = 32 B per quadrature point for the operators that contract with J^T J (Umat, Uhmat, WtQUmat),
+    8 B per point (one factor: Q/det, or the rotational factor) for Wmat, Whmat, RotMat."""
+    mp12 = (pn + 1)**2
+    n0, n1, n2 = sizes
+    sp = {"UMAT": (n1, None, n1, 32), "WMAT": (n2, None, n2, 8), "UHMAT": (n1, n2, n1, 32), "WTQUMAT": (n1, n1, n2, 32),
+          "ROTMAT": (n1, n0, n1, 8), "WHMAT": (n2, n2, n2, 8)}[op]
+    nin, ncf, nout, metric = sp
+    return nlev*8*(nin + (ncf or 0) + nout) + nEl*nlev*mp12*8 + nEl*mp12*metric
+
+
+def families_extras(eng, dm, rng, torch):
+    """every operator family of the hot path on the headline grid (3 456 elements x 30 levels), kernel time from the
+    context's HIP events (both launches where an operator has two), compulsory bytes -> fraction of the 8 TB/s roofline"""
+    x1 = eng.tensor(rng.standard_normal((NK, dm.n1))); x2 = eng.tensor(rng.standard_normal((NK, dm.n2)))
+    h = eng.tensor(rng.uniform(1, 2, (NK, dm.n2))*1e3); q0 = eng.tensor(rng.standard_normal((NK, dm.n0))*1e-4)
+    y1, y2 = eng.zeros(NK, dm.n1), eng.zeros(NK, dm.n2)
+    units = dm.nEl*NK
+    res = {}
+    for row, op, fin, fcf, fl in FAMILIES:
+        xin = x1 if fin == 1 else x2
+        f = {None: None, 0: q0, 1: x1, 2: h}[fcf]
+        out = y1 if op in ("UMAT", "UHMAT", "ROTMAT") else y2
+        call, _ = eng.prepare_apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl, out=out)
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize(); eng.set_profiling(1); t1 = time.perf_counter()
+        for _ in range(40):
+            call()
+        torch.cuda.synchronize(); wall = (time.perf_counter() - t1)/40
+        c1, c2, cn = eng.profile_read(); eng.set_profiling(0)
+        kus = (c1 + c2)/max(cn, 1)*1e3 if cn else wall*1e6
+        b = family_bytes(op, dm.nEl, (dm.n0, dm.n1, dm.n2), NK)
+        res[row] = {"op": op, "applies_per_s": units/wall, "kernel_us": kus, "kernels": 2 if c2 > 0 else 1, "bytes_per_launch": b,
+                    "achieved_GBs": b/(kus*1e-6)/1e9, "frac": b/(kus*1e-6)/1e9/HBM_PEAK_GBS}
+    return {"workload": "3 456 elements x 30 levels per launch (cache resident), compulsory bytes / HIP-event kernel time against 8 TB/s", "rows": res}
+
+
+def local_layout_extras(local_rank, rng, torch):
+    """What an UNCHANGED reference rank gets: ONE 12 x 12-element patch of the 24-patch config-4 sphere in the
+    reference's own rank-local numbering (eul/Topo.cpp:82-86, 214-240: no slot-pair plan -> the two-pass kernels) and in the
+    co-located local numbering Topo(paired=True) (the two-line Topo.cpp change of INTEGRATION 1.1 -> the wave-level kernels), as
+    30-level calls and as the reference's own single-level mult() calls"""
+    import ctypes as C
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from tests.helpers import z_levels
+    cs = CubedSphere(PN, NE, NPATCH); coords = sphere_coords(PN, NE)
+    res = {}
+    for paired in (False, True):
+        t = Topo(cs, 5, NK, paired=paired)
+        g = Geom(t, cs, coords, NK); g.set_levels(z_levels(NK, g.n0))
+        dmp = DeviceMesh([t], [g], nk=NK, numbering="local")
+        e = Engine(dmp, device=local_rank)
+        st = (C.c_int*5)()
+        wave = e.L.mimsem_op_wave_stats(e.ctx, NK, st) == 1
+        x = e.tensor(rng.standard_normal((NK, dmp.n1))); y = e.zeros(NK, dmp.n1)
+        row = {"form": "wave-level (k_apply_wave + k_wave_perim)" if wave else "two-pass (k_elem_apply + k_gather_sum)", "elements": dmp.nEl}
+        for label, nl, reps in (("30_levels_per_call", NK, 200), ("1_level_per_call", 1, 400)):
+            call, _ = e.prepare_apply("UMAT", x[:nl], lev0=0, scale=SCALE, flags=1, out=y[:nl])
+            for _ in range(10):
+                call()
+            torch.cuda.synchronize(); e.set_profiling(1); t1 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize(); wall = (time.perf_counter() - t1)/reps
+            c1, c2, cn = e.profile_read(); e.set_profiling(0)
+            row[label] = {"applies_per_s": dmp.nEl*nl/wall, "us_per_call_wall": wall*1e6, "kernel_us": (c1 + c2)/cn*1e3}
+        res["paired_local" if paired else "reference_local"] = row
+        del e
+    return {"workload": "Umat apply on ONE 12x12-element patch (144 elements) of the config-4 sphere in a rank-LOCAL vector layout", "rows": res}
+
+
 def roofline_entry(bm, k1, k12, cache_resident, note, kname="k_elem_apply<3,UMAT>", k2name="k_gather_sum<2>"):
     """roofline object of the dominant kernel from in-run HIP-event durations (seconds) and the launch's compulsory bytes; the
     whole operator (both kernels) and SURVEY 8(d)'s per-unit figures ride along as secondary entries"""
@@ -401,9 +501,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--families", action="store_true", help="also report every operator family (untimed extras)")
+    ap.add_argument("--families", action="store_true", help="(default at N = 1) every operator family with its roofline fraction, the p=4 box, the local layouts")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-family / box_p4 / reference_local_layout extras")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep extra (on by default at N = 1)")
     ap.add_argument("--column", action="store_true", help="also report the column (HEVI) path: Schur solves/s, transposes/s")
-    ap.add_argument("--box", action="store_true", help="extra: BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
+    ap.add_argument("--box", action="store_true", help="(default at N = 1, with the families) BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
     ap.add_argument("--pcie", action="store_true", help="extra: the same step with the input copied host->device and the result device->host "
                                                         "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
     ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
@@ -460,17 +562,24 @@ def main():
     rng = np.random.default_rng(20241024 + rank)
     x = eng.tensor(rng.standard_normal((NK, dm.n1)))
     y = eng.zeros(NK, dm.n1)
-    halo = None
+    deng = None
     if use_dist:
-        plan1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)[1]
-        halo = HaloExchanger(plan1, engine=eng)
+        # N > 1: the halo through the C ABI (mimsem_halo_create / _begin / _end): boundary wave-groups first, the exchange in flight on
+        # the plan's communication stream -- grouped ncclSend / ncclRecv over xGMI on an ncclComm_t made here the way a C++ host would
+        # (RcclComm); the one-GPU rehearsal has no RCCL between ranks of one device and uses the host-callback transport -- while the
+        # interior groups are computed, then the unpack (what replaces MatMult + VecScatterBegin/End, eul/Assembly.cpp:2194-2195)
+        from mimsem_amd.distributed import DistEngine
+        plans = build_plans(cs, world, rank, dm.gid0, dm.gid1)
+        deng = DistEngine(eng, cs, world, rank, overlap=True, transport="dist" if (rehearsal or dist.get_backend() != "nccl") else "auto",
+                          plans=plans)
 
     apply_b1, _ = eng.prepare_apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)
 
     def step():
-        apply_b1()
-        if halo is not None:
-            halo.reverse_add(y)
+        if deng is not None:
+            deng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)       # every copy of a shared edge holds the complete sum afterwards
+        else:
+            apply_b1()
 
     def fence():
         torch.cuda.synchronize()
@@ -502,10 +611,13 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Umat (B1, 1-form mass) matrix-free apply over every (element, level) pair of the "
-                               "p=3 24x24x6 cubed sphere x 30 levels (BASELINE config 4 grid); N>1 adds the xGMI halo reduce",
+                               "p=3 24x24x6 cubed sphere x 30 levels (BASELINE config 4 grid); N>1: patches dealt to the ranks, boundary "
+                               "groups -> halo exchange through the C ABI (RCCL send/recv over xGMI) overlapped with the interior groups",
                    "order": PN, "elements": cs.ne * cs.ne * 6, "levels": NK, "units_per_step": units_total,
                    "patches": NPATCH, "patches_per_gpu": len(pids), "scale": SCALE, "level_chunk": None},
     }
+    if deng is not None:
+        out["config"]["halo_transport"] = getattr(deng, "transport", None)
     bm, kname, k2name, lch = launch_bytes(eng, dm, NK)
     out["config"]["level_chunk"] = lch
     out["config"]["form"] = "wave-level fused (k_apply_wave + k_wave_perim)" if "wave" in kname else "two-pass (k_elem_apply + k_gather_sum)"
@@ -526,24 +638,7 @@ def main():
                     "constant, not an observation of this run"}
             except Exception:
                 pass
-    if a.families and rank == 0 and world == 1:
-        fam = {}
-        h = eng.tensor(rng.uniform(1, 2, (NK, dm.n2)) * 1e3)
-        q0 = eng.tensor(rng.standard_normal((NK, dm.n0)) * 1e-4)
-        x2 = eng.tensor(rng.standard_normal((NK, dm.n2)))
-        x0 = eng.tensor(rng.standard_normal((NK, dm.n0)))
-        cases = [("UMAT", x, None, 1), ("UHMAT", x, h, 1), ("ROTMAT", x, q0, 0), ("WTQUMAT", x, x, 0), ("WMAT", x2, None, 1),
-                 ("WHMAT", x2, h, 1), ("PMAT", x0, None, 0), ("UTQWMAT", x2, x, 0)]
-        for op, xin, f, fl in cases:
-            for _ in range(5):
-                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(50):
-                eng.apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl)
-            torch.cuda.synchronize()
-            fam[op] = units_rank * 50 / (time.perf_counter() - t1)
-        out["families"] = fam
-    if a.box and rank == 0 and world == 1:
+    def box_extras():
         from mimsem_amd.geom import BoxGeom
         from mimsem_amd.mesh import PeriodicBox, box_coords
         bx = PeriodicBox(4, 32, 4); bc = box_coords(4, 32, 1000.0); nkb = 64
@@ -561,22 +656,31 @@ def main():
         torch.cuda.synchronize(); dtb = time.perf_counter() - t1
         b1, b2, bn = engb.profile_read(); engb.set_profiling(0)
         ub = dmb.nEl * nkb
-        out["box_p4"] = {"workload": "Umat apply, p=4 32x32 periodic box x 64 levels (65 536 units)", "value": ub * 200 / dtb,
-                         "kernel1_us": b1 / bn * 1e3, "kernel2_us": b2 / bn * 1e3, "bytes_per_unit_op": 2320,
-                         "op_GBs": ub * 2320 / ((b1 + b2) / bn * 1e-3) / 1e9}
+        opb = family_bytes("UMAT", dmb.nEl, (dmb.n0, dmb.n1, dmb.n2), nkb, pn=4)
+        kus = (b1 + b2) / bn * 1e3
+        r = {"workload": "Umat apply, p=4 32x32 periodic box x 64 levels (65 536 units, BASELINE config 5 grid)", "value": ub * 200 / dtb,
+             "kernel1_us": b1 / bn * 1e3, "kernel2_us": b2 / bn * 1e3,
+             "roofline": {"bound": "hbm", "kernels": "k_apply_wave<4,UMAT> + k_wave_perim", "bytes_per_launch": opb, "avg_us": kus,
+                          "achieved": opb / (kus * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": opb / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "byte_model": "whole operator: x and y once per level, thickInv per unit (25 points), metric record 32 B per point once per element",
+                          "algorithmic_reference_bytes_per_unit": 2320}}
         del engb
+        return r
     # N > 1: the extras below run collectives of paths that no multi-GPU hardware has executed yet.  A rank that fails alone leaves
     # its peers waiting in a collective; the headline measured above must survive that: past the budget rank 0 prints the line
     # with what is there and every rank leaves (os._exit: a blocked collective cannot be unwound).
     import threading
     printed = threading.Lock()
 
+    in_flight = {"extra": None}
+
     def bail():
         if printed.acquire(blocking=False):
-            out["extras_watchdog"] = "extras did not finish within %d s: line printed without the unfinished ones" % budget
+            out["extras_watchdog"] = {"note": "extras did not finish within %d s: line printed without the unfinished ones; exit status 3" % budget,
+                                      "in_flight": in_flight["extra"]}
             if rank == 0:
                 sys.stdout.write(json.dumps(out) + "\n"); sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)               # a hung collective is NOT a clean run: the headline survives, the status says what happened
     budget = int(os.environ.get("MIMSEM_BENCH_EXTRAS_BUDGET", "300"))
     watchdog = None
     if world > 1:
@@ -584,12 +688,17 @@ def main():
 
     def extra(key, fn):
         """an extra must never cost the headline line: a failure is reported under its key instead of aborting the run"""
+        in_flight["extra"] = key
         try:
             out[key] = fn()
         except Exception as ex:          # noqa: BLE001 -- reported, not hidden
             import traceback
             out[key] = {"error": "%s: %s" % (type(ex).__name__, ex), "where": traceback.format_exc().strip().splitlines()[-3:]}
 
+    if rank == 0 and world == 1 and not a.no_families:                 # SURVEY 8(d)'s per-family table: on by default at N = 1 (seconds)
+        extra("families", lambda: families_extras(eng, dm, rng, torch))
+        extra("box_p4", box_extras)
+        extra("reference_local_layout", lambda: local_layout_extras(local_rank, rng, torch))
     if (a.column or not a.no_column) and rank == 0 and world == 1:     # the column half of the hot path: on by default at N = 1 (~3 s)
         extra("column", lambda: column_extras(eng, dm, rng, torch))
     if a.pcie and rank == 0 and world == 1:
@@ -644,11 +753,53 @@ def main():
                             "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
     if (a.sw or not a.no_sw) and rank == 0 and world == 1:        # the second half of BASELINE's metric: on by default at N = 1
         extra("sw", lambda: sw_extras(local_rank, torch))
-    if a.sweep and rank == 0 and world == 1:
+    if (a.sweep or not a.no_sweep) and rank == 0 and world == 1:
         extra("sweep", lambda: sweep_extras(local_rank, torch))
     if rank == 0 and world == 1 and a.cold != 0:
         # the HBM number: on by default (--cold 0 skips it), R = 8 spheres = 829 440 units per launch
         extra("roofline_cold", lambda: cold_workload(dm, a.cold, local_rank, rng, torch))
+    if world > 1:
+        # WEAK-scaled companion of the headline: every rank holds 8 spheres' worth of work whatever N is (its 24/N patches, 8 N
+        # independent copies: 829 440 units and ~1 GB per rank, the size of roofline_cold), the halo of all copies in ONE exchange,
+        # overlapped with the interior groups -- the strong-scaled 21 us step above is smaller than one exchange and can only measure
+        # RCCL latency
+        def weak_scaled():
+            import types
+            from mimsem_amd.partition import CHalo
+            R = 8 * world
+            dmw = replicate(dm, R)
+            engw = Engine(dmw, device=local_rank)
+            p1 = plans[1]
+            rep = lambda d: {r: np.concatenate([np.asarray(v, dtype=np.int64) + k * dm.n1 for k in range(R)]).astype(np.int32) for r, v in d.items()}
+            pw = types.SimpleNamespace(gids=np.arange(dmw.n1), ghost_slots=rep(p1.ghost_slots), mirror_slots=rep(p1.mirror_slots))
+            pw.neighbours = p1.neighbours
+            tr = "dist" if deng.transport != "rccl" else deng.rccl.comm
+            chw = CHalo(pw, engw, max_nlev=NK, transport=tr)
+            engw.set_halo_slots(1, chw.shared)
+            xw = engw.tensor(rng.standard_normal((NK, dmw.n1))); yw = engw.zeros(NK, dmw.n1)
+
+            def stepw():
+                engw.apply_part("UMAT", "boundary", xw, lev0=0, scale=SCALE, flags=1, out=yw)
+                tok = chw.begin("pair", yw, True)
+                engw.apply_part("UMAT", "interior", xw, lev0=0, scale=SCALE, flags=1, out=yw)
+                chw.end(tok)
+            for _ in range(3):
+                stepw()
+            fence(); t1 = time.perf_counter()
+            nst = 20
+            for _ in range(nst):
+                stepw()
+            fence(); el = time.perf_counter() - t1
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            halo_bytes = int(sum(len(v) for v in pw.ghost_slots.values()) + sum(len(v) for v in pw.mirror_slots.values())) * NK * 8
+            chw.close()
+            return {"workload": "Umat apply, %d copies of the rank's %d patches x 30 levels per rank (fixed work per rank), halo of all copies "
+                                "in one exchange overlapped with the interior groups" % (R, len(pids)),
+                    "scaling": "weak", "units_per_rank": dmw.nEl * NK, "value": world * dmw.nEl * NK * nst / tt.item(),
+                    "unit": "element operator-applies/s", "ms_per_step": 1e3 * tt.item() / nst, "halo_bytes_sent_per_rank_per_step": halo_bytes,
+                    "transport": deng.transport}
+        extra("weak_scaled", weak_scaled)
     if world > 1 and not a.no_column:
         # the column half of the hot path sharded: all nk levels of an element live on one GPU, so the Schur solves and the Newton loop
         # need no halo at all -- only the MPI_Allreduce(MAX) of the four norms per iteration.  Aggregate = all columns / slowest rank.
@@ -703,8 +854,7 @@ def main():
             xqg = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
             for g in geoms:
                 xqg[g.loc0] = coords[g.loc0]
-            deng = DistEngine(eng, cs, world, rank)
-            hs = HorizSolve(deng, quad_coords=xqg[dm.gidq])
+            hs = HorizSolve(deng, quad_coords=xqg[dm.gidq])            # the headline's DistEngine: every completion through the C ABI's halo plans
             area = float(dm.det.mean()) * 4.0 / (PN * PN); dz = float(dm.thick.mean()); ln = area ** 0.5
             rg = np.random.default_rng(777)                                   # the same global fields on every rank
             U1 = rg.standard_normal((NK, cs.nDofs1G)) * 20.0 * ln * dz
@@ -723,7 +873,8 @@ def main():
             fence(); el = (time.perf_counter() - t1) / 3
             tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels dealt to the ranks, halo per operator",
+            return {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels dealt to the ranks, halo per operator "
+                                "(C ABI plans, transport %s; Umat / Uhmat / RotMat applies split boundary | exchange | interior)" % deng.transport,
                     "ms_per_evaluation": 1e3 * tt.item(), "evaluations_per_s": 1.0 / tt.item(), "elements_per_rank": dm.nEl}
         if not a.no_horiz_sharded:
             extra("horiz_sharded", horiz_sharded)

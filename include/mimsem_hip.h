@@ -138,7 +138,12 @@ int  mimsem_op_wave_stats(const mimsem_ctx* ctx, int nlev, int out[5]);
  * After the BOUNDARY part every marked slot of y holds its complete local sum; the INTERIOR part writes the remaining slots.
  * Operators / orders without the wave-level form (and contexts without marked slots) run whole in the BOUNDARY part and do nothing
  * in the INTERIOR part, so the sequence above is always valid.  MIMSEM_PART_ALL = mimsem_op_apply.  Set-up call: not inside a
- * stream capture (MIMSEM_ERR_STATE), invalidates nothing a captured graph holds (old tables are retired, not freed).          */
+ * stream capture (MIMSEM_ERR_STATE), invalidates nothing a captured graph holds (old tables are retired, not freed).
+ * CONTRACT of a split apply: the BOUNDARY part leaves partial sums for the INTERIOR part in a buffer of the context that only split
+ * applies use (no other entry point touches it), and the context remembers the pending part {op, levels, y, stride}.  Until the
+ * matching INTERIOR part has run, a second BOUNDARY part, or an INTERIOR part with another op / level range / y, returns
+ * MIMSEM_ERR_STATE and changes nothing; any other call (whole applies, block / Krylov / column calls) may run in between.
+ * mimsem_op_apply_part_reset forgets a pending part (error recovery of the host).                                              */
 #define MIMSEM_PART_ALL      0
 #define MIMSEM_PART_BOUNDARY 1
 #define MIMSEM_PART_INTERIOR 2
@@ -146,6 +151,7 @@ int  mimsem_ctx_set_halo_slots(mimsem_ctx* ctx, int form, const int* slots, int 
 int  mimsem_op_apply_part(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                           const double* f, long long f_stride, const double* x, long long x_stride,
                           double* y, long long y_stride, double alpha, int part);
+int  mimsem_op_apply_part_reset(mimsem_ctx* ctx);
 /* Measurement hook (bench.py): when on = n > 0, every n-th mimsem_op_apply brackets its element kernel (pass 1) and its
  * gather-sum kernel (pass 2) with hipEvents on the context's stream.  mimsem_ctx_profile_read waits for
  * the stream, returns the accumulated kernel milliseconds and launch count since the last read, resets. */
@@ -470,6 +476,11 @@ int  mimsem_halo_create(mimsem_ctx* ctx, int nneigh, const int* ranks, const int
                         const int* recv_idx, const int* recv_off, int nslots, int max_nlev, mimsem_halo** out);
 void mimsem_halo_destroy(mimsem_halo* plan);
 int  mimsem_halo_set_rccl(mimsem_halo* plan, void* nccl_comm);        /* ncclComm_t of the host, ranks as in that communicator */
+/* The RCCL entry points are taken from the library instance that created the communicator: the handle the host passes here (its
+ * dlopen handle of librccl; call before the first mimsem_halo_set_rccl, MIMSEM_ERR_STATE afterwards), else the copy the process has
+ * already loaded under the name librccl.so[.1].  This library never loads a copy of its own (mimsem_halo_set_rccl returns
+ * MIMSEM_ERR_STATE when neither exists).                                                                                          */
+int  mimsem_halo_use_rccl_library(void* dl_handle);
 int  mimsem_halo_set_transport(mimsem_halo* plan, mimsem_halo_transport_fn fn, void* user);
 int  mimsem_halo_set_loopback(mimsem_halo* plan);
 int  mimsem_halo_begin(mimsem_halo* plan, int mode, int nlev, double* v, long long v_stride);

@@ -120,13 +120,23 @@ int build_fused_plan(int n1, int nEl, int n1e, int G, const int* ix, const int* 
 //                every other slot of the group (its perimeter, and complete slots whose partner is outside the group) leaves a
 //                partial sum in a densely packed row of the workspace -- again in pairs -- that k_wave_perim finishes.
 //                MIMSEM_WAVE_SINGLES=1: no mixed pairs, unpaired complete slots in a second, 8-byte store round instead.
+constexpr int WMP = 16;     // entries of a side (its slots, padded): 8 pairs x 8 levels x 2 parts = two 64-lane rounds of the finishing phase
+constexpr int WNS = 8;      // sides a wave-group can take part in
 struct WavePlan {
-    int ngroups = 0, nps = 0, npart = 0, nsing = 0, ndirect = 0, nbgroups = 0, nbrec = 0;
-    std::vector<int> perm, pslot, ppart, node;
+    int ngroups = 0, nps = 0, npart = 0, npwritten = 0, nsing = 0, ndirect = 0, nbgroups = 0, nbrec = 0, nsides = 0;
+    bool fin_ok = true;
+    std::vector<int> perm, pslot, ppart, node, sslot;
     std::vector<int4> lane, plan;
     std::vector<int2> sing;
+    std::vector<int4> fin;
 };
-int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles,
+// Round 3: the partial sums are laid out per SIDE -- the (<= WMP) perimeter slots two wave-groups share, in ascending slot order; row
+// of a level = [side][part A (lower group) | part B][WMP] -- so that whichever group reaches a side second can finish its slots inside
+// the same launch (elem_wave.inc, finishing phase): no second kernel, no second trip of the partial sums through HBM.  A complete
+// slot that cannot be written in a 16-byte pair (its partner lies outside the group) rides along as an extra entry of one of the
+// group's sides (the other part of that entry is written as 0).  The perimeter records (k_wave_perim: split applies, MIMSEM_WAVE_FIN=0)
+// address the same layout.
+int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles, bool mixed,
                     const char* marked /* [n1] halo slots or null */, WavePlan& P) {
     const int nd = 2*n1e, lpe = 64/G, mp1 = order + 1;
     const int RS = mp1 + (mp1 & 1), XT = n1e + mp1*RS, sxe0 = XT + 2*(lpe - n1e), SXE = sxe0 + (sxe0 & 1);     // as k_apply_wave
@@ -183,16 +193,19 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         for (int g : inn) perm2.insert(perm2.end(), P.perm.begin() + (size_t)g*G, P.perm.begin() + (size_t)(g + 1)*G);
         P.perm.swap(perm2); P.nbgroups = (int)bnd.size();
     }
+    std::vector<int> grp(nEl, -1);
+    for (int g = 0; g < P.ngroups; g++) for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e >= 0) grp[e] = g; }
     P.lane.assign((size_t)P.ngroups*64, int4{0, 0, 0, 0});
     P.plan.resize((size_t)P.ngroups*64);
     P.node.resize((size_t)P.ngroups*64);
     if (singles) P.sing.assign((size_t)P.ngroups*64, int2{-1, (int)(ZERO | (ZERO << 16))});
-    std::vector<int> part((size_t)n1*2, -1);
     struct Use { int nx = 0; unsigned x[2] = {0, 0}; int na = 0; unsigned a[2] = {0, 0}; };      // staging / result positions of a slot in the group
     std::vector<Use> use(n1);
     std::vector<std::vector<int4>> entries(P.ngroups);
-    for (int g = 0; g < P.ngroups; g++) {
-        std::vector<int> slots;
+    std::vector<std::vector<int>> extras(P.ngroups), gsides(P.ngroups), routed_of(P.ngroups);
+    // the slots of group g with their positions in its staging / result strips (filled, used, cleared per group)
+    auto mark_group = [&](int g, std::vector<int>& slots) {
+        slots.clear();
         for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e < 0) continue;
             for (int j = 0; j < nd; j++) {
                 const int s = slot_of(e, j); Use& u = use[s];
@@ -200,10 +213,16 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
                 u.x[u.nx++] = xpos(k, j); u.a[u.na++] = (unsigned)(k*nd + j);
             } }
         std::sort(slots.begin(), slots.end());
-        auto in_group = [&](int s) { return s >= 0 && s < n1 && use[s].nx > 0; };
-        auto complete = [&](int s) { return in_group(s) && use[s].nx == cnt[s]; };
-        auto xpack = [&](int s) { unsigned a0 = DUMPX, a1 = DUMPX; if (in_group(s)) { a0 = use[s].x[0]; if (use[s].nx > 1) a1 = use[s].x[1]; } return (int)(a0 | (a1 << 16)); };
-        auto apack = [&](int s) { unsigned a0 = ZERO, a1 = ZERO; if (in_group(s)) { a0 = use[s].a[0]; if (use[s].na > 1) a1 = use[s].a[1]; } return (int)(a0 | (a1 << 16)); };
+    };
+    auto in_group = [&](int s) { return s >= 0 && s < n1 && use[s].nx > 0; };
+    auto complete = [&](int s) { return in_group(s) && use[s].nx == cnt[s]; };
+    auto xpack = [&](int s) { unsigned a0 = DUMPX, a1 = DUMPX; if (in_group(s)) { a0 = use[s].x[0]; if (use[s].nx > 1) a1 = use[s].x[1]; } return (int)(a0 | (a1 << 16)); };
+    auto apack = [&](int s) { unsigned a0 = ZERO, a1 = ZERO; if (in_group(s)) { a0 = use[s].a[0]; if (use[s].na > 1) a1 = use[s].a[1]; } return (int)(a0 | (a1 << 16)); };
+    // sides: (lower group, upper group) -> the perimeter slots they share
+    std::vector<std::pair<std::pair<int, int>, int>> shared;               // ((gA, gB), slot): every perimeter slot is reported by both groups
+    std::vector<int> slots;
+    for (int g = 0; g < P.ngroups; g++) {
+        mark_group(g, slots);
         // lane table: element + node slot of every lane, load pair of the first lanes
         for (int l = 0; l < 64; l++) {
             const int pe = P.perm[(size_t)g*G + l/lpe], e = pe >= 0 ? pe : 0, q = l%lpe;
@@ -220,17 +239,19 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
             last = b + 1;
         }
         for (int l = nload; l < 64 && nload; l++) P.lane[(size_t)g*64 + l].y = P.lane[(size_t)g*64].y;   // idle loader lanes re-read the first pair
-        // store pairs
+        // store pairs written straight into y
         std::vector<int> routed;
         for (size_t i = 0; i < slots.size(); i++) {
             const int s = slots[i];
             if (!(s & 1) && s + 1 < n1 && complete(s) && complete(s + 1)) { entries[g].push_back(int4{s, apack(s), apack(s + 1), 0}); P.ndirect += 2; i++; continue; }
-            if (!(s & 1) && in_group(s + 1) && complete(s) != complete(s + 1) && !singles) {
-                // MIXED pair, both slots in the group: the complete one is written in a full 16-byte store whose other half carries 0
-                // (accumulate form: adds 0).  That half belongs to a perimeter slot NO group writes directly -- its value comes from
-                // k_wave_perim, strictly later in the stream --, so the store clobbers nothing; the partial sum of the perimeter slot
-                // goes to the workspace as usual.  (A complete slot whose partner is not in the group at all stays routed: the
-                // partner may be written directly by its own group at the same time.)
+            if (mixed && !(s & 1) && in_group(s + 1) && complete(s) != complete(s + 1) && !singles) {
+                // MIXED pair (MIMSEM_WAVE_MIXED=1: round 2's form, perimeter pass only), both slots in the group: the complete one is
+                // written in a full 16-byte store whose other half carries 0 (accumulate form: adds 0).  That half belongs to a
+                // perimeter slot NO group writes directly -- its value comes from k_wave_perim, strictly later in the stream --, so the
+                // store clobbers nothing.  Inside ONE launch nothing orders that 0 -- dirty in the storing XCD's L2 until the kernel
+                // ends -- before the value a finishing wave on another XCD writes: with the finishing phase such a complete slot rides
+                // through the side as an extra entry instead.  (A complete slot whose partner is not in the group at all stays
+                // routed: the partner may be written directly by its own group at the same time.)
                 const int zz = (int)(ZERO | (ZERO << 16));
                 entries[g].push_back(int4{s, complete(s) ? apack(s) : zz, complete(s + 1) ? apack(s + 1) : zz, 0});
                 P.ndirect += 1;
@@ -247,12 +268,86 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
             }
             routed.swap(keep); P.nsing += ns; P.ndirect += ns;
         }
-        for (size_t i = 0; i < routed.size(); i += 2) {
-            const int s0 = routed[i], s1 = i + 1 < routed.size() ? routed[i + 1] : -1;
-            const int pi = P.npart; P.npart += 2;
-            auto reg = [&](int s, int idx) { if (s < 0) return; if (part[(size_t)s*2] < 0) part[(size_t)s*2] = idx; else part[(size_t)s*2 + 1] = idx; };
-            reg(s0, pi); reg(s1, pi + 1);
-            entries[g].push_back(int4{-(pi + 2), apack(s0), apack(s1), 0});
+        routed_of[g] = routed;
+        for (int s : routed) {
+            if (mixed) break;                                          // dense layout below: no sides
+            if (complete(s)) { extras[g].push_back(s); continue; }
+            int go = -1;
+            for (int w = 0; w < 2; w++) { const int o = own[(size_t)s*2 + w]; if (o >= 0 && grp[o] != g) go = grp[o]; }
+            if (go < 0) return MIMSEM_ERR_STATE;                       // (cannot happen: an incomplete slot has a contributor elsewhere)
+            shared.push_back({{std::min(g, go), std::max(g, go)}, s});
+        }
+        for (int s : slots) use[s] = Use();
+    }
+    std::sort(shared.begin(), shared.end());
+    shared.erase(std::unique(shared.begin(), shared.end()), shared.end());
+    struct Side { int ga, gb; std::vector<int> slots; };
+    std::vector<Side> sides;
+    for (size_t i = 0; i < shared.size(); i++) {
+        const bool fresh = sides.empty() || sides.back().ga != shared[i].first.first || sides.back().gb != shared[i].first.second ||
+                           (int)sides.back().slots.size() >= WMP;
+        if (fresh) { sides.push_back(Side{shared[i].first.first, shared[i].first.second, {}});
+                     gsides[shared[i].first.first].push_back((int)sides.size() - 1); gsides[shared[i].first.second].push_back((int)sides.size() - 1); }
+        sides.back().slots.push_back(shared[i].second);
+    }
+    for (int g = 0; g < P.ngroups; g++)
+        for (int s : extras[g]) {
+            int sd = -1;
+            for (int t : gsides[g]) if ((int)sides[t].slots.size() < WMP) { sd = t; break; }
+            if (sd < 0) { sides.push_back(Side{g, -1, {}}); sd = (int)sides.size() - 1; gsides[g].push_back(sd); }     // a side of the group's own
+            sides[sd].slots.push_back(s);
+        }
+    P.nsides = (int)sides.size();
+    P.npart = P.nsides*2*WMP;
+    P.sslot.assign((size_t)P.nsides*WMP, -1);
+    P.fin.assign((size_t)P.ngroups*WNS, int4{-1, 0, 0, 0});
+    std::vector<int> part((size_t)n1*2, -1);
+    for (int t = 0; t < P.nsides; t++)
+        for (size_t j = 0; j < sides[t].slots.size(); j++) P.sslot[(size_t)t*WMP + j] = sides[t].slots[j];
+    if (mixed) {
+        // round 2's dense layout (the default: the perimeter pass finishes every slot): the routed slots of a group in pairs, one after
+        // the other in the row -- 26 values in three cache lines per group and level
+        P.npart = 0;
+        for (int g = 0; g < P.ngroups; g++) {
+            if (routed_of[g].empty()) continue;
+            mark_group(g, slots);
+            const std::vector<int>& routed = routed_of[g];
+            for (size_t i = 0; i < routed.size(); i += 2) {
+                const int s0 = routed[i], s1 = i + 1 < routed.size() ? routed[i + 1] : -1;
+                const int pi = P.npart; P.npart += 2; P.npwritten += 2;
+                auto reg = [&](int s, int idx) { if (s < 0) return; if (part[(size_t)s*2] < 0) part[(size_t)s*2] = idx; else part[(size_t)s*2 + 1] = idx; };
+                reg(s0, pi); reg(s1, pi + 1);
+                entries[g].push_back(int4{-(pi + 2), apack(s0), apack(s1), 0});
+            }
+            if (entries[g].size() > 64) return MIMSEM_ERR_UNSUPPORTED;
+            for (int s : slots) use[s] = Use();
+        }
+    }
+    for (int g = 0; g < P.ngroups && !mixed; g++) {
+        if ((int)gsides[g].size() > WNS) P.fin_ok = false;
+        if (gsides[g].empty()) continue;
+        mark_group(g, slots);
+        for (size_t k = 0; k < gsides[g].size(); k++) {
+            const int t = gsides[g][k]; const Side& S = sides[t];
+            const int base = t*2*WMP + (g == S.ga ? 0 : WMP);
+            if (k < (size_t)WNS) P.fin[(size_t)g*WNS + k] = int4{t, S.gb < 0 ? 1 : 2, (int)S.slots.size(), 0};
+            // the whole 128-byte part, padding included, by ONE store instruction (8 lanes x 16 bytes): a full line travels to the
+            // uncached row as one write -- partial-line writes are read-modify-writes at the memory side (measured: 23 scattered
+            // 16-byte pairs per group and level made the launch 3x slower)
+            size_t need = 0;                                              // (groups with many sides: no room for the padding pairs)
+            for (size_t k2 = k; k2 < gsides[g].size(); k2++) need += (sides[gsides[g][k2]].slots.size() + 1)/2;
+            const bool whole = entries[g].size() + (gsides[g].size() - k)*(WMP/2) <= 64 || entries[g].size() + need + (WMP/2 - (S.slots.size() + 1)/2) > 64 ? 
+                               entries[g].size() + (gsides[g].size() - k)*(WMP/2) <= 64 : false;
+            for (size_t j = 0; j < (whole ? (size_t)WMP : S.slots.size()); j += 2) {
+                const int s0 = j < S.slots.size() ? S.slots[j] : -1, s1 = j + 1 < S.slots.size() ? S.slots[j + 1] : -1;
+                entries[g].push_back(int4{-(base + (int)j + 2), apack(s0), apack(s1), 0});     // a slot the group has no share of: 0
+                if (s0 >= 0) P.npwritten += 2;
+            }
+            for (size_t j = 0; j < S.slots.size(); j++)
+                if (in_group(S.slots[j])) { const int s = S.slots[j], idx = base + (int)j;
+                    if (part[(size_t)s*2] < 0) part[(size_t)s*2] = idx;
+                    else if (idx < part[(size_t)s*2]) { part[(size_t)s*2 + 1] = part[(size_t)s*2]; part[(size_t)s*2] = idx; }
+                    else part[(size_t)s*2 + 1] = idx; }               // part A first: the perimeter pass and the finishing phase add A + B
         }
         if (entries[g].size() > 64) return MIMSEM_ERR_UNSUPPORTED;
         for (int s : slots) use[s] = Use();
@@ -273,6 +368,7 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         for (int s = 0; s < n1; s++) {
             const bool m = marked && marked[s];
             if ((pass == 0) != m) continue;
+            if (cnt[s] == 0) P.fin_ok = false;                        // a slot no element touches: only the perimeter pass zeroes it
             if (part[(size_t)s*2] >= 0 || cnt[s] == 0) seg.push_back({s, s});
         }
         std::sort(seg.begin(), seg.end());
@@ -280,6 +376,7 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         if (pass == 0) P.nbrec = (int)seg.size();
     }
     P.nps = (int)P.pslot.size();
+    if (singles || mixed) P.fin_ok = false;
     return MIMSEM_OK;
 }
 
@@ -355,6 +452,26 @@ int mimsem_ctx::ensure_ye(long long doubles) {
     ye_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
 }
+int mimsem_ctx::ensure_wpart(long long doubles) {
+    if (doubles <= wpart_doubles) return MIMSEM_OK;
+    if (is_capturing()) return MIMSEM_ERR_STATE;
+    if (d_wpart) { retired.push_back(d_wpart); d_wpart = nullptr; wpart_doubles = 0; }
+    // UNCACHED device memory: a plain store is acknowledged by the memory side, not by the storing XCD's L2 (MIMSEM_WPART_MEM=finegrained |
+    // plain select other kinds for experiments; `plain` is NOT coherent across XCDs inside one launch)
+    if (w_partmem == 2) MIMSEM_HIP_TRY(hipMalloc((void**)&d_wpart, (size_t)doubles*sizeof(double)));
+    else MIMSEM_HIP_TRY(hipExtMallocWithFlags((void**)&d_wpart, (size_t)doubles*sizeof(double),
+                                              w_partmem == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached));
+    wpart_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
+int mimsem_ctx::ensure_wsplit(long long doubles) {
+    if (doubles <= wsplit_doubles) return MIMSEM_OK;
+    if (is_capturing() || split.pending) return MIMSEM_ERR_STATE;
+    if (d_wsplit) { retired.push_back(d_wsplit); d_wsplit = nullptr; wsplit_doubles = 0; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_wsplit, (size_t)doubles*sizeof(double)));
+    wsplit_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
 int mimsem_ctx::ensure_kry(long long doubles) {
     if (doubles <= kry_doubles) return MIMSEM_OK;
     if (is_capturing()) return MIMSEM_ERR_STATE;
@@ -385,12 +502,17 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     WavePlan P;
     const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
     const bool singles = getenv("MIMSEM_WAVE_SINGLES") && atoi(getenv("MIMSEM_WAVE_SINGLES")) != 0;
-    int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, marked, P);
+    // MIMSEM_WAVE_FIN=1: the experimental in-kernel finishing phase (side layout of the partial sums, no mixed pairs); default: round 2's
+    // dense layout with mixed pairs + the perimeter pass (measured faster: DESIGN 4.6)
+    const bool want_fin = getenv("MIMSEM_WAVE_FIN") && atoi(getenv("MIMSEM_WAVE_FIN")) != 0;
+    const bool mixed = !want_fin && !(getenv("MIMSEM_WAVE_MIXED") && atoi(getenv("MIMSEM_WAVE_MIXED")) == 0);
+    int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, mixed, marked, P);
     if (rc) return rc;
-    void* old[] = {c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR};
+    void* old[] = {c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt};
     for (void* p : old) if (p) c->retired.push_back(p);
     c->d_wlane = nullptr; c->d_wplan = nullptr; c->d_wprec = nullptr; c->d_wnode = nullptr; c->d_wsing = nullptr; c->d_wG = nullptr; c->d_wR = nullptr;
-    c->wave1 = false;
+    c->d_wfin = nullptr; c->d_wsslot = nullptr; c->d_wcnt = nullptr;
+    c->wave1 = false; c->w_fin = false;
     if ((rc = upload(&c->d_wlane, P.lane.data(), P.lane.size(), c))) return rc;
     if ((rc = upload(&c->d_wplan, P.plan.data(), P.plan.size(), c))) return rc;
     {
@@ -400,6 +522,14 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     }
     if ((rc = upload(&c->d_wnode, P.node.data(), P.node.size(), c))) return rc;
     if (P.nsing && (rc = upload(&c->d_wsing, P.sing.data(), P.sing.size(), c))) return rc;
+    if ((rc = upload(&c->d_wfin, P.fin.data(), P.fin.size(), c))) return rc;
+    if ((rc = upload(&c->d_wsslot, P.sslot.data(), P.sslot.size(), c))) return rc;
+    {   // arrival counters of the finishing phase: one per (side, work item of a group), zero between launches
+        const size_t n = (size_t)std::max(P.nsides, 1)*(size_t)std::max(c->nk, 1);
+        MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_wcnt, n*sizeof(int)));
+        MIMSEM_HIP_TRY(hipMemset(c->d_wcnt, 0, n*sizeof(int)));
+        c->bytes += (long long)(n*sizeof(int));
+    }
     // packed metric of the wave kernel: {gaa, gab, gbb, 1/det} = Q/det J^T J per quadrature point (16-byte loads) and the
     // rotational factor (-J00 J11 + J01 J10) Q/det of RotMat, in wave-group order
     {
@@ -421,14 +551,17 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
         if ((rc = upload(&c->d_wR, Rv.data(), Rv.size(), c))) return rc;
     }
     c->w_ndirect = P.ndirect; c->w_ngroups = P.ngroups; c->w_nsing = P.nsing; c->w_nps = P.nps; c->w_npart = P.npart;
+    c->w_npwritten = P.npwritten; c->w_nsides = P.nsides;
+    if (const char* kind = getenv("MIMSEM_WPART_MEM")) c->w_partmem = !strcmp(kind, "plain") ? 2 : (!strcmp(kind, "finegrained") ? 1 : 0);
+    c->w_fin = P.fin_ok && want_fin;
     c->w_nbgroups = P.nbgroups; c->w_nbrec = P.nbrec; c->w_split = marked != nullptr; c->wave1 = true;
     if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
     if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
     if (const char* ev = getenv("MIMSEM_WAVE_CPP")) c->wave_cpp = atoi(ev);
     if (const char* ev = getenv("MIMSEM_WAVE2")) c->wave2_mode = atoi(ev);
     if (getenv("MIMSEM_VERBOSE"))
-        fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials) of %d\n",
-                P.ngroups, 64/lpe, P.nbgroups, P.nps, P.npart, c->n1);
+        fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials in %d sides) of %d; "
+                        "in-kernel finishing %s\n", P.ngroups, 64/lpe, P.nbgroups, P.nps, P.npwritten, P.nsides, c->n1, c->w_fin ? "on" : "off");
     return MIMSEM_OK;
 }
 
@@ -437,7 +570,7 @@ extern "C" {
 int mimsem_ctx_set_profiling(mimsem_ctx* c, int on) {
     if (!c) return MIMSEM_ERR_ARG;
     // on = n > 0: time every n-th mimsem_op_apply (n = 1: all of them); 0 = off
-    c->profiling = on != 0; c->prof_every = on > 0 ? on : 1; c->prof_count = 0; c->ev_used = 0;
+    c->profiling = on != 0; c->prof_every = on > 0 ? on : 1; c->prof_count = 0; c->ev_used = 0; c->ev_has2.clear();
     return MIMSEM_OK;
 }
 int mimsem_ctx_profile_read(mimsem_ctx* c, double* ms1, double* ms2, long long* launches) {
@@ -447,12 +580,15 @@ int mimsem_ctx_profile_read(mimsem_ctx* c, double* ms1, double* ms2, long long* 
     for (size_t i = 0; i + 3 < c->ev_used; i += 4) {
         float t = 0.f;
         MIMSEM_HIP_TRY(hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1])); a += t;
-        if (hipEventElapsedTime(&t, c->ev_pool[i + 2], c->ev_pool[i + 3]) == hipSuccess) b += t;   // unset when the op has no pass 2
+        if (i/4 < c->ev_has2.size() && c->ev_has2[i/4]) {                                          // only when THIS apply recorded its second pair
+            if (hipEventElapsedTime(&t, c->ev_pool[i + 2], c->ev_pool[i + 3]) == hipSuccess) b += t;
+            else (void)hipGetLastError();
+        }
     }
     if (ms1) *ms1 = a;
     if (ms2) *ms2 = b;
     if (launches) *launches = (long long)(c->ev_used/4);
-    c->ev_used = 0;
+    c->ev_used = 0; c->ev_has2.clear();
     return MIMSEM_OK;
 }
 
@@ -622,7 +758,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wpart, c->d_wsplit, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -638,7 +774,7 @@ int mimsem_op_wave_stats(const mimsem_ctx* c, int nlev, int out[5]) {
     if (!c || !out || nlev < 1) return MIMSEM_ERR_ARG;
     for (int i = 0; i < 5; i++) out[i] = 0;
     if (!c->wave1) return 0;
-    out[0] = c->w_ngroups; out[1] = c->w_ndirect; out[2] = c->w_npart; out[3] = c->w_nps;
+    out[0] = c->w_ngroups; out[1] = c->w_ndirect; out[2] = c->w_npwritten; out[3] = c->w_nps;
     { const int lch = wave_level_chunk(c, nlev); out[4] = lch*wave_chunks_per_item(c, nlev, lch, c->w_ngroups); }
     return 1;
 }
@@ -715,7 +851,7 @@ static bool is_up_op(int op) {
 }
 int mimsem_ctx_set_halo_slots(mimsem_ctx* c, int form, const int* slots, int n) {
     if (!c || form != 1 || n < 0 || (n && !slots)) return MIMSEM_ERR_ARG;
-    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    if (c->is_capturing() || c->split.pending) return MIMSEM_ERR_STATE;      // (a pending BOUNDARY part belongs to the plan in force)
     if (!c->wave1 && c->h_i1x.empty()) return MIMSEM_OK;      // two-pass form: nothing to reorder (the split degenerates, see mimsem_op_apply_part)
     std::vector<char> marked(std::max(c->n1, 1), 0);
     for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= c->n1) return MIMSEM_ERR_ARG; marked[slots[i]] = 1; }
@@ -729,6 +865,12 @@ int mimsem_op_apply_part(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
                          double* y, long long ys, double alpha, int part) {
     if (is_up_op(op) || part < MIMSEM_PART_ALL || part > MIMSEM_PART_INTERIOR) return MIMSEM_ERR_ARG;
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, y, ys, alpha, nullptr, nullptr, part);
+}
+
+int mimsem_op_apply_part_reset(mimsem_ctx* c) {
+    if (!c) return MIMSEM_ERR_ARG;
+    c->split.pending = false;
+    return MIMSEM_OK;
 }
 
 int mimsem_op_apply_up(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
@@ -765,6 +907,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
 
     const ElemSizes& es = c->es;
     ElemArgs a;
+    a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr;
     a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
     a.flags = flags; a.scale = scale; a.alpha = alpha;
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.E = c->d_E; a.w = c->d_w;
@@ -778,7 +921,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     }
     int rc;
     c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
-    if (c->profiling && (c->prof_count++ % c->prof_every) == 0) { c->ev_k1[0] = c->next_event(); c->ev_k1[1] = c->next_event(); c->ev_k2[0] = c->next_event(); c->ev_k2[1] = c->next_event(); }
+    if (c->profiling && (c->prof_count++ % c->prof_every) == 0) { c->ev_k1[0] = c->next_event(); c->ev_k1[1] = c->next_event(); c->ev_k2[0] = c->next_event(); c->ev_k2[1] = c->next_event(); c->ev_has2.push_back(0); }
     if (outsp == 2) {
         a.out = y; a.os = ys;
         // Wmat itself stays on k_elem_apply by default: measured 9.3e9 applies/s there against 8.2e9 on the DPP kernel (its element algebra
@@ -838,7 +981,6 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     if (c->wave1 && wave_fits && wave_op) {
         // wave-level fused path: complete slots straight into y, one partial per perimeter slot into the workspace, perimeter pass
         const long long prow = (long long)c->w_npart + 128;              // partial sums of a level + the dump tail (64 lanes x 16 bytes)
-        if ((rc = c->ensure_ye(prow*nlev))) return rc;
         int g0 = 0, g1 = c->w_ngroups, r0 = 0, r1 = c->w_nps;
         if (splits && part == MIMSEM_PART_BOUNDARY) { g1 = c->w_nbgroups; r1 = c->w_nbrec; }
         if (splits && part == MIMSEM_PART_INTERIOR) { g0 = c->w_nbgroups; r0 = c->w_nbrec; }
@@ -847,7 +989,20 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         a.lch = wave_level_chunk(c, nlev);
         a.wcpp = wave_chunks_per_item(c, nlev, a.lch, g1 - g0);
         a.swz = c->wave_order;
-        a.y = y; a.ys = ys; a.out = c->d_ye; a.os = prow;
+        // the whole operator in ONE launch: each side of the perimeter is finished by the group that reaches it second (not for the
+        // parts of a split apply: their partial sums wait for the other part, and the perimeter pass finishes them)
+        const bool fin = c->w_fin && !splits && (nlev + a.lch*a.wcpp - 1)/(a.lch*a.wcpp) <= std::max(c->nk, 1);
+        a.wfin = fin ? c->d_wfin : nullptr; a.wsslot = c->d_wsslot; a.wcnt = c->d_wcnt;
+        if (splits) {
+            // the pending BOUNDARY part and its INTERIOR part must match; nothing else can consume or overwrite the partial sums
+            if (part == MIMSEM_PART_BOUNDARY) {
+                if (c->split.pending) return MIMSEM_ERR_STATE;
+            } else if (!c->split.pending || c->split.op != op || c->split.lev0 != geom_lev0 || c->split.nlev != nlev ||
+                       c->split.flags != flags || c->split.y != y || c->split.ys != ys) return MIMSEM_ERR_STATE;
+        }
+        if ((rc = fin ? c->ensure_wpart(prow*nlev) : (splits ? c->ensure_wsplit(prow*nlev) : c->ensure_ye(prow*nlev)))) return rc;
+        double* const prt = fin ? c->d_wpart : (splits ? c->d_wsplit : c->d_ye);
+        a.y = y; a.ys = ys; a.out = prt; a.os = prow;
         a.flags = flags & ~MIMSEM_FLAG_ACCUM;
         a.wstamps = nullptr;
         for (size_t k = 0; k < 20; k++) a.Etab[k] = k < c->tab.E.size() ? c->tab.E[k] : 0.0;
@@ -870,7 +1025,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
             for (size_t i = 0; i < items; i++) { t0 = std::min(t0, h[i*16]); t1 = std::max(t1, h[i*16 + 15]); }
             fprintf(stderr, "[stamps] items %zu lch %d  first entry -> last done: %lld ticks\n", items, a.lch, t1 - t0);
             const char* names[16] = {"entry(rel. first)", "barrier", "tables requested", "level loads issued", "batch0", "batch1", "batch2", "batch3",
-                                     "b4", "b5", "b6", "b7", "", "", "", "stores acked"};
+                                     "b4", "b5", "b6", "chunks done", "fin: stores acked", "fin: arrival counted", "fin: sides finished", "stores acked"};
             for (int k = 0; k < 16; k++) {
                 std::vector<long long> v;
                 for (size_t i = 0; i < items; i++) if (h[i*16 + k]) v.push_back(k == 0 ? h[i*16] - t0 : h[i*16 + k] - h[i*16]);
@@ -881,7 +1036,12 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
             }
         }
 #endif
-        if (!rc) rc = launch_wave_perim(c, nlev, c->d_ye, prow, a.accum, y, ys, r0, r1);
+        if (!rc && !fin) rc = launch_wave_perim(c, nlev, prt, prow, a.accum, y, ys, r0, r1);
+        if (splits && !rc) {
+            if (part == MIMSEM_PART_BOUNDARY) { c->split.pending = true; c->split.op = op; c->split.lev0 = geom_lev0; c->split.nlev = nlev;
+                                                c->split.flags = flags; c->split.y = y; c->split.ys = ys; }
+            else c->split.pending = false;
+        }
         c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
         return rc;
     }

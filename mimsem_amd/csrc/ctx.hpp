@@ -72,6 +72,22 @@ struct mimsem_ctx {
     int wave2_mode = 1;                 // MIMSEM_WAVE2: 2-form-valued operators on k_apply_wave2 (p = 3): 0 none, 1 Whmat / WtQUmat / WtQdUdz, 2 also Wmat
     int wave_cpp = 0;                   // MIMSEM_WAVE_CPP override of the chunks per work item (0: heuristic)
     int w_ngroups = 0, w_nsing = 0, w_nps = 0, w_npart = 0, w_ndirect = 0;
+    int w_npwritten = 0;                // partial sums a level really gets (w_npart is the padded row: w_nsides x 2 x 16)
+    // in-kernel completion of the perimeter (round 3, elem_wave.inc "finishing phase"): the partial sums are laid out per SIDE (the
+    // slots two wave-groups share), and the group that arrives second at a side's counter finishes its slots -- no second launch
+    bool w_fin = false;                 // the plan supports it (MIMSEM_WAVE_FIN=0 keeps the perimeter pass)
+    int w_nsides = 0; int w_partmem = 0;      // w_partmem: 0 uncached, 1 fine-grained, 2 plain (MIMSEM_WPART_MEM, experiments)
+    int4* d_wfin = nullptr;             // [w_ngroups][8] {side, arrivals that complete it (2; 1: a side of the group's own), entries, 0} or {-1, 0, 0, 0}
+    int* d_wsslot = nullptr;            // [w_nsides][16] y slot of entry j of the side (-1: none)
+    int* d_wcnt = nullptr;              // [w_nsides][nk] arrival counters, zero between launches (the finishing wave resets its own)
+    double* d_wpart = nullptr;          // [nlev][w_npart + 128] partial sums of the finishing phase: UNCACHED device memory (plain stores go
+    long long wpart_doubles = 0;        //   through to the memory side: visible to a finishing wave on another XCD once acknowledged)
+    int ensure_wpart(long long doubles);
+    // a split apply (mimsem_op_apply_part): its partial sums live in a buffer no other entry point uses, and the pending BOUNDARY part
+    // is remembered so that only the matching INTERIOR part can consume it
+    double* d_wsplit = nullptr; long long wsplit_doubles = 0;
+    int ensure_wsplit(long long doubles);
+    struct { bool pending = false; int op = 0, lev0 = 0, nlev = 0; unsigned flags = 0; const double* y = nullptr; long long ys = 0; } split;
     int w_nbgroups = 0, w_nbrec = 0; bool w_split = false;     // interior / boundary split (mimsem_ctx_set_halo_slots): boundary prefix sizes
     std::vector<int> h_i1x, h_i1y, h_i0; std::vector<double> h_J, h_det;      // host copies of the mesh for re-deriving the plan
     int4* d_wlane = nullptr;            // [w_ngroups][64] {element of the lane, load pair: even slot b, staging positions of x[b] and of x[b+1]
@@ -107,6 +123,8 @@ struct mimsem_ctx {
     hipEvent_t next_event();
     hipEvent_t ev_k1[2] = {nullptr, nullptr};   // start/stop events of the next element kernel (null = not profiling)
     hipEvent_t ev_k2[2] = {nullptr, nullptr};   // ... of the next gather-sum kernel
+    std::vector<char> ev_has2;                  // per profiled apply: a second kernel recorded its pair (pooled events keep OLD stamps otherwise)
+    void mark_k2() { if (ev_k2[0] && !ev_has2.empty()) ev_has2.back() = 1; }
 
     std::vector<void*> retired;          // outgrown workspaces (still referenced by captured graphs), freed with the context
     bool is_capturing() const;           // the context's stream is inside a hipGraph capture (workspaces must not grow there)
@@ -138,6 +156,7 @@ struct ElemArgs {
     double* y; long long ys; int accum;
     // wave-level fused scatter-add (k_apply_wave)
     const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump; int wcpp;
+    const int4* wfin; const int* wsslot; int* wcnt;      // finishing phase (null: the perimeter pass follows)
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
     double Wq[5];                    // GLL weights by value (orders <= 4)
     long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null

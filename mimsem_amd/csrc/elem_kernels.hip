@@ -1502,6 +1502,7 @@ int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps
     if (c->ev_k2[0]) hipExtLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0,
                                            yp, yps, pslot, ppart, nps, nlev, accum, y, ys);
     else hipLaunchKernelGGL(k_gather_perim, grid, dim3(256), 0, c->stream, yp, yps, pslot, ppart, nps, nlev, accum, y, ys);
+    c->mark_k2();
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
@@ -1565,6 +1566,7 @@ int launch_wave_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, 
     if (c->ev_k2[0]) hipExtLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, c->ev_k2[0], c->ev_k2[1], 0, yp, yps, rec, nps, nlev, y, ys); \
     else hipLaunchKernelGGL((k_wave_perim<ACC>), grid, dim3(256), 0, c->stream, yp, yps, rec, nps, nlev, y, ys)
     if (accum) { MIMSEM_WP(true); } else { MIMSEM_WP(false); }
+    c->mark_k2();
 #undef MIMSEM_WP
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
@@ -1592,6 +1594,7 @@ int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long 
     if (form == 1) { MIMSEM_GS(2, c->d_g1); }
     else if (c->G0 == 4) { MIMSEM_GS(4, c->d_g0); }
     else { MIMSEM_GS(8, c->d_g0); }
+    c->mark_k2();
 #undef MIMSEM_GS
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;

@@ -10,6 +10,7 @@
 // there is one --, the communicator is the host's), a host callback (GPU-aware MPI, torch.distributed, a test double), or loop-back
 // (a plan whose only neighbour is the rank itself: periodic single-rank layouts and tests).
 #include <dlfcn.h>
+#include <mutex>
 #include <set>
 #include <vector>
 #include "ctx.hpp"
@@ -38,22 +39,28 @@ struct Rccl {
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     bool ok = false;
 };
-Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);          // the copy the process already uses (e.g. PyTorch's), if any
+// The communicator handed to mimsem_halo_set_rccl belongs to ONE instance of the library: the host's.  So the entry points are taken
+// from (1) the handle the host passed (mimsem_halo_use_rccl_library), else (2) the copy the process has ALREADY loaded
+// (RTLD_NOLOAD) -- never from a second copy this library would load by itself (a bundled or renamed librccl would otherwise end up
+// with an ncclComm_t created by another instance of it).
+std::once_flag g_rccl_once;
+void* g_rccl_handle = nullptr;                                        // set before the first use, if at all
+Rccl g_rccl;
+void rccl_resolve() {
+    void* h = g_rccl_handle;
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return r;
+    if (!h) return;
+    Rccl& r = g_rccl;
     r.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
     r.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
     r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
     r.ok = r.GroupStart && r.GroupEnd && r.Send && r.Recv;
-    return r;
+}
+Rccl& rccl() {
+    std::call_once(g_rccl_once, rccl_resolve);
+    return g_rccl;
 }
 constexpr int kNcclFloat64 = 8;                                       // ncclDataType_t: ncclDouble
 }  // namespace
@@ -65,6 +72,7 @@ int mimsem_halo_create(mimsem_ctx* c, int nneigh, const int* ranks, const int* s
     if (!c || !out || nneigh < 0 || nneigh > MIMSEM_HALO_MAX_SEGMENTS || max_nlev < 1 || nslots < 0) return MIMSEM_ERR_ARG;
     *out = nullptr;
     if (nneigh && (!ranks || !send_off || !recv_off)) return MIMSEM_ERR_ARG;
+    if (nneigh && (send_off[0] != 0 || recv_off[0] != 0)) return MIMSEM_ERR_ARG;        // prefix sums start at 0
     for (int i = 0; i < nneigh; i++) if (send_off[i + 1] < send_off[i] || recv_off[i + 1] < recv_off[i]) return MIMSEM_ERR_ARG;
     const int ns = nneigh ? send_off[nneigh] : 0, nr = nneigh ? recv_off[nneigh] : 0;
     if ((ns && !send_idx) || (nr && !recv_idx)) return MIMSEM_ERR_ARG;
@@ -76,10 +84,13 @@ int mimsem_halo_create(mimsem_ctx* c, int nneigh, const int* ranks, const int* s
     h->ranks.assign(ranks, ranks + nneigh);
     h->send_off.assign(send_off, send_off + nneigh + 1); h->recv_off.assign(recv_off, recv_off + nneigh + 1);
     if (!nneigh) { h->send_off = {0}; h->recv_off = {0}; }
-    // ADD order: greedy ranges of neighbours (in the order given) with pairwise disjoint receive slots
+    // ADD order: greedy ranges of neighbours (in the order given) with pairwise disjoint receive slots.  A slot listed TWICE inside
+    // one neighbour's segment cannot be split off that way (k_halo_segments adds a segment's entries concurrently): rejected.
     {
         std::set<int> seen; int start = 0;
         for (int i = 0; i < nneigh; i++) {
+            std::set<int> own;
+            for (int k = recv_off[i]; k < recv_off[i + 1]; k++) if (!own.insert(recv_idx[k]).second) { delete h; return MIMSEM_ERR_ARG; }
             bool clash = false;
             for (int k = recv_off[i]; k < recv_off[i + 1] && !clash; k++) clash = seen.count(recv_idx[k]) != 0;
             if (clash) { h->add_ranges.push_back({start, i}); start = i; seen.clear(); }
@@ -125,9 +136,17 @@ int mimsem_halo_set_loopback(mimsem_halo* h) {
     h->transport = 2;
     return MIMSEM_OK;
 }
+int mimsem_halo_use_rccl_library(void* dl_handle) {
+    if (!dl_handle) return MIMSEM_ERR_ARG;
+    bool first = false;
+    g_rccl_handle = dl_handle;                                     // read once, by the first rccl() below or later
+    std::call_once(g_rccl_once, [&] { first = true; rccl_resolve(); });
+    if (!first) return MIMSEM_ERR_STATE;                           // the entry points were resolved before: too late to change the library
+    return g_rccl.ok ? MIMSEM_OK : MIMSEM_ERR_STATE;
+}
 int mimsem_halo_set_rccl(mimsem_halo* h, void* nccl_comm) {
     if (!h || !nccl_comm || h->in_flight) return MIMSEM_ERR_ARG;
-    if (!rccl().ok) return MIMSEM_ERR_STATE;                       // librccl not loadable here
+    if (!rccl().ok) return MIMSEM_ERR_STATE;                       // no librccl loaded in this process, and none handed over
     h->transport = 3; h->nccl_comm = nccl_comm;
     return MIMSEM_OK;
 }
@@ -155,12 +174,13 @@ int mimsem_halo_begin(mimsem_halo* h, int mode, int nlev, double* v, long long v
         } else {
             Rccl& r = rccl();
             if (r.GroupStart()) return MIMSEM_ERR_STATE;
-            for (int i = 0; i < h->nneigh; i++) {
+            bool failed = false;                                     // a group once opened is ALWAYS closed: an open group would swallow the host's next collectives
+            for (int i = 0; i < h->nneigh && !failed; i++) {
                 const size_t ns = (size_t)(h->send_off[i + 1] - h->send_off[i])*nlev, nr = (size_t)(h->recv_off[i + 1] - h->recv_off[i])*nlev;
-                if (ns && r.Send(h->d_send + (size_t)h->send_off[i]*nlev, ns, kNcclFloat64, h->ranks[i], h->nccl_comm, h->comm)) return MIMSEM_ERR_STATE;
-                if (nr && r.Recv(h->d_recv + (size_t)h->recv_off[i]*nlev, nr, kNcclFloat64, h->ranks[i], h->nccl_comm, h->comm)) return MIMSEM_ERR_STATE;
+                if (ns && r.Send(h->d_send + (size_t)h->send_off[i]*nlev, ns, kNcclFloat64, h->ranks[i], h->nccl_comm, h->comm)) failed = true;
+                if (!failed && nr && r.Recv(h->d_recv + (size_t)h->recv_off[i]*nlev, nr, kNcclFloat64, h->ranks[i], h->nccl_comm, h->comm)) failed = true;
             }
-            if (r.GroupEnd()) return MIMSEM_ERR_STATE;
+            if (r.GroupEnd() || failed) return MIMSEM_ERR_STATE;
         }
     }
     MIMSEM_HIP_TRY(hipEventRecord(h->ev_done, h->comm));

@@ -212,7 +212,8 @@ class Engine:
 
     def apply_part(self, op, part, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
         """the boundary or the interior part of apply(): part "boundary" first (all marked slots of `out` complete afterwards), then
-        "interior" into the SAME out, with no other operator call of this engine in between (the parts share the workspace)"""
+        "interior" into the SAME out with the same arguments.  The pending boundary part keeps its partial sums in a buffer of its own:
+        other calls may run in between, but a second boundary part or a non-matching interior part is refused (MIMSEM_ERR_STATE)"""
         sin, sf, sout = self._SPACES[op]
         x2 = x if x.dim() == 2 else x.unsqueeze(0)
         nlev = x2.shape[0]

@@ -14,18 +14,79 @@ from .device import Engine
 from .partition import CHalo, HaloExchanger, build_plans
 
 
+class RcclComm:
+    """An ncclComm_t over the ranks of the default process group, made the way a C++ host would make it (ncclGetUniqueId on rank 0,
+    the 128 bytes broadcast, ncclCommInitRank on every rank) through ctypes on the librccl this process has loaded -- PyTorch's,
+    when the process group's backend is "nccl".  It is what mimsem_halo_set_rccl takes: the library's grouped ncclSend / ncclRecv
+    then run on the plan's communication stream (xGMI), with no Python between pack, transport and unpack.
+    One rank per DEVICE: RCCL refuses two ranks on one GPU (the one-GPU rehearsals use the callback transport instead)."""
+
+    def __init__(self, device):
+        import ctypes as C
+        import os
+        torch.cuda.set_device(device)
+        lib = None
+        for name in ("librccl.so", "librccl.so.1"):
+            try:
+                lib = C.CDLL(name, mode=os.RTLD_NOLOAD | os.RTLD_NOW)       # the copy already in the process (torch's)
+                break
+            except OSError:
+                continue
+        if lib is None:
+            lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        self.lib = lib
+
+        class UID(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UID()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        raw = [bytes(uid)] if rank == 0 else [None]
+        dist.broadcast_object_list(raw, src=0)
+        C.memmove(C.byref(uid), raw[0], 128)
+        comm = C.c_void_p()
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+        rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0 or not comm.value:
+            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+        self.comm = comm.value
+        self.handle = lib._handle
+
+    def close(self):
+        import ctypes as C
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(C.c_void_p(self.comm))
+            self.comm = None
+
+
 class DistEngine:
-    def __init__(self, eng, sphere, world, rank, overlap=False, transport="dist"):
+    def __init__(self, eng, sphere, world, rank, overlap=False, transport="dist", plans=None):
         """overlap=True: 1-form operator results are completed through the C ABI's halo plan (CHalo) with the INTERIOR / BOUNDARY
         split of the apply -- boundary element groups first, exchange started, interior groups while it travels
-        (mimsem_op_apply_part + mimsem_halo_begin/_end); transport: "dist" (host callback over the process group) or an ncclComm_t."""
+        (mimsem_op_apply_part + mimsem_halo_begin/_end), and every other completion (complete(), incidence, blocks) goes through the
+        C ABI's plans too; transport: "dist" (host callback over the process group), an RcclComm / ncclComm_t, or "auto" = an RcclComm
+        of its own when the process group runs on RCCL, else "dist"."""
         self.eng, self.world, self.rank = eng, world, rank
         dm = eng.mesh
-        plans = build_plans(sphere, world, rank, dm.gid0, dm.gid1)
+        if plans is None:
+            plans = build_plans(sphere, world, rank, dm.gid0, dm.gid1)
         self.halo = {0: HaloExchanger(plans[0], engine=eng), 1: HaloExchanger(plans[1], engine=eng)}
         self.chalo = None
+        self.chalo0 = None
+        self.rccl = None
         if overlap and world > 1:
+            if transport == "auto":
+                transport = "dist"
+                if dist.get_backend() == "nccl":
+                    self.rccl = transport = RcclComm(eng.device.index if hasattr(eng.device, "index") else 0)
+            if isinstance(transport, RcclComm):
+                eng.L.mimsem_halo_use_rccl_library(transport.handle)     # (MIMSEM_ERR_STATE when resolved before: the same library then)
+                transport = transport.comm
+            self.transport = "rccl" if isinstance(transport, int) else transport
             self.chalo = CHalo(plans[1], eng, max_nlev=eng.nk, transport=transport)
+            self.chalo0 = CHalo(plans[0], eng, max_nlev=eng.nk + 1, transport=transport)
             eng.set_halo_slots(1, self.chalo.shared)
         f = lambda m: torch.as_tensor(m, dtype=torch.float64, device=eng.device)
         self.own = {0: f(plans[0].owned), 1: f(plans[1].owned), 2: torch.ones(dm.n2, dtype=torch.float64, device=eng.device)}
@@ -38,9 +99,21 @@ class DistEngine:
 
     # ---- completion ---------------------------------------------------------------------------------------------------------
     def complete(self, form, y):
-        if form in (0, 1):
-            self.halo[form].sum_all(y)             # edges: one symmetric exchange; nodes shared by > 2 ranks: owner sums, then scatters
+        if form == 1 and self.chalo is not None and y.shape[0] <= self.eng.nk:
+            self.chalo.sum_all(y)                  # edges: one symmetric exchange through the C ABI (pack, transport, unpack in the library)
+        elif form == 0 and self.chalo0 is not None and y.shape[0] <= self.eng.nk + 1:
+            self.chalo0.reverse_add(y); self.chalo0.forward_insert(y)       # nodes shared by > 2 ranks: owner sums, then scatters
+        elif form in (0, 1):
+            self.halo[form].sum_all(y)
         return y
+
+    def close(self):
+        for h in (self.chalo, self.chalo0):
+            if h is not None:
+                h.close()
+        self.chalo = self.chalo0 = None
+        if self.rccl is not None:
+            self.rccl.close(); self.rccl = None
 
     def allreduce(self, t, op="sum"):
         if self.world == 1:
@@ -91,11 +164,14 @@ class DistEngine:
         x2 = x if x.dim() == 2 else x.unsqueeze(0)
         if self.chalo is not None and form == 1 and Engine._SPACES[op][0] == 1 and op in ("UMAT", "UHMAT", "ROTMAT", "UTMAT", "UTMAT_H"):
             # boundary groups -> exchange in flight -> interior groups -> unpack: the halo travels while the interior is computed
-            tmp = torch.empty(x2.shape[0], self.eng.sizes[1], dtype=torch.float64, device=x2.device)
+            direct = out is not None and not (flags & 2) and out.dim() == 2 and out.is_contiguous()
+            tmp = out if direct else torch.empty(x2.shape[0], self.eng.sizes[1], dtype=torch.float64, device=x2.device)
             self.eng.apply_part(op, "boundary", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
             tok = self.chalo.begin("pair", tmp, True)
             self.eng.apply_part(op, "interior", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
             self.chalo.end(tok)
+            if direct:
+                return out
             if out is None:
                 return tmp if x.dim() == 2 else tmp[0]
             o = out if out.dim() == 2 else out.unsqueeze(0)

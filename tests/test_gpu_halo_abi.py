@@ -160,3 +160,52 @@ def test_interior_boundary_split_of_an_apply(oracle, op, fl):
     eng.apply_part(op, "boundary", x, f=f, lev0=0, scale=SCALE, flags=fl | 2, alpha=0.5, out=got)
     eng.apply_part(op, "interior", x, f=f, lev0=0, scale=SCALE, flags=fl | 2, alpha=0.5, out=got)
     assert torch.equal(got, want)
+
+
+def test_split_apply_contract():
+    """A pending BOUNDARY part can only be consumed by ITS interior part: anything else that would read or overwrite its partial sums
+    is refused (MIMSEM_ERR_STATE), whole applies and other workspace users may run in between without disturbing it"""
+    import torch
+    from mimsem_amd._lib import MimsemError
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from tests.helpers import SCALE, z_levels
+    cs = CubedSphere(3, 4, 6); coords = sphere_coords(3, 4)
+    topos = [Topo(cs, p, 9) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 9) for t in topos]
+    for g in geoms:
+        g.set_levels(z_levels(9, g.n0))
+    dm = DeviceMesh(topos, geoms, nk=9, numbering="global")
+    eng = Engine(dm)
+    r = np.random.default_rng(4)
+    x = eng.tensor(r.standard_normal((9, dm.n1))); x2 = eng.tensor(r.standard_normal((9, dm.n1)))
+    h = eng.tensor(r.uniform(0.5, 1.5, (9, dm.n2)) * 1e6)
+    marked = np.sort(r.choice(dm.n1, 80, replace=False)).astype(np.int32)
+    eng.set_halo_slots(1, marked)
+    whole = eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1)
+    out = torch.zeros_like(whole); other = torch.zeros_like(whole)
+    eng.apply_part("UMAT", "boundary", x, lev0=0, scale=SCALE, flags=1, out=out)
+    with pytest.raises(MimsemError):                                         # a second boundary part while one is pending
+        eng.apply_part("UMAT", "boundary", x2, lev0=0, scale=SCALE, flags=1, out=other)
+    with pytest.raises(MimsemError):                                         # an interior part of another apply (other y)
+        eng.apply_part("UMAT", "interior", x, lev0=0, scale=SCALE, flags=1, out=other)
+    with pytest.raises(MimsemError):                                         # ... other operator
+        eng.apply_part("UHMAT", "interior", x, f=h, lev0=0, scale=SCALE, flags=1, out=out)
+    with pytest.raises(MimsemError):                                         # ... other level range
+        eng.apply_part("UMAT", "interior", x[:4], lev0=0, scale=SCALE, flags=1, out=out[:4])
+    with pytest.raises(MimsemError):                                         # re-planning under a pending part
+        eng.set_halo_slots(1, marked[:10])
+    # users of the shared workspace in between: whole applies (wave and two-pass kernels), a 2-form-valued operator
+    eng.apply("UHMAT", x2, f=h, lev0=0, scale=SCALE, flags=1)
+    eng.apply("PMAT", eng.tensor(r.standard_normal((9, dm.n0))), lev0=0, scale=SCALE, flags=0)
+    eng.apply("UMAT", x2, lev0=0, scale=SCALE, flags=1)
+    eng.apply_part("UMAT", "interior", x, lev0=0, scale=SCALE, flags=1, out=out)
+    assert torch.equal(out, whole)
+    # error recovery: forget a pending part
+    eng.apply_part("UMAT", "boundary", x, lev0=0, scale=SCALE, flags=1, out=out)
+    assert eng.L.mimsem_op_apply_part_reset(eng.ctx) == 0
+    eng.apply_part("UMAT", "boundary", x2, lev0=0, scale=SCALE, flags=1, out=other)
+    eng.apply_part("UMAT", "interior", x2, lev0=0, scale=SCALE, flags=1, out=other)
+    assert torch.equal(other, eng.apply("UMAT", x2, lev0=0, scale=SCALE, flags=1))

@@ -108,13 +108,16 @@ def test_bench_multi_rank_control_flow_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["patches_per_gpu"] == 12 and d["config"]["units_per_step"] == 103680
-    for key in ("column_sharded", "horiz_sharded"):                    # the N > 1 extras with real work per rank ran too
+    assert d["config"]["halo_transport"] == "dist"                     # the C ABI's halo plans with the host-callback transport (rehearsal)
+    for key in ("weak_scaled", "column_sharded", "horiz_sharded"):     # the N > 1 extras with real work per rank ran too
         assert key in d and "error" not in d[key], d.get(key)
+    assert d["weak_scaled"]["scaling"] == "weak" and d["weak_scaled"]["units_per_rank"] == 829440
 
 
 def test_bench_extras_watchdog_keeps_the_headline_line():
     """N > 1: an extra that does not come back (here: a budget of 0 s) must not cost the headline -- rank 0 prints the
-    line measured so far with `extras_watchdog` set and every rank leaves with exit code 0"""
+    line measured so far with `extras_watchdog` set (naming the extra that was in flight) -- and must not pass for a clean run
+    either: every rank leaves with exit status 3"""
     import json
     import subprocess
     import sys
@@ -123,11 +126,12 @@ def test_bench_extras_watchdog_keeps_the_headline_line():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode != 0, "a run whose extras hung must not exit 0"
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and "extras_watchdog" in d and "roofline" in d
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "roofline" in d
+    assert "in_flight" in d["extras_watchdog"] and "exit status 3" in d["extras_watchdog"]["note"]
 
 
 def _sw_worker(rank, world, port, q):

@@ -1,4 +1,5 @@
-"""The device-tensor RCCL branch of HaloExchanger (all_to_all_single on GPU buffers over xGMI) and bench.py's N = 2 launch: needs TWO
+"""The device-tensor RCCL branch of HaloExchanger (all_to_all_single on GPU buffers over xGMI), the C ABI's RCCL transport
+(mimsem_halo_set_rccl on a communicator made by RcclComm, with the boundary | exchange | interior split) and bench.py's N = 2 launch: needs TWO
 visible GPUs, so it is skipped on the one-GPU test box (where the same control flow runs over gloo, tests/test_gpu_multiproc.py) and
 runs wherever a multi-GPU node executes the suite."""
 import os
@@ -48,7 +49,21 @@ def _worker(rank, world, port, q):
         dm1, eng1 = build(list(range(npatch)), rank)
         want = eng1.apply("UMAT", eng1.tensor(xg), lev0=0, scale=SCALE, flags=1).cpu().numpy()
         err = np.linalg.norm(y.cpu().numpy() - want[:, dm.gid1]) / np.linalg.norm(want)
-        q.put((rank, bool(err < 1e-12)))
+        ok = bool(err < 1e-12)
+        # the C ABI's own transport: an ncclComm_t made as a C++ host would (RcclComm), mimsem_halo_set_rccl, grouped ncclSend/ncclRecv on
+        # the plan's stream, the apply split boundary | exchange | interior -- bit for bit the exchanger's result
+        from mimsem_amd.distributed import DistEngine
+        dm2, eng2 = build(patches_of_rank(npatch, world, rank), rank)
+        de = DistEngine(eng2, cs, world, rank, overlap=True, transport="auto")
+        ok = ok and de.transport == "rccl"
+        y3 = de.apply("UMAT", eng2.tensor(xg[:, dm2.gid1]), lev0=0, scale=SCALE, flags=1)
+        ok = ok and bool(torch.equal(y3, y))
+        x0 = np.random.default_rng(5).standard_normal((nk, cs.nDofs0G))
+        p3 = de.apply("PMAT", eng2.tensor(x0[:, dm2.gid0]), lev0=0, scale=SCALE, flags=0)          # 0-forms: reverse_add + forward_insert plans
+        p1 = eng1.apply("PMAT", eng1.tensor(x0), lev0=0, scale=SCALE, flags=0).cpu().numpy()
+        ok = ok and bool(np.linalg.norm(p3.cpu().numpy() - p1[:, dm2.gid0]) / np.linalg.norm(p1) < 1e-12)
+        de.close()
+        q.put((rank, ok))
     except Exception as exc:                            # report instead of leaving the parent to time out
         q.put((rank, "%s: %s" % (type(exc).__name__, exc)))
         raise

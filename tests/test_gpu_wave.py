@@ -46,6 +46,11 @@ def engines(request):
     finally:
         del os.environ["MIMSEM_WAVE2"]
     wave.wave_all = wave_all
+    os.environ["MIMSEM_WAVE_FIN"] = "1"                  # opt-in: the perimeter slots finished inside k_apply_wave (no second launch)
+    try:
+        wave.fin = Engine(dm)
+    finally:
+        del os.environ["MIMSEM_WAVE_FIN"]
     assert two.L.mimsem_op_wave_stats(two.ctx, NK, st) == 0
     return pn, dm, wave, two, (cs, topos, geoms)
 
@@ -78,6 +83,34 @@ def test_wave_form_equals_two_pass_form(engines, op, fl):
     a1 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
     a2 = wave.apply(op, wave.tensor(x[:nl]), f=None if f is None else wave.tensor(f[:nl]), lev0=0, scale=SCALE, flags=fl)
     assert torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("op,fl", CASES, ids=["%s_%d" % c for c in CASES])
+def test_finishing_phase_equals_perimeter_pass(engines, op, fl):
+    """Round 3 experiment (MIMSEM_WAVE_FIN=1): the perimeter slots finished inside k_apply_wave by whichever wave-group
+    reaches a side second -- bit for bit what the default form (k_wave_perim, second launch) writes: both add the lower group's partial
+    sum first.  Inputs change from launch to launch, so a partial sum read stale (from an earlier launch) cannot go unnoticed."""
+    import torch
+    pn, dm, per, two, _ = engines
+    wave = per.fin
+    r = np.random.default_rng(29)
+    nl = NK - 1 if op == "UTMAT" else NK
+    f = {"UHMAT": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6, "UTMAT_H": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6,
+         "ROTMAT": r.standard_normal((NK, dm.n0)) * 1e-4}.get(op)
+    ft = None if f is None else wave.tensor(f)
+    ya, yb = wave.zeros(nl, dm.n1), per.zeros(nl, dm.n1)
+    for it in range(12):
+        x = wave.tensor(r.standard_normal((nl, dm.n1)) * (1.0 + it))
+        for lev0, nlev in ((0, nl), (1, 3), (4, 1), (0, 8)):
+            fs = None if ft is None else ft[:nlev]
+            a = wave.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
+            b = per.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
+            assert torch.equal(a, b), (op, it, lev0, nlev, int((a != b).sum()))
+        base = wave.tensor(r.standard_normal((nl, dm.n1)))
+        ya.copy_(base); yb.copy_(base)
+        wave.apply(op, x, f=None if ft is None else ft[:nl], lev0=0, scale=SCALE, flags=fl | 2, alpha=0.25, out=ya)
+        per.apply(op, x, f=None if ft is None else ft[:nl], lev0=0, scale=SCALE, flags=fl | 2, alpha=0.25, out=yb)
+        assert torch.equal(ya, yb), (op, it, "accumulate", int((ya != yb).sum()))
 
 
 CASES2 = [("WMAT", 1), ("WMAT", 0), ("WHMAT", 1), ("WHMAT", 0), ("WTQUMAT", 0), ("WTQDUDZ", 0)]
