@@ -2540,6 +2540,17 @@ int mimsem_column_helmholtz_blocks(mimsem_ctx* c, double dt, const double* theta
     return MIMSEM_OK;
 }
 
+int mimsem_column_solve_status(mimsem_ctx* c, int* n_unconverged, int* column_status, double* column_ratio) {
+    if (!c || !n_unconverged) return MIMSEM_ERR_ARG;
+    *n_unconverged = -1;
+    if (!c->colstat_valid || !c->d_colstat) return MIMSEM_OK;           // the last solve ran on a path that keeps no status
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    MIMSEM_HIP_TRY(hipMemcpy(n_unconverged, c->d_colstat, sizeof(int), hipMemcpyDeviceToHost));
+    if (column_status && c->nEl) MIMSEM_HIP_TRY(hipMemcpy(column_status, c->d_colstat + 1, (size_t)c->nEl*sizeof(int), hipMemcpyDeviceToHost));
+    if (column_ratio && c->nEl) MIMSEM_HIP_TRY(hipMemcpy(column_ratio, c->d_colratio, (size_t)c->nEl*sizeof(double), hipMemcpyDeviceToHost));
+    return MIMSEM_OK;
+}
+
 int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
         const double* theta, const double* rho, const double* eta, const double* pi,
         double* F_u, double* F_rho, double* F_eta, double* F_pi,
@@ -2547,7 +2558,12 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
     if (!c || !theta || !rho || !eta || !pi || !F_u || !F_rho || !F_eta || !F_pi || !d_u || !d_rho || !d_eta || !d_pi)
         return MIMSEM_ERR_ARG;
     if (c->nk < 2) return MIMSEM_ERR_ARG;
-    if (use_sweep(c)) return sweep_solve_eta(c, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi, d_u, d_rho, d_eta, d_pi);
+    c->colstat_valid = false;
+    if (use_sweep(c)) {
+        const int rc = sweep_solve_eta(c, dt, theta, rho, eta, pi, F_u, F_rho, F_eta, F_pi, d_u, d_rho, d_eta, d_pi);
+        c->colstat_valid = rc == MIMSEM_OK;
+        return rc;
+    }
     const int nk = c->nk, nm = nk - 1, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;
     const double hdt = 0.5*dt, gam = RD/CV;
     Schur S;

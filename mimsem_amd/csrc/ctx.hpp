@@ -107,6 +107,9 @@ struct mimsem_ctx {
     int *d_d0 = nullptr, *d_d1x = nullptr, *d_d1y = nullptr;   // direct-write slots (single-contributor DoFs), see ElemArgs
     int *d_sh0 = nullptr, *d_sh1 = nullptr; int nsh0 = 0, nsh1 = 0;   // slots with >= 2 contributors: the only ones pass 2 visits
     bool direct = false;
+    bool colstat_valid = false;
+    double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
+    int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
     long long col_doubles = 0;
     double col_param = 0.0;             // scalar argument of the *_ex column operators (dt_fric / dt)

@@ -643,6 +643,14 @@ class Engine:
                                                    _ptr(d_u), _ptr(d_rho), _ptr(d_eta), _ptr(d_pi)), "solve_schur_eta")
         return d_u, d_rho, d_eta, d_pi
 
+    def solve_status(self):
+        """(columns whose refinement did not converge in the last solve_schur_eta, or -1 when that path keeps no status; per-column status
+        array: 0 converged, 1 not converged, 2 refinement off; per-column |last correction| / |solution|) -- mimsem_column_solve_status"""
+        n = C.c_int(-1)
+        st = np.zeros(max(self.nEl, 1), dtype=np.int32); ratio = np.zeros(max(self.nEl, 1))
+        check(self.L.mimsem_column_solve_status(self.ctx, C.byref(n), st.ctypes.data, ratio.ctypes.data), "column_solve_status")
+        return n.value, st[:self.nEl], ratio[:self.nEl]
+
     # ---- Krylov building blocks ----------------------------------------------------------------
     def mdot(self, V, w, k=None, out=None):
         """h[i] = <V[i], w> for i < k; V: [m, n] contiguous rows"""

@@ -143,6 +143,31 @@ def test_schur_column_solve(setup):
             assert rel_l2(got[e].cpu().numpy(), ref[name]) < max(TOL, 50.0 * bound), (name, b)
 
 
+def test_two_sided_thomas_sweep_equals_the_one_sided(setup):
+    """Round 3: for even nk the Helmholtz system is solved by the two-sided (twisted) block-Thomas sweep -- top and bottom halves of a
+    column in two DPP rows at once -- instead of the one-sided chain (MIMSEM_THOMAS2=0): same system, same refinement rule, solutions
+    equal to the round-off the conditioning allows, identical status"""
+    import os
+    eng, P = setup
+    if P.nk % 2 or P.nk < 4 or P.n2e > 9:
+        pytest.skip("two-sided sweep: even nk >= 4, orders <= 3")
+    F = _col_fields(P)
+    r = np.random.default_rng(21)
+    nEl, N, Nm = P.nEl, P.nk * P.n2e, (P.nk - 1) * P.n2e
+    rhs = [r.standard_normal((nEl, n)) * 1e8 for n in (Nm, N, N, N)]
+    t = eng.tensor
+    args = lambda: (75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]), *[t(x) for x in rhs])
+    two = eng.solve_schur_eta(*args()); st2 = eng.solve_status()
+    os.environ["MIMSEM_THOMAS2"] = "0"
+    try:
+        one = eng.solve_schur_eta(*args()); st1 = eng.solve_status()
+    finally:
+        del os.environ["MIMSEM_THOMAS2"]
+    assert st1[0] == 0 and st2[0] == 0 and (st1[1] == 0).all() and (st2[1] == 0).all() and st2[2].max() <= 1e-10
+    for a, b, name in zip(two, one, ("d_u", "d_rho", "d_eta", "d_pi")):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, name
+
+
 def test_residual_compositions(setup):
     """C8: diagnose_F_z / diagnose_Phi_z / assemble_residual_ec (eul/VertSolve.cpp:237-286, 432-502) issued for all
     columns through the ABI vs the same chain written with the oracle's dense column matrices"""

@@ -134,6 +134,54 @@ def test_column_solve_satisfies_its_block_tridiagonal_system(full):
     assert all(bool(torch.isfinite(v).all()) for v in (d_u, d_rho, d_eta, d_pi))
 
 
+def test_column_solve_reports_the_columns_it_cannot_resolve(full):
+    """The block-Thomas sweep does not pivot across blocks (the reference's PCLU does, eul/VertSolve.cpp:645-653): on the rare rough
+    random column with cond(L) ~ 1e13 (scripts/diag_thomas_residual.py: 1 of 13 824) its refinement stagnates.  The ABI must say so:
+    every column either meets the residual bound or carries status 1 in mimsem_column_solve_status -- never a silent MIMSEM_OK."""
+    import os
+    import torch
+    cs, dm, eng, _ = full
+    n2, nEl = eng.n2e, dm.nEl
+    area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    flagged_total, worst_unflagged, worst_ratio = 0, 0.0, 0.0
+    for seed in (77, 1, 2, 3):
+        rng = np.random.default_rng(seed)
+        lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+        theta, rho, eta, pi = lev(NK, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 5, 6), lev(NK, 700, 1000)
+        F = [eng.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (NK - 1, NK, NK, NK)]
+        L = eng.helmholtz_blocks(75.0, theta, rho, eta, pi).view(nEl, NK, 3, n2, n2)
+        d = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)[3].view(nEl, NK, n2)
+        nbad, st, ratio = eng.solve_status()
+        assert nbad == int((st == 1).sum()) and set(np.unique(st)) <= {0, 1}, (nbad, np.unique(st))
+        assert (ratio[st == 0] <= 1e-10).all() and (ratio[st == 1] > 1e-10).all()
+        rhs = F[3].view(nEl, NK, n2)
+        Ld = torch.einsum("ekij,ekj->eki", L[:, :, 1], d)
+        Ld[:, 1:] += torch.einsum("ekij,ekj->eki", L[:, 1:, 0], d[:, :-1])
+        Ld[:, :-1] += torch.einsum("ekij,ekj->eki", L[:, :-1, 2], d[:, 1:])
+        rel = (torch.linalg.vector_norm(Ld - rhs, dim=(1, 2)) / torch.linalg.vector_norm(rhs, dim=(1, 2))).cpu().numpy()
+        ok = st == 0
+        # a converged column: residual at the level LAPACK's pivoted LU leaves on such columns (eps |L| |d| / |f| <= ~1e-8 at cond 1e10)
+        assert rel[ok].max() < 1e-7, (seed, float(rel[ok].max()))
+        worst_unflagged = max(worst_unflagged, float(rel[ok].max()))
+        flagged_total += nbad
+        # a flagged column: the reported ratio says how far it got.  Most settle just above the bar (1e-10 .. 1e-9: the conditioning
+        # floor of a cond ~ 1e10 column); seed 2 holds the column of DESIGN 2 with cond(L) ~ 1e13, whose correction stalls orders of
+        # magnitude higher although its RESIDUAL looks fine (the mark of an ill-conditioned system) -- that one must not pass as solved
+        worst_ratio = max(worst_ratio, float(ratio.max()))
+        print("seed %d: %d of %d columns flagged (largest ratio %.1e), worst residual flagged %.1e / unflagged %.1e"
+              % (seed, nbad, nEl, float(ratio.max()), float(rel[~ok].max()) if nbad else 0.0, float(rel[ok].max())))
+    assert flagged_total <= 70                                          # ~0.2 % of 13 824 rough random columns (cond ~ 1e10) stop above 1e-10
+    assert worst_ratio > 1e-7                                           # the pathological column was seen, and it was flagged (ratio[st == 0] <= 1e-10 above)
+    # the switch: without refinement every column says so
+    os.environ["MIMSEM_NO_REFINE"] = "1"
+    try:
+        eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+        nbad, st, ratio = eng.solve_status()
+    finally:
+        del os.environ["MIMSEM_NO_REFINE"]
+    assert nbad == 0 and (st == 2).all()
+
+
 def test_column_solve_3_satisfies_its_block_pentadiagonal_system(full):
     """solve_schur_column_3 at full size (row-per-lane 18x18 super-block sweep + refinement): L d_rt = F_rt with the
     block-pentadiagonal L the call itself returns ([nEl, nk, 5, n2, n2], block column = row - 2 + b); F_rt is the updated
