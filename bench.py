@@ -618,6 +618,8 @@ def main():
     }
     if deng is not None:
         out["config"]["halo_transport"] = getattr(deng, "transport", None)
+        if getattr(deng, "transport_note", None):
+            out["config"]["halo_transport_note"] = deng.transport_note
     bm, kname, k2name, lch = launch_bytes(eng, dm, NK)
     out["config"]["level_chunk"] = lch
     out["config"]["form"] = "wave-level fused (k_apply_wave + k_wave_perim)" if "wave" in kname else "two-pass (k_elem_apply + k_gather_sum)"

@@ -729,7 +729,10 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     // Wave-level fused scatter-add of the 1-form -> 1-form operators (k_apply_wave): the default since round 2
     // (MIMSEM_WAVE=0 selects the two-pass form for every operator).  Host copies of the index maps and the metric stay with the
     // context: mimsem_ctx_set_halo_slots re-derives the plan with the boundary groups first.
-    c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") && atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0;      // off by default: measured, no gain
+    // block pass of the Chebyshev / Richardson sweeps on the matrix cores: the default at p = 4 (40 x 40 blocks: 32.1 us against 32.8 us for
+    // the register-row form on the config-5 grid, profiles/r03_mfma_p4_ab.txt), off at p <= 3 (24 x 24: 25.3 against 23.8 us);
+    // MIMSEM_BLOCKS_MFMA=0 | 1 overrides
+    c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") ? atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
         c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
         c->h_i0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e);

@@ -43,7 +43,7 @@ struct mimsem_ctx {
     double* d_det = nullptr;    // [nEl][mp12]
     double* d_th = nullptr;     // [nk][nEl][mp12] thickness at the element's own quad points
     double* d_tI = nullptr;     // [nk][nEl][mp12] inverse thickness
-    bool blocks_mfma = false;   // block pass of the Chebyshev / Richardson sweeps on the matrix cores (MIMSEM_BLOCKS_MFMA=1 at context creation; default: register-row form)
+    bool blocks_mfma = false;   // block pass of the Chebyshev / Richardson sweeps on the matrix cores (default at p = 4, MIMSEM_BLOCKS_MFMA=0|1 at context creation overrides; p <= 3: register-row form)
     double* d_tIp = nullptr;    // [2][nk/2 + 1][nEl][mp12][2]: the same in level PAIRS {L, L+1}, first index = parity of L (k_apply_wave: one 16-byte load per two levels)
     bool have_levels = false;
     int* d_i0 = nullptr;        // [nEl][n0e]

@@ -77,10 +77,25 @@ class DistEngine:
         self.chalo0 = None
         self.rccl = None
         if overlap and world > 1:
+            self.transport_note = None
             if transport == "auto":
                 transport = "dist"
                 if dist.get_backend() == "nccl":
-                    self.rccl = transport = RcclComm(eng.device.index if hasattr(eng.device, "index") else 0)
+                    # every rank must end up on the same transport: a rank that cannot make its communicator (library not found, ...)
+                    # makes all of them fall back to the host-staged callback, and the record says so
+                    ok, err = 1, None
+                    try:
+                        self.rccl = RcclComm(eng.device.index if hasattr(eng.device, "index") else 0)
+                    except Exception as ex:                              # noqa: BLE001 -- reported through transport_note
+                        ok, err = 0, "%s: %s" % (type(ex).__name__, ex)
+                    flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 1:
+                        transport = self.rccl
+                    else:
+                        self.transport_note = "RCCL communicator not available on every rank (%s): host-staged callback transport" % (err or "another rank failed")
+                        if self.rccl is not None:
+                            self.rccl.close(); self.rccl = None
             if isinstance(transport, RcclComm):
                 eng.L.mimsem_halo_use_rccl_library(transport.handle)     # (MIMSEM_ERR_STATE when resolved before: the same library then)
                 transport = transport.comm

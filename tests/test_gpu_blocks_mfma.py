@@ -22,12 +22,14 @@ def _engines(pn, ne, nk):
     for g in geoms:
         g.set_levels(z_levels(nk, g.n0))
     dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
-    rr = Engine(dm)
-    os.environ["MIMSEM_BLOCKS_MFMA"] = "1"
-    try:
-        mf = Engine(dm)
-    finally:
-        del os.environ["MIMSEM_BLOCKS_MFMA"]
+    engs = []
+    for flag in ("0", "1"):                              # explicit both ways: the default differs by order (p = 4: matrix cores)
+        os.environ["MIMSEM_BLOCKS_MFMA"] = flag
+        try:
+            engs.append(Engine(dm))
+        finally:
+            del os.environ["MIMSEM_BLOCKS_MFMA"]
+    rr, mf = engs
     return dm, mf, rr
 
 
