@@ -1,12 +1,12 @@
 #!/bin/bash
-# A/B of the Helmholtz solve inside solve_schur_column_eta (3 456 columns x 30 levels): one-sided sweep (MIMSEM_THOMAS2=0), two-sided
-# sweep compiled for two wavefronts per SIMD (default; spills) and without a register cap (build_ab/libmimsem_hip_td2wpe1.so)
+# The Helmholtz solve inside solve_schur_column_eta (3 456 columns x 30 levels): one-sided sweep (MIMSEM_THOMAS2=0) against the two-sided
+# sweep (default); wall clock per solve and rocprofv3 kernel averages of the three kernels of the solve.
 out=gpurun_out/ab_thomas.log; : > $out
 cd /tmp && export TMPDIR=/tmp
-for v in "MIMSEM_THOMAS2=0" "DEFAULT=1" "MIMSEM_LIB=$GRAFT_REPO_ROOT/build_ab/libmimsem_hip_td2wpe1.so"; do
+for v in "MIMSEM_THOMAS2=0" "DEFAULT=1"; do
   echo "== $v" >> $GRAFT_REPO_ROOT/$out
   d=$GRAFT_REPO_ROOT/gpurun_out/prof_thomas_$(echo $v | tr -c 'A-Za-z0-9' '_')
-  env $v python3 $GRAFT_REPO_ROOT/scripts/prof_column.py >> $GRAFT_REPO_ROOT/$out 2>&1
+  env $v python3 $GRAFT_REPO_ROOT/scripts/prof_column.py 2>/dev/null | tail -1 >> $GRAFT_REPO_ROOT/$out
   env $v rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 $GRAFT_REPO_ROOT/scripts/prof_column.py > /dev/null 2>&1
   python3 - "$d" >> $GRAFT_REPO_ROOT/$out <<'PY'
 import csv, glob, sys

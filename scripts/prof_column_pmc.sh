@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/pmc_col; mkdir -p $O
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"
 B="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS"
-for mode in sweep rows; do
+for mode in ${MODES:-sweep rows}; do
   export MIMSEM_SCHUR_FUSED=$mode
   rocprofv3 --pmc $A --kernel-trace --output-format csv -d $O/${mode}_a -o p -- python3 $R/scripts/prof_column.py > $O/${mode}_a.log 2>&1 || exit 1
   rocprofv3 --pmc $B --kernel-trace --output-format csv -d $O/${mode}_b -o p -- python3 $R/scripts/prof_column.py > $O/${mode}_b.log 2>&1 || exit 1
@@ -14,7 +14,7 @@ done
 python3 - <<PY
 import csv, collections, glob
 O="$O"
-for mode in ("sweep", "rows"):
+for mode in "${MODES:-sweep rows}".split():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for part in ("a", "b"):
         for f in glob.glob(f"{O}/{mode}_{part}/*counter_collection.csv"):
