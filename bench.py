@@ -40,8 +40,8 @@ FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: FP64 vector (= matrix) peak
 # solve x 64 lanes (FMA = 2 flop), rocprofv3 --pmc over scripts/prof_column.py / prof_column3.py (profiles/r02_column_pmc.txt;
 # refreshed in profiles/r03_column_pmc.txt).  Padding lanes of the 16-lane DPP rows (9 of 16 rows carry data) are executed work and
 # count: the figure is what the ALUs did, not the algorithm's minimum (~3 700 flop per level).
-SCHUR_ETA_FLOP_PER_COLUMN_LEVEL = 1.54e5
-SCHUR_3_FLOP_PER_COLUMN_LEVEL = 4.3e5
+SCHUR_ETA_FLOP_PER_COLUMN_LEVEL = 1.55e5
+SCHUR_3_FLOP_PER_COLUMN_LEVEL = 2.63e5
 
 
 def b1_launch_bytes(nEl, n1, nlev, lch, pn=PN):
@@ -920,6 +920,15 @@ def main():
                         out[key]["traffic_frac"] = out[key]["traffic_GBs"] / HBM_PEAK_GBS
                         out[key]["traffic_note"] = ("FETCH_SIZE x %.2f (calibrated on a launch of known byte count) + WRITE_SIZE of this launch, "
                                                     "child rocprofv3 --pmc passes of this run (scripts/pmc_traffic.py)" % pm["fetch_correction"])
+                # the whole operator: both kernels' HBM-side bytes against every input and output once (<= 1.25x asked)
+                k2n = out["roofline"]["whole_operator"]["kernels"].split(" + ")[-1]
+                l2 = sorted(pm["kernels"].get(k2n, []), key=lambda r: r["grid_threads"])
+                if l2:
+                    for key, r1, r2 in (("roofline", launches[0], l2[0]), ("roofline_cold", launches[-1], l2[-1])):
+                        if key in out and "whole_operator" in out[key] and (key == "roofline" or (len(launches) > 1 and len(l2) > 1)):
+                            w = out[key]["whole_operator"]
+                            w["traffic"] = r1["total_bytes"] + r2["total_bytes"]
+                            w["traffic_over_compulsory"] = w["traffic"] / w["bytes_per_launch"]
                 out["roofline"].pop("traffic_from_committed_profile", None)
                 out["pmc_traffic"] = pm
         except Exception as ex:          # noqa: BLE001 -- the headline line never depends on the profiler being usable

@@ -23,7 +23,8 @@ for g in geoms:
 dm = DeviceMesh(topos, geoms, nk=NK, numbering="global")
 rng = np.random.default_rng(1)
 reps = int(os.environ.get("REPS", "10"))
-for R in (1, int(os.environ.get("COLD", "8"))):
+only = os.environ.get("ONLY", "")                       # "hot" | "cold": one workload per process, so that a rocprofv3 summary has one row per size
+for R in [r for r, tag in ((1, "hot"), (int(os.environ.get("COLD", "8")), "cold")) if not only or only == tag]:
     d = dm if R == 1 else bench.replicate(dm, R)
     eng = Engine(d, device=0)
     x = eng.tensor(rng.standard_normal((NK, d.n1))); y = eng.zeros(NK, d.n1)
