@@ -470,6 +470,22 @@ def roofline_entry(bm, k1, k12, cache_resident, note, kname="k_elem_apply<3,UMAT
                                "algorithmic_reference_bytes_per_unit": BYTES_OP_B1}}
 
 
+def copy_reference_us(nbytes, torch, device, reps=30):
+    """HIP-event time of a device-to-device copy that moves `nbytes` in total (half read, half written): what a kernel with no work,
+    no gather and no dependent address chain needs for the same bytes at this size -- context for `frac`, never a roofline"""
+    n = max(int(nbytes) // 16, 1)
+    a = torch.empty(n, dtype=torch.float64, device=device).normal_(); b = torch.empty_like(a)
+    for _ in range(5):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = []
+    for _ in range(reps):
+        e0.record(); b.copy_(a); e1.record(); e1.synchronize()
+        best.append(e0.elapsed_time(e1) * 1e3)
+    best.sort()
+    return best[len(best) // 2]
+
+
 def cold_workload(dm, R, local_rank, rng, torch, steps=20):
     """the same step on R independent copies of the sphere: working set >> the 256 MiB Infinity Cache, i.e. HBM-resident"""
     from mimsem_amd.device import Engine
@@ -489,6 +505,7 @@ def cold_workload(dm, R, local_rank, rng, torch, steps=20):
     ws = engc.L.mimsem_ctx_workspace_bytes(engc.ctx) / 1e6 + 2 * xc.numel() * 8 / 1e6
     r = roofline_entry(bm, c1 / cn * 1e-3, (c1 + c2) / cn * 1e-3, cache_resident=False,
                        note="%d independent spheres in one launch, context + vectors %.0f MB >> Infinity Cache" % (R, ws), kname=kname, k2name=k2name)
+    r["whole_operator"]["copy_of_the_same_bytes_us"] = copy_reference_us(bm["op_compulsory"], torch, engc.device)
     r.update({"replicas": R, "level_chunk": lch, "working_set_MB": ws, "value": bm["units"] * steps / dtc,
               "value_unit": "element operator-applies/s (wall clock over %d back-to-back steps)" % steps})
     del engc
@@ -630,6 +647,7 @@ def main():
                                          note="working set (~35 MB fields + metric) sits inside the 256 MiB Infinity Cache and is re-read "
                                               "every step: see roofline_cold for the HBM-resident workload", kname=kname, k2name=k2name)
         if world == 1:
+            out["roofline"]["whole_operator"]["copy_of_the_same_bytes_us"] = copy_reference_us(bm["op_compulsory"], torch, eng.device)
             # NOT measured in this run: the PMC passes need rocprofv3 (scripts/pmc_traffic.py); the committed summary of the
             # same 103 680-unit launch is quoted for orientation only
             try:
