@@ -422,8 +422,13 @@ int mimsem_krylov_orthogonalize(mimsem_ctx* ctx, int k, long long n, const doubl
  * memory (hipHostMalloc): the Hessenberg column then reaches the host without a copy of its own. */
 int mimsem_krylov_normalize(mimsem_ctx* ctx, long long n, const double* w, double* v, int k, const double* h1, const double* h2,
                             double* col, int norm_slot);
-/* Second Gram-Schmidt pass and normalisation together, three launches: h2 = V w; w -= V^T h2 (the norm of the result is
- * accumulated by the same kernel); v = w/|w|, col[0..k) = h1 + h2, col[norm_slot] = |w|. */
+/* Second Gram-Schmidt pass and normalisation together: h2 = V w; w -= V^T h2; v = w/|w|, col[0..k) = h1 + h2, col[norm_slot] = |w|.
+ * Two launches (round 3): the k dots of the pass and w.w in one, then update + normalisation + column in one, with
+ * |w - V^T h2|^2 = w.w - h2.h2 (exact for an orthonormal V; h2 is the small correction of a RE-orthogonalisation, nothing cancels).
+ * Should more than half of w.w sit in h2 -- the first pass lost its orthogonality altogether -- the word given to
+ * mimsem_krylov_gs_control is set to 1 and the caller repeats the step with the three-launch form (norm accumulated from the updated
+ * vector; fused = 0 selects it, also MIMSEM_GS_FUSED_NORM=0).  flag: device or pinned host memory, NULL = none. */
+int mimsem_krylov_gs_control(mimsem_ctx* ctx, int fused /* 0 | 1, < 0: leave */, int* flag);
 int mimsem_krylov_reorthonormalize(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
                                    const double* h1, double* h2, double* col, int norm_slot);
 /* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in

@@ -104,6 +104,7 @@ _SIGS = {
     "mimsem_halo_set_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mimsem_halo_use_rccl_library": (C.c_int, [C.c_void_p]),
     "mimsem_op_apply_part_reset": (C.c_int, [C.c_void_p]),
+    "mimsem_krylov_gs_control": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_column_solve_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     "mimsem_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_halo_set_loopback": (C.c_int, [C.c_void_p]),

@@ -133,6 +133,8 @@ struct mimsem_ctx {
     bool is_capturing() const;           // the context's stream is inside a hipGraph capture (workspaces must not grow there)
     int ensure_ye(long long doubles);
     int ensure_col(long long doubles);
+    int gs_fused = -1;                  // second Gram-Schmidt pass + normalisation in two launches (mimsem_krylov_gs_control; -1: from the environment)
+    int* gs_flag = nullptr;             // caller's word (device or pinned host), set to 1 when that form's Pythagorean norm would cancel
     double* d_kry = nullptr;            // partial sums of the Krylov multi-dot
     long long kry_doubles = 0;
     int ensure_kry(long long doubles);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.hpp"
 
@@ -95,6 +96,58 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(long long n, long long c
     if (lane == 0) red[wave] = s;
     __syncthreads();
     if (tid == 0) part[(size_t)row*gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// the k rows V_i . w of a Gram-Schmidt pass AND w . w (row k) in one launch: what the second pass needs to normalise without a
+// reduction of its own (|w - V h|^2 = |w|^2 - |h|^2 for an orthonormal V)
+__global__ __launch_bounds__(256) void k_mdot_self_partial(int k, long long n, long long chunk, const double* __restrict__ V, long long ldv,
+                                                           const double* __restrict__ w, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.y;
+    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
+    const double* a = row < k ? V + (size_t)row*ldv : w;
+    double s = 0.0;
+    for (long long t = lo + tid; t < hi; t += 256) s += a[t]*w[t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) part[(size_t)row*gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// second Gram-Schmidt pass, normalisation and the Hessenberg column in ONE launch: every block reduces the partial sums of
+// h2 = V w and of w . w (fixed order), takes |w - V h2| = sqrt(w.w - h2.h2) -- exact for an orthonormal V, and h2 is the small
+// correction of a re-orthogonalisation, so nothing cancels; if more than half of w.w went into h2 (the first pass had lost its
+// orthogonality altogether) *flag is raised and the caller repeats the step with the three-launch form -- and writes
+// w <- w - V^T h2, v = w/|w|; block 0 stores h2 and the column (col may be pinned host memory).
+__global__ __launch_bounds__(256) void k_maxpy_reduce_normalize(int k, int nb, long long n, const double* __restrict__ V, long long ldv,
+                                                                const double* __restrict__ part, double* __restrict__ w, double* __restrict__ v,
+                                                                const double* __restrict__ h1, double* __restrict__ h2, double* __restrict__ col,
+                                                                int norm_slot, int* __restrict__ flag) {
+    extern __shared__ double sh[];                       // k + 1 reduced dots
+    for (int base = 0; base <= k; base += 64) {
+        const int i = base + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        double s = 0.0;
+        if (i <= k) for (int b = sub; b < nb; b += 4) s += part[(size_t)i*nb + b];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (i <= k && sub == 0) sh[i] = s;
+    }
+    __syncthreads();
+    double hh = 0.0;
+    for (int i = 0; i < k; i++) hh += sh[i]*sh[i];       // (every thread, same order: the same bits everywhere)
+    const double ww = sh[k];
+    const double n2 = ww - hh;
+    const double nrm = sqrt(n2 > 0.0 ? n2 : 0.0);
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < k; i += 256) { h2[i] = sh[i]; col[i] = h1[i] + sh[i]; }
+        if (threadIdx.x == 0) { col[norm_slot] = nrm; if (flag && !(hh <= 0.5*ww)) *flag = 1; }
+    }
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t < n) {
+        double s = 0.0;
+        for (int i = 0; i < k; i++) s += sh[i]*V[(size_t)i*ldv + t];
+        const double wn = w[t] - s;
+        w[t] = wn;
+        v[t] = wn/nrm;
+    }
 }
 __global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
     const int row = blockIdx.x, lane = threadIdx.x;
@@ -248,13 +301,31 @@ int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const doub
     if (!c || !V || !w || !v || !h1 || !h2 || !col || k <= 0 || n <= 0 || ldv < n || norm_slot < 0) return MIMSEM_ERR_ARG;
     const unsigned gb = (unsigned)((n + 255)/256);
     int nb = 0;
-    int rc = c->ensure_kry((long long)RD_BLOCKS*k + gb);
+    int rc = c->ensure_kry((long long)RD_BLOCKS*(k + 1) + gb);
     if (rc) return rc;
+    if (c->gs_fused < 0) c->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
+    if (c->gs_fused) {
+        // round 3: two launches -- the dots of the pass and w . w together, then update + normalisation + column in one kernel
+        nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+        const long long chunk = (n + nb - 1)/nb;
+        hipLaunchKernelGGL(k_mdot_self_partial, dim3(nb, k + 1), dim3(256), 0, c->stream, k, n, chunk, V, ldv, w, c->d_kry);
+        hipLaunchKernelGGL(k_maxpy_reduce_normalize, dim3(gb), dim3(256), (size_t)(k + 1)*sizeof(double), c->stream, k, nb, n, V, ldv, c->d_kry,
+                           w, v, h1, h2, col, norm_slot, c->gs_flag);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     if ((rc = rowdot_partials(c, k, n, V, ldv, w, 0, &nb))) return rc;
     double* npart = c->d_kry + (size_t)RD_BLOCKS*k;
     hipLaunchKernelGGL(k_maxpy_reduce, dim3(gb), dim3(256), (size_t)k*sizeof(double), c->stream, k, nb, n, V, ldv, c->d_kry, -1.0, w, h2, npart);
     hipLaunchKernelGGL(k_normalize, dim3(gb), dim3(256), 0, c->stream, (int)gb, n, npart, w, v, k, h1, h2, col, norm_slot);
     MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+int mimsem_krylov_gs_control(mimsem_ctx* c, int fused, int* flag) {
+    if (!c) return MIMSEM_ERR_ARG;
+    if (fused >= 0) c->gs_fused = fused != 0;
+    c->gs_flag = flag;
     return MIMSEM_OK;
 }
 

@@ -672,7 +672,7 @@ class Engine:
         return w
 
     def reorthonormalize(self, V, w, v, k, h1, h2, col, norm_slot):
-        """second Gram-Schmidt pass + normalisation in three launches: h2[:k] = V[:k] w; w -= V[:k]^T h2; v = w/|w|;
+        """second Gram-Schmidt pass + normalisation in two launches: h2[:k] = V[:k] w; w -= V[:k]^T h2; v = w/|w|;
         col[:k] = h1 + h2; col[norm_slot] = |w| (col: device or pinned host tensor)"""
         assert w.numel() == v.numel() and v.is_contiguous() and col.dtype == torch.float64 and col.is_contiguous()
         assert col.is_cuda or col.is_pinned(), "col must be device or pinned host memory"

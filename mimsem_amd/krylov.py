@@ -191,11 +191,33 @@ class MassSolver:
             if not self._cheb_checked and not torch.cuda.is_current_stream_capturing():
                 # one-time check of the spectral bounds on a real right-hand side: a step count derived from wrong bounds would
                 # silently under-solve; fall back to PCG for good if the true residual is not at round-off
-                res = torch.linalg.vector_norm(b - self.apply(x, lev0), dim=1) / torch.linalg.vector_norm(b, dim=1).clamp_min(1e-300)
+                bn = torch.linalg.vector_norm(b, dim=1).clamp_min(1e-300)
+                true_res = lambda y: float((torch.linalg.vector_norm(b - self.apply(y, lev0), dim=1) / bn).max())
+                res = true_res(x)
                 self._cheb_checked = True
-                if not bool(res.max() < 1e-11):
+                if not res < 1e-11:
                     self.chebyshev = False
                     return self.solve(b, lev0, rtol, maxit)
+                # ... and one-time CALIBRATION of the step count (round 3): the bound-based count (interval widened by 10 % / 5 %, 1e-15)
+                # over-solves.  Take the smallest count whose TRUE residual -- on this right-hand side and on a random one, which
+                # excites every eigenmode -- meets the tolerance the caller asked for (`rtol`, 1e-14: the stopping rule of the PCG
+                # path of this class) or is within a factor 2 of the round-off floor, plus one step; MIMSEM_CHEB_CALIBRATE=0 keeps the bound.
+                if os.environ.get("MIMSEM_CHEB_CALIBRATE", "1") != "0":
+                    full = ch.steps
+                    g = torch.Generator(device="cpu"); g.manual_seed(4321)
+                    rnd = torch.randn(b.shape, generator=g, dtype=b.dtype).to(b.device) * bn[:, None] / math.sqrt(b.shape[1])
+                    rn = torch.linalg.vector_norm(rnd, dim=1).clamp_min(1e-300)
+                    rnd_res = lambda y: float((torch.linalg.vector_norm(rnd - self.apply(y, lev0), dim=1) / rn).max())
+                    floor_rnd = rnd_res(ch.solve(rnd))             # a random right-hand side excites every eigenmode: the count must hold for it too
+                    need = full
+                    for k in range(max(4, full // 2), full):
+                        ch.set_steps(k)
+                        if true_res(ch.solve(b)) <= max(2.0 * res, rtol) and rnd_res(ch.solve(rnd)) <= max(2.0 * floor_rnd, rtol):
+                            need = min(full, k + 1)
+                            break
+                    ch.set_steps(need)
+                    self.cheb_calibration = {"bound_steps": full, "steps": need, "floor": res, "floor_random": floor_rnd}
+                    x = ch.solve(b)
             return x, ch.steps
         if self.kind != "jacobi":
             with self.eng.space(1):
@@ -299,6 +321,11 @@ class GraphedGMRES:
         self.graphs = [None] * restart
         self.pool = None
         self.lookahead = int(os.environ.get("MIMSEM_GMRES_LOOKAHEAD", "8"))
+        # the two-launch re-orthonormalisation takes its norm from w.w - h2.h2; the kernel raises this (pinned) word should that
+        # ever cancel, and the cycle is then repeated on the three-launch form
+        self.gs_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        loc = getattr(eng, "eng", eng)
+        loc.L.mimsem_krylov_gs_control(loc.ctx, -1, self.gs_flag.data_ptr())
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1
@@ -367,6 +394,13 @@ class GraphedGMRES:
                 for j in range(j0, j0 + s):
                     self._graph(j).replay()
                 torch.cuda.current_stream(dev).synchronize()
+                if int(self.gs_flag[0]) != 0:                    # (never seen on the operators of this repository)
+                    loc = getattr(self.eng, "eng", self.eng)
+                    loc.L.mimsem_krylov_gs_control(loc.ctx, 0, self.gs_flag.data_ptr())
+                    self.gs_flag[0] = 0
+                    self.graphs = [None] * m                      # re-capture with the three-launch form
+                    k = 0; done = False
+                    break                                         # restart the cycle from the current x
                 for j in range(j0, j0 + s):
                     col = self.col_host[j].tolist()
                     for i in range(j + 1):
@@ -391,7 +425,8 @@ class GraphedGMRES:
             for i in range(k - 1, -1, -1):
                 sacc = g[i] - sum(H[i][l] * y[l] for l in range(i + 1, k))
                 y[i] = sacc / H[i][i]
-            self.eng.maxpy(self.V, torch.tensor(y, dtype=bf.dtype, device=bf.device), x, alpha=1.0, k=k)
+            if k > 0:
+                self.eng.maxpy(self.V, torch.tensor(y, dtype=bf.dtype, device=bf.device), x, alpha=1.0, k=k)
             if res <= tol:
                 break
         # capture ahead: the look-ahead replays run up to `lookahead` steps past the one that converges, and the count moves by a
@@ -513,10 +548,16 @@ class ChebyshevMass:
         """sweep(x, b, p, alpha, beta, upd): one fused step (closure over op, blocks, elem_scale, lev0, scale, flags)"""
         self.eng, self.sweep = eng, sweep
         self.lmin, self.lmax = 0.90 * lmin, 1.05 * lmax
-        th, de = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
         kappa = self.lmax / self.lmin
         sg = (math.sqrt(kappa) - 1.0) / (math.sqrt(kappa) + 1.0)
-        self.steps = max(2, int(math.ceil(math.log(2.0 / rtol) / math.log(1.0 / sg))))
+        self.set_steps(max(2, int(math.ceil(math.log(2.0 / rtol) / math.log(1.0 / sg)))))
+        self.p = None
+        self.upd = None
+
+    def set_steps(self, steps):
+        """fix the number of steps (the coefficients of step k depend on the spectral interval only, not on how many steps follow)"""
+        self.steps = steps
+        th, de = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
         # x_{k+1} = x_k + c1_k z_k + c2_k (x_k - x_{k-1}) written as q_k = z_k + beta_k q_{k-1}, x += alpha_k q_k
         s1 = th / de
         rho_prev = 1.0 / s1
@@ -527,8 +568,6 @@ class ChebyshevMass:
             c1, c2 = 2.0 * rho / de, rho * rho_prev
             self.coef.append((c1, c2 * c1_prev / c1))
             rho_prev, c1_prev = rho, c1
-        self.p = None
-        self.upd = None
 
     def solve(self, b, x0=None, want_residual=False):
         """returns x; capturable (fixed shapes and step count, no host synchronisation unless want_residual)"""

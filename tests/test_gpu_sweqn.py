@@ -217,19 +217,48 @@ def test_sw_fused_krylov_body_and_reorthonormalize(sw):
     ref = S.precond_A(S.apply_A(x, dt), dt)
     got = S._krylov_body(dt)(x)
     assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    # the second Gram-Schmidt pass as it occurs: V orthonormal, w already orthogonalised once (what is left in span V is round-off
+    # sized -- here made 1e-9 so that the pass does something).  Two-launch form (|w - V h2|^2 = w.w - h2.h2) against the separate
+    # pass + normalisation: same h2, same w bit for bit, the norm to round-off
     n, m = dm.n1 + dm.n2, 12
-    V = eng.tensor(r.standard_normal((m, n))); w0 = eng.tensor(r.standard_normal(n))
+    Q, _ = torch.linalg.qr(eng.tensor(r.standard_normal((n, m))))
+    V = Q.T.contiguous()
+    w0 = eng.tensor(r.standard_normal(n))
+    w0 = w0 - V.T @ (V @ w0) + 1e-9 * (V.T @ eng.tensor(r.standard_normal(m)))
     h1 = eng.tensor(r.standard_normal(m))
-    for k in (1, 5, m):
-        wa, wb = w0.clone(), w0.clone()
+    flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    assert eng.L.mimsem_krylov_gs_control(eng.ctx, 1, flag.data_ptr()) == 0
+    try:
+        for k in (1, 5, m):
+            wa, wb = w0.clone(), w0.clone()
+            h2a = torch.zeros(m, dtype=torch.float64, device=eng.device); h2b = torch.zeros_like(h2a)
+            cola = torch.zeros(m + 2, dtype=torch.float64, device=eng.device); colb = torch.zeros_like(cola)
+            va, vb = torch.empty_like(w0), torch.empty_like(w0)
+            eng.orthogonalize(V, wa, h2a, k=k); eng.normalize(wa, va, k, h1, h2a, cola, m + 1)
+            eng.reorthonormalize(V, wb, vb, k, h1, h2b, colb, m + 1)
+            torch.cuda.synchronize()
+            assert torch.equal(wa, wb) and torch.equal(h2a, h2b) and torch.equal(cola[:k], colb[:k])
+            assert abs(float(cola[m + 1] - colb[m + 1])) < 1e-14 * float(cola[m + 1])
+            assert float((va - vb).abs().max()) < 1e-14 * float(va.abs().max())
+            assert int(flag[0]) == 0
+        # a vector that still lies mostly INSIDE span V (a first pass that did nothing): the Pythagorean norm would cancel -- flagged
+        wbad = (V.T @ eng.tensor(r.standard_normal(m))) + 0.1 * w0
+        eng.reorthonormalize(V, wbad, torch.empty_like(w0), m, h1, torch.zeros_like(h1), torch.zeros(m + 2, dtype=torch.float64, device=eng.device), m + 1)
+        torch.cuda.synchronize()
+        assert int(flag[0]) == 1
+        # ... and the three-launch form, selected by the same call, is what the fall-back uses: equal to pass + normalisation for any V
+        flag[0] = 0
+        assert eng.L.mimsem_krylov_gs_control(eng.ctx, 0, flag.data_ptr()) == 0
+        Vr = eng.tensor(r.standard_normal((m, n))); wr = eng.tensor(r.standard_normal(n))
+        wa, wb = wr.clone(), wr.clone()
         h2a = torch.zeros(m, dtype=torch.float64, device=eng.device); h2b = torch.zeros_like(h2a)
         cola = torch.zeros(m + 2, dtype=torch.float64, device=eng.device); colb = torch.zeros_like(cola)
-        va, vb = torch.empty_like(w0), torch.empty_like(w0)
-        eng.orthogonalize(V, wa, h2a, k=k); eng.normalize(wa, va, k, h1, h2a, cola, m + 1)
-        eng.reorthonormalize(V, wb, vb, k, h1, h2b, colb, m + 1)
-        assert torch.equal(wa, wb) and torch.equal(h2a, h2b) and torch.equal(cola[:k], colb[:k])
-        assert abs(float(cola[m + 1] - colb[m + 1])) < 1e-13 * float(cola[m + 1])
-        assert float((va - vb).abs().max()) < 1e-14 * float(va.abs().max())
+        va, vb = torch.empty_like(wr), torch.empty_like(wr)
+        eng.orthogonalize(Vr, wa, h2a, k=m); eng.normalize(wa, va, m, h1, h2a, cola, m + 1)
+        eng.reorthonormalize(Vr, wb, vb, m, h1, h2b, colb, m + 1)
+        assert torch.equal(wa, wb) and torch.equal(h2a, h2b) and abs(float(cola[m + 1] - colb[m + 1])) < 1e-13 * float(cola[m + 1])
+    finally:
+        eng.L.mimsem_krylov_gs_control(eng.ctx, 1, None)
 
 
 @pytest.mark.parametrize("env", [{"MIMSEM_SW_PC": "diag"}, {"MIMSEM_SW_RICHARDSON": "0"}, {"MIMSEM_SW_FUSED_SWEEPS": "0"},
