@@ -45,6 +45,7 @@ class SWEqn:
         self._rq = None
         self._rM1 = None
         self._guess = {}
+        self._m0fg = None
         self.chunk = int(os.environ.get("MIMSEM_SW_CHUNK", "10"))
         self.fused_sweeps = os.environ.get("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
         self.warm_start = os.environ.get("MIMSEM_SW_WARM_START", "1") == "1"
@@ -123,16 +124,19 @@ class SWEqn:
 
     def diagnose_Phi(self, ui, uj, hi, hj):
         """:289-320 (integral form): 1/3 K(ui) ui + 1/3 K(ui) uj + 1/3 K(uj) uj + g/2 M2 (hi + hj)"""
-        Phi = (1.0 / 3.0) * self.K(ui, ui)
-        Phi += (1.0 / 3.0) * self.K(ui, uj)
-        Phi += (1.0 / 3.0) * self.K(uj, uj)
-        Phi += (self.grav / 2.0) * self.M2(hi)
-        Phi += (self.grav / 2.0) * self.M2(hj)
+        # (the factors ride in the applies' alpha, the sums in their accumulate form, M2 is applied once to hi + hj: 4 launches + 1
+        # instead of 5 applies and 9 framework kernels -- the step is launch-bound)
+        Phi = self.eng.apply("WTQUMAT", ui, f=ui, alpha=1.0 / 3.0)
+        self.eng.apply("WTQUMAT", uj, f=ui, alpha=1.0 / 3.0, flags=2, out=Phi)
+        self.eng.apply("WTQUMAT", uj, f=uj, alpha=1.0 / 3.0, flags=2, out=Phi)
+        self.eng.apply("WMAT", hi + hj, alpha=self.grav / 2.0, flags=2, out=Phi)
         return Phi
 
     def diagnose_q(self, dt, u, h):
         """:322-341: M0h q = M0 f + E01 M1 u ; M0h upwinded (Phmat::assemble_up) when dt > 1e-6"""
-        rhs = self.m0 * self.fg + self.E("E01", self.M1(u))
+        if self._m0fg is None:
+            self._m0fg = self.m0 * self.fg
+        rhs = self._m0fg + self.E("E01", self.M1(u))
         m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
         if dt > 1.0e-6:
             A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
@@ -186,18 +190,22 @@ class SWEqn:
             Phi = Phi + self.grav * self.M2(bot)
         fu = self.E("E12", Phi)
         if q_exact:
-            um, hm = 0.5 * ui + 0.5 * uj, 0.5 * hi + 0.5 * hj
+            um, hm = torch.add(ui, uj).mul_(0.5), torch.add(hi, hj).mul_(0.5)
             q = self.diagnose_q(0.0, um, hm)
-            fu = fu + self.R(q, F)
+            self.eng.apply("ROTMAT", F, f=q, flags=2, out=fu)                                    # fu += R(q) F
         else:
             qi = self.diagnose_q(dt, ui, hi) if qi is None else qi
             qj = self.diagnose_q(dt, uj, hj) if qj is None else qj
-            fu = fu + 0.5 * self.R_up(qi, ui, dt, F)
-            fu = fu + 0.5 * self.R_up(qj, uj, dt, F)
-        fh = self.M2(self.E("E21", F))                            # continuity term
-        mu = self.M1(uj) - self.M1(ui)
-        mh = self.M2(hj) - self.M2(hi)
-        return self.pack(mu + dt * fu, mh + dt * fh)
+            self.eng.apply_up("ROTMAT_UP", F, qi, ui, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)      # fu += 1/2 R_up(qi, ui) F
+            self.eng.apply_up("ROTMAT_UP", F, qj, uj, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)
+        # the mass terms are linear: M1 (uj - ui) and M2 (hj - hi + dt E21 F) -- two applies instead of five; both halves of the packed
+        # residual are written in place (no concatenation)
+        res = torch.empty(ui.shape[0], self.n1 + self.n2, dtype=ui.dtype, device=ui.device)
+        ru, rh = res[:, :self.n1], res[:, self.n1:]
+        self.eng.apply("UMAT", uj - ui, out=ru)
+        ru.add_(fu, alpha=dt)
+        self.eng.apply("WMAT", torch.add(hj - hi, self.E("E21", F), alpha=dt), out=rh)
+        return res
 
     def apply_A(self, x, dt):
         """:622-725 without forming A: [[M1 + a dt R(f), a dt g E12 M2], [a dt H M2 E21, M2]] -- one fused element pass
@@ -288,8 +296,8 @@ class SWEqn:
 
     def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
         """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
-        ui, hi = un.clone(), hn.clone()
-        uj, hj = un.clone(), hn.clone()
+        ui, hi = un, hn                                                    # (read only: the iterate lives in x)
+        uj, hj = un, hn
         x = self.pack(uj, hj)
         it, hist = 0, []
         qi = None if q_exact else self.diagnose_q(dt, ui, hi)             # depends on the start-of-step state only
