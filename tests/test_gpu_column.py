@@ -168,6 +168,40 @@ def test_two_sided_thomas_sweep_equals_the_one_sided(setup):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, name
 
 
+@pytest.mark.parametrize("nk", [4, 8, 10, 14, 16, 22])
+def test_two_sided_thomas_sweep_at_other_level_counts(oracle, nk):
+    """the rotating prefetch / batched loads of k_thomas_dpp2 with half-lengths m = nk/2 that are not multiples of its batch sizes (3, 4):
+    two-sided against one-sided on the same columns, and the residual of the block-tridiagonal system itself"""
+    import os
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    cs, topo, geom, P, rng = make_patch(oracle, 3, 2, 6, 1, nk=nk, seed=100 + nk)
+    eng = Engine(DeviceMesh([topo], [geom], nk=nk, numbering="local"))
+    F = _col_fields(P, seed=nk)
+    r = np.random.default_rng(nk)
+    nEl, n2 = P.nEl, P.n2e
+    rhs = [r.standard_normal((nEl, n * n2)) * 1e8 for n in (nk - 1, nk, nk, nk)]
+    t = eng.tensor
+    args = lambda: (75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]), *[t(x) for x in rhs])
+    a2 = args(); two = eng.solve_schur_eta(*a2); st2 = eng.solve_status()
+    os.environ["MIMSEM_THOMAS2"] = "0"
+    try:
+        one = eng.solve_schur_eta(*args()); st1 = eng.solve_status()
+    finally:
+        del os.environ["MIMSEM_THOMAS2"]
+    assert st1[0] == 0 and st2[0] == 0
+    for a, b, name in zip(two, one, ("d_u", "d_rho", "d_eta", "d_pi")):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, (name, nk)
+    L = eng.helmholtz_blocks(75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"])).view(nEl, nk, 3, n2, n2)
+    d = two[3].view(nEl, nk, n2); f = a2[8].view(nEl, nk, n2)                 # F_pi after the in-place update = the solve's right-hand side
+    Ld = torch.einsum("ekij,ekj->eki", L[:, :, 1], d)
+    Ld[:, 1:] += torch.einsum("ekij,ekj->eki", L[:, 1:, 0], d[:, :-1])
+    Ld[:, :-1] += torch.einsum("ekij,ekj->eki", L[:, :-1, 2], d[:, 1:])
+    Ln = torch.sqrt((L * L).sum(dim=(1, 2, 3, 4)))
+    bwd = torch.linalg.vector_norm(Ld - f, dim=(1, 2)) / (Ln * torch.linalg.vector_norm(d, dim=(1, 2)) + torch.linalg.vector_norm(f, dim=(1, 2)))
+    assert float(bwd.max()) < 1e-13, (nk, float(bwd.max()))
+
+
 def test_residual_compositions(setup):
     """C8: diagnose_F_z / diagnose_Phi_z / assemble_residual_ec (eul/VertSolve.cpp:237-286, 432-502) issued for all
     columns through the ABI vs the same chain written with the oracle's dense column matrices"""

@@ -62,6 +62,12 @@ def _worker(rank, world, port, q):
                 de = DistEngine(eng2, cs, world, rank, overlap=True)
                 y3 = de.apply(op, eng2.tensor(xglob[:, gid]), lev0=0, scale=SCALE, flags=1)
                 ok = ok and bool(torch.equal(y3, y))
+                # ... and the 0-form completion of the same DistEngine: REVERSE/ADD then FORWARD/INSERT plans of the C ABI
+                p3 = de.apply("PMAT", eng2.tensor(x0g[:, dm2.gid0]), lev0=0, scale=SCALE, flags=0)
+                p0 = eng.apply("PMAT", eng.tensor(x0g[:, dm.gid0]), lev0=0, scale=SCALE, flags=0)
+                h0 = HaloExchanger(plans[0], engine=eng); h0.reverse_add(p0); h0.forward_insert(p0)
+                ok = ok and bool(torch.equal(p3, p0))
+                de.close()
             if rank == 0:
                 dm1, eng1 = build(list(range(npatch)))
                 want = eng1.apply(op, eng1.tensor(xglob), lev0=0, scale=SCALE, flags=1 if form == 1 else 0).cpu().numpy()
