@@ -409,7 +409,10 @@ int wave_chunks_per_item(const mimsem_ctx* c, int nlev, int lch, int ngroups) {
     const int nch = (nlev + lch - 1)/lch;
     if (lch != 8 || nch <= 1) return 1;
     if (c->wave_cpp > 0) return std::min(c->wave_cpp, nch);
-    const int nparts = std::min(nch, std::max(1, (1536 + ngroups - 1)/std::max(ngroups, 1)));      // balanced parts
+    int nparts = std::min(nch, std::max(1, (1536 + ngroups - 1)/std::max(ngroups, 1)));
+    // EQUAL parts where the chunk count allows: the launch ends with its longest work item (p = 4 box, 8 chunks: 3 parts of 3 + 3 + 2
+    // chunks took 17.2 us, 4 parts of 2 take 14.0 us -- round 3)
+    for (int np = nparts; np <= nch; np++) if (nch%np == 0) { nparts = np; break; }
     return (nch + nparts - 1)/nparts;
 }
 
