@@ -176,6 +176,9 @@ public:
     VecScatterHalo(const VecScatterHalo&) = delete;
     VecScatterHalo& operator=(const VecScatterHalo&) = delete;
     void use_rccl(void* nccl_comm) { check(mimsem_halo_set_rccl(rev, nccl_comm), "set_rccl"); check(mimsem_halo_set_rccl(fwd, nccl_comm), "set_rccl"); }
+    // the librccl instance that made the communicator (the host's dlopen handle), before the first use_rccl; optional when the process
+    // has librccl.so[.1] loaded under that name.  Returns the ABI's code (MIMSEM_ERR_STATE: resolved earlier, nothing changed)
+    static int use_rccl_library(void* dl_handle) { return mimsem_halo_use_rccl_library(dl_handle); }
     void use_transport(mimsem_halo_transport_fn fn, void* user) { check(mimsem_halo_set_transport(rev, fn, user), "set_transport"); check(mimsem_halo_set_transport(fwd, fn, user), "set_transport"); }
     void use_loopback() { check(mimsem_halo_set_loopback(rev), "set_loopback"); check(mimsem_halo_set_loopback(fwd), "set_loopback"); }
     void begin_reverse_add(double* v, int nlev, long long stride) { check(mimsem_halo_begin(rev, MIMSEM_HALO_ADD, nlev, v, stride), "halo_begin"); }
@@ -205,6 +208,8 @@ public:
     void mult(const double* x, double* y) const { apply(x, y, 0u); }
     // the same MatMult in two parts around a halo exchange: mult_part(x, y, MIMSEM_PART_BOUNDARY); halo.begin_reverse_add(y, ...);
     // mult_part(x, y, MIMSEM_PART_INTERIOR); halo.end_reverse_add()  -- no other operator of this Mesh between the two parts
+    // error path of a host: forget a BOUNDARY part whose INTERIOR part will not come (the contract of a split apply, mimsem_hip.h)
+    void reset_parts() const { check(mimsem_op_apply_part_reset(mesh->ctx), "apply_part_reset"); }
     void mult_part(const double* x, double* y, int part) const {
         if (up) { if (part != MIMSEM_PART_INTERIOR) apply(x, y, 0u); return; }      // upwinded variants run whole in the boundary part
         check(mimsem_op_apply_part(mesh->ctx, op, lev, 1, scale, flags, field, 0, x, 0, y, 0, 1.0, part), "mimsem_op_apply_part");
@@ -456,6 +461,11 @@ struct VertSolve {
         check(mimsem_column_solve_schur_3(mesh->ctx, dt, box_twin ? MIMSEM_SCHUR3_BOX : 0u, theta, velz, rho, rt, pi,
                                           F_u, F_rho, F_rt, F_pi, d_u, d_rho, d_rt, d_pi, nullptr), "solve_schur_column_3");
     }
+    // what PCLU's band-wide pivoting would have guaranteed (eul/VertSolve.cpp:645-653), asked instead: the number of columns of the last
+    // solve_schur_column_eta whose refinement did not reach 1e-10 of their solution (-1: the path in use keeps no status), per-column
+    // status (0 / 1 / 2) and achieved |correction| / |solution| on request (host arrays of nEl entries, or nullptr)
+    int solve_status(int* column_status = nullptr, double* column_ratio = nullptr) {
+        int n = -1; check(mimsem_column_solve_status(mesh->ctx, &n, column_status, column_ratio), "column_solve_status"); return n; }
     void diagTheta2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 1, rho, rt, theta), "diagTheta2"); }
     void diagTheta_L2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 0, rho, rt, theta), "diagTheta_L2"); }
     void diagTheta_up(const double* rho, const double* rt, double* theta, const double* ul, long long ul_stride) {

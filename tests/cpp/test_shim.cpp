@@ -243,6 +243,13 @@ int main() {
             worst = std::max(worst, std::sqrt(num/den));
         }
         std::printf("%-8s rel L2 = %.3e\n", "Schur", worst); if (!(worst < 1e-10)) fails++;
+        {   // the status a caller reads instead of trusting a band-wide pivoted LU: every column of this solve converged
+            std::vector<int> st(nEl, -7); std::vector<double> ratio(nEl, -1.0);
+            const int nbad = vert.solve_status(st.data(), ratio.data());
+            int ok = (nbad == 0 || nbad == -1);                       // -1: a path without status (orders >= 4)
+            if (nbad == 0) for (int e = 0; e < nEl; e++) ok = ok && st[e] == 0 && ratio[e] >= 0.0 && ratio[e] <= 1e-10;
+            std::printf("%-8s unconverged columns = %d\n", "Status", nbad); if (!ok) fails++;
+        }
         // vert->diagTheta2(rho, rt, theta) / diagTheta_L2  (eul/VertSolve.cpp:289-352), every column
         {
             std::vector<double> rt = field(nk, 250, 400), t2((size_t)nEl*(nk + 1)*n2e), tl((size_t)nEl*N), w2((nk + 1)*n2e), wl(N);
@@ -286,6 +293,15 @@ int main() {
         double worst = 0.0;
         for (int i = 0; i < P->n1; i++) worst = std::max(worst, std::fabs(split[i] - whole[i]));
         std::printf("%-8s max abs diff = %.3e\n", "Halo", worst); if (!(worst == 0.0)) fails++;
+        // the contract of the two parts: a second BOUNDARY part while one is pending is refused, reset_parts() forgets it
+        M1.mult_part(d_u, d_y, MIMSEM_PART_BOUNDARY);
+        const int rc2 = mimsem_op_apply_part(mesh.ctx, MIMSEM_OP_UMAT, 0, 1, 1.0e8, MIMSEM_FLAG_VERT, nullptr, 0, d_u, P->n1, d_y, P->n1, 1.0, MIMSEM_PART_BOUNDARY);
+        M1.reset_parts();
+        M1.mult_part(d_u, d_y, MIMSEM_PART_BOUNDARY); M1.mult_part(d_u, d_y, MIMSEM_PART_INTERIOR);
+        int wst[5]; const int really_split = mimsem_op_wave_stats(mesh.ctx, 1, wst) == 1;       // (the two-pass form runs whole in the BOUNDARY part: nothing pending)
+        std::printf("%-8s second BOUNDARY while pending -> %d (split in force: %d, MIMSEM_ERR_STATE = %d)\n", "Parts", rc2, really_split, MIMSEM_ERR_STATE);
+        if (rc2 != (really_split ? MIMSEM_ERR_STATE : MIMSEM_OK)) fails++;
+        if (VecScatterHalo::use_rccl_library(nullptr) != MIMSEM_ERR_ARG) fails++;
     }
     // the co-located local layout (Topo(..., paired = true)): the same operator on the permuted vector, now on the
     // wave-level kernels (mimsem_op_wave_stats reports a plan), against the oracle's result in the reference's layout
