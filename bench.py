@@ -641,8 +641,11 @@ def main():
     out["config"]["level_chunk"] = lch
     out["config"]["form"] = "wave-level fused (k_apply_wave + k_wave_perim)" if "wave" in kname else "two-pass (k_elem_apply + k_gather_sum)"
     if nl:
-        k1 = ms1 / nl * 1e-3
-        k12 = (ms1 + ms2) / nl * 1e-3
+        # N > 1: a step is TWO part launches of the operator (boundary groups, interior groups), each sampled apply one of them: per STEP
+        # the kernel time is twice the per-launch average (the byte model is the rank's whole apply)
+        pps = 2 if (deng is not None and deng.chalo is not None) else 1
+        k1 = ms1 / nl * 1e-3 * pps
+        k12 = (ms1 + ms2) / nl * 1e-3 * pps
         out["roofline"] = roofline_entry(bm, k1, k12, cache_resident=True,
                                          note="working set (~35 MB fields + metric) sits inside the 256 MiB Infinity Cache and is re-read "
                                               "every step: see roofline_cold for the HBM-resident workload", kname=kname, k2name=k2name)
