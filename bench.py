@@ -271,6 +271,80 @@ def column_extras(eng, dm, rng, torch):
     return res
 
 
+def box_column_workload(local_rank, rng):
+    """BASELINE config 5's column half: p = 4, 32 x 32 periodic box x 64 levels (1 024 columns, 16 x 16 blocks), hydrostatic state"""
+    from mimsem_amd.geom import BoxGeom, gll_points
+    from mimsem_amd.mesh import PeriodicBox, box_coords
+    pn, nkb = 4, 64
+    bx = PeriodicBox(pn, 32, 4); bc = box_coords(pn, 32, 1000.0)
+    bt = [Topo(bx, p, nkb) for p in range(4)]; bg = [BoxGeom(t, bx, bc, nkb, 1000.0) for t in bt]
+    dz = 1500.0 / nkb
+    levs = np.repeat(np.linspace(0.0, 1500.0, nkb + 1)[:, None], bg[0].n0, axis=1)
+    levs[1:-1] += 0.05 * dz * rng.uniform(-1, 1, (nkb - 1, bg[0].n0))
+    for g in bg:
+        g.set_levels(levs)
+    dmb = DeviceMesh(bt, bg, nk=nkb, numbering="global"); engb = Engine(dmb, device=local_rank)
+    nEl, n2 = dmb.nEl, engb.n2e
+    wd = np.diff(gll_points(pn)); wj = np.outer(wd, wd).ravel()
+    detm = dmb.det.mean(axis=1); thm = dmb.thick.mean(axis=2).T
+    zi = levs.mean(axis=1); zm = 0.5 * (zi[1:] + zi[:-1])
+    th_v = 300.0 + 0.004 * zm; thI_v = 300.0 + 0.004 * zi
+    pi_v = 1004.5 - (9.80616 / 0.004) * np.log(th_v / 300.0)
+    rho_v = (1.0e5 / 287.0) * (pi_v / 1004.5) ** (717.5 / 287.0) / th_v
+    pert = lambda nl: 1.0 + 1e-2 * rng.standard_normal((nEl, nl * n2))
+    lev = lambda v: engb.tensor((detm[:, None, None] * thm[:, :, None] * v[None, :, None] * wj[None, None, :]).reshape(nEl, nkb * n2) * pert(nkb))
+    itf = lambda v, nl: (detm[:, None, None] * v[None, :nl, None] * wj[None, None, :]).reshape(nEl, nl * n2) * pert(nl)
+    fld = dict(rho=lev(rho_v), rt=lev(rho_v * th_v), pi=lev(pi_v), thetaL=lev(th_v), eta=lev(np.log(th_v)),
+               theta=engb.tensor(itf(thI_v, nkb + 1)),
+               velz=engb.tensor(itf(np.ones(nkb + 1), nkb - 1) * 0.5 * rng.standard_normal((nEl, (nkb - 1) * n2))))
+    F = [engb.tensor(rng.standard_normal((nEl, n * n2)) * 1e8) for n in (nkb - 1, nkb, nkb, nkb)]
+    return engb, dmb, levs, fld, F, (rho_v, th_v, pi_v, detm, thm, wj)
+
+
+def column_box_p4_extras(local_rank, rng, torch):
+    """config 5's column half in the driver line: solve_schur_column_eta, the box twin of solve_schur_column_3
+    (box/VertSolve.cpp:879-1058) and one Newton iteration of VertSolve::solve_schur_eta on 1 024 columns x 64 levels at p = 4"""
+    from mimsem_amd.vertsolve import VertSolve
+    engb, dmb, levs, fld, F, (rho_v, th_v, pi_v, detm, thm, wj) = box_column_workload(local_rank, rng)
+    nEl, nkb, n2 = dmb.nEl, 64, engb.n2e
+    mp12 = 25
+
+    def timeit(fn, reps):
+        fn(); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    res = {"workload": "p=4, 32x32 periodic box x 64 levels: 1 024 columns, 16x16 blocks (BASELINE config 5, column half)"}
+    dt = 0.5
+    t = timeit(lambda: engb.solve_schur_eta(dt, fld["thetaL"], fld["rho"], fld["eta"], fld["pi"], *[f.clone() for f in F]), 5)
+    nun, _, _ = engb.solve_status()
+    # algorithmic figures of SURVEY 8(d) for C5 at p = 4: (768 + 32) x 8 x nk bytes per column; block-Thomas 2/3 n^3 + 2 n^3 + 2 n^3 flop per level
+    by = nEl * (768 + 32) * 8 * nkb
+    fl = nEl * nkb * (14.0 / 3.0 * 16 ** 3 + 2 * 16 * 16 * 2)
+    res["schur_eta"] = {"ms_all_columns": t * 1e3, "column_solves_per_s": nEl / t, "unconverged_columns": nun,
+                        "algorithmic_bytes": by, "GBs": by / t / 1e9, "hbm_frac": by / t / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_flop": fl, "TFLOPs": fl / t / 1e12, "flop_frac": fl / t / 1e12 / FP64_PEAK_TFLOPS}
+    t = timeit(lambda: engb.solve_schur_3(dt, fld["theta"], fld["velz"], fld["rho"], fld["rt"], fld["pi"], *[f.clone() for f in F], flags=3), 3)
+    by3 = nEl * (5 * 256 + 32) * 8 * nkb
+    res["schur_3_box"] = {"ms_all_columns": t * 1e3, "column_solves_per_s": nEl / t,
+                          "algorithmic_bytes": by3, "GBs": by3 / t / 1e9, "hbm_frac": by3 / t / 1e9 / HBM_PEAK_GBS}
+    vs = VertSolve(engb, dt)
+    lq = np.zeros((nkb + 1, dmb.nq))
+    for g in dmb.geoms:
+        lq[:, np.searchsorted(dmb.gidq, g.loc0[np.arange(g.n0)])] = g.levs
+    zv = vs.init_gz(lq)
+    st = (engb.zeros(nEl, (nkb - 1) * n2), fld["rho"], fld["rt"], fld["pi"])
+    vs.solve_schur_eta(*st, zv, maxit=2, tol=0.0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    vs.solve_schur_eta(*st, zv, maxit=4, tol=0.0)
+    torch.cuda.synchronize(); tn = (time.perf_counter() - t0) / 4
+    res["vertical_newton_iteration_ms"] = tn * 1e3
+    res["vertical_newton_norms_last"] = vs.history[-1]
+    del engb
+    return res
+
+
 def sweep_extras(local_rank, torch):
     """SURVEY 8(d) throughput sweep: applies/s of the operator families B1, B3, B4, B8, B9, B11 at the batch sizes of the BASELINE
     configurations (384 / 1 536 / 3 456 / 103 680 element-level pairs) and ~1e6 pairs (the config 4 sphere with 290 levels),
@@ -724,6 +798,7 @@ def main():
         extra("reference_local_layout", lambda: local_layout_extras(local_rank, rng, torch))
     if (a.column or not a.no_column) and rank == 0 and world == 1:     # the column half of the hot path: on by default at N = 1 (~3 s)
         extra("column", lambda: column_extras(eng, dm, rng, torch))
+        extra("column_box_p4", lambda: column_box_p4_extras(local_rank, rng, torch))
     if a.pcie and rank == 0 and world == 1:
         import ctypes as C
         xh = np.ascontiguousarray(rng.standard_normal((NK, dm.n1))); yh = np.empty_like(xh)

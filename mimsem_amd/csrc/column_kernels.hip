@@ -2393,7 +2393,7 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
 
 }  // namespace
 
-namespace { bool diag_theta_fused_supported(const mimsem_ctx* c) { return c->es.n >= 1 && c->es.n <= 3 && c->nk >= 2; } }
+namespace { bool diag_theta_fused_supported(const mimsem_ctx* c) { return c->es.n >= 1 && c->es.n <= 4 && c->nk >= 2; } }
 extern "C" {
 int mimsem_column_diag_theta_blend(mimsem_ctx* c, const double* rho, const double* rt, double* theta2, const double* blend2,
                                    double* thetaL, const double* blendL, double wa, double wb);

@@ -112,7 +112,7 @@ class VertSolve:
         Returns (velz, rho, rt, exner) at the new time level and leaves theta_h / theta_l2_h / exner_h (the time-centred fields
         the horizontal corrector reads) and the per-iteration max-norms in self.*"""
         eng, nk, dt = self.eng, self.nk, self.dt
-        if self.fused and eng.mesh.n <= 3:
+        if self.fused and eng.mesh.n <= 4:
             return self._solve_schur_eta_fused(velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing, udwdx, hs_lat, maxit, tol, verbose)
         mv = self._mv
         velz_j, rho_j, rt_j, exner_j = velz_i.clone(), rho_i.clone(), rt_i.clone(), exner_i.clone()
