@@ -273,8 +273,10 @@ def column_extras(eng, dm, rng, torch):
 
 def box_column_workload(local_rank, rng):
     """BASELINE config 5's column half: p = 4, 32 x 32 periodic box x 64 levels (1 024 columns, 16 x 16 blocks), hydrostatic state"""
+    from mimsem_amd.device import DeviceMesh, Engine
     from mimsem_amd.geom import BoxGeom, gll_points
     from mimsem_amd.mesh import PeriodicBox, box_coords
+    from mimsem_amd.topo import Topo
     pn, nkb = 4, 64
     bx = PeriodicBox(pn, 32, 4); bc = box_coords(pn, 32, 1000.0)
     bt = [Topo(bx, p, nkb) for p in range(4)]; bg = [BoxGeom(t, bx, bc, nkb, 1000.0) for t in bt]

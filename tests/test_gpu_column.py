@@ -149,8 +149,8 @@ def test_two_sided_thomas_sweep_equals_the_one_sided(setup):
     equal to the round-off the conditioning allows, identical status"""
     import os
     eng, P = setup
-    if P.nk % 2 or P.nk < 4 or P.n2e > 9:
-        pytest.skip("two-sided sweep: even nk >= 4, orders <= 3")
+    if P.nk % 2 or P.nk < 4 or P.n2e > 16:
+        pytest.skip("two-sided sweep: even nk >= 4, orders <= 4")
     F = _col_fields(P)
     r = np.random.default_rng(21)
     nEl, N, Nm = P.nEl, P.nk * P.n2e, (P.nk - 1) * P.n2e
@@ -168,14 +168,15 @@ def test_two_sided_thomas_sweep_equals_the_one_sided(setup):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, name
 
 
-@pytest.mark.parametrize("nk", [4, 8, 10, 14, 16, 22])
-def test_two_sided_thomas_sweep_at_other_level_counts(oracle, nk):
+@pytest.mark.parametrize("nk,pn", [(4, 3), (8, 3), (10, 3), (14, 3), (16, 3), (22, 3), (8, 4), (10, 4)],
+                         ids=lambda v: str(v))
+def test_two_sided_thomas_sweep_at_other_level_counts(oracle, nk, pn):
     """the rotating prefetch / batched loads of k_thomas_dpp2 with half-lengths m = nk/2 that are not multiples of its batch sizes (3, 4):
     two-sided against one-sided on the same columns, and the residual of the block-tridiagonal system itself"""
     import os
     import torch
     from mimsem_amd.device import DeviceMesh, Engine
-    cs, topo, geom, P, rng = make_patch(oracle, 3, 2, 6, 1, nk=nk, seed=100 + nk)
+    cs, topo, geom, P, rng = make_patch(oracle, pn, 2 if pn == 3 else 1, 6, 1, nk=nk, seed=100 + nk)
     eng = Engine(DeviceMesh([topo], [geom], nk=nk, numbering="local"))
     F = _col_fields(P, seed=nk)
     r = np.random.default_rng(nk)
