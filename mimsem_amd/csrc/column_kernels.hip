@@ -2517,6 +2517,7 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
 }  // namespace
 
 #include "column_dpp.inc"
+#include "column_penta.inc"
 #include "column_newton.inc"
 
 namespace {
