@@ -2676,4 +2676,5 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* c, double dt,
 }  // extern "C"
 
 #include "column_schur3_dpp.inc"
+#include "column_schur3_sweep.inc"
 #include "column_hs.inc"
