@@ -229,11 +229,15 @@ def column_extras(eng, dm, rng, torch):
     by = nEl * 8 * (4 * nk * n2 + 2 * (4 * nk - 1) * n2 + mp12 * (1 + 2 * nk))
     res["schur_roofline"] = {"bound": "fp64 valu (latency chain of the block-Thomas sweep)", "flop_per_solve_all_columns": fl, "TFLOPs": fl / t / 1e12,
                              "flop_frac": fl / t / 1e12 / FP64_PEAK_TFLOPS, "compulsory_bytes": by, "GBs": by / t / 1e9, "hbm_frac": by / t / 1e9 / HBM_PEAK_GBS}
-    thetaI, rt = lev(nk + 1, 280, 320), lev(nk, 150, 350)            # solve_schur_column_3: theta on the nk+1 interfaces
-    velz = eng.tensor(rng.standard_normal((nEl, (nk - 1) * n2)) * 0.1 * area)
+    # solve_schur_column_3: theta and velz live on interfaces -- cell integrals WITHOUT the thickness (the scaling of tests/test_gpu_column.py's
+    # _col_fields).  Rounds 1-3 scaled theta by dz as well (~1e3 too large): a pathologically conditioned L_rt_rt that no physical column has;
+    # harmless while the solve did a fixed amount of work, wrong for the adaptive refinement of round 4's pentadiagonal solve
+    thetaI, rt = lev(nk + 1, 280, 320) / dz, lev(nk, 250, 400)
+    velz = lev(nk - 1, -1.0, 1.0) / dz
     t = timeit(lambda: eng.solve_schur_3(75.0, thetaI, velz, rho, rt, pi, *[f.clone() for f in F]), 3)
     res["schur3_column_solves_per_s"] = nEl / t
     res["schur3_ms_all_columns"] = t * 1e3
+    res["schur3_unconverged_columns"] = int(eng.solve_status()[0])
     by3 = nEl * 8 * ((nk + 1) * n2 + (nk - 1) * n2 + 3 * nk * n2 + 2 * (4 * nk - 1) * n2 + mp12 * (1 + 2 * nk))
     fl3 = SCHUR_3_FLOP_PER_COLUMN_LEVEL * nEl * nk
     res["schur3_roofline"] = {"bound": "fp64 valu", "flop_per_solve_all_columns": fl3, "TFLOPs": fl3 / t / 1e12, "flop_frac": fl3 / t / 1e12 / FP64_PEAK_TFLOPS,

@@ -18,12 +18,13 @@ rng = np.random.default_rng(0)
 nEl, n2 = dm.nEl, eng.n2e
 area = float(dm.det.mean())*4.0/n2; dz = float(dm.thick.mean())
 lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl*n2))*area*dz)
-theta, rho, rt, pi = lev(NK + 1, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 150, 350), lev(NK, 700, 1000)
-velz = eng.tensor(rng.standard_normal((nEl, (NK - 1)*n2))*0.1*area)
+# interface fields (theta, velz) carry no thickness: tests/test_gpu_column.py::_col_fields (rounds 1-3 multiplied theta by dz too: unphysical)
+theta, rho, rt, pi = lev(NK + 1, 280, 320)/dz, lev(NK, 0.5, 1.2), lev(NK, 250, 400), lev(NK, 700, 1000)
+velz = lev(NK - 1, -1.0, 1.0)/dz
 F = [eng.tensor(rng.standard_normal((nEl, n*n2))*1e8) for n in (NK-1, NK, NK, NK)]
 for _ in range(2):
     eng.solve_schur_3(75.0, theta, velz, rho, rt, pi, *[f.clone() for f in F])
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(5):
     eng.solve_schur_3(75.0, theta, velz, rho, rt, pi, *[f.clone() for f in F])
-torch.cuda.synchronize(); print("ms per sweep (solve_schur_column_3)", (time.perf_counter()-t)/5*1e3)
+torch.cuda.synchronize(); print("ms per sweep (solve_schur_column_3)", (time.perf_counter()-t)/5*1e3, "unconverged columns", eng.solve_status()[0])
