@@ -431,6 +431,12 @@ int mimsem_krylov_normalize(mimsem_ctx* ctx, long long n, const double* w, doubl
 int mimsem_krylov_gs_control(mimsem_ctx* ctx, int fused /* 0 | 1, < 0: leave */, int* flag);
 int mimsem_krylov_reorthonormalize(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
                                    const double* h1, double* h2, double* col, int norm_slot);
+/* The same with the form and the flag word as ARGUMENTS (round 4; the context-wide word of mimsem_krylov_gs_control was shared by every
+ * solver object on the context: two GraphedGMRES instances overwrote each other's word).  fused != 0: the two-launch form, which sets
+ * *flag = 1 (flag: device or pinned host memory, may be NULL) when more than half of w.w went into h2; a zero or non-finite w.w leaves
+ * the flag alone and writes v = 0 instead of inf.                                                                                  */
+int mimsem_krylov_reorthonormalize_ex(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                                      const double* h1, double* h2, double* col, int norm_slot, int fused, int* flag);
 /* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in
  * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
  * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */
@@ -447,6 +453,59 @@ int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const doubl
                             double* x, long long ldx, double* r, long long ldr);
 int mimsem_krylov_cg_direction(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
                                const double* z, long long ldz, double* p, long long ldp);
+
+/* ---- rows N1..N3 from C / C++: the solve loops (round 4) ------------------------------------------------------------------------
+ * What the reference does after almost every operator assembly (eul/HorizSolve.cpp:77-96: KSPCreate(ksp1); KSPSetOperators(ksp1, M1->M,
+ * M1->M); KSPSetTolerances(ksp1, 1e-16, 1e-50, PETSC_DEFAULT, 1000); KSPSetType(KSPGMRES); PCSetType(PCBJACOBI);
+ * PCBJacobiSetTotalBlocks(size*nElsX*nElsX); then KSPSolve(ksp1, b, x) at :224, :246, :310, :322; kspA of the shallow-water step,
+ * src/SWEqn_Picard.cpp:600-606, :751-765) as ONE object of this library: operator = an engine operator applied matrix-free (all
+ * `nlev` levels: independent systems for CG, one block-diagonal system for GMRES), the packed shallow-water operator, or a callback;
+ * preconditioner = none, a diagonal, element blocks (the PCBJACOBI-per-element of the reference with exact block inverses), the
+ * coupled [u|h] element blocks, or a callback.  Iterations run on the context's stream; the host reads one scalar set per
+ * convergence test (CG: every `check_every` iterations; GMRES: the Hessenberg column through pinned memory each iteration).
+ * All vectors are device pointers, rows `stride` doubles apart.                                                                   */
+typedef struct mimsem_ksp mimsem_ksp;
+enum mimsem_ksp_type { MIMSEM_KSP_CG = 0, MIMSEM_KSP_GMRES = 1 };
+enum mimsem_ksp_reason {                        /* KSPConvergedReason, the values PETSc uses */
+    MIMSEM_KSP_CONVERGED_RTOL = 2, MIMSEM_KSP_CONVERGED_ATOL = 3, MIMSEM_KSP_CONVERGED_ITS = 4,
+    MIMSEM_KSP_DIVERGED_ITS = -3, MIMSEM_KSP_DIVERGED_BREAKDOWN = -5, MIMSEM_KSP_DIVERGED_NANORINF = -9 };
+typedef int (*mimsem_ksp_apply_fn)(void* user, int nlev, const double* x, long long x_stride, double* y, long long y_stride);
+int  mimsem_ksp_create(mimsem_ctx* ctx, int type, mimsem_ksp** out);                       /* KSPCreate + KSPSetType            */
+void mimsem_ksp_destroy(mimsem_ksp* ksp);                                                  /* KSPDestroy                        */
+/* KSPSetOperators: A = engine operator `op` on geometry levels [geom_lev0, geom_lev0 + nlev) with the arguments of mimsem_op_apply
+ * (square operators: equal input and result space); f must stay valid until the last solve.                                        */
+int  mimsem_ksp_set_operator(mimsem_ksp* ksp, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                             const double* f, long long f_stride);
+/* A = the packed [u|h] shallow-water operator of mimsem_sw_operator_apply (rows of n1 + n2 doubles)                                */
+int  mimsem_ksp_set_operator_sw(mimsem_ksp* ksp, int nlev, double a, double grav, double H, const double* f0, long long f0_stride);
+/* A = caller's routine (a MATSHELL): y = A x for `nlev` rows of `n` doubles, on the context's stream                               */
+int  mimsem_ksp_set_operator_shell(mimsem_ksp* ksp, int nlev, long long n, mimsem_ksp_apply_fn fn, void* user);
+/* PCSetType: */
+int  mimsem_ksp_set_pc_none(mimsem_ksp* ksp);
+int  mimsem_ksp_set_pc_jacobi(mimsem_ksp* ksp, const double* dinv, long long dinv_stride);              /* z = dinv .* r       */
+/* PCBJACOBI with one block per element, built HERE from the operator given to mimsem_ksp_set_operator (1-form mass-like operators:
+ * UMAT / UHMAT / UTMAT(_H)): P = sum_e R_e^T D_e (A_e)^-1 D_e R_e with A_e the element's dense 2 n1e x 2 n1e block at geometry
+ * level geom_lev0 without its thickness factor, D_e = 1 / (number of elements sharing the edge), times 1 / mean(thickInv) of the
+ * element per level when the operator carries the thickness flag (exact where a layer's thickness is uniform over an element).     */
+int  mimsem_ksp_set_pc_bjacobi(mimsem_ksp* ksp);
+/* caller-built element blocks, as mimsem_elem_blocks_apply takes them (form 0 / 1 / 2; elem_scale may be NULL)                      */
+int  mimsem_ksp_set_pc_elem_blocks(mimsem_ksp* ksp, int form, const double* blocks, const double* elem_scale, long long elem_scale_stride);
+/* coupled [u|h] element blocks of mimsem_sw_blocks_apply (with the shallow-water operator: the fused z = P A x of
+ * mimsem_sw_operator_precond_apply is used inside the iteration)                                                                   */
+int  mimsem_ksp_set_pc_sw_blocks(mimsem_ksp* ksp, const double* blocks);
+/* the same blocks built HERE from the operator given to mimsem_ksp_set_operator_sw (what PCSetUp does with the matrix of KSPSetOperators):
+ * A_e = [[M1_e + a R_e(f0), a g E12_e M2_e], [a H M2_e E21_e, M2_e]] per element, inverted, weighted by 1 / edge multiplicity; orders 1..4 */
+int  mimsem_ksp_set_pc_sw_bjacobi(mimsem_ksp* ksp);
+int  mimsem_ksp_set_pc_shell(mimsem_ksp* ksp, mimsem_ksp_apply_fn fn, void* user);                       /* PCSHELL             */
+/* KSPSetTolerances (restart: GMRES only, PETSc's default 30; check_every: CG iterations between two looks at the residual, <= 0: 2) */
+int  mimsem_ksp_set_tolerances(mimsem_ksp* ksp, double rtol, double atol, int maxit, int restart, int check_every);
+int  mimsem_ksp_set_initial_guess_nonzero(mimsem_ksp* ksp, int flag);                                    /* KSPSetInitialGuessNonzero */
+/* KSPSolve.  CG monitors |b - A x| / |b| per row (every row must meet rtol or atol); GMRES the PRECONDITIONED residual as PETSc's
+ * default does.  Returns MIMSEM_OK also when the iteration limit was hit: ask mimsem_ksp_get_info.                                  */
+int  mimsem_ksp_solve(mimsem_ksp* ksp, const double* b, long long b_stride, double* x, long long x_stride);
+/* KSPGetIterationNumber / KSPGetResidualNorm / KSPGetConvergedReason of the last solve (rnorm: relative, worst row)                 */
+int  mimsem_ksp_get_info(const mimsem_ksp* ksp, int* iterations, double* rnorm, int* reason);
+
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer

@@ -67,6 +67,23 @@ _SIGS = {
                                                c_dp, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_precond_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_krylov_reorthonormalize": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),
+    "mimsem_krylov_reorthonormalize_ex": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_void_p]),
+    "mimsem_ksp_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mimsem_ksp_destroy": (None, [C.c_void_p]),
+    "mimsem_ksp_set_operator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll]),
+    "mimsem_ksp_set_operator_sw": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll]),
+    "mimsem_ksp_set_operator_shell": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_void_p, C.c_void_p]),
+    "mimsem_ksp_set_pc_none": (C.c_int, [C.c_void_p]),
+    "mimsem_ksp_set_pc_jacobi": (C.c_int, [C.c_void_p, c_dp, c_ll]),
+    "mimsem_ksp_set_pc_bjacobi": (C.c_int, [C.c_void_p]),
+    "mimsem_ksp_set_pc_elem_blocks": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_ll]),
+    "mimsem_ksp_set_pc_sw_blocks": (C.c_int, [C.c_void_p, c_dp]),
+    "mimsem_ksp_set_pc_sw_bjacobi": (C.c_int, [C.c_void_p]),
+    "mimsem_ksp_set_pc_shell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mimsem_ksp_set_tolerances": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "mimsem_ksp_set_initial_guess_nonzero": (C.c_int, [C.c_void_p, C.c_int]),
+    "mimsem_ksp_solve": (C.c_int, [C.c_void_p, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_ksp_get_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mimsem_colop_apply_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "mimsem_l2_transpose": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll, c_dp]),
     "mimsem_colop_nblocks": (C.c_int, [C.c_void_p, C.c_int]),

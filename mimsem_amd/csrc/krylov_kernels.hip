@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_maxpy_reduce_normalize(int k, int nb, l
     const double nrm = sqrt(n2 > 0.0 ? n2 : 0.0);
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < k; i += 256) { h2[i] = sh[i]; col[i] = h1[i] + sh[i]; }
-        if (threadIdx.x == 0) { col[norm_slot] = nrm; if (flag && !(hh <= 0.5*ww)) *flag = 1; }
+        // (a zero or non-finite w.w -- a look-ahead step past a breakdown -- is not a cancellation: the flag stays down)
+        if (threadIdx.x == 0) { col[norm_slot] = nrm; if (flag && ww > 0.0 && hh > 0.5*ww && ww < 1.0e300) *flag = 1; }
     }
     const long long t = (long long)blockIdx.x*256 + threadIdx.x;
     if (t < n) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void k_maxpy_reduce_normalize(int k, int nb, l
         for (int i = 0; i < k; i++) s += sh[i]*V[(size_t)i*ldv + t];
         const double wn = w[t] - s;
         w[t] = wn;
-        v[t] = wn/nrm;
+        v[t] = nrm > 0.0 ? wn/nrm : 0.0;
     }
 }
 __global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
@@ -296,21 +297,20 @@ int mimsem_krylov_orthogonalize(mimsem_ctx* c, int k, long long n, const double*
 
 // second Gram-Schmidt pass and normalisation in three launches: h2 = V w ; w -= V^T h2 (the norm of the result accumulated by the
 // same kernel) ; v = w/|w|, col[0..k) = h1 + h2, col[norm_slot] = |w|
-int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
-                                   const double* h1, double* h2, double* col, int norm_slot) {
+int mimsem_krylov_reorthonormalize_ex(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                                      const double* h1, double* h2, double* col, int norm_slot, int fused, int* flag) {
     if (!c || !V || !w || !v || !h1 || !h2 || !col || k <= 0 || n <= 0 || ldv < n || norm_slot < 0) return MIMSEM_ERR_ARG;
     const unsigned gb = (unsigned)((n + 255)/256);
     int nb = 0;
     int rc = c->ensure_kry((long long)RD_BLOCKS*(k + 1) + gb);
     if (rc) return rc;
-    if (c->gs_fused < 0) c->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
-    if (c->gs_fused) {
+    if (fused) {
         // round 3: two launches -- the dots of the pass and w . w together, then update + normalisation + column in one kernel
         nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
         const long long chunk = (n + nb - 1)/nb;
         hipLaunchKernelGGL(k_mdot_self_partial, dim3(nb, k + 1), dim3(256), 0, c->stream, k, n, chunk, V, ldv, w, c->d_kry);
         hipLaunchKernelGGL(k_maxpy_reduce_normalize, dim3(gb), dim3(256), (size_t)(k + 1)*sizeof(double), c->stream, k, nb, n, V, ldv, c->d_kry,
-                           w, v, h1, h2, col, norm_slot, c->gs_flag);
+                           w, v, h1, h2, col, norm_slot, flag);
         MIMSEM_HIP_TRY(hipGetLastError());
         return MIMSEM_OK;
     }
@@ -320,6 +320,13 @@ int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const doub
     hipLaunchKernelGGL(k_normalize, dim3(gb), dim3(256), 0, c->stream, (int)gb, n, npart, w, v, k, h1, h2, col, norm_slot);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
+}
+// the context-state form (round 3): form and flag word from mimsem_krylov_gs_control / MIMSEM_GS_FUSED_NORM
+int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                                   const double* h1, double* h2, double* col, int norm_slot) {
+    if (!c) return MIMSEM_ERR_ARG;
+    if (c->gs_fused < 0) c->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
+    return mimsem_krylov_reorthonormalize_ex(c, k, n, V, ldv, w, v, h1, h2, col, norm_slot, c->gs_fused, c->gs_flag);
 }
 
 int mimsem_krylov_gs_control(mimsem_ctx* c, int fused, int* flag) {

@@ -1,0 +1,491 @@
+// ksp.hip -- the solve loops of rows N1..N3 behind the C ABI (round 4): mimsem_ksp_* of include/mimsem_hip.h.
+//
+// Reference: every operator assembly is followed by KSPSolve on a GMRES + PCBJACOBI(one block per element) object
+// (eul/HorizSolve.cpp:77-96, :224, :246, :310, :322; kspA of the shallow-water Picard step, src/SWEqn_Picard.cpp:600-606, :751-765).
+// Rounds 1-3 had these loops in Python only (mimsem_amd/krylov.py); a C++ host could reach the operator applies but nothing above
+// them.  Here the loops are library code on the context's stream, composed from the ABI's own entry points:
+//   CG     batched over the rows (one independent SPD system per level): mimsem_krylov_rowdot / cg_update / cg_direction keep the
+//          per-row scalars on the device; the host looks at |r|^2 every `check_every` iterations (one small copy);
+//   GMRES  restarted, left-preconditioned, classical Gram-Schmidt with re-orthogonalisation (mimsem_krylov_orthogonalize +
+//          mimsem_krylov_reorthonormalize_ex: four launches), Hessenberg column through pinned host memory, Givens rotations on the host.
+// mimsem_amd/krylov.py calls the same entry points (MassSolver's PCG path, gmres()): one code path.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "ctx.hpp"
+#include "../../include/mimsem_hip.h"
+
+#define KTRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+namespace {
+enum { A_NONE = 0, A_OP = 1, A_SW = 2, A_SHELL = 3 };
+enum { P_NONE = 0, P_JACOBI = 1, P_BLOCKS = 2, P_SW = 3, P_SHELL = 4 };
+
+// B'[e][i][j] = d[e][i] B[e][i][j] d[e][j]
+__global__ __launch_bounds__(256) void k_scale_blocks(long long total, int nd, const double* __restrict__ d, double* __restrict__ B) {
+    const long long x = (long long)blockIdx.x*256 + threadIdx.x;
+    if (x >= total) return;
+    const int j = (int)(x%nd); const long long t = x/nd; const int i = (int)(t%nd); const long long e = t/nd;
+    B[x] *= d[e*nd + i]*d[e*nd + j];
+}
+// element matrices [nEl][2][2][n1e][n1e] (UtQU UtQV VtQU VtQV) -> one dense block [nEl][2 n1e][2 n1e] per element
+__global__ __launch_bounds__(256) void k_em_to_block(long long total, int n1e, const double* __restrict__ em, double* __restrict__ B) {
+    const long long x = (long long)blockIdx.x*256 + threadIdx.x;
+    if (x >= total) return;
+    const int nd = 2*n1e;
+    const int j = (int)(x%nd); const long long t = x/nd; const int i = (int)(t%nd); const long long e = t/nd;
+    B[x] = em[(((e*2 + i/n1e)*2 + j/n1e)*n1e + i%n1e)*n1e + j%n1e];
+}
+// escale[k][e] = 1 / mean_q thickInv[k][e][q]
+__global__ __launch_bounds__(256) void k_escale(long long total, int mp12, const double* __restrict__ tI, double* __restrict__ es) {
+    const long long x = (long long)blockIdx.x*256 + threadIdx.x;
+    if (x >= total) return;
+    double s = 0.0;
+    for (int q = 0; q < mp12; q++) s += tI[x*mp12 + q];
+    es[x] = (double)mp12/s;
+}
+// E21 of ONE element (eul/Assembly.cpp:1170-1220, element-local numbering: x-edges then y-edges): entry (face q, edge col)
+__device__ __forceinline__ double e21_local(int n, int n1e, int q, int col) {
+    const int jj = q%n, ii = q/n;
+    if (col == ii*(n + 1) + jj) return -1.0;
+    if (col == ii*(n + 1) + jj + 1) return 1.0;
+    if (col == n1e + ii*n + jj) return -1.0;
+    if (col == n1e + (ii + 1)*n + jj) return 1.0;
+    return 0.0;
+}
+// the element block of the packed shallow-water operator (SWEqn::assemble_operator, src/SWEqn_Picard.cpp:622-725):
+//   A_e = [[M1_e + a R_e(f), a g E12_e M2_e], [a H M2_e E21_e, M2_e]],   E12_e = -E21_e^T;   ND = 2 n1e + n2e, row-major
+__global__ __launch_bounds__(256) void k_sw_block(long long total, int n, int n1e, int n2e, double a, double grav, double H,
+                                                   const double* __restrict__ em1, const double* __restrict__ rot, const double* __restrict__ em2,
+                                                   double* __restrict__ Ae) {
+    const long long x = (long long)blockIdx.x*256 + threadIdx.x;
+    if (x >= total) return;
+    const int nd1 = 2*n1e, ND = nd1 + n2e;
+    const int j = (int)(x%ND); const long long t = x/ND; const int i = (int)(t%ND); const long long e = t/ND;
+    const double* M2 = em2 + e*n2e*n2e;
+    double v;
+    if (i < nd1 && j < nd1) {
+        v = em1[(((e*2 + i/n1e)*2 + j/n1e)*n1e + i%n1e)*n1e + j%n1e];
+        if (i < n1e && j >= n1e) v += a*rot[((e*2 + 0)*n1e + i)*n1e + (j - n1e)];
+        else if (i >= n1e && j < n1e) v += a*rot[((e*2 + 1)*n1e + (i - n1e))*n1e + j];
+    } else if (i < nd1) {
+        const int q = j - nd1; double s = 0.0;
+        for (int p = 0; p < n2e; p++) s += e21_local(n, n1e, p, i)*M2[p*n2e + q];
+        v = -(a*grav)*s;
+    } else if (j < nd1) {
+        const int p = i - nd1; double s = 0.0;
+        for (int q = 0; q < n2e; q++) s += M2[p*n2e + q]*e21_local(n, n1e, q, j);
+        v = (a*H)*s;
+    } else v = M2[(i - nd1)*n2e + (j - nd1)];
+    Ae[x] = v;
+}
+// out[e][c*ND + r] = d[e][r] Inv[e][r][c] d[e][c]   (column-major per element: what mimsem_sw_blocks_apply reads)
+__global__ __launch_bounds__(256) void k_scale_transpose(long long total, int ND, const double* __restrict__ d, const double* __restrict__ Inv,
+                                                         double* __restrict__ out) {
+    const long long x = (long long)blockIdx.x*256 + threadIdx.x;
+    if (x >= total) return;
+    const int r = (int)(x%ND); const long long t = x/ND; const int c = (int)(t%ND); const long long e = t/ND;
+    out[x] = d[e*ND + r]*Inv[(e*ND + r)*ND + c]*d[e*ND + c];
+}
+// z = dinv .* r  (rows at their own strides)
+__global__ __launch_bounds__(256) void k_rowmul(int nrows, long long n, const double* __restrict__ a, long long as_, const double* __restrict__ b,
+                                                long long bs, double* __restrict__ out, long long os) {
+    const long long j = (long long)blockIdx.x*256 + threadIdx.x;
+    if (j >= n) return;
+    for (int r = blockIdx.y; r < nrows; r += gridDim.y) out[(size_t)r*os + j] = a[(size_t)r*as_ + j]*b[(size_t)r*bs + j];
+}
+}  // namespace
+
+struct mimsem_ksp {
+    mimsem_ctx* c = nullptr;
+    int type = MIMSEM_KSP_GMRES;
+    // operator
+    int akind = A_NONE, op = 0, lev0 = 0, nlev = 0; double scale = 1.0; unsigned flags = 0; const double* f = nullptr; long long fs = 0;
+    int form = -1; long long n = 0;
+    double sw_a = 0, sw_g = 0, sw_H = 0; const double* f0 = nullptr; long long f0s = 0;
+    mimsem_ksp_apply_fn afn = nullptr; void* auser = nullptr;
+    // preconditioner
+    int pkind = P_NONE; const double* dinv = nullptr; long long dinvs = 0;
+    int bform = 1; bool btrans = false; const double* blocks = nullptr; const double* escale = nullptr; long long escales = 0;
+    double* own_blocks = nullptr; double* own_escale = nullptr;
+    mimsem_ksp_apply_fn pfn = nullptr; void* puser = nullptr;
+    // controls
+    double rtol = 1.0e-16, atol = 1.0e-50; int maxit = 1000, restart = 30, check_every = 2; bool guess_nonzero = false;
+    // workspace
+    double* ws = nullptr; long long ws_doubles = 0;
+    double* host = nullptr; long long host_doubles = 0;      // pinned
+    int* flag = nullptr;                                     // pinned word of the two-launch re-orthonormalisation (this object's own)
+    bool gs_fused = true;
+    // results of the last solve
+    int its = 0; double rnorm = 0.0; int reason = 0;
+
+    int ensure(long long doubles, long long hostd) {
+        if (doubles > ws_doubles) {
+            if (c->is_capturing()) return MIMSEM_ERR_STATE;
+            if (ws) c->retired.push_back(ws);
+            MIMSEM_HIP_TRY(hipMalloc((void**)&ws, (size_t)doubles*sizeof(double)));
+            ws_doubles = doubles;
+        }
+        if (hostd > host_doubles) {
+            if (host) (void)hipHostFree(host);
+            MIMSEM_HIP_TRY(hipHostMalloc((void**)&host, (size_t)hostd*sizeof(double), hipHostMallocDefault));
+            host_doubles = hostd;
+        }
+        if (!flag) { MIMSEM_HIP_TRY(hipHostMalloc((void**)&flag, sizeof(int), hipHostMallocDefault)); *flag = 0; }
+        return MIMSEM_OK;
+    }
+    int A(const double* x, long long xs, double* y, long long ys) const {
+        switch (akind) {
+        case A_OP: return mimsem_op_apply(c, op, lev0, nlev, scale, flags, f, fs, x, xs, y, ys, 1.0);
+        case A_SW: return mimsem_sw_operator_apply(c, nlev, sw_a, sw_g, sw_H, f0, f0s, x, xs, y, ys);
+        case A_SHELL: return afn(auser, nlev, x, xs, y, ys);
+        }
+        return MIMSEM_ERR_STATE;
+    }
+    int P(const double* r, long long rs, double* z, long long zs) const {
+        switch (pkind) {
+        case P_NONE: MIMSEM_HIP_TRY(hipMemcpy2DAsync(z, (size_t)zs*8, r, (size_t)rs*8, (size_t)n*8, (size_t)nlev, hipMemcpyDeviceToDevice, c->stream)); return MIMSEM_OK;
+        case P_JACOBI: hipLaunchKernelGGL(k_rowmul, dim3((unsigned)((n + 255)/256), (unsigned)std::min(nlev, 64)), dim3(256), 0, c->stream,
+                                          nlev, n, r, rs, dinv, dinvs, z, zs); MIMSEM_HIP_TRY(hipGetLastError()); return MIMSEM_OK;
+        case P_BLOCKS: return mimsem_elem_blocks_apply(c, bform, nlev, btrans ? MIMSEM_FLAG_TRANSPOSE : 0u, blocks, 0, escale, escales, r, rs, z, zs, 1.0);
+        case P_SW: return mimsem_sw_blocks_apply(c, nlev, blocks, r, rs, z, zs);
+        case P_SHELL: return pfn(puser, nlev, r, rs, z, zs);
+        }
+        return MIMSEM_ERR_STATE;
+    }
+    // z = P A x (the body of the left-preconditioned iteration); t: scratch for A x
+    int PA(const double* x, long long xs, double* t, double* z, long long zs) const {
+        if (akind == A_SW && pkind == P_SW) return mimsem_sw_operator_precond_apply(c, nlev, sw_a, sw_g, sw_H, f0, f0s, blocks, x, xs, z, zs);
+        KTRY(A(x, xs, t, n));
+        return P(t, n, z, zs);
+    }
+};
+
+namespace {
+int combine(mimsem_ctx* c, int nrows, long long n, double alpha, const double* a, long long as_, double beta, const double* b, long long bs,
+            double* out, long long os) {
+    return mimsem_vec_combine(c, nrows, n, alpha, a, as_, 0, nullptr, 0, beta, b, bs, out, os);
+}
+int to_host(mimsem_ctx* c, double* h, const double* d, long long count) {
+    MIMSEM_HIP_TRY(hipMemcpyAsync(h, d, (size_t)count*sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MIMSEM_OK;
+}
+
+// ---- batched preconditioned CG ------------------------------------------------------------------------------------------------------
+int solve_cg(mimsem_ksp* k, const double* b, long long bs, double* x, long long xs) {
+    mimsem_ctx* c = k->c; const int nr = k->nlev; const long long n = k->n;
+    KTRY(k->ensure(4*nr*n + 6*(long long)nr, 2*(long long)nr));
+    double *r = k->ws, *z = r + nr*n, *p = z + nr*n, *Ap = p + nr*n, *sc = Ap + nr*n;
+    double *rz = sc, *rz2 = sc + nr, *pAp = sc + 2*nr, *rr = sc + 3*nr, *bb = sc + 4*nr;
+    if (k->guess_nonzero) { KTRY(k->A(x, xs, Ap, n)); KTRY(combine(c, nr, n, 1.0, b, bs, -1.0, Ap, n, r, n)); }
+    else { MIMSEM_HIP_TRY(hipMemset2DAsync(x, (size_t)xs*8, 0, (size_t)n*8, (size_t)nr, c->stream)); KTRY(combine(c, nr, n, 1.0, b, bs, 0.0, nullptr, 0, r, n)); }
+    KTRY(mimsem_krylov_rowdot(c, nr, n, b, bs, b, bs, bb));
+    KTRY(to_host(c, k->host, bb, nr));
+    std::vector<double> tol2(nr);
+    bool all_zero = true;
+    for (int i = 0; i < nr; i++) { const double t = std::max(k->rtol*std::sqrt(k->host[i]), k->atol); tol2[i] = t*t; if (k->host[i] > 0.0) all_zero = false; }
+    k->its = 0; k->rnorm = 0.0; k->reason = MIMSEM_KSP_CONVERGED_ATOL;
+    if (all_zero && !k->guess_nonzero) return MIMSEM_OK;
+    KTRY(k->P(r, n, z, n));
+    KTRY(combine(c, nr, n, 1.0, z, n, 0.0, nullptr, 0, p, n));
+    KTRY(mimsem_krylov_rowdot(c, nr, n, r, n, z, n, rz));
+    const int every = k->check_every > 0 ? k->check_every : 2;
+    k->reason = MIMSEM_KSP_DIVERGED_ITS;
+    for (int it = 0; it < k->maxit; it++) {
+        KTRY(k->A(p, n, Ap, n));
+        KTRY(mimsem_krylov_rowdot(c, nr, n, p, n, Ap, n, pAp));
+        KTRY(mimsem_krylov_cg_update(c, nr, n, rz, pAp, p, n, Ap, n, x, xs, r, n));
+        k->its = it + 1;
+        if (k->its%every == 0 || k->its == k->maxit) {
+            KTRY(mimsem_krylov_rowdot(c, nr, n, r, n, r, n, rr));
+            KTRY(to_host(c, k->host + nr, rr, nr));
+            bool ok = true, rt = true; double worst = 0.0;
+            for (int i = 0; i < nr; i++) {
+                const double v = k->host[nr + i];
+                if (!(v == v) || v > 1.0e300) { k->reason = MIMSEM_KSP_DIVERGED_NANORINF; k->rnorm = v; return MIMSEM_OK; }
+                if (v > tol2[i]) ok = false;
+                const double bn = k->host[i];
+                const double rel = bn > 0.0 ? std::sqrt(v/bn) : std::sqrt(v);
+                worst = std::max(worst, rel);
+                if (!(rel <= k->rtol)) rt = false;
+            }
+            k->rnorm = worst;
+            if (ok) { k->reason = rt ? MIMSEM_KSP_CONVERGED_RTOL : MIMSEM_KSP_CONVERGED_ATOL; return MIMSEM_OK; }
+        }
+        KTRY(k->P(r, n, z, n));
+        KTRY(mimsem_krylov_rowdot(c, nr, n, r, n, z, n, rz2));
+        KTRY(mimsem_krylov_cg_direction(c, nr, n, rz2, rz, z, n, p, n));
+        std::swap(rz, rz2);
+    }
+    return MIMSEM_OK;
+}
+
+// ---- restarted left-preconditioned GMRES on the rows taken as ONE vector ---------------------------------------------------------------
+int solve_gmres(mimsem_ksp* k, const double* b, long long bs, double* x, long long xs) {
+    mimsem_ctx* c = k->c; const int nr = k->nlev; const long long n = k->n, N = nr*n; const int m = std::max(1, k->restart);
+    KTRY(k->ensure((long long)(m + 1)*N + 4*N + 3*(long long)(m + 2), (long long)(m + 2) + 4));
+    double *V = k->ws, *w = V + (long long)(m + 1)*N, *t = w + N, *xc = t + N, *pb = xc + N, *h = pb + N, *h2 = h + (m + 2), *yd = h2 + (m + 2);
+    double* col = k->host;                    // [m + 2] pinned: the Hessenberg column of the step, [m + 1] = the norm
+    auto norm = [&](const double* v, double* out) -> int {
+        KTRY(mimsem_krylov_rowdot(c, 1, N, v, N, v, N, h2));
+        KTRY(to_host(c, col, h2, 1));
+        *out = std::sqrt(col[0]);
+        return MIMSEM_OK;
+    };
+    // contiguous copy of x (the iteration treats the rows as one vector)
+    if (k->guess_nonzero) KTRY(combine(c, nr, n, 1.0, x, xs, 0.0, nullptr, 0, xc, n));
+    else MIMSEM_HIP_TRY(hipMemsetAsync(xc, 0, (size_t)N*8, c->stream));
+    KTRY(k->P(b, bs, pb, n));
+    double bnorm = 0.0;
+    KTRY(norm(pb, &bnorm));
+    k->its = 0; k->rnorm = 0.0; k->reason = MIMSEM_KSP_CONVERGED_ATOL;
+    if (bnorm == 0.0 && !k->guess_nonzero) { MIMSEM_HIP_TRY(hipMemset2DAsync(x, (size_t)xs*8, 0, (size_t)n*8, (size_t)nr, c->stream)); return MIMSEM_OK; }
+    if (!(bnorm == bnorm)) { k->reason = MIMSEM_KSP_DIVERGED_NANORINF; return MIMSEM_OK; }
+    const double tol = std::max(k->rtol*bnorm, k->atol);
+    std::vector<double> H((size_t)(m + 1)*m), cs(m), sn(m), g(m + 1), y(m);
+    double res = bnorm;
+    k->reason = MIMSEM_KSP_DIVERGED_ITS;
+    bool first = true;
+    while (k->its < k->maxit) {
+        // r = P (b - A x)
+        if (first && !k->guess_nonzero) MIMSEM_HIP_TRY(hipMemcpyAsync(w, pb, (size_t)N*8, hipMemcpyDeviceToDevice, c->stream));
+        else { KTRY(k->A(xc, n, t, n)); KTRY(combine(c, nr, n, 1.0, b, bs, -1.0, t, n, t, n)); KTRY(k->P(t, n, w, n)); }
+        first = false;
+        double beta = 0.0;
+        KTRY(norm(w, &beta));
+        res = beta;
+        if (!(beta == beta)) { k->reason = MIMSEM_KSP_DIVERGED_NANORINF; break; }
+        if (beta <= tol) { k->reason = beta <= k->rtol*bnorm ? MIMSEM_KSP_CONVERGED_RTOL : MIMSEM_KSP_CONVERGED_ATOL; break; }
+        KTRY(combine(c, 1, N, 1.0/beta, w, N, 0.0, nullptr, 0, V, N));
+        std::fill(H.begin(), H.end(), 0.0);
+        std::fill(g.begin(), g.end(), 0.0);
+        g[0] = beta;
+        int kk = 0; bool done = false;
+        for (int j = 0; j < m && !done; j++) {
+            KTRY(k->PA(V + (long long)j*N, n, t, w, n));
+            KTRY(mimsem_krylov_orthogonalize(c, j + 1, N, V, N, -1.0, w, h));
+            *k->flag = 0;
+            KTRY(mimsem_krylov_reorthonormalize_ex(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, k->gs_fused ? 1 : 0, k->flag));
+            MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (*k->flag) {
+                // the Pythagorean norm of the two-launch form cancelled: this object switches to the three-launch form for good and
+                // the cycle restarts from the current iterate (nothing of the failed step is used)
+                k->gs_fused = false; *k->flag = 0; kk = 0; done = false;
+                break;
+            }
+            for (int i = 0; i <= j; i++) H[(size_t)i*m + j] = col[i];
+            H[(size_t)(j + 1)*m + j] = col[m + 1];
+            for (int i = 0; i < j; i++) {
+                const double a = H[(size_t)i*m + j], bq = H[(size_t)(i + 1)*m + j];
+                H[(size_t)i*m + j] = cs[i]*a + sn[i]*bq;
+                H[(size_t)(i + 1)*m + j] = -sn[i]*a + cs[i]*bq;
+            }
+            const double a = H[(size_t)j*m + j], bq = H[(size_t)(j + 1)*m + j], d = std::sqrt(a*a + bq*bq);
+            if (d == 0.0) { cs[j] = 1.0; sn[j] = 0.0; } else { cs[j] = a/d; sn[j] = bq/d; }
+            H[(size_t)j*m + j] = d; H[(size_t)(j + 1)*m + j] = 0.0;
+            g[j + 1] = -sn[j]*g[j]; g[j] = cs[j]*g[j];
+            k->its++; kk = j + 1;
+            res = std::fabs(g[j + 1]);
+            if (!(res == res)) { k->reason = MIMSEM_KSP_DIVERGED_NANORINF; done = true; }
+            else if (res <= tol) { k->reason = res <= k->rtol*bnorm ? MIMSEM_KSP_CONVERGED_RTOL : MIMSEM_KSP_CONVERGED_ATOL; done = true; }
+            else if (k->its >= k->maxit) done = true;
+            else if (col[m + 1] == 0.0) { k->reason = MIMSEM_KSP_DIVERGED_BREAKDOWN; done = true; }
+        }
+        if (kk > 0) {
+            for (int i = kk - 1; i >= 0; i--) {
+                double s = g[i];
+                for (int l = i + 1; l < kk; l++) s -= H[(size_t)i*m + l]*y[l];
+                y[i] = s/H[(size_t)i*m + i];
+            }
+            MIMSEM_HIP_TRY(hipMemcpyAsync(yd, y.data(), (size_t)kk*8, hipMemcpyHostToDevice, c->stream));
+            KTRY(mimsem_krylov_maxpy(c, kk, N, V, N, yd, 1.0, xc));
+            MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));         // (y lives in pageable host memory: keep it until the copy is done)
+        }
+        if (done) break;
+    }
+    k->rnorm = bnorm > 0.0 ? res/bnorm : res;
+    return combine(c, nr, n, 1.0, xc, n, 0.0, nullptr, 0, x, xs);
+}
+}  // namespace
+
+extern "C" {
+
+int mimsem_ksp_create(mimsem_ctx* ctx, int type, mimsem_ksp** out) {
+    if (!ctx || !out || (type != MIMSEM_KSP_CG && type != MIMSEM_KSP_GMRES)) return MIMSEM_ERR_ARG;
+    mimsem_ksp* k = new mimsem_ksp();
+    k->c = ctx; k->type = type;
+    k->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
+    *out = k;
+    return MIMSEM_OK;
+}
+void mimsem_ksp_destroy(mimsem_ksp* k) {
+    if (!k) return;
+    if (k->ws) (void)hipFree(k->ws);
+    if (k->host) (void)hipHostFree(k->host);
+    if (k->flag) (void)hipHostFree(k->flag);
+    if (k->own_blocks) (void)hipFree(k->own_blocks);
+    if (k->own_escale) (void)hipFree(k->own_escale);
+    delete k;
+}
+int mimsem_ksp_set_operator(mimsem_ksp* k, int op, int geom_lev0, int nlev, double scale, unsigned flags, const double* f, long long fs) {
+    if (!k || nlev <= 0 || geom_lev0 < 0) return MIMSEM_ERR_ARG;
+    int in = -1, out = -1;
+    switch (op) {                                            // square operators on one space
+    case MIMSEM_OP_UMAT: case MIMSEM_OP_UTMAT: case MIMSEM_OP_UHMAT: case MIMSEM_OP_UTMAT_H: case MIMSEM_OP_ROTMAT: in = out = 1; break;
+    case MIMSEM_OP_WMAT: case MIMSEM_OP_WHMAT: in = out = 2; break;
+    case MIMSEM_OP_PMAT: case MIMSEM_OP_PHMAT: in = out = 0; break;
+    default: return MIMSEM_ERR_ARG;
+    }
+    k->akind = A_OP; k->op = op; k->lev0 = geom_lev0; k->nlev = nlev; k->scale = scale; k->flags = flags; k->f = f; k->fs = fs;
+    k->form = in; k->n = in == 0 ? k->c->n0 : (in == 1 ? k->c->n1 : k->c->n2);
+    (void)out;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_operator_sw(mimsem_ksp* k, int nlev, double a, double grav, double H, const double* f0, long long f0s) {
+    if (!k || nlev <= 0 || !f0) return MIMSEM_ERR_ARG;
+    k->akind = A_SW; k->nlev = nlev; k->sw_a = a; k->sw_g = grav; k->sw_H = H; k->f0 = f0; k->f0s = f0s;
+    k->form = -1; k->n = (long long)k->c->n1 + k->c->n2;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_operator_shell(mimsem_ksp* k, int nlev, long long n, mimsem_ksp_apply_fn fn, void* user) {
+    if (!k || nlev <= 0 || n <= 0 || !fn) return MIMSEM_ERR_ARG;
+    k->akind = A_SHELL; k->nlev = nlev; k->n = n; k->afn = fn; k->auser = user; k->form = -1;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_pc_none(mimsem_ksp* k) { if (!k) return MIMSEM_ERR_ARG; k->pkind = P_NONE; return MIMSEM_OK; }
+int mimsem_ksp_set_pc_jacobi(mimsem_ksp* k, const double* dinv, long long s) {
+    if (!k || !dinv) return MIMSEM_ERR_ARG;
+    k->pkind = P_JACOBI; k->dinv = dinv; k->dinvs = s;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_pc_elem_blocks(mimsem_ksp* k, int form, const double* blocks, const double* es, long long ess) {
+    if (!k || !blocks || form < 0 || form > 2) return MIMSEM_ERR_ARG;
+    k->pkind = P_BLOCKS; k->bform = form; k->btrans = false; k->blocks = blocks; k->escale = es; k->escales = ess;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_pc_sw_blocks(mimsem_ksp* k, const double* blocks) {
+    if (!k || !blocks) return MIMSEM_ERR_ARG;
+    k->pkind = P_SW; k->blocks = blocks;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_pc_shell(mimsem_ksp* k, mimsem_ksp_apply_fn fn, void* user) {
+    if (!k || !fn) return MIMSEM_ERR_ARG;
+    k->pkind = P_SHELL; k->pfn = fn; k->puser = user;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_pc_bjacobi(mimsem_ksp* k) {
+    if (!k || k->akind != A_OP || k->form != 1) return MIMSEM_ERR_STATE;
+    mimsem_ctx* c = k->c;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    const int n1e = c->es.n1e, nd = 2*n1e, nEl = c->nEl;
+    if ((int)c->h_i1x.size() != nEl*n1e || (int)c->h_i1y.size() != nEl*n1e) return MIMSEM_ERR_STATE;
+    // D_e = 1 / multiplicity of the element's edges
+    std::vector<int> mult(c->n1, 0);
+    for (int v : c->h_i1x) mult[v]++;
+    for (int v : c->h_i1y) mult[v]++;
+    std::vector<double> d((size_t)nEl*nd);
+    for (int e = 0; e < nEl; e++)
+        for (int i = 0; i < nd; i++) d[(size_t)e*nd + i] = 1.0/mult[i < n1e ? c->h_i1x[(size_t)e*n1e + i] : c->h_i1y[(size_t)e*n1e + i - n1e]];
+    const long long tot = (long long)nEl*nd*nd;
+    double *em = nullptr, *dd = nullptr;
+    if (k->own_blocks) { (void)hipFree(k->own_blocks); k->own_blocks = nullptr; }
+    if (k->own_escale) { (void)hipFree(k->own_escale); k->own_escale = nullptr; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&k->own_blocks, (size_t)tot*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&em, (size_t)tot*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&dd, d.size()*8));
+    int rc = MIMSEM_OK;
+    do {
+        if (hipMemcpyAsync(dd, d.data(), d.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        // the element's dense block WITHOUT its thickness factor (flag bit 0 off): one inverse per element serves every level
+        const bool vert = (k->flags & 1u) != 0;
+        if ((rc = mimsem_op_element_matrices(c, k->op, k->lev0, k->scale, k->flags & ~1u, k->f, em))) break;
+        hipLaunchKernelGGL(k_em_to_block, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, n1e, em, k->own_blocks);
+        if ((rc = mimsem_block_inverse(c, nEl, nd, k->own_blocks))) break;
+        hipLaunchKernelGGL(k_scale_blocks, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, nd, dd, k->own_blocks);
+        if (vert) {
+            const long long ne = (long long)k->nlev*nEl;
+            if (hipMalloc((void**)&k->own_escale, (size_t)ne*8) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+            hipLaunchKernelGGL(k_escale, dim3((unsigned)((ne + 255)/256)), dim3(256), 0, c->stream, ne, c->es.mp12,
+                               c->d_tI + (size_t)k->lev0*nEl*c->es.mp12, k->own_escale);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+    } while (0);
+    (void)hipFree(em); (void)hipFree(dd);
+    if (rc) return rc;
+    k->pkind = P_BLOCKS; k->bform = 1; k->btrans = true /* symmetric blocks: the coalesced read direction */; k->blocks = k->own_blocks; k->escale = k->own_escale; k->escales = nEl;
+    return MIMSEM_OK;
+}
+// the coupled [u|h] element blocks of the shallow-water operator, built from the operator given to mimsem_ksp_set_operator_sw
+int mimsem_ksp_set_pc_sw_bjacobi(mimsem_ksp* k) {
+    if (!k || k->akind != A_SW) return MIMSEM_ERR_STATE;
+    mimsem_ctx* c = k->c;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    const int n = c->es.n, n1e = c->es.n1e, n2e = c->es.n2e, nd1 = 2*n1e, ND = nd1 + n2e, nEl = c->nEl;
+    if (ND > 64) return MIMSEM_ERR_UNSUPPORTED;                        // mimsem_sw_blocks_apply: orders 1..4
+    if ((int)c->h_i1x.size() != nEl*n1e || (int)c->h_i1y.size() != nEl*n1e) return MIMSEM_ERR_STATE;
+    std::vector<int> mult(c->n1, 0);
+    for (int v : c->h_i1x) mult[v]++;
+    for (int v : c->h_i1y) mult[v]++;
+    std::vector<double> d((size_t)nEl*ND, 1.0);
+    for (int e = 0; e < nEl; e++)
+        for (int i = 0; i < nd1; i++) d[(size_t)e*ND + i] = 1.0/mult[i < n1e ? c->h_i1x[(size_t)e*n1e + i] : c->h_i1y[(size_t)e*n1e + i - n1e]];
+    const long long tot = (long long)nEl*ND*ND;
+    double *em1 = nullptr, *rot = nullptr, *em2 = nullptr, *Ae = nullptr, *dd = nullptr;
+    if (k->own_blocks) { (void)hipFree(k->own_blocks); k->own_blocks = nullptr; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&k->own_blocks, (size_t)tot*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&em1, (size_t)nEl*4*n1e*n1e*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&rot, (size_t)nEl*2*n1e*n1e*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&em2, (size_t)nEl*n2e*n2e*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&Ae, (size_t)tot*8));
+    MIMSEM_HIP_TRY(hipMalloc((void**)&dd, d.size()*8));
+    int rc = MIMSEM_OK;
+    do {
+        if (hipMemcpyAsync(dd, d.data(), d.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        // src/ flavour: unit scale, no thickness (mimsem_sw_operator_apply)
+        if ((rc = mimsem_op_element_matrices(c, MIMSEM_OP_UMAT, 0, 1.0, 0, nullptr, em1))) break;
+        if ((rc = mimsem_op_element_matrices(c, MIMSEM_OP_ROTMAT, 0, 1.0, 0, k->f0, rot))) break;
+        if ((rc = mimsem_op_element_matrices(c, MIMSEM_OP_WMAT, 0, 1.0, 0, nullptr, em2))) break;
+        hipLaunchKernelGGL(k_sw_block, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, n, n1e, n2e, k->sw_a, k->sw_g, k->sw_H, em1, rot, em2, Ae);
+        if ((rc = mimsem_block_inverse(c, nEl, ND, Ae))) break;
+        hipLaunchKernelGGL(k_scale_transpose, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, ND, dd, Ae, k->own_blocks);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+    } while (0);
+    (void)hipFree(em1); (void)hipFree(rot); (void)hipFree(em2); (void)hipFree(Ae); (void)hipFree(dd);
+    if (rc) return rc;
+    k->pkind = P_SW; k->blocks = k->own_blocks;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_tolerances(mimsem_ksp* k, double rtol, double atol, int maxit, int restart, int check_every) {
+    if (!k || rtol < 0.0 || atol < 0.0) return MIMSEM_ERR_ARG;
+    k->rtol = rtol; k->atol = atol;
+    if (maxit > 0) k->maxit = maxit;
+    if (restart > 0) k->restart = restart;
+    k->check_every = check_every > 0 ? check_every : 2;
+    return MIMSEM_OK;
+}
+int mimsem_ksp_set_initial_guess_nonzero(mimsem_ksp* k, int flag) { if (!k) return MIMSEM_ERR_ARG; k->guess_nonzero = flag != 0; return MIMSEM_OK; }
+
+int mimsem_ksp_solve(mimsem_ksp* k, const double* b, long long bs, double* x, long long xs) {
+    if (!k || !b || !x || k->akind == A_NONE) return MIMSEM_ERR_ARG;
+    if (k->nlev == 1) { bs = std::max(bs, k->n); xs = std::max(xs, k->n); }        // one row: any stride will do (a reference-style single-level solve)
+    if (bs < k->n || xs < k->n) return MIMSEM_ERR_ARG;
+    if (k->pkind == P_SW && k->akind != A_SW && k->n != (long long)k->c->n1 + k->c->n2) return MIMSEM_ERR_ARG;
+    if (k->pkind == P_BLOCKS) {
+        const long long want = k->bform == 0 ? k->c->n0 : (k->bform == 1 ? k->c->n1 : k->c->n2);
+        if (want != k->n) return MIMSEM_ERR_ARG;
+    }
+    return k->type == MIMSEM_KSP_CG ? solve_cg(k, b, bs, x, xs) : solve_gmres(k, b, bs, x, xs);
+}
+int mimsem_ksp_get_info(const mimsem_ksp* k, int* its, double* rnorm, int* reason) {
+    if (!k) return MIMSEM_ERR_ARG;
+    if (its) *its = k->its;
+    if (rnorm) *rnorm = k->rnorm;
+    if (reason) *reason = k->reason;
+    return MIMSEM_OK;
+}
+
+}  // extern "C"

@@ -671,12 +671,19 @@ class Engine:
         check(self.L.mimsem_krylov_orthogonalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), alpha, _ptr(w), _ptr(h)), "krylov_orthogonalize")
         return w
 
-    def reorthonormalize(self, V, w, v, k, h1, h2, col, norm_slot):
+    def reorthonormalize(self, V, w, v, k, h1, h2, col, norm_slot, fused=None, flag=None):
         """second Gram-Schmidt pass + normalisation in two launches: h2[:k] = V[:k] w; w -= V[:k]^T h2; v = w/|w|;
-        col[:k] = h1 + h2; col[norm_slot] = |w| (col: device or pinned host tensor)"""
+        col[:k] = h1 + h2; col[norm_slot] = |w| (col: device or pinned host tensor).  fused / flag given: the explicit form
+        (mimsem_krylov_reorthonormalize_ex: the caller's own flag word, nothing shared through the context)"""
         assert w.numel() == v.numel() and v.is_contiguous() and col.dtype == torch.float64 and col.is_contiguous()
         assert col.is_cuda or col.is_pinned(), "col must be device or pinned host memory"
         assert col.numel() > max(k - 1, norm_slot)
+        if fused is not None:
+            assert flag is None or (flag.dtype == torch.int32 and (flag.is_cuda or flag.is_pinned()))
+            check(self.L.mimsem_krylov_reorthonormalize_ex(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(w), _ptr(v), _ptr(h1), _ptr(h2),
+                                                           col.data_ptr(), norm_slot, 1 if fused else 0,
+                                                           flag.data_ptr() if flag is not None else None), "krylov_reorthonormalize_ex")
+            return
         check(self.L.mimsem_krylov_reorthonormalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(w), _ptr(v), _ptr(h1), _ptr(h2),
                                                     col.data_ptr(), norm_slot), "krylov_reorthonormalize")
         return v

@@ -204,6 +204,9 @@ protected:
     }
 public:
     Mesh* device_mesh() const { return mesh; }
+    // what the last assemble() set: KSPSetOperators(ksp, X->M, X->M) reads it (class KSP below)
+    int op_id() const { return op; } int level() const { return lev; } double op_scale() const { return scale; } unsigned op_flags() const { return flags; }
+    const double* op_field() const { return field; } bool is_up() const { return up; }
     // MatMult(X->M, x, y) on device vectors (single level, like the reference)
     void mult(const double* x, double* y) const { apply(x, y, 0u); }
     // the same MatMult in two parts around a halo exchange: mult_part(x, y, MIMSEM_PART_BOUNDARY); halo.begin_reverse_add(y, ...);
@@ -222,6 +225,61 @@ public:
     }
     int elmat_size() const { return mimsem_op_elmat_size(mesh->ctx, op); }
 };
+
+// ---- KSP: the solve that follows an operator assembly (eul/HorizSolve.cpp:77-96, :224, :246, :310, :322) -----------------------------
+//   KSPCreate(MPI_COMM_WORLD, &ksp1); KSPSetOperators(ksp1, M1->M, M1->M); KSPSetTolerances(ksp1, 1.0e-16, 1.0e-50, PETSC_DEFAULT, 1000);
+//   KSPSetType(ksp1, KSPGMRES); KSPGetPC(ksp1, &pc); PCSetType(pc, PCBJACOBI); PCBJacobiSetTotalBlocks(pc, size*nElsX*nElsX, NULL); ...
+//   KSPSolve(ksp1, b, x);
+// becomes
+//   KSP ksp1(&M1_mesh);  ksp1.setOperators(M1);  ksp1.setTolerances(1.0e-16, 1.0e-50, 1000);  ksp1.setType(KSP::GMRES);  ksp1.setPCBJacobi();
+//   ksp1.solve(b, x);        // after every M1->assemble(lev, SCALE, true): setOperators(M1) again (the reference re-assembles M1->M in place)
+// The loops run inside libmimsem_hip (mimsem_ksp_*): no host code between the iterations except the convergence test.
+class KSP {
+public:
+    enum Type { CG = MIMSEM_KSP_CG, GMRES = MIMSEM_KSP_GMRES };
+    explicit KSP(Mesh* m, Type t = GMRES) : mesh(m), type(t) { check(mimsem_ksp_create(mesh->ctx, (int)t, &h), "mimsem_ksp_create"); }
+    ~KSP() { mimsem_ksp_destroy(h); }
+    KSP(const KSP&) = delete; KSP& operator=(const KSP&) = delete;
+    void setType(Type t) {                                   // KSPSetType (re-creates the object: tolerances are kept)
+        if (t == type) return;
+        mimsem_ksp_destroy(h); h = nullptr; type = t; pc_set = false;
+        check(mimsem_ksp_create(mesh->ctx, (int)t, &h), "mimsem_ksp_create");
+        check(mimsem_ksp_set_tolerances(h, rtol, atol, maxit, restart, 2), "mimsem_ksp_set_tolerances");
+    }
+    void setTolerances(double rtol_, double atol_, int maxit_, int restart_ = 30) {       // KSPSetTolerances (dtol unused, as in the reference)
+        rtol = rtol_; atol = atol_; maxit = maxit_; restart = restart_;
+        check(mimsem_ksp_set_tolerances(h, rtol, atol, maxit, restart, 2), "mimsem_ksp_set_tolerances");
+    }
+    // KSPSetOperators(ksp, X->M, X->M): the operator in the state its last assemble() left it (one level, like the reference's Mat)
+    void setOperators(const OperatorBase& A) {
+        if (A.is_up()) fail("KSP::setOperators: the upwinded operators go through setOperatorsShell");
+        check(mimsem_ksp_set_operator(h, A.op_id(), A.level(), 1, A.op_scale(), A.op_flags(), A.op_field(), 0), "mimsem_ksp_set_operator");
+        if (bjacobi) check(mimsem_ksp_set_pc_bjacobi(h), "mimsem_ksp_set_pc_bjacobi");        // PCSetUp on the new matrix
+    }
+    // the packed [u|h] operator of SWEqn::assemble_operator (src/SWEqn_Picard.cpp:622-725) and its coupled element-block preconditioner
+    // (PCBJACOBI: the blocks are built from the operator -- PCSetUp -- unless the caller brings its own)
+    void setOperatorsSW(double a, double grav, double H, const double* f0, const double* blocks = nullptr) {
+        check(mimsem_ksp_set_operator_sw(h, 1, a, grav, H, f0, 0), "mimsem_ksp_set_operator_sw");
+        if (blocks) check(mimsem_ksp_set_pc_sw_blocks(h, blocks), "mimsem_ksp_set_pc_sw_blocks");
+        else if (bjacobi) check(mimsem_ksp_set_pc_sw_bjacobi(h), "mimsem_ksp_set_pc_sw_bjacobi");
+    }
+    void setOperatorsShell(long long n, mimsem_ksp_apply_fn fn, void* user) { check(mimsem_ksp_set_operator_shell(h, 1, n, fn, user), "mimsem_ksp_set_operator_shell"); }
+    void setPCBJacobi() { bjacobi = true; }                  // PCSetType(pc, PCBJACOBI) + PCBJacobiSetTotalBlocks(one block per element)
+    void setPCNone() { bjacobi = false; check(mimsem_ksp_set_pc_none(h), "mimsem_ksp_set_pc_none"); }
+    void setPCShell(mimsem_ksp_apply_fn fn, void* user) { bjacobi = false; check(mimsem_ksp_set_pc_shell(h, fn, user), "mimsem_ksp_set_pc_shell"); }
+    void setInitialGuessNonzero(bool f) { check(mimsem_ksp_set_initial_guess_nonzero(h, f ? 1 : 0), "mimsem_ksp_set_initial_guess_nonzero"); }
+    void solve(const double* b, double* x) {                 // KSPSolve(ksp, b, x)
+        check(mimsem_ksp_solve(h, b, 0, x, 0), "mimsem_ksp_solve");
+        check(mimsem_ksp_get_info(h, &its, &rnorm, &reason), "mimsem_ksp_get_info");
+    }
+    int iterations() const { return its; } double residualNorm() const { return rnorm; } int convergedReason() const { return reason; }
+private:
+    static void fail(const char* m) { throw std::runtime_error(m); }
+    Mesh* mesh; Type type; mimsem_ksp* h = nullptr; bool bjacobi = false, pc_set = false;
+    double rtol = 1.0e-16, atol = 1.0e-50; int maxit = 1000, restart = 30;
+    int its = 0, reason = 0; double rnorm = 0.0;
+};
+inline void KSPSolve(KSP& ksp, const double* b, double* x) { ksp.solve(b, x); }
 
 // ---- eul/Assembly.h classes (same names, same assemble() argument order) ---------------------------
 struct Umat : OperatorBase {     // eul/Assembly.h:1-16

@@ -13,6 +13,83 @@ import torch
 from .device import no_gc
 
 
+class KSP:
+    """mimsem_ksp_* of the C ABI (round 4, csrc/ksp.hip): the solve loops as library code -- the object a C++ host uses in place of
+    PETSc's KSP (mimsem_amd/host/mimsem_shim.hpp: KSP).  Python callers reach the same loops through this wrapper: one code path.
+    type "cg" (batched over the rows: one SPD system per level) | "gmres" (restarted, left-preconditioned, the rows as one vector)."""
+    REASONS = {2: "rtol", 3: "atol", 4: "its", -3: "diverged_its", -5: "breakdown", -9: "nan_or_inf", 0: "none"}
+
+    def __init__(self, eng, ksp_type="gmres"):
+        import ctypes as C
+        from .device import check
+        self.eng = getattr(eng, "eng", eng)
+        self._C, self._check = C, check
+        h = C.c_void_p()
+        check(self.eng.L.mimsem_ksp_create(self.eng.ctx, {"cg": 0, "gmres": 1}[ksp_type], C.byref(h)), "ksp_create")
+        self.h = h
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.eng.ctx:
+                self.eng.L.mimsem_ksp_destroy(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+    def set_operator(self, op, nlev, lev0=0, scale=1.0, flags=0, f=None):
+        from .device import OPS, _ptr
+        self._keep.append(f)
+        self._check(self.eng.L.mimsem_ksp_set_operator(self.h, OPS[op], lev0, nlev, scale, flags, _ptr(f), f.stride(0) if f is not None else 0),
+                    "ksp_set_operator")
+        return self
+
+    def set_operator_sw(self, nlev, a, grav, H, f0):
+        from .device import _ptr
+        self._keep.append(f0)
+        self._check(self.eng.L.mimsem_ksp_set_operator_sw(self.h, nlev, a, grav, H, _ptr(f0), f0.stride(0) if f0.dim() > 1 and f0.shape[0] > 1 else 0),
+                    "ksp_set_operator_sw")
+        return self
+
+    def set_pc(self, kind, blocks=None, elem_scale=None, dinv=None, form=1):
+        from .device import _ptr
+        L, h = self.eng.L, self.h
+        self._keep += [blocks, elem_scale, dinv]
+        if kind == "none":
+            self._check(L.mimsem_ksp_set_pc_none(h), "ksp_set_pc_none")
+        elif kind == "bjacobi":
+            self._check(L.mimsem_ksp_set_pc_bjacobi(h), "ksp_set_pc_bjacobi")
+        elif kind == "jacobi":
+            self._check(L.mimsem_ksp_set_pc_jacobi(h, _ptr(dinv), dinv.stride(0) if dinv.dim() > 1 else 0), "ksp_set_pc_jacobi")
+        elif kind == "elem_blocks":
+            self._check(L.mimsem_ksp_set_pc_elem_blocks(h, form, _ptr(blocks), _ptr(elem_scale), elem_scale.stride(0) if elem_scale is not None else 0),
+                        "ksp_set_pc_elem_blocks")
+        elif kind == "sw_blocks":
+            self._check(L.mimsem_ksp_set_pc_sw_blocks(h, _ptr(blocks)), "ksp_set_pc_sw_blocks")
+        elif kind == "sw_bjacobi":
+            self._check(L.mimsem_ksp_set_pc_sw_bjacobi(h), "ksp_set_pc_sw_bjacobi")
+        else:
+            raise ValueError(kind)
+        return self
+
+    def set_tolerances(self, rtol=1e-16, atol=1e-50, maxit=1000, restart=30, check_every=2):
+        self._check(self.eng.L.mimsem_ksp_set_tolerances(self.h, rtol, atol, maxit, restart, check_every), "ksp_set_tolerances")
+        return self
+
+    def solve(self, b, x=None, guess_nonzero=False):
+        from .device import _ptr
+        C = self._C
+        b2 = b if b.dim() == 2 else b.view(1, -1)
+        assert b2.stride(1) == 1
+        x2 = torch.zeros_like(b2) if x is None else (x if x.dim() == 2 else x.view(1, -1))
+        self._check(self.eng.L.mimsem_ksp_set_initial_guess_nonzero(self.h, 1 if guess_nonzero else 0), "ksp_guess")
+        self._check(self.eng.L.mimsem_ksp_solve(self.h, _ptr(b2), b2.stride(0), _ptr(x2), x2.stride(0)), "ksp_solve")
+        its, rn, rs = C.c_int(), C.c_double(), C.c_int()
+        self._check(self.eng.L.mimsem_ksp_get_info(self.h, C.byref(its), C.byref(rn), C.byref(rs)), "ksp_get_info")
+        self.iterations, self.rnorm, self.reason = its.value, rn.value, self.REASONS.get(rs.value, rs.value)
+        return x2.view(b.shape)
+
+
 def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, allreduce=None, precond=None):
     """Solve A x = b for a batch of systems (rows of b).  apply_A(x)->A x on [nlev, n] tensors.
     minv: elementwise preconditioner (Jacobi) of the same shape, or precond(r)->z (symmetric positive definite).
@@ -166,6 +243,13 @@ class MassSolver:
     def precond(self, r, lev0=0):
         return self.eng.blocks_apply(1, self.blocks, r, transpose=True, elem_scale=self.escale[lev0:lev0 + r.shape[0]])
 
+    def _blocks_t(self):
+        """the blocks as mimsem_ksp_set_pc_elem_blocks applies them (no transpose flag): B^T, contiguous -- the same products as
+        precond()'s transposed read of B"""
+        if getattr(self, "_bt", None) is None:
+            self._bt = self.blocks.transpose(1, 2).contiguous()
+        return self._bt
+
     def apply(self, x, lev0=0):
         return self.eng.apply("UMAT", x, lev0=lev0, scale=self.scale, flags=self.flags)
 
@@ -220,6 +304,16 @@ class MassSolver:
                     x = ch.solve(b)
             return x, ch.steps
         if self.kind != "jacobi":
+            if not hasattr(self.eng, "halo") and not self.fixed_its and os.environ.get("MIMSEM_PCG", "c") == "c":
+                # the batched PCG loop of the C ABI (mimsem_ksp_*, csrc/ksp.hip) with this object's blocks: what a C++ host runs
+                key = (lev0, nlev)
+                if getattr(self, "_ksp_key", None) != key:
+                    self._ksp = KSP(self.eng, "cg").set_operator("UMAT", nlev, lev0=lev0, scale=self.scale, flags=self.flags)
+                    self._ksp.set_pc("elem_blocks", blocks=self._blocks_t(), elem_scale=self.escale[lev0:lev0 + nlev])
+                    self._ksp_key = key
+                self._ksp.set_tolerances(rtol=rtol, atol=1e-300, maxit=maxit, check_every=2)
+                x = self._ksp.solve(b)
+                return x, self._ksp.iterations
             with self.eng.space(1):
                 return pcg_engine(self.eng, lambda v: self.apply(v, lev0), b, lambda r: self.precond(r, lev0), rtol=rtol, maxit=maxit,
                                   fixed_its=self.fixed_its)
@@ -323,9 +417,10 @@ class GraphedGMRES:
         self.lookahead = int(os.environ.get("MIMSEM_GMRES_LOOKAHEAD", "8"))
         # the two-launch re-orthonormalisation takes its norm from w.w - h2.h2; the kernel raises this (pinned) word should that
         # ever cancel, and the cycle is then repeated on the three-launch form
+        # (round 4: this object's OWN word and form, handed to every call -- rounds 2-3 registered the word with the context, where a
+        # second GraphedGMRES on the same engine overwrote it)
         self.gs_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        loc = getattr(eng, "eng", eng)
-        loc.L.mimsem_krylov_gs_control(loc.ctx, -1, self.gs_flag.data_ptr())
+        self.gs_fused = os.environ.get("MIMSEM_GS_FUSED_NORM", "1") != "0"
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1
@@ -334,7 +429,7 @@ class GraphedGMRES:
             w = w.contiguous()
         eng.orthogonalize(V, w, self.h, k=k)
         # re-orthogonalisation + normalisation in three launches; the Hessenberg column goes straight to pinned memory
-        eng.reorthonormalize(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1)
+        eng.reorthonormalize(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1, fused=self.gs_fused, flag=self.gs_flag)
 
     def _graph(self, j):
         if self.graphs[j] is None:
@@ -395,8 +490,7 @@ class GraphedGMRES:
                     self._graph(j).replay()
                 torch.cuda.current_stream(dev).synchronize()
                 if int(self.gs_flag[0]) != 0:                    # (never seen on the operators of this repository)
-                    loc = getattr(self.eng, "eng", self.eng)
-                    loc.L.mimsem_krylov_gs_control(loc.ctx, 0, self.gs_flag.data_ptr())
+                    self.gs_fused = False
                     self.gs_flag[0] = 0
                     self.graphs = [None] * m                      # re-capture with the three-launch form
                     k = 0; done = False
