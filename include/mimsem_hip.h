@@ -437,6 +437,12 @@ int mimsem_krylov_reorthonormalize(mimsem_ctx* ctx, int k, long long n, const do
  * the flag alone and writes v = 0 instead of inf.                                                                                  */
 int mimsem_krylov_reorthonormalize_ex(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
                                       const double* h1, double* h2, double* col, int norm_slot, int fused, int* flag);
+/* Both Gram-Schmidt passes, the normalisation and the Hessenberg column of ONE Arnoldi step in three launches (round 4): the update of
+ * the first pass and the dots of the second share a kernel (an entry of w is final as soon as its own update is done).  h1, h2: device
+ * [k] (outputs); norm and flag as in the two-launch re-orthonormalisation: a raised *flag means "repeat the step with
+ * mimsem_krylov_orthogonalize + mimsem_krylov_reorthonormalize_ex(fused = 0)".                                                     */
+int mimsem_krylov_cgs2(mimsem_ctx* ctx, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                       double* h1, double* h2, double* col, int norm_slot, int* flag);
 /* Batched CG (one independent system per row = per level; the ksp1 solves of all levels at once).  The per-row scalars stay in
  * device memory, so an iteration needs no host synchronisation:  rowdot: out[i] = <A_i, B_i> (deterministic two-stage reduction);
  * cg_update: alpha_i = num[i]/den[i], x_i += alpha_i p_i, r_i -= alpha_i Ap_i;  cg_direction: p_i = z_i + (num[i]/den[i]) p_i.      */

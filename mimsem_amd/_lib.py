@@ -68,6 +68,7 @@ _SIGS = {
     "mimsem_sw_operator_precond_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_krylov_reorthonormalize": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),
     "mimsem_krylov_reorthonormalize_ex": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_void_p]),
+    "mimsem_krylov_cgs2": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_void_p]),
     "mimsem_ksp_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mimsem_ksp_destroy": (None, [C.c_void_p]),
     "mimsem_ksp_set_operator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll]),

@@ -150,6 +150,57 @@ __global__ __launch_bounds__(256) void k_maxpy_reduce_normalize(int k, int nb, l
         v[t] = nrm > 0.0 ? wn/nrm : 0.0;
     }
 }
+// Round 4: the UPDATE of the first Gram-Schmidt pass and the DOTS of the second in one launch.  A block reduces the partial sums of
+// h1 = V w (as k_maxpy_reduce does), updates its EPB entries  w <- w - V^T h1  and -- the dots of the second pass being sums over entries,
+// and each entry final as soon as its own update is done -- accumulates V_i . w and w . w over those entries.  With k_rowdot_partial before it
+// and k_maxpy_reduce_normalize after it a whole CGS2 step with normalisation and Hessenberg column is THREE launches (rounds 2-3: four).
+constexpr int GS_EPB = 512;         // entries per block of k_gs_update_dots
+__global__ __launch_bounds__(256) void k_gs_update_dots(int k, int nb, long long n, const double* __restrict__ V, long long ldv,
+                                                        const double* __restrict__ part1, double* __restrict__ w, double* __restrict__ h_out,
+                                                        double* __restrict__ part2) {
+    extern __shared__ double sh[];                       // [k] h1, then [(k + 1)][4] per-wave partial dots
+    double* red = sh + k;
+    for (int base = 0; base < k; base += 64) {
+        const int i = base + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+        double s = 0.0;
+        if (i < k) for (int b = sub; b < nb; b += 4) s += part1[(size_t)i*nb + b];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (i < k && sub == 0) { sh[i] = s; if (blockIdx.x == 0) h_out[i] = s; }
+    }
+    __syncthreads();
+    const long long t0 = (long long)blockIdx.x*GS_EPB + threadIdx.x, t1 = t0 + 256;
+    const bool a0 = t0 < n, a1 = t1 < n;
+    double w0 = 0.0, w1 = 0.0;
+    // (entries past n read entry n-1 and contribute 0: no exec-masked loads, and the loops below are unrolled by 8 so that eight rows' loads
+    //  are in flight together -- rolled, every row waited for its own L2 round trip: 8 us for k = 30)
+    const long long u0 = a0 ? t0 : n - 1, u1 = a1 ? t1 : n - 1;
+    {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < k; i++) {
+            const double hi = sh[i];
+            s0 += hi*V[(size_t)i*ldv + u0];
+            s1 += hi*V[(size_t)i*ldv + u1];
+        }
+        if (a0) { w0 = w[t0] - s0; w[t0] = w0; }
+        if (a1) { w1 = w[t1] - s1; w[t1] = w1; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 8
+    for (int i = 0; i < k; i++) {
+        double d = V[(size_t)i*ldv + u0]*w0 + V[(size_t)i*ldv + u1]*w1;
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) red[i*4 + wave] = d;
+    }
+    {
+        double d = w0*w0 + w1*w1;
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) red[k*4 + wave] = d;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= k; i += 256) part2[(size_t)i*gridDim.x + blockIdx.x] = (red[i*4] + red[i*4 + 1]) + (red[i*4 + 2] + red[i*4 + 3]);
+}
 __global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
     const int row = blockIdx.x, lane = threadIdx.x;
     double s = (lane < nb) ? part[(size_t)row*nb + lane] : 0.0;
@@ -321,6 +372,26 @@ int mimsem_krylov_reorthonormalize_ex(mimsem_ctx* c, int k, long long n, const d
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
+// One whole Arnoldi orthogonalisation (two classical Gram-Schmidt passes, normalisation, Hessenberg column) in THREE launches:
+// dots of pass 1; update of pass 1 + dots of pass 2 (k_gs_update_dots); update of pass 2 + norm + column (k_maxpy_reduce_normalize, with the
+// norm from w.w - h2.h2 and the flag word of the two-launch re-orthonormalisation).  h1, h2: device [k].
+int mimsem_krylov_cgs2(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
+                       double* h1, double* h2, double* col, int norm_slot, int* flag) {
+    if (!c || !V || !w || !v || !h1 || !h2 || !col || k <= 0 || n <= 0 || ldv < n || norm_slot < 0) return MIMSEM_ERR_ARG;
+    const int nb1 = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+    const long long chunk = (n + nb1 - 1)/nb1;
+    const unsigned gb2 = (unsigned)((n + GS_EPB - 1)/GS_EPB), gb = (unsigned)((n + 255)/256);
+    int rc = c->ensure_kry((long long)RD_BLOCKS*(k + 1) + (long long)(k + 1)*gb2);
+    if (rc) return rc;
+    double* part1 = c->d_kry; double* part2 = c->d_kry + (size_t)RD_BLOCKS*(k + 1);
+    hipLaunchKernelGGL(k_rowdot_partial, dim3(nb1, k), dim3(256), 0, c->stream, n, chunk, V, ldv, w, 0, part1);
+    hipLaunchKernelGGL(k_gs_update_dots, dim3(gb2), dim3(256), (size_t)(k + 4*(k + 1))*sizeof(double), c->stream, k, nb1, n, V, ldv, part1, w, h1, part2);
+    hipLaunchKernelGGL(k_maxpy_reduce_normalize, dim3(gb), dim3(256), (size_t)(k + 1)*sizeof(double), c->stream, k, (int)gb2, n, V, ldv, part2,
+                       w, v, h1, h2, col, norm_slot, flag);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 // the context-state form (round 3): form and flag word from mimsem_krylov_gs_control / MIMSEM_GS_FUSED_NORM
 int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
                                    const double* h1, double* h2, double* col, int norm_slot) {

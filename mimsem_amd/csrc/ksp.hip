@@ -7,7 +7,8 @@
 //   CG     batched over the rows (one independent SPD system per level): mimsem_krylov_rowdot / cg_update / cg_direction keep the
 //          per-row scalars on the device; the host looks at |r|^2 every `check_every` iterations (one small copy);
 //   GMRES  restarted, left-preconditioned, classical Gram-Schmidt with re-orthogonalisation (mimsem_krylov_orthogonalize +
-//          mimsem_krylov_reorthonormalize_ex: four launches), Hessenberg column through pinned host memory, Givens rotations on the host.
+//          mimsem_krylov_reorthonormalize_ex: four launches; MIMSEM_GS_CGS2=1: the three-launch mimsem_krylov_cgs2, measured slower),
+//          Hessenberg column through pinned host memory, Givens rotations on the host.
 // mimsem_amd/krylov.py calls the same entry points (MassSolver's PCG path, gmres()): one code path.
 #include <algorithm>
 #include <cmath>
@@ -119,6 +120,7 @@ struct mimsem_ksp {
     double* host = nullptr; long long host_doubles = 0;      // pinned
     int* flag = nullptr;                                     // pinned word of the two-launch re-orthonormalisation (this object's own)
     bool gs_fused = true;
+    bool cgs2 = false;                                       // MIMSEM_GS_CGS2=1: the three-launch CGS2 step (measured slower than the four launches: opt-in)
     // results of the last solve
     int its = 0; double rnorm = 0.0; int reason = 0;
 
@@ -267,9 +269,12 @@ int solve_gmres(mimsem_ksp* k, const double* b, long long bs, double* x, long lo
         int kk = 0; bool done = false;
         for (int j = 0; j < m && !done; j++) {
             KTRY(k->PA(V + (long long)j*N, n, t, w, n));
-            KTRY(mimsem_krylov_orthogonalize(c, j + 1, N, V, N, -1.0, w, h));
             *k->flag = 0;
-            KTRY(mimsem_krylov_reorthonormalize_ex(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, k->gs_fused ? 1 : 0, k->flag));
+            if (k->gs_fused && k->cgs2) KTRY(mimsem_krylov_cgs2(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, k->flag));
+            else {
+                KTRY(mimsem_krylov_orthogonalize(c, j + 1, N, V, N, -1.0, w, h));
+                KTRY(mimsem_krylov_reorthonormalize_ex(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, k->gs_fused ? 1 : 0, k->flag));
+            }
             MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
             if (*k->flag) {
                 // the Pythagorean norm of the two-launch form cancelled: this object switches to the three-launch form for good and
@@ -319,6 +324,7 @@ int mimsem_ksp_create(mimsem_ctx* ctx, int type, mimsem_ksp** out) {
     mimsem_ksp* k = new mimsem_ksp();
     k->c = ctx; k->type = type;
     k->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
+    k->cgs2 = getenv("MIMSEM_GS_CGS2") && atoi(getenv("MIMSEM_GS_CGS2")) == 1;
     *out = k;
     return MIMSEM_OK;
 }

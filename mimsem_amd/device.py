@@ -671,6 +671,14 @@ class Engine:
         check(self.L.mimsem_krylov_orthogonalize(self.ctx, k, w.numel(), _ptr(V), V.stride(0), alpha, _ptr(w), _ptr(h)), "krylov_orthogonalize")
         return w
 
+    def cgs2(self, V, w, v, k, h1, h2, col, norm_slot, flag=None):
+        """both Gram-Schmidt passes of an Arnoldi step + normalisation + Hessenberg column in three launches (mimsem_krylov_cgs2)"""
+        assert w.numel() == v.numel() and v.is_contiguous() and w.is_contiguous() and col.dtype == torch.float64 and col.is_contiguous()
+        assert col.is_cuda or col.is_pinned(), "col must be device or pinned host memory"
+        assert col.numel() > max(k - 1, norm_slot) and h1.numel() >= k and h2.numel() >= k
+        check(self.L.mimsem_krylov_cgs2(self.ctx, k, w.numel(), _ptr(V), V.stride(0), _ptr(w), _ptr(v), _ptr(h1), _ptr(h2),
+                                        col.data_ptr(), norm_slot, flag.data_ptr() if flag is not None else None), "krylov_cgs2")
+
     def reorthonormalize(self, V, w, v, k, h1, h2, col, norm_slot, fused=None, flag=None):
         """second Gram-Schmidt pass + normalisation in two launches: h2[:k] = V[:k] w; w -= V[:k]^T h2; v = w/|w|;
         col[:k] = h1 + h2; col[norm_slot] = |w| (col: device or pinned host tensor).  fused / flag given: the explicit form

@@ -421,14 +421,22 @@ class GraphedGMRES:
         # second GraphedGMRES on the same engine overwrote it)
         self.gs_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.gs_fused = os.environ.get("MIMSEM_GS_FUSED_NORM", "1") != "0"
+        # mimsem_krylov_cgs2 (round 4: the whole CGS2 step in three launches) is OPT-IN: measured SLOWER than the four launches it replaces
+        # (config 3: 175 against 204 steps/s, config 2: 13.5 against 15.4) -- its middle kernel serialises k block reductions and the last
+        # one then reduces n/512 partials per row instead of 32; kept with its parity test as the record (profiles/r04_sw_cgs2_ab.txt)
+        self.cgs2 = os.environ.get("MIMSEM_GS_CGS2", "0") == "1" and not hasattr(eng, "halo")      # (a DistEngine reduces its dots over the ranks)
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1
         w = self.body(V[j:j + 1]).reshape(-1)
         if not w.is_contiguous():
             w = w.contiguous()
+        if self.gs_fused and self.cgs2:
+            # round 4: both passes, normalisation and column in THREE launches (mimsem_krylov_cgs2); the column goes straight to pinned memory
+            eng.cgs2(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1, flag=self.gs_flag)
+            return
         eng.orthogonalize(V, w, self.h, k=k)
-        # re-orthogonalisation + normalisation in three launches; the Hessenberg column goes straight to pinned memory
+        # re-orthogonalisation + normalisation in two (three) launches
         eng.reorthonormalize(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1, fused=self.gs_fused, flag=self.gs_flag)
 
     def _graph(self, j):

@@ -188,6 +188,41 @@ def test_krylov_mdot_maxpy(sphere):
         assert float((w2 - ref2).abs().max()) < 1e-10 * float(ref2.abs().max())
 
 
+def test_krylov_cgs2_three_launches(sphere):
+    """mimsem_krylov_cgs2 (round 4: both Gram-Schmidt passes, normalisation and Hessenberg column in three launches -- the update of
+    pass 1 and the dots of pass 2 share a kernel) against the four-launch composition orthogonalize + reorthonormalize_ex on an
+    ORTHONORMAL basis (what Arnoldi hands it), bitwise reproducible, flag word down; sizes that are not multiples of its 512-entry blocks"""
+    import torch
+    cs, eng, mats, rng = sphere
+    for n, m in ((93312, 31), (5003, 9)):
+        Q, _ = torch.linalg.qr(eng.tensor(rng.standard_normal((n, m))))
+        V = Q.T.contiguous()
+        w0 = eng.tensor(rng.standard_normal(n))
+        for k in (1, 6, m - 1):
+            flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            out = []
+            for which in ("cgs2", "four", "cgs2"):
+                w = w0.clone(); v = torch.empty_like(w)
+                h1 = torch.zeros(m + 1, dtype=torch.float64, device=eng.device); h2 = torch.zeros_like(h1)
+                col = torch.zeros(m + 2, dtype=torch.float64).pin_memory()
+                if which == "cgs2":
+                    eng.cgs2(V, w, v, k, h1, h2, col, m + 1, flag=flag)
+                else:
+                    eng.orthogonalize(V, w, h1, k=k)
+                    eng.reorthonormalize(V, w, v, k, h1, h2, col, m + 1, fused=True, flag=flag)
+                torch.cuda.synchronize()
+                out.append((w.clone(), v.clone(), col.clone()))
+            assert int(flag[0]) == 0
+            (wa, va, ca), (wb, vb, cb), (wc, vc, cc) = out
+            assert torch.equal(wa, wc) and torch.equal(va, vc) and torch.equal(ca, cc)                   # run-to-run bitwise
+            scale = float(w0.abs().max())
+            assert float((wa - wb).abs().max()) < 1e-13 * scale and float((va - vb).abs().max()) < 1e-12
+            assert float((ca[:k] - cb[:k]).abs().max()) < 1e-12 * scale and abs(float(ca[m + 1] - cb[m + 1])) < 1e-12 * float(cb[m + 1])
+            href = V[:k] @ w0
+            assert float((ca[:k].to(eng.device) - href).abs().max()) < 1e-12 * scale
+            assert float((V[:k] @ va).abs().max()) < 1e-14 and abs(float(torch.linalg.vector_norm(va)) - 1.0) < 1e-13
+
+
 def test_krylov_fused_gram_schmidt_and_normalize(sphere):
     """mimsem_krylov_orthogonalize (h = V w, w -= V^T h in two launches) and mimsem_krylov_normalize (v = w/|w| plus the finished
     Hessenberg column written to device or pinned host memory) against torch, bitwise reproducible"""

@@ -178,6 +178,34 @@ def test_sw_coupled_block_preconditioner(sw):
     assert its_c * 2 <= its_d, (its_c, its_d)
 
 
+def test_c_abi_ksp_on_the_shallow_water_operator(sw):
+    """kspA through the C ABI (mimsem_ksp_*, csrc/ksp.hip): GMRES on the packed [u|h] operator with the coupled element blocks the
+    LIBRARY builds from the operator (mimsem_ksp_set_pc_sw_bjacobi) -- the blocks equal SWEqn's own, the solve equals the Python GMRES
+    to the tolerance and takes the same number of iterations"""
+    import torch
+    from mimsem_amd.krylov import KSP, gmres
+    from mimsem_amd.sweqn import H_MEAN, ROS_ALPHA
+    cs, eng, O, S, uq, hq = sw
+    dt = 3600.0
+    dm = eng.mesh
+    r = _t(eng, np.random.default_rng(6).standard_normal(dm.n1 + dm.n2))
+    b = S.apply_A(r, dt)
+    x_py, its_py, _ = gmres(lambda v: S.apply_A(v, dt), b, precond=lambda v: S.precond_A(v, dt), rtol=1e-13, restart=100, eng=eng)
+    ksp = KSP(eng, "gmres").set_operator_sw(1, ROS_ALPHA * dt, S.grav, H_MEAN, S.fg)
+    ksp.set_pc("sw_bjacobi").set_tolerances(rtol=1e-13, atol=1e-300, maxit=1000, restart=100)
+    x_c = ksp.solve(b)
+    assert ksp.reason in ("rtol", "atol") and abs(ksp.iterations - its_py) <= 1, (ksp.reason, ksp.iterations, its_py)
+    # (left preconditioning monitors P (b - A x); on this long step A is ill conditioned and the solutions follow the residual at ~1e-7,
+    #  as in test_sw_coupled_block_preconditioner)
+    assert rel_l2(x_c[0].cpu().numpy(), x_py[0].cpu().numpy()) < 1e-6
+    assert rel_l2(S.apply_A(x_c, dt)[0].cpu().numpy(), b[0].cpu().numpy()) < 1e-7
+    # the caller's blocks instead of the library's: the same iteration
+    ksp2 = KSP(eng, "gmres").set_operator_sw(1, ROS_ALPHA * dt, S.grav, H_MEAN, S.fg)
+    ksp2.set_pc("sw_blocks", blocks=S._coupled_element_blocks(dt)).set_tolerances(rtol=1e-13, atol=1e-300, maxit=1000, restart=100)
+    x_c2 = ksp2.solve(b)
+    assert abs(ksp2.iterations - ksp.iterations) <= 1 and rel_l2(x_c2[0].cpu().numpy(), x_c[0].cpu().numpy()) < 1e-6
+
+
 def test_richardson_sweeps_match_composition(sw):
     """mimsem_block_richardson_sweep / mimsem_op_richardson_sweep (operator result never written, update applied in the gather pass)
     against the same sweep composed from the individual engine calls"""
