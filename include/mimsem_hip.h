@@ -212,6 +212,9 @@ int mimsem_op_element_matrices_ex(mimsem_ctx* ctx, int op, int geom_lev, double 
  * algorithm as the fall-back) for the element-block preconditioners of the Krylov solves (PCBJACOBI blocks, eul/HorizSolve.cpp:88-90):
  * one block per thread in LDS above n = 16; MIMSEM_ERR_UNSUPPORTED when a single block no longer fits 160 KB (n > ~140).                 */
 int mimsem_block_inverse(mimsem_ctx* ctx, long long nblocks, int n, double* blocks);
+/* The same with the count of blocks for which the reference's Inv reports an error (a pivot below 1e-12 under full pivoting,
+ * eul/LinAlg.cpp:243-246; its callers ignore it, e.g. eul/VertOps.cpp:434): returns MIMSEM_OK and *n_singular >= 0; synchronises. */
+int mimsem_block_inverse_status(mimsem_ctx* ctx, long long nblocks, int n, double* blocks, int* n_singular);
 int mimsem_elem_blocks_apply(mimsem_ctx* ctx, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
                              const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long x_stride, double* y, long long y_stride, double alpha);

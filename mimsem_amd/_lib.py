@@ -111,6 +111,7 @@ _SIGS = {
     "mimsem_krylov_cg_update": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_dp, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_krylov_cg_direction": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_block_inverse": (C.c_int, [C.c_void_p, c_ll, C.c_int, c_dp]),
+    "mimsem_block_inverse_status": (C.c_int, [C.c_void_p, c_ll, C.c_int, c_dp, C.POINTER(C.c_int)]),
     "mimsem_vec_combine": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_double, c_dp, c_ll, C.c_int, c_dp, c_ll, C.c_double, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_interface_average": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_halo_segments": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_ll]),

@@ -1110,6 +1110,23 @@ int mimsem_block_inverse(mimsem_ctx* c, long long nblocks, int n, double* blocks
     return mimsem_block_inverse_inplace(c, nblocks, n, blocks);      // MIMSEM_ERR_UNSUPPORTED when one block no longer fits a workgroup's LDS
 }
 
+// the same, and the number of blocks in which LinAlg::Inv would have returned its error (a pivot below 1e-12 after full pivoting,
+// eul/LinAlg.cpp:243-246): MIMSEM_OK with *n_singular > 0 -- the blocks are inverted as the reference inverts them, garbage included
+int mimsem_block_inverse_status(mimsem_ctx* c, long long nblocks, int n, double* blocks, int* n_singular) {
+    if (!c || !n_singular || nblocks < 0 || n < 1 || (nblocks && !blocks)) return MIMSEM_ERR_ARG;
+    *n_singular = 0;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;                  // (reads a counter back)
+    int* d_err = nullptr;
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_err, sizeof(int)));
+    int rc = MIMSEM_OK;
+    if (hipMemsetAsync(d_err, 0, sizeof(int), c->stream) != hipSuccess) rc = MIMSEM_ERR_HIP;
+    if (!rc) rc = mimsem_block_inverse_inplace(c, nblocks, n, blocks, d_err);
+    if (!rc && hipMemcpyAsync(n_singular, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MIMSEM_ERR_HIP;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = MIMSEM_ERR_HIP;
+    (void)hipFree(d_err);
+    return rc;
+}
+
 int mimsem_elem_blocks_apply(mimsem_ctx* c, int form, int nlev, unsigned flags, const double* blocks, long long blocks_level_stride,
                              const double* elem_scale, long long elem_scale_stride,
                              const double* x, long long xs, double* y, long long ys, double alpha) {

@@ -479,30 +479,32 @@ __global__ __launch_bounds__(64) void k_block_inverse_reg(long long nb, double* 
     if (err && errcount) atomicAdd(errcount, 1);
 }
 template <int N>
-int launch_inverse_reg(mimsem_ctx* c, long long nb, double* blocks) {
-    hipLaunchKernelGGL((k_block_inverse_reg<N>), dim3((unsigned)((nb + 63)/64)), dim3(64), 0, c->stream, nb, blocks, (int*)nullptr);
+int launch_inverse_reg(mimsem_ctx* c, long long nb, double* blocks, int* err) {
+    hipLaunchKernelGGL((k_block_inverse_reg<N>), dim3((unsigned)((nb + 63)/64)), dim3(64), 0, c->stream, nb, blocks, err);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
 
 template <int N, int LPM>
-int launch_inverse_rows(mimsem_ctx* c, long long nb, double* blocks) {
+int launch_inverse_rows(mimsem_ctx* c, long long nb, double* blocks, int* err) {
     const long long threads = nb*LPM;
     hipLaunchKernelGGL((k_block_inverse_rows<N, LPM>), dim3((unsigned)((threads + 255)/256)), dim3(256), 0, c->stream,
-                       nb, blocks, (int*)nullptr);
+                       nb, blocks, err);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
 
 }  // namespace
 
-int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks) {
+// err (device int, may be null): incremented once per block in which the reference's Inv would have reported a pivot below 1e-12
+// (eul/LinAlg.cpp:243; the reference's callers drop that return value, e.g. eul/VertOps.cpp:434 -- mimsem_block_inverse_status hands it out)
+int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks, int* err) {
     if (nblocks <= 0) return MIMSEM_OK;
     switch (n) {                     // register-resident one-lane-per-row kernel for the block sizes of p <= 4
-    case 1:  return launch_inverse_reg<1>(c, nblocks, blocks);
-    case 4:  return launch_inverse_reg<4>(c, nblocks, blocks);
-    case 9:  return getenv("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks) : launch_inverse_reg<9>(c, nblocks, blocks);
-    case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks);
+    case 1:  return launch_inverse_reg<1>(c, nblocks, blocks, err);
+    case 4:  return launch_inverse_reg<4>(c, nblocks, blocks, err);
+    case 9:  return getenv("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks, err) : launch_inverse_reg<9>(c, nblocks, blocks, err);
+    case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks, err);
     default: break;                  // 25, 36, 49: thread-per-matrix in LDS below
     }
     // matrices per workgroup: as many as fit a 144 KiB LDS budget (64 for n<=16, fewer for the 25..49-wide blocks of p>=5)
@@ -514,7 +516,7 @@ int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double
     if (lds > 64*1024)
         MIMSEM_HIP_TRY(hipFuncSetAttribute((const void*)k_block_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_block_inverse, dim3((unsigned)((nblocks + T - 1)/T)), dim3(64), lds, c->stream,
-                       nblocks, n, T, blocks, (int*)nullptr);
+                       nblocks, n, T, blocks, err);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

@@ -210,7 +210,7 @@ int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const d
 int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);
 
 // column_kernels.hip internals used by api.hip
-int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks);
+int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double* blocks, int* err = nullptr);
 int mimsem_colop_block_inverse_apply(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                                      const double* f, long long fs, const double* x, long long xs,
                                      double* y, long long ys, double alpha);

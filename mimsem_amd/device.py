@@ -757,6 +757,16 @@ class Engine:
         check(self.L.mimsem_block_inverse(self.ctx, out.shape[0], out.shape[1], out.data_ptr()), "block_inverse")
         return out
 
+    def block_inverse_status(self, blocks):
+        """block_inverse plus the number of blocks for which the reference's LinAlg::Inv reports a (near-)singular pivot
+        (mimsem_block_inverse_status; eul/LinAlg.cpp:243-246)"""
+        if blocks.dim() != 3 or blocks.shape[1] != blocks.shape[2] or blocks.dtype != torch.float64:
+            raise _lib.MimsemError("block_inverse: [nblocks, n, n] float64 tensor required")
+        out = blocks.contiguous().clone()
+        ns = C.c_int(0)
+        check(self.L.mimsem_block_inverse_status(self.ctx, out.shape[0], out.shape[1], out.data_ptr(), C.byref(ns)), "block_inverse_status")
+        return out, ns.value
+
     def norm(self, x):
         """2-norm of a whole (single-rank) vector by the library's two-stage row-dot; DistEngine overrides with the ownership-weighted,
         all-reduced version"""

@@ -460,3 +460,40 @@ def test_vertical_newton_loop_matches_oracle(setup):
     want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, 2, hs_forcing=True, udwdx=udwdx)
     for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
         assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < TOL, name
+
+
+@pytest.mark.parametrize("n", [1, 4, 9, 16, 24, 33])
+def test_block_inverse_against_the_oracle_inv(oracle, n):
+    """A5 as an entry point (mimsem_block_inverse: the PCBJACOBI blocks and WmatInv / the column inverses run through it): the batched
+    Gauss-Jordan against the oracle's restatement of LinAlg::Inv (eul/LinAlg.cpp:186-269, pinned bit-for-bit against the compiled
+    reference in tests/test_oracle_pins.py) on SPD mass-like blocks, on non-symmetric well-conditioned blocks that need the pivoting
+    fall-back, and -- mimsem_block_inverse_status -- with ONE singular block among them: the count comes back instead of being dropped"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    cs, topo, geom, P, rng = make_patch(oracle, 2, 1, 6, 0, nk=2, seed=5)
+    eng = Engine(DeviceMesh([topo], [geom], nk=2, numbering="local"))
+    r = np.random.default_rng(100 + n)
+    nb = 37
+    G = r.standard_normal((nb, n, n))
+    spd = np.einsum("bij,bkj->bik", G, G) + n * np.eye(n)[None]
+    gen = r.standard_normal((nb, n, n)) + 0.1 * np.eye(n)[None]           # zero-ish diagonal entries now and then: row pivoting needed
+    if n > 1:
+        gen[::5, 0, 0] = 0.0
+    for name, B in (("spd", spd), ("general", gen)):
+        want = np.stack([oracle.inv(b)[0] for b in B])
+        got, nsing = eng.block_inverse_status(eng.tensor(B))
+        got = got.cpu().numpy()
+        assert nsing == 0, (name, nsing)
+        cond = np.array([np.linalg.cond(b) for b in B])
+        err = np.array([rel_l2(got[i], want[i]) for i in range(nb)])
+        assert (err < 1e-10 * np.maximum(1.0, cond / 1e3)).all(), (name, float(err.max()), float(cond.max()))
+        assert max(np.abs(got[i] @ B[i] - np.eye(n)).max() for i in range(nb)) < 1e-9 * cond.max()
+    if n > 1:
+        S = spd.copy()
+        S[11, :, -1] = S[11, :, 0]; S[11, -1, :] = S[11, 0, :]             # two equal rows and columns: exactly singular
+        _, err = oracle.inv(S[11])
+        got, nsing = eng.block_inverse_status(eng.tensor(S))
+        assert err != 0 and nsing == 1, (err, nsing)
+        ok = [i for i in range(nb) if i != 11]
+        want = np.stack([oracle.inv(S[i])[0] for i in ok])
+        assert max(rel_l2(got[i].cpu().numpy(), w) for i, w in zip(ok, want)) < 1e-10 * max(1.0, np.linalg.cond(S[ok[0]]) / 1e3)

@@ -161,7 +161,7 @@ def test_column_solve_reports_the_columns_it_cannot_resolve(full):
         rel = (torch.linalg.vector_norm(Ld - rhs, dim=(1, 2)) / torch.linalg.vector_norm(rhs, dim=(1, 2))).cpu().numpy()
         ok = st == 0
         # a converged column: residual at the level LAPACK's pivoted LU leaves on such columns (eps |L| |d| / |f| <= ~1e-8 at cond 1e10)
-        assert rel[ok].max() < 1e-7, (seed, float(rel[ok].max()))
+        assert rel[ok].max() < 1e-8, (seed, float(rel[ok].max()))      # (1.4e-9 is the worst seen: gpurun_out/r3_col_t1.txt)
         worst_unflagged = max(worst_unflagged, float(rel[ok].max()))
         flagged_total += nbad
         # a flagged column: the reported ratio says how far it got.  Most settle just above the bar (1e-10 .. 1e-9: the conditioning
