@@ -883,9 +883,13 @@ def main():
             xw = engw.tensor(rng.standard_normal((NK, dmw.n1))); yw = engw.zeros(NK, dmw.n1)
 
             def stepw():
-                engw.apply_part("UMAT", "boundary", xw, lev0=0, scale=SCALE, flags=1, out=yw)
-                tok = chw.begin("pair", yw, True)
-                engw.apply_part("UMAT", "interior", xw, lev0=0, scale=SCALE, flags=1, out=yw)
+                try:
+                    engw.apply_part("UMAT", "boundary", xw, lev0=0, scale=SCALE, flags=1, out=yw)
+                    tok = chw.begin("pair", yw, True)
+                    engw.apply_part("UMAT", "interior", xw, lev0=0, scale=SCALE, flags=1, out=yw)
+                except Exception:
+                    engw.reset_parts()        # (a pending BOUNDARY part would refuse every later split apply on this context)
+                    raise
                 chw.end(tok)
             for _ in range(3):
                 stepw()

@@ -210,6 +210,10 @@ class Engine:
         sl = np.ascontiguousarray(slots, dtype=np.int32)
         check(self.L.mimsem_ctx_set_halo_slots(self.ctx, form, sl.ctypes.data, sl.size), "ctx_set_halo_slots")
 
+    def reset_parts(self):
+        """forget a BOUNDARY part whose INTERIOR part will not come (error path of a split apply; mimsem_op_apply_part_reset)"""
+        check(self.L.mimsem_op_apply_part_reset(self.ctx), "op_apply_part_reset")
+
     def apply_part(self, op, part, x, f=None, lev0=0, scale=1.0, flags=0, alpha=1.0, out=None):
         """the boundary or the interior part of apply(): part "boundary" first (all marked slots of `out` complete afterwards), then
         "interior" into the SAME out with the same arguments.  The pending boundary part keeps its partial sums in a buffer of its own:

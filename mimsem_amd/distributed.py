@@ -21,10 +21,23 @@ class RcclComm:
     then run on the plan's communication stream (xGMI), with no Python between pack, transport and unpack.
     One rank per DEVICE: RCCL refuses two ranks on one GPU (the one-GPU rehearsals use the callback transport instead)."""
 
+    @staticmethod
+    def find_library():
+        """the librccl this process can use, or an exception -- the LOCAL precondition of the constructor, checked by every rank and
+        agreed on (all_reduce MIN) before any rank enters the constructor's collectives"""
+        import ctypes as C
+        import os
+        for name in ("librccl.so", "librccl.so.1"):
+            try:
+                return C.CDLL(name, mode=os.RTLD_NOLOAD | os.RTLD_NOW)       # the copy already in the process (torch's)
+            except OSError:
+                continue
+        return C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
     def __init__(self, device):
         import ctypes as C
         import os
-        torch.cuda.set_device(device)
+        torch.cuda.set_device(0 if device is None else device)
         lib = None
         for name in ("librccl.so", "librccl.so.1"):
             try:
@@ -40,10 +53,17 @@ class RcclComm:
             _fields_ = [("internal", C.c_char * 128)]
         uid = UID()
         world, rank = dist.get_world_size(), dist.get_rank()
+        lib.ncclGetUniqueId.restype = C.c_int; lib.ncclGetUniqueId.argtypes = [C.POINTER(UID)]
+        lib.ncclCommInitRank.restype = C.c_int
+        ok = 1
         if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        raw = [bytes(uid)] if rank == 0 else [None]
+            ok = 0
+        raw = [bytes(uid) if ok else None] if rank == 0 else [None]
+        # (a rank that failed BEFORE this point never reaches the broadcast: `agree` -- called by DistEngine on EVERY rank before the
+        #  constructor runs its collectives -- is what keeps the ranks in step; here only rank 0's failure is left to report)
         dist.broadcast_object_list(raw, src=0)
+        if raw[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
         C.memmove(C.byref(uid), raw[0], 128)
         comm = C.c_void_p()
         lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
@@ -84,12 +104,23 @@ class DistEngine:
                     # every rank must end up on the same transport: a rank that cannot make its communicator (library not found, ...)
                     # makes all of them fall back to the host-staged callback, and the record says so
                     ok, err = 1, None
+                    # step 1: the local preconditions (library found) agreed on BEFORE anybody enters RcclComm's collectives -- a rank
+                    # that failed alone would otherwise go straight to the all_reduce below while its peers sit in the broadcast
                     try:
-                        self.rccl = RcclComm(eng.device.index if hasattr(eng.device, "index") else 0)
+                        RcclComm.find_library()
                     except Exception as ex:                              # noqa: BLE001 -- reported through transport_note
                         ok, err = 0, "%s: %s" % (type(ex).__name__, ex)
                     flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 1:
+                        # step 2: every rank constructs (the same collectives on every rank), then the outcomes are agreed on
+                        try:
+                            idx = getattr(eng.device, "index", None)
+                            self.rccl = RcclComm(torch.cuda.current_device() if idx is None else idx)
+                        except Exception as ex:                          # noqa: BLE001
+                            ok, err = 0, "%s: %s" % (type(ex).__name__, ex)
+                        flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+                        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                     if int(flag.item()) == 1:
                         transport = self.rccl
                     else:
@@ -181,9 +212,15 @@ class DistEngine:
             # boundary groups -> exchange in flight -> interior groups -> unpack: the halo travels while the interior is computed
             direct = out is not None and not (flags & 2) and out.dim() == 2 and out.is_contiguous()
             tmp = out if direct else torch.empty(x2.shape[0], self.eng.sizes[1], dtype=torch.float64, device=x2.device)
-            self.eng.apply_part(op, "boundary", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
-            tok = self.chalo.begin("pair", tmp, True)
-            self.eng.apply_part(op, "interior", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
+            try:
+                self.eng.apply_part(op, "boundary", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
+                tok = self.chalo.begin("pair", tmp, True)
+                self.eng.apply_part(op, "interior", x2, f=f, lev0=lev0, scale=scale, flags=flags & ~2, alpha=alpha, out=tmp)
+            except Exception:
+                # a failure between the two parts (transport, halo state) must not leave the BOUNDARY part pending: every later split
+                # apply on this context would be refused with MIMSEM_ERR_STATE for good (the contract of mimsem_op_apply_part)
+                self.eng.reset_parts()
+                raise
             self.chalo.end(tok)
             if direct:
                 return out

@@ -271,6 +271,14 @@ class MassSolver:
             es = self.escale[lev0:lev0 + nlev]
             ch.sweep = lambda x, rhs, p, al, be, upd: self.eng.block_chebyshev_sweep(
                 "UMAT", self._blocks_cm, x, rhs, p, al, be, elem_scale=es, lev0=lev0, scale=self.scale, flags=self.flags, upd=upd)
+            # the calibrated step count holds for the tolerance and the level range it was calibrated on (advisor, round 3): a call that asks
+            # for a tighter rtol, or covers levels the calibration did not see, goes back to the bound-based count and re-calibrates
+            cal = getattr(self, "_cheb_cal", None)
+            if cal is not None and not torch.cuda.is_current_stream_capturing() and \
+                    (rtol < cal["rtol"] or lev0 < cal["lev0"] or lev0 + nlev > cal["lev0"] + cal["nlev"]):
+                ch.set_steps(cal["bound_steps"])
+                self._cheb_checked = False
+                self._cheb_cal = None
             x = ch.solve(b)
             if not self._cheb_checked and not torch.cuda.is_current_stream_capturing():
                 # one-time check of the spectral bounds on a real right-hand side: a step count derived from wrong bounds would
@@ -301,6 +309,7 @@ class MassSolver:
                             break
                     ch.set_steps(need)
                     self.cheb_calibration = {"bound_steps": full, "steps": need, "floor": res, "floor_random": floor_rnd}
+                    self._cheb_cal = {"rtol": rtol, "lev0": lev0, "nlev": nlev, "bound_steps": full}
                     x = ch.solve(b)
             return x, ch.steps
         if self.kind != "jacobi":
