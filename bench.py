@@ -146,13 +146,19 @@ def measure_pmc_traffic(timeout=150):
 
 def cpu_worker(args):
     """one host core: reference-structure assemble+MatMult on a 12x12-element patch for ~`budget` seconds"""
-    budget, seed = args
+    budget, seed, barrier = args
     from oracle import pyoracle
     from tests.helpers import make_patch
     cs, topo, geom, P, rng = make_patch(pyoracle, PN, 12, 6, 0, nk=2, seed=seed)
     x = rng.standard_normal(P.n1)
-    sec, _ = P.bench_assemble_mult("UMAT", x, 2, lev=1, scale=SCALE, flag=1)
-    reps = max(2, int(budget / (sec / 2)))
+    # calibrate with EVERY worker loaded (round 3 calibrated while the others were still setting up: the slowest then ran 2.6x its budget)
+    if barrier is not None:
+        try:
+            barrier.wait(timeout=120)
+        except Exception:
+            pass
+    sec, _ = P.bench_assemble_mult("UMAT", x, 4, lev=1, scale=SCALE, flag=1)
+    reps = max(2, int(budget / (sec / 4)))
     sec, _ = P.bench_assemble_mult("UMAT", x, reps, lev=1, scale=SCALE, flag=1)
     # the reference's OWN matrix-free variant of the same product (Uvec::assemble, eul/Assembly.cpp:2124-2196): no matrix,
     # no CSR insertion -- the fairer comparison for a matrix-free GPU engine
@@ -168,10 +174,13 @@ def cpu_worker(args):
 def cpu_baseline(budget=6.0):
     import multiprocessing as mp
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
-    with mp.get_context("spawn").Pool(cores) as pool:
-        t0 = time.time()
-        res = pool.map(cpu_worker, [(budget, s) for s in range(cores)])
-        wall = time.time() - t0
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        barrier = mgr.Barrier(cores)
+        with ctx.Pool(cores) as pool:
+            t0 = time.time()
+            res = pool.map(cpu_worker, [(budget, s, barrier) for s in range(cores)], chunksize=1)
+            wall = time.time() - t0
     units = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)
     mf_units = sum(r[2] for r in res)
@@ -699,6 +708,23 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    # `value` is the contract's number: EXACTLY `steps` steps, once.  At the driver's --steps 20 that is a 0.4 ms sample, so the same timed
+    # region is repeated a few more times (same step count, same fences, max over ranks each) and the median is reported BESIDE it
+    rep_dts = [dt]
+    for _ in range(max(0, int(os.environ.get("MIMSEM_BENCH_REPEATS", "7")) - 1)):
+        fence()
+        tr0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        dr = time.perf_counter() - tr0
+        if use_dist:
+            t = torch.tensor([dr], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dr = t.item()
+        rep_dts.append(dr)
+    rep_sorted = sorted(rep_dts)
+    dt_median = rep_sorted[len(rep_sorted) // 2]
 
     units_total = cs.ne * cs.ne * 6 * NK            # all ranks together
     units_rank = dm.nEl * NK
@@ -706,6 +732,9 @@ def main():
     out = {
         "metric": "element operator-applies/sec", "value": value, "unit": "element operator-applies/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "ms_per_step_median": 1e3 * dt_median / a.steps, "value_median": units_total * a.steps / dt_median,
+        "timed_region_repeats": {"count": len(rep_dts), "ms_per_step_min": 1e3 * rep_sorted[0] / a.steps, "ms_per_step_max": 1e3 * rep_sorted[-1] / a.steps,
+                                 "note": "the first repeat is the contract's timed region (value, ms_per_step); the others repeat it unchanged"},
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Umat (B1, 1-form mass) matrix-free apply over every (element, level) pair of the "
                                "p=3 24x24x6 cubed sphere x 30 levels (BASELINE config 4 grid); N>1: patches dealt to the ranks, boundary "
