@@ -91,7 +91,7 @@ def launch_bytes(eng, dmesh, nlev):
     return bm, "k_elem_apply<3,UMAT>", "k_gather_sum<2>", lch
 
 
-def measure_pmc_traffic(timeout=150):
+def measure_pmc_traffic(timeout=240):
     """HBM-side bytes per launch of the step's kernels, measured IN THIS RUN: two child `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE --
     separately, with --kernel-trace only, the program itself after `--`, as MI355X_MICROARCH.md prescribes) over
     scripts/pmc_traffic.py: a calibration launch of known byte count (k_halo_pack over an identity index list: pins the gfx950
@@ -133,14 +133,23 @@ def measure_pmc_traffic(timeout=150):
     n = cal[0][0][1]                                       # one thread per packed double: n*8 bytes of data + n*4 of indices read
     factor = (n * 8 + n * 4) / cal[0][1]
     out = {"fetch_correction": round(factor, 4), "kernels": {}}
-    names = (("k_apply_wave", "k_apply_wave<3,UMAT>"), ("k_wave_perim", "k_wave_perim"), ("k_elem_apply", "k_elem_apply<3,UMAT>"),
-             ("k_gather_sum", "k_gather_sum<2>"))
+    import re
+    from mimsem_amd._lib import OPS
+    opname = {v: k for k, v in OPS.items()}
     for (k, g), v in sorted(F.items(), key=lambda kv: kv[0][1]):
-        for key, name in names:
-            if key in k:
-                out["kernels"].setdefault(name, []).append({"grid_threads": g, "read_bytes": v * factor, "write_bytes": W.get((k, g), 0.0),
-                                                            "total_bytes": v * factor + W.get((k, g), 0.0)})
-                break
+        m = re.search(r"k_(apply_wave2|apply_wave|elem_apply)<(\d+), *(\d+)", k)
+        if m and m.group(1) == "apply_wave2":                      # template <int OP, int LCT, bool ACCUM>: p = 3 only, the operator comes first
+            name = "k_apply_wave2<3,%s>" % opname.get(int(m.group(2)), m.group(2))
+        elif m:
+            name = "k_%s<%s,%s>" % (m.group(1), m.group(2), opname.get(int(m.group(3)), m.group(3)))
+        elif "k_wave_perim" in k:
+            name = "k_wave_perim"
+        elif "k_gather_sum" in k:
+            name = "k_gather_sum<2>"
+        else:
+            continue
+        out["kernels"].setdefault(name, []).append({"grid_threads": g, "read_bytes": v * factor, "write_bytes": W.get((k, g), 0.0),
+                                                    "total_bytes": v * factor + W.get((k, g), 0.0)})
     return out
 
 
@@ -597,8 +606,30 @@ def cold_workload(dm, R, local_rank, rng, torch, steps=20):
     r["whole_operator"]["copy_of_the_same_bytes_us"] = copy_reference_us(bm["op_compulsory"], torch, engc.device)
     r.update({"replicas": R, "level_chunk": lch, "working_set_MB": ws, "value": bm["units"] * steps / dtc,
               "value_unit": "element operator-applies/s (wall clock over %d back-to-back steps)" % steps})
+    # every family of SURVEY 8(d) on the same HBM-resident workload: kernel time from the context's HIP events, compulsory
+    # bytes (family_bytes); the PMC passes at the end of the run add traffic / traffic_over_compulsory per row
+    x2 = engc.tensor(rng.standard_normal((NK, dmc.n2))); hh = engc.tensor(rng.uniform(1, 2, (NK, dmc.n2))*1e3)
+    q0 = engc.tensor(rng.standard_normal((NK, dmc.n0))*1e-4); y2 = engc.zeros(NK, dmc.n2)
+    rows = {}
+    for row, op, fin, fcf, fl in FAMILIES:
+        xin = xc if fin == 1 else x2
+        f = {None: None, 0: q0, 1: xc, 2: hh}[fcf]
+        o = yc if op in ("UMAT", "UHMAT", "ROTMAT") else y2
+        callf, _ = engc.prepare_apply(op, xin, f=f, lev0=0, scale=SCALE, flags=fl, out=o)
+        for _ in range(3):
+            callf()
+        torch.cuda.synchronize(); engc.set_profiling(1)
+        for _ in range(10):
+            callf()
+        torch.cuda.synchronize()
+        f1, f2, fn = engc.profile_read(); engc.set_profiling(0)
+        kus = (f1 + f2)/max(fn, 1)*1e3
+        b = family_bytes(op, dmc.nEl, (dmc.n0, dmc.n1, dmc.n2), NK)
+        rows[row] = {"op": op, "kernel_us": kus, "kernels": 2 if f2 > 0 else 1, "bytes_per_launch": b, "achieved_GBs": b/(kus*1e-6)/1e9,
+                     "frac": b/(kus*1e-6)/1e9/HBM_PEAK_GBS, "applies_per_s": dmc.nEl*NK/(kus*1e-6), "traffic": None, "traffic_over_compulsory": None}
     del engc
-    return r
+    return r, {"workload": "%d spheres per launch (%d units, HBM resident): compulsory bytes / HIP-event kernel time against 8 TB/s; traffic = "
+                           "FETCH_SIZE x2 + WRITE_SIZE of the family's kernels from this run's PMC passes" % (R, dmc.nEl*NK), "rows": rows}
 
 
 def main():
@@ -796,7 +827,24 @@ def main():
                           "achieved": opb / (kus * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": opb / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           "byte_model": "whole operator: x and y once per level, thickInv per unit (25 points), metric record 32 B per point once per element",
                           "algorithmic_reference_bytes_per_unit": 2320}}
+        # the same operator HBM resident: 8 independent boxes in one launch (524 288 units)
         del engb
+        dmc = replicate(dmb, 8); engc = Engine(dmc, device=local_rank)
+        xc = engc.tensor(rng.standard_normal((nkb, dmc.n1))); yc = engc.zeros(nkb, dmc.n1)
+        callc, _ = engc.prepare_apply("UMAT", xc, lev0=0, scale=SCALE, flags=1, out=yc)
+        for _ in range(3):
+            callc()
+        torch.cuda.synchronize(); engc.set_profiling(1)
+        for _ in range(10):
+            callc()
+        torch.cuda.synchronize()
+        c1, c2, cn = engc.profile_read(); engc.set_profiling(0)
+        opc = family_bytes("UMAT", dmc.nEl, (dmc.n0, dmc.n1, dmc.n2), nkb, pn=4)
+        kc = (c1 + c2) / cn * 1e3
+        r["roofline_cold"] = {"bound": "hbm", "kernels": "k_apply_wave<4,UMAT> + k_wave_perim", "replicas": 8, "units": dmc.nEl * nkb, "bytes_per_launch": opc,
+                              "avg_us": kc, "kernel1_us": c1 / cn * 1e3, "kernel2_us": c2 / cn * 1e3, "achieved": opc / (kc * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": opc / (kc * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_over_compulsory": None}
+        del engc
         return r
     # N > 1: the extras below run collectives of paths that no multi-GPU hardware has executed yet.  A rank that fails alone leaves
     # its peers waiting in a collective; the headline measured above must survive that: past the budget rank 0 prints the line
@@ -890,7 +938,11 @@ def main():
         extra("sweep", lambda: sweep_extras(local_rank, torch))
     if rank == 0 and world == 1 and a.cold != 0:
         # the HBM number: on by default (--cold 0 skips it), R = 8 spheres = 829 440 units per launch
-        extra("roofline_cold", lambda: cold_workload(dm, a.cold, local_rank, rng, torch))
+        def cold_all():
+            rc_, fam = cold_workload(dm, a.cold, local_rank, rng, torch)
+            out["families_cold"] = fam
+            return rc_
+        extra("roofline_cold", cold_all)
     if world > 1:
         # WEAK-scaled companion of the headline: every rank holds 8 spheres' worth of work whatever N is (its 24/N patches, 8 N
         # independent copies: 829 440 units and ~1 GB per rank, the size of roofline_cold), the halo of all copies in ONE exchange,
@@ -1066,6 +1118,27 @@ def main():
                             w["traffic_over_compulsory"] = w["traffic"] / w["bytes_per_launch"]
                 out["roofline"].pop("traffic_from_committed_profile", None)
                 out["pmc_traffic"] = pm
+            # per-family traffic on the 8-sphere workload: the family's element kernel (the launch with the larger grid) + the perimeter pass
+            fam_kernel = {"UMAT": "k_apply_wave<3,UMAT>", "UHMAT": "k_apply_wave<3,UHMAT>", "ROTMAT": "k_apply_wave<3,ROTMAT>",
+                          "WMAT": "k_elem_apply<3,WMAT>", "WTQUMAT": "k_apply_wave2<3,WTQUMAT>", "WHMAT": "k_apply_wave2<3,WHMAT>"}
+            big = lambda name: max(pm["kernels"].get(name, []), key=lambda r_: r_["grid_threads"], default=None)
+            perim = big("k_wave_perim")
+            for row in (out.get("families_cold") or {}).get("rows", {}).values():
+                k1r = big(fam_kernel[row["op"]])
+                if k1r is None:
+                    continue
+                tb = k1r["total_bytes"] + (perim["total_bytes"] if (row["kernels"] == 2 and perim) else 0.0)
+                row["traffic"] = tb; row["traffic_over_compulsory"] = tb / row["bytes_per_launch"]
+                row["traffic_GBs"] = tb / (row["kernel_us"] * 1e-6) / 1e9
+            bc = (out.get("box_p4") or {}).get("roofline_cold")
+            kb = pm["kernels"].get("k_apply_wave<4,UMAT>", [])
+            if bc and kb:
+                kb1 = max(kb, key=lambda r_: r_["grid_threads"])
+                pb = [r_ for r_ in pm["kernels"].get("k_wave_perim", []) if r_ is not perim]
+                # (the box's perimeter launch: the largest k_wave_perim grid that is not the sphere's)
+                pbx = max(pb, key=lambda r_: r_["grid_threads"], default=None) if pb else None
+                bc["traffic"] = kb1["total_bytes"] + (pbx["total_bytes"] if pbx else 0.0)
+                bc["traffic_over_compulsory"] = bc["traffic"] / bc["bytes_per_launch"]
         except Exception as ex:          # noqa: BLE001 -- the headline line never depends on the profiler being usable
             out["roofline"]["traffic_note"] = "PMC passes not available in this run (%s: %s): traffic stays null" % (type(ex).__name__, str(ex)[:200])
     if rank == 0 and world == 1 and not a.no_cpu:
