@@ -37,11 +37,12 @@ BYTES_K1_B1 = 1248          # the element kernel alone: 120 dbl in + 24 dbl out 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: FP64 vector (= matrix) peak
 # executed FP64 work of the column solves per (column, level), p = 3, nk = 30: SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of every kernel of the
-# solve x 64 lanes (FMA = 2 flop), rocprofv3 --pmc over scripts/prof_column.py / prof_column3.py (profiles/r02_column_pmc.txt;
-# refreshed in profiles/r03_column_pmc.txt).  Padding lanes of the 16-lane DPP rows (9 of 16 rows carry data) are executed work and
+# solve x 64 lanes (FMA = 2 flop), rocprofv3 --pmc over scripts/prof_column.py / prof_column3.py (profiles/r02_column_pmc.txt,
+# r03_column_pmc.txt; round 4: profiles/r04_column_pmc_eta.txt, r04_column_pmc_s3.txt -- the three-launch schur_3 executes 1.66e5 where
+# round 3's 30 launches executed 2.63e5).  Padding lanes of the 16-lane DPP rows (9 of 16 rows carry data) are executed work and
 # count: the figure is what the ALUs did, not the algorithm's minimum (~3 700 flop per level).
-SCHUR_ETA_FLOP_PER_COLUMN_LEVEL = 1.55e5
-SCHUR_3_FLOP_PER_COLUMN_LEVEL = 2.63e5
+SCHUR_ETA_FLOP_PER_COLUMN_LEVEL = 1.45e5
+SCHUR_3_FLOP_PER_COLUMN_LEVEL = 1.66e5
 
 
 def b1_launch_bytes(nEl, n1, nlev, lch, pn=PN):
@@ -183,6 +184,19 @@ def cpu_worker(args):
 def cpu_baseline(budget=6.0):
     import multiprocessing as mp
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    # the box may grant fewer CPUs than it shows (a cgroup quota: 64 visible cores, 16 granted, on the one-GPU boxes of this pool): more
+    # workers than granted CPUs are time-sliced, every one of them then runs a multiple of its budget and "cores" overstates what computed
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            cores = max(1, min(cores, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        try:
+            qq = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); pp = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if qq > 0:
+                cores = max(1, min(cores, qq // pp))
+        except Exception:
+            pass
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         barrier = mgr.Barrier(cores)

@@ -5,11 +5,11 @@ set -e
 name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_ab/obj_$name; mkdir -p $d
-for f in api elem_kernels column_kernels krylov_kernels halo; do
+for f in api elem_kernels column_kernels krylov_kernels halo ksp; do
   if [ "$f" = api ] || [ "$f" = elem_kernels ] || [ ! -f $d/$f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable $flags -c $root/mimsem_amd/csrc/$f.hip -o $d/$f.o &
   fi
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/build_ab/libmimsem_hip_$name.so $d/api.o $d/elem_kernels.o $d/column_kernels.o $d/krylov_kernels.o $d/halo.o -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/build_ab/libmimsem_hip_$name.so $d/api.o $d/elem_kernels.o $d/column_kernels.o $d/krylov_kernels.o $d/halo.o $d/ksp.o -ldl
 echo built $root/build_ab/libmimsem_hip_$name.so
