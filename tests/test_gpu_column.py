@@ -497,3 +497,41 @@ def test_block_inverse_against_the_oracle_inv(oracle, n):
         ok = [i for i in range(nb) if i != 11]
         want = np.stack([oracle.inv(S[i])[0] for i in ok])
         assert max(rel_l2(got[i].cpu().numpy(), w) for i, w in zip(ok, want)) < 1e-10 * max(1.0, np.linalg.cond(S[ok[0]]) / 1e3)
+
+
+@pytest.mark.parametrize("pn,ne,nk", [(3, 2, 4), (3, 2, 5), (3, 2, 7), (3, 2, 9), (3, 1, 12), (2, 2, 5), (2, 1, 11)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("flags", [0, 3], ids=["eul", "box"])
+def test_fused_schur_3_walk_at_other_level_counts(oracle, pn, ne, nk, flags):
+    """Round 4's three-launch solve_schur_column_3 (k_s3_sweep + k_penta_dpp + k_s3_backsub) against round 2's chain + 2 x 2 super-block
+    sweep (MIMSEM_SCHUR3_CHAIN=1 MIMSEM_SCHUR3_SUPERBLOCKS=1: itself held to the oracle in test_schur_column_3_pentadiagonal) at level
+    counts that are odd (one-sided pentadiagonal elimination), not multiples of anything, and on meshes so small that a column is split
+    over several tasks (the walk's warm-up steps, the dump blocks, the peeled last step); bands, every right-hand side, every solution;
+    the per-column status is valid and clean after it"""
+    import os
+    from mimsem_amd.device import DeviceMesh, Engine
+    cs, topo, geom, P, rng = make_patch(oracle, pn, ne, 6, 1, nk=nk, seed=300 + 7 * nk + pn)
+    eng = Engine(DeviceMesh([topo], [geom], nk=nk, numbering="local"))
+    F = _col_fields(P, seed=nk + pn)
+    r = np.random.default_rng(41 + nk)
+    nEl, n2 = P.nEl, P.n2e
+    rhs = [r.standard_normal((nEl, n * n2)) * 1e8 for n in (nk - 1, nk, nk, nk)]
+    t = eng.tensor
+    run = lambda: eng.solve_schur_3(75.0, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]), *[t(x) for x in rhs],
+                                    want_L=True, flags=flags)
+    new = run()
+    nbad, st, ratio = eng.solve_status()
+    assert nbad == 0 and (st == 0).all() and ratio.max() <= 1e-10, (nbad, float(ratio.max()))
+    lane_major = eng.solve_schur_3(75.0, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]), *[t(x) for x in rhs], flags=flags)
+    os.environ["MIMSEM_SCHUR3_CHAIN"] = "1"; os.environ["MIMSEM_SCHUR3_SUPERBLOCKS"] = "1"
+    try:
+        old = run()
+    finally:
+        del os.environ["MIMSEM_SCHUR3_CHAIN"], os.environ["MIMSEM_SCHUR3_SUPERBLOCKS"]
+    assert eng.solve_status()[0] == -1                                  # the round-2 path keeps no status
+    names = ("d_u", "d_rho", "d_rt", "d_pi", "L")
+    for a, b, name in zip(new, old, names):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < (1e-12 if name == "L" else TOL), (name, pn, nk)
+    # the solve that keeps its bands in the internal lane-major layout (no L_out) gives the same solutions
+    for a, b, name in zip(lane_major, new, names[:4]):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-12, name
