@@ -2,6 +2,7 @@
 two-wait-state rule hipcc cannot see through inline asm.  This compiles column_kernels.hip to gfx950 ISA (device side only, no GPU
 needed: ~25 s) and re-checks the rule on what the compiler actually produced (scripts/check_dpp_hazards.py; a compiler or flag change
 that slips a copy between the s_nop and the DPP read fails here instead of corrupting column solves silently).
+The same ISA is checked for register spills hipcc placed where the exec mask drops lanes (scripts/check_spill_slots.py, round 4).
 Limit of the check, stated: its look-back window restarts at labels, so a hazard across a loop back-edge is not seen; the source keeps
 every DPP operand behind an `s_nop 1` in the SAME basic block for that reason."""
 import os
@@ -25,3 +26,8 @@ def test_no_dpp_hazard_in_the_generated_isa(tmp_path):
     assert c.returncode == 0, c.stdout[-2000:]
     n = int(c.stdout.split()[0])
     assert n > 10000 and "0 hazard(s)" in c.stdout, c.stdout          # the DPP kernels are really in there
+    # round 4: no register spill in a divergent "Flow" block ahead of its exec restore, no reload of a slot some path leaves unwritten
+    # (scripts/check_spill_slots.py: the pattern behind the wrong, run-to-run different bands of k_s3_sweep<4, box>)
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_spill_slots.py"), str(asm)], capture_output=True, text=True)
+    assert c.returncode == 0 and " 0 finding(s)" in c.stdout, c.stdout[-3000:]
+    assert int(c.stdout.strip().split("\n")[-1].split()[0]) > 100, c.stdout[-300:]

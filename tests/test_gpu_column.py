@@ -1,5 +1,6 @@
 """GPU parity for the vertical (column) operators and the column Schur solve, rows C1..C9."""
 import numpy as np
+import torch
 import pytest
 
 from tests.helpers import dense_from_band, make_patch, rel_l2, solve_error_budget
@@ -499,7 +500,7 @@ def test_block_inverse_against_the_oracle_inv(oracle, n):
         assert max(rel_l2(got[i].cpu().numpy(), w) for i, w in zip(ok, want)) < 1e-10 * max(1.0, np.linalg.cond(S[ok[0]]) / 1e3)
 
 
-@pytest.mark.parametrize("pn,ne,nk", [(3, 2, 4), (3, 2, 5), (3, 2, 7), (3, 2, 9), (3, 1, 12), (2, 2, 5), (2, 1, 11)],
+@pytest.mark.parametrize("pn,ne,nk", [(3, 2, 4), (3, 2, 5), (3, 2, 7), (3, 2, 9), (3, 1, 12), (2, 2, 5), (2, 1, 11), (4, 1, 5), (4, 1, 8), (4, 2, 6), (4, 2, 9)],
                          ids=lambda v: str(v))
 @pytest.mark.parametrize("flags", [0, 3], ids=["eul", "box"])
 def test_fused_schur_3_walk_at_other_level_counts(oracle, pn, ne, nk, flags):
@@ -523,12 +524,19 @@ def test_fused_schur_3_walk_at_other_level_counts(oracle, pn, ne, nk, flags):
     nbad, st, ratio = eng.solve_status()
     assert nbad == 0 and (st == 0).all() and ratio.max() <= 1e-10, (nbad, float(ratio.max()))
     lane_major = eng.solve_schur_3(75.0, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]), *[t(x) for x in rhs], flags=flags)
-    os.environ["MIMSEM_SCHUR3_CHAIN"] = "1"; os.environ["MIMSEM_SCHUR3_SUPERBLOCKS"] = "1"
+    again = run()                                                       # run-to-run: the same bits (a spill lost in a divergent region showed here first)
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)
+    os.environ["MIMSEM_SCHUR3_CHAIN"] = "1"
+    if pn < 4:
+        os.environ["MIMSEM_SCHUR3_SUPERBLOCKS"] = "1"                   # (order 4: the chain's bands + k_penta_dpp, held to the oracle on config 5's columns)
     try:
         old = run()
     finally:
-        del os.environ["MIMSEM_SCHUR3_CHAIN"], os.environ["MIMSEM_SCHUR3_SUPERBLOCKS"]
-    assert eng.solve_status()[0] == -1                                  # the round-2 path keeps no status
+        del os.environ["MIMSEM_SCHUR3_CHAIN"]
+        os.environ.pop("MIMSEM_SCHUR3_SUPERBLOCKS", None)
+    if pn < 4:
+        assert eng.solve_status()[0] == -1                              # the round-2 path keeps no status
     names = ("d_u", "d_rho", "d_rt", "d_pi", "L")
     for a, b, name in zip(new, old, names):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < (1e-12 if name == "L" else TOL), (name, pn, nk)
