@@ -763,7 +763,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
 void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp,
+    void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
                     c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -808,6 +808,35 @@ int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thic
             for (size_t i = 0; i < row; i++) { o[2*i] = a0[i]; o[2*i + 1] = a1[i]; }
         }
         MIMSEM_HIP_TRY(hipMemcpy(c->d_tIp, tp.data(), tp.size()*sizeof(double), hipMemcpyHostToDevice));
+        // the same table per NODE (experiment, MIMSEM_WAVE_TNODE=1): the reference's thickInv lives on the nodes (eul/Geom.cpp:143-146, :761) and
+        // the ABI takes it gathered per element: 16 values per element at p = 3 of which 9 are distinct per element on average.  Only when
+        // every element holds the same bits at a shared node (and quadrature points are the nodes: mp12 == n0e)
+        if (c->d_tIn) { (void)hipFree(c->d_tIn); c->d_tIn = nullptr; }
+        if (getenv("MIMSEM_WAVE_TNODE") && atoi(getenv("MIMSEM_WAVE_TNODE")) == 1 && c->es.mp12 == c->es.n0e && !c->h_i0.empty() && c->n0 > 0) {
+            const size_t n0 = (size_t)c->n0;
+            std::vector<double> nod((size_t)c->nk*n0, 1.0), tn(2*np*n0*2, 1.0);
+            std::vector<unsigned char> seen(n0);
+            bool same = true;
+            for (size_t L = 0; L < (size_t)c->nk && same; L++) {
+                std::fill(seen.begin(), seen.end(), 0);
+                const double* a0 = ti.data() + L*row;
+                double* nl = nod.data() + L*n0;
+                for (size_t i = 0; i < row; i++) {
+                    const size_t nd = (size_t)c->h_i0[i];
+                    if (nd >= n0 || (seen[nd] && std::memcmp(&nl[nd], &a0[i], 8))) { same = false; break; }
+                    nl[nd] = a0[i]; seen[nd] = 1;
+                }
+            }
+            for (int par = 0; par < 2 && same; par++) for (size_t m = 0; m < np; m++) {
+                const size_t L0 = std::min<size_t>(2*m + par, c->nk - 1), L1 = std::min<size_t>(2*m + par + 1, c->nk - 1);
+                double* o = tn.data() + ((size_t)par*np + m)*n0*2;
+                for (size_t nd = 0; nd < n0; nd++) { o[2*nd] = nod[L0*n0 + nd]; o[2*nd + 1] = nod[L1*n0 + nd]; }
+            }
+            if (same) {
+                MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_tIn, tn.size()*sizeof(double)));
+                MIMSEM_HIP_TRY(hipMemcpy(c->d_tIn, tn.data(), tn.size()*sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
     }
     c->have_levels = (thick != nullptr) || (thickInv != nullptr);
     return MIMSEM_OK;
@@ -916,7 +945,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
     a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr;
     a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
     a.flags = flags; a.scale = scale; a.alpha = alpha;
-    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.E = c->d_E; a.w = c->d_w;
+    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.tps = (long long)c->nEl*c->es.mp12*2; a.tnode = 0; a.E = c->d_E; a.w = c->d_w;
     a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2; a.iq = c->d_iq;
     if (in == 3 && !c->d_iq) return MIMSEM_ERR_STATE;     // projection operators need mimsem_mesh_desc::indsq
     a.f = f; a.fs = fs; a.x = x; a.xs = xs;
@@ -992,6 +1021,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         if (splits && part == MIMSEM_PART_INTERIOR) { g0 = c->w_nbgroups; r0 = c->w_nbrec; }
         a.wlane = c->d_wlane; a.wplan = c->d_wplan; a.wgroups = g1 - g0; a.wg0 = g0; a.wdump = c->w_npart;
         a.wsing = c->w_nsing ? c->d_wsing : nullptr; a.wnode = c->d_wnode; a.wG = c->d_wG; a.wR = c->d_wR;
+        if (c->d_tIn) { a.tIp = c->d_tIn; a.tps = (long long)c->n0*2; a.tnode = 1; }     // (MIMSEM_WAVE_TNODE=1: thickInv per node)
         a.lch = wave_level_chunk(c, nlev);
         a.wcpp = wave_chunks_per_item(c, nlev, a.lch, g1 - g0);
         a.swz = c->wave_order;

@@ -45,6 +45,7 @@ struct mimsem_ctx {
     double* d_tI = nullptr;     // [nk][nEl][mp12] inverse thickness
     bool blocks_mfma = false;   // block pass of the Chebyshev / Richardson sweeps on the matrix cores (default at p = 4, MIMSEM_BLOCKS_MFMA=0|1 at context creation overrides; p <= 3: register-row form)
     double* d_tIp = nullptr;    // [2][nk/2 + 1][nEl][mp12][2]: the same in level PAIRS {L, L+1}, first index = parity of L (k_apply_wave: one 16-byte load per two levels)
+    double* d_tIn = nullptr;    // [2][nk/2 + 1][n0][2]: the same per NODE (MIMSEM_WAVE_TNODE=1; null unless every element holds the same value at a shared node)
     bool have_levels = false;
     int* d_i0 = nullptr;        // [nEl][n0e]
     int* d_i1x = nullptr;       // [nEl][n1e]
@@ -149,6 +150,7 @@ struct ElemArgs {
     double scale, alpha;
     const double *J, *det, *tI, *th, *E, *w;
     const double* tIp; int tnp;          // level-pair copy of tI, pairs per parity
+    long long tps; int tnode;            // doubles between two pair rows of tIp; tnode: tIp is the NODAL table (entry = node slot of the point, wnode) instead of [element][point]
     const int *i0, *i1x, *i1y, *i2, *iq;
     const double* f; long long fs;
     const double* f2; long long f2s;   // second coefficient field (velocity of the upwinded operators)
