@@ -253,6 +253,16 @@ def column_extras(eng, dm, rng, torch):
     t = timeit(lambda: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F]), 5)
     res["schur_column_solves_per_s"] = nEl / t
     res["schur_ms_all_columns"] = t * 1e3
+    # the columns the unpivoted sweep cannot resolve to 1e-10 (status 1), and what the opt-in remedy costs: the same call with
+    # mimsem_column_set_pivot_fallback(1) re-solves exactly those by a band LU with partial pivoting (the reference's PCLU) inside the call
+    res["schur_unconverged_columns"] = int(eng.solve_status()[0])
+    eng.set_pivot_fallback(1)
+    try:
+        tf = timeit(lambda: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[f.clone() for f in F]), 5)
+        nb, stf, _ = eng.solve_status()
+    finally:
+        eng.set_pivot_fallback(0)
+    res["schur_pivot_fallback"] = {"ms_all_columns": tf * 1e3, "columns_resolved_by_pivoted_lu": int((stf == 3).sum()), "unconverged_columns": int(nb)}
     # what bounds it: FP64 work counted by the SQ counters (profiles/r03_column_pmc.txt: FMA = 2 flop, MUL / ADD = 1, x 64 lanes per wave
     # instruction, all three kernels of the solve) against the 78.6 TFLOP/s vector FP64 peak, and the bytes the solve must move (the four
     # fields and four right-hand sides in, the four updated right-hand sides out, det + thickness per quadrature point) against 8 TB/s

@@ -351,6 +351,14 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
  * *n_unconverged = number of columns with status 1, or -1 when the last solve ran on a path that keeps no status (orders >= 4,
  * MIMSEM_SCHUR_FUSED=rows|wave|0: pivoted Gauss-Jordan inside the blocks + one refinement step).  Synchronises the context's stream. */
 int mimsem_column_solve_status(mimsem_ctx* ctx, int* n_unconverged, int* column_status, double* column_ratio);
+/* The remedy for status 1 (round 4; off by default, MIMSEM_COLUMN_PIVOT_FALLBACK=1 switches it on at context creation): with on != 0 every
+ * later mimsem_column_solve_schur_eta / _3 re-solves the columns its unpivoted sweep flags INSIDE the call -- an unblocked band LU with
+ * partial pivoting over the whole band, what the reference's PCLU does for every column (eul/VertSolve.cpp:645-653, :806-812), plus one
+ * refinement step -- before the back substitution reads the solution.  Such a column reports status 3 and the ratio of that step; it no
+ * longer counts in *n_unconverged.  Cost: one extra small launch per solve when nothing is flagged, about a millisecond per flagged
+ * column otherwise (at most 64 per call; the rest stay 1).  Columns with more than 1 024 unknowns (nk n2e) are left as they are.
+ * on == 2: EVERY column goes through the pivoted LU (validation mode: the reference's algorithm for all columns, at its price). */
+int mimsem_column_set_pivot_fallback(mimsem_ctx* ctx, int on);
 /* the assembled block-tridiagonal L_pi itself: out [nEl][nk][3][n2e][n2e] (sub, diag, super)       */
 int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
         const double* theta, const double* rho, const double* eta, const double* pi, double* out);

@@ -125,6 +125,7 @@ _SIGS = {
     "mimsem_op_apply_part_reset": (C.c_int, [C.c_void_p]),
     "mimsem_krylov_gs_control": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_column_solve_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
+    "mimsem_column_set_pivot_fallback": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_halo_set_transport": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_halo_set_loopback": (C.c_int, [C.c_void_p]),
     "mimsem_halo_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_ll]),

@@ -736,6 +736,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     // the register-row form on the config-5 grid, profiles/r03_mfma_p4_ab.txt), off at p <= 3 (24 x 24: 25.3 against 23.8 us);
     // MIMSEM_BLOCKS_MFMA=0 | 1 overrides
     c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") ? atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
+    c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 0;      // (mimsem_column_set_pivot_fallback)
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
         c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
         c->h_i0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e);
@@ -764,7 +765,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);

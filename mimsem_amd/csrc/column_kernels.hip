@@ -2518,6 +2518,7 @@ int schur_operator(mimsem_ctx* c, double dt, const double* theta, const double* 
 
 }  // namespace
 
+#include "column_pivot.inc"
 #include "column_dpp.inc"
 #include "column_penta.inc"
 #include "column_newton.inc"
@@ -2540,6 +2541,12 @@ int mimsem_column_helmholtz_blocks(mimsem_ctx* c, double dt, const double* theta
     if (rc) return rc;
     MIMSEM_HIP_TRY(hipMemcpyAsync(out, S.L.p, (size_t)c->nEl*c->nk*3*c->es.n2e*c->es.n2e*sizeof(double),
                                   hipMemcpyDeviceToDevice, c->stream));
+    return MIMSEM_OK;
+}
+
+int mimsem_column_set_pivot_fallback(mimsem_ctx* c, int on) {
+    if (!c) return MIMSEM_ERR_ARG;
+    c->pivot_fallback = on == 2 ? 2 : (on ? 1 : 0);
     return MIMSEM_OK;
 }
 

@@ -112,6 +112,9 @@ struct mimsem_ctx {
     double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
     int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
+    int pivot_fallback = 0;     // mimsem_column_set_pivot_fallback: flagged columns are re-solved by a band LU with partial pivoting (column_pivot.inc)
+    double* d_lu = nullptr;     // its workspace: slot counter + band storage of up to 64 flagged columns
+    long long lu_doubles = 0;
     long long col_doubles = 0;
     double col_param = 0.0;             // scalar argument of the *_ex column operators (dt_fric / dt)
     const double* col_uh = nullptr;     // horizontal velocity [nk][n1] of the *_up column operators

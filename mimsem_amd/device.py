@@ -649,11 +649,16 @@ class Engine:
 
     def solve_status(self):
         """(columns whose refinement did not converge in the last solve_schur_eta, or -1 when that path keeps no status; per-column status
-        array: 0 converged, 1 not converged, 2 refinement off; per-column |last correction| / |solution|) -- mimsem_column_solve_status"""
+        array: 0 converged, 1 not converged, 2 refinement off, 3 solved by the pivoted fallback (set_pivot_fallback); per-column |last correction| / |solution|) -- mimsem_column_solve_status"""
         n = C.c_int(-1)
         st = np.zeros(max(self.nEl, 1), dtype=np.int32); ratio = np.zeros(max(self.nEl, 1))
         check(self.L.mimsem_column_solve_status(self.ctx, C.byref(n), st.ctypes.data, ratio.ctypes.data), "column_solve_status")
         return n.value, st[:self.nEl], ratio[:self.nEl]
+
+    def set_pivot_fallback(self, on=True):
+        """later solve_schur_eta / solve_schur_3 calls re-solve the columns their unpivoted sweep flags by a band LU with partial pivoting (what
+        the reference's PCLU does for every column); such columns report status 3 -- mimsem_column_set_pivot_fallback"""
+        check(self.L.mimsem_column_set_pivot_fallback(self.ctx, int(on)), "column_set_pivot_fallback")      # (2: every column, validation mode)
 
     # ---- Krylov building blocks ----------------------------------------------------------------
     def mdot(self, V, w, k=None, out=None):

@@ -543,3 +543,62 @@ def test_fused_schur_3_walk_at_other_level_counts(oracle, pn, ne, nk, flags):
     # the solve that keeps its bands in the internal lane-major layout (no L_out) gives the same solutions
     for a, b, name in zip(lane_major, new, names[:4]):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-12, name
+
+
+@pytest.mark.parametrize("pn,ne,nk", [(2, 2, 6), (3, 2, 6), (3, 2, 5), (4, 1, 6)], ids=lambda v: str(v))
+@pytest.mark.parametrize("kind", ["eta", "s3_eul", "s3_box"])
+def test_pivoted_band_lu_solves_every_column(oracle, pn, ne, nk, kind):
+    """Round 4: mimsem_column_set_pivot_fallback(2) sends EVERY column of solve_schur_column_eta / _3 through the unblocked band LU with
+    partial pivoting of column_pivot.inc (what the reference's PCLU does, eul/VertSolve.cpp:645-653, :806-812) instead of the unpivoted
+    block sweep: status 3 for all columns, each solution held to an extended-precision pivoted solve of the bands the call returns, and
+    every output of the call equal to the default path's up to the conditioning; switching the mode off restores the default bit for bit"""
+    from mimsem_amd.device import DeviceMesh, Engine
+    from tests.helpers import _ld_lu_solve
+    cs, topo, geom, P, rng = make_patch(oracle, pn, ne, 6, 1, nk=nk, seed=500 + 11 * nk + pn)
+    eng = Engine(DeviceMesh([topo], [geom], nk=nk, numbering="local"))
+    F = _col_fields(P, seed=2 * nk + pn)
+    r = np.random.default_rng(17 + nk)
+    nEl, n2 = P.nEl, P.n2e
+    rhs = [r.standard_normal((nEl, n * n2)) * 1e8 for n in (nk - 1, nk, nk, nk)]
+    t = eng.tensor
+    if kind == "eta":
+        lo, sol = 1, 3                                                   # block-tridiagonal, solved for d_pi from F_pi
+        bands = lambda: eng.helmholtz_blocks(75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"])).cpu().numpy()
+
+        def run():
+            Fs = [t(x) for x in rhs]
+            out = eng.solve_schur_eta(75.0, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]), *Fs)
+            return list(out), Fs, None
+    else:
+        lo, sol = 2, 2                                                   # block-pentadiagonal, solved for d_rt from F_rt
+        flags = 3 if kind == "s3_box" else 0
+
+        def run():
+            Fs = [t(x) for x in rhs]
+            out = eng.solve_schur_3(75.0, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]), *Fs, want_L=True, flags=flags)
+            return list(out[:4]), Fs, out[4].cpu().numpy()
+    ref_out, ref_F, L = run()
+    n0, st0, _ = eng.solve_status()
+    assert n0 == 0 and (st0 == 0).all()                                  # (well-conditioned columns: the default path converges on all of them)
+    if L is None:
+        L = bands()
+    eng.set_pivot_fallback(2)
+    try:
+        out, Fs, _ = run()
+        nbad, st, ratio = eng.solve_status()
+    finally:
+        eng.set_pivot_fallback(0)
+    assert nbad == 0 and (st == 3).all() and (ratio < 1e-10).all(), (nbad, np.unique(st), float(ratio.max()))
+    f_key = 3 if kind == "eta" else 2
+    for e in range(nEl):
+        A = dense_from_band(L[e], nk, n2, lo=lo)
+        b = Fs[f_key][e].cpu().numpy()
+        want = np.asarray(_ld_lu_solve(A, b, (lo + 1) * n2 - 1), dtype=np.float64)
+        got = out[sol][e].cpu().numpy()
+        assert rel_l2(got, want) < 1e-15 * max(1e4, np.linalg.cond(A)), (e, rel_l2(got, want), np.linalg.cond(A))
+    for a, b, name in zip(out + Fs, ref_out + ref_F, ("d_u", "d_rho", "d_rt|d_eta", "d_pi", "F_u", "F_rho", "F_rt|F_eta", "F_pi")):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < TOL, name       # back substitution from either solve: the same numbers to 1e-10
+    again, _, _ = run()                                                   # the mode is off again: the default path, bit for bit
+    for a, b in zip(again, ref_out):
+        assert torch.equal(a, b)
+    assert (eng.solve_status()[1] == 0).all()

@@ -5,7 +5,7 @@ round trips, residual of the block-tridiagonal solve, discrete mass conservation
 import numpy as np
 import pytest
 
-from tests.helpers import SCALE, z_levels
+from tests.helpers import SCALE, dense_from_band, rel_l2, z_levels
 
 pytestmark = pytest.mark.gpu
 PN, NE, NK, NPATCH = 3, 24, 30, 24
@@ -180,6 +180,52 @@ def test_column_solve_reports_the_columns_it_cannot_resolve(full):
     finally:
         del os.environ["MIMSEM_NO_REFINE"]
     assert nbad == 0 and (st == 2).all()
+
+
+def test_pivot_fallback_resolves_the_flagged_columns(full):
+    """Round 4: with mimsem_column_set_pivot_fallback(1) the columns the unpivoted sweep flags (the test above) are re-solved inside the
+    call by a band LU with partial pivoting -- the reference's PCLU (eul/VertSolve.cpp:806-812) for exactly the columns that need it:
+    no column is left with status 1, the re-solved ones (status 3) satisfy their system as well as LAPACK's pivoted solve of the same
+    bands does, and every other column keeps its bits"""
+    import torch
+    cs, dm, eng, _ = full
+    n2, nEl = eng.n2e, dm.nEl
+    area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    seen = 0
+    for seed in (2, 77):                                                 # seed 2 holds the column with cond(L) ~ 1e13
+        rng = np.random.default_rng(seed)
+        lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+        theta, rho, eta, pi = lev(NK, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 5, 6), lev(NK, 700, 1000)
+        F0 = [rng.standard_normal((nEl, n * n2)) * 1e8 for n in (NK - 1, NK, NK, NK)]
+        L = eng.helmholtz_blocks(75.0, theta, rho, eta, pi).view(nEl, NK, 3, n2, n2)
+        F = [eng.tensor(x) for x in F0]
+        ref = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+        nbad0, st0, _ = eng.solve_status()
+        assert nbad0 > 0
+        eng.set_pivot_fallback(1)
+        try:
+            F = [eng.tensor(x) for x in F0]
+            out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+            nbad, st, ratio = eng.solve_status()
+        finally:
+            eng.set_pivot_fallback(0)
+        assert nbad == 0 and set(np.unique(st)) <= {0, 3}, (nbad, np.unique(st))
+        assert ((st == 3) == (st0 == 1)).all()                          # exactly the flagged columns were re-solved
+        keep = torch.as_tensor(st0 == 0, device=out[0].device)
+        for a, b in zip(out, ref):
+            assert torch.equal(a[keep], b[keep])                         # ... and nobody else was touched
+        rhs = F[3].view(nEl, NK, n2).cpu().numpy(); Lh = L.cpu().numpy(); d = out[3].view(nEl, NK * n2).cpu().numpy()
+        for e in np.nonzero(st == 3)[0]:
+            A = dense_from_band(Lh[e], NK, n2, lo=1)
+            b = rhs[e].reshape(-1)
+            lap = np.linalg.solve(A, b)                                  # LAPACK dgesv: partial pivoting, as PCLU
+            res = lambda x: np.linalg.norm(A @ x - b) / (np.linalg.norm(A, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+            assert res(d[e]) < max(4.0 * res(lap), 1e-15), (seed, int(e), res(d[e]), res(lap))      # backward error at LAPACK's level
+            cond = np.linalg.cond(A)
+            assert rel_l2(d[e], lap) < 1e-14 * cond, (seed, int(e), rel_l2(d[e], lap), cond)      # and the same solution up to the conditioning
+            seen += 1
+        print("seed %d: %d columns re-solved by the pivoted fallback, largest ratio %.1e" % (seed, int((st == 3).sum()), float(ratio[st == 3].max())))
+    assert seen > 0
 
 
 def test_column_solve_3_satisfies_its_block_pentadiagonal_system(full):
