@@ -525,7 +525,8 @@ struct VertSolve {
     int solve_status(int* column_status = nullptr, double* column_ratio = nullptr) {
         int n = -1; check(mimsem_column_solve_status(mesh->ctx, &n, column_status, column_ratio), "column_solve_status"); return n; }
     // ... and PCLU's pivoting itself, for the columns that need it: later solves re-solve flagged columns by a band LU with partial pivoting (status 3)
-    void set_pivot_fallback(bool on = true) { check(mimsem_column_set_pivot_fallback(mesh->ctx, on ? 1 : 0), "column_set_pivot_fallback"); }
+    // (mode 1: the flagged columns; 2: every column -- the reference's algorithm throughout, at its price; 0: off)
+    void set_pivot_fallback(int mode = 1) { check(mimsem_column_set_pivot_fallback(mesh->ctx, mode), "column_set_pivot_fallback"); }
     void diagTheta2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 1, rho, rt, theta), "diagTheta2"); }
     void diagTheta_L2(const double* rho, const double* rt, double* theta) { check(mimsem_column_diag_theta(mesh->ctx, 0, rho, rt, theta), "diagTheta_L2"); }
     void diagTheta_up(const double* rho, const double* rt, double* theta, const double* ul, long long ul_stride) {

@@ -250,6 +250,24 @@ int main() {
             if (nbad == 0) for (int e = 0; e < nEl; e++) ok = ok && st[e] == 0 && ratio[e] >= 0.0 && ratio[e] <= 1e-10;
             std::printf("%-8s unconverged columns = %d\n", "Status", nbad); if (!ok) fails++;
         }
+        {   // PCLU's pivoting itself (round 4): every column through the band LU with partial pivoting -- the same solutions, status 3
+            std::vector<double*> dF;
+            for (auto* f : {&Fu, &Fr, &Fe, &Fp}) dF.push_back(mesh.to_device(f->data(), f->size()));
+            vert.set_pivot_fallback(2);
+            vert.solve_schur_column_eta(dv[0], nullptr, dv[1], dv[2], dv[3], dF[0], dF[1], dF[2], dF[3], d_du, d_dr, d_de, d_dp);
+            std::vector<int> st(nEl, -7);
+            const int nbad = vert.solve_status(st.data(), nullptr);
+            vert.set_pivot_fallback(0);
+            std::vector<double> gp2((size_t)nEl*N);
+            mesh.to_host(gp2.data(), d_dp, gp2.size());
+            double num = 0, den = 0;
+            for (size_t i = 0; i < gp2.size(); i++) { num += (gp2[i] - gp[i])*(gp2[i] - gp[i]); den += gp[i]*gp[i]; }
+            int ok = nbad == 0 || nbad == -1;
+            if (nbad == 0) for (int e = 0; e < nEl; e++) ok = ok && st[e] == 3;
+            std::printf("%-8s rel L2 = %.3e (pivoted band LU for every column vs the block sweep)\n", "PivotLU", std::sqrt(num/den));
+            if (!ok || !(std::sqrt(num/den) < 1e-10)) fails++;
+            for (double* p : dF) mimsem_free(p);
+        }
         // vert->diagTheta2(rho, rt, theta) / diagTheta_L2  (eul/VertSolve.cpp:289-352), every column
         {
             std::vector<double> rt = field(nk, 250, 400), t2((size_t)nEl*(nk + 1)*n2e), tl((size_t)nEl*N), w2((nk + 1)*n2e), wl(N);
