@@ -342,13 +342,14 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
         double* F_u, double* F_rho, double* F_eta, double* F_pi,
         double* d_u, double* d_rho, double* d_eta, double* d_pi);
 /* Per-column status of the most recent mimsem_column_solve_schur_eta of this context.  The block-Thomas sweep of the default path
- * (orders 1..3) does not pivot ACROSS blocks (the reference's PCLU, eul/VertSolve.cpp:645-653, pivots over the whole band); it is
+ * (orders 1..4) does not pivot ACROSS blocks (the reference's PCLU, eul/VertSolve.cpp:645-653, pivots over the whole band); it is
  * followed by up to four steps of iterative refinement, and a column stops when its correction is below 1e-10 of its solution.
  * column_status[e] (host, [nEl], may be NULL): 0 = converged, 1 = NOT converged within the allowed steps (conditioning beyond what the
- * unpivoted sweep + refinement resolves to 1e-10: judge d_* of that column by column_ratio), 2 = refinement was switched off.
+ * unpivoted sweep + refinement resolves to 1e-10: judge d_* of that column by column_ratio), 2 = refinement was switched off,
+ * 3 = re-solved by the pivoted fallback (mimsem_column_set_pivot_fallback below; column_ratio: of its refinement step).
  * column_ratio[e] (host, [nEl], may be NULL): |last correction| / |solution| of the column -- how far its refinement got (on rough random
  * columns with cond(L) ~ 1e10 it settles near 1e-9, where LAPACK's pivoted LU leaves the same residual; a ratio >> 1e-8 is a failed solve).
- * *n_unconverged = number of columns with status 1, or -1 when the last solve ran on a path that keeps no status (orders >= 4,
+ * *n_unconverged = number of columns with status 1, or -1 when the last solve ran on a path that keeps no status (orders >= 5,
  * MIMSEM_SCHUR_FUSED=rows|wave|0: pivoted Gauss-Jordan inside the blocks + one refinement step).  Synchronises the context's stream. */
 int mimsem_column_solve_status(mimsem_ctx* ctx, int* n_unconverged, int* column_status, double* column_ratio);
 /* The remedy for status 1 (round 4; off by default, MIMSEM_COLUMN_PIVOT_FALLBACK=1 switches it on at context creation): with on != 0 every
