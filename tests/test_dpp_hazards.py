@@ -31,3 +31,37 @@ def test_no_dpp_hazard_in_the_generated_isa(tmp_path):
     c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_spill_slots.py"), str(asm)], capture_output=True, text=True)
     assert c.returncode == 0 and " 0 finding(s)" in c.stdout, c.stdout[-3000:]
     assert int(c.stdout.strip().split("\n")[-1].split()[0]) > 100, c.stdout[-300:]
+
+
+def test_spill_checker_sees_the_pattern_it_was_written_for(tmp_path):
+    """scripts/check_spill_slots.py on two hand-written kernels: a spill store at the top of a structuriser "Flow" block (entered by
+    s_cbranch_execz with the else-lanes still disabled) ahead of the s_or_saveexec that re-enables them -- the code hipcc produced in
+    k_s3_sweep<4, box> -- is reported; the same store behind the exec restore is not"""
+    bad = """
+k_bad:
+	s_and_saveexec_b64 s[0:1], vcc
+	s_xor_b64 s[0:1], exec, s[0:1]
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	v_mov_b32_e32 v2, 1
+.LBB0_2:
+	v_readlane_b32 s4, v254, 0
+	scratch_store_dwordx2 off, v[88:89], off offset:8 ; 8-byte Folded Spill
+	s_or_saveexec_b64 s[0:1], s[0:1]
+	v_mov_b32_e32 v88, v2
+	s_xor_b64 exec, exec, s[0:1]
+	s_or_b64 exec, exec, s[0:1]
+	scratch_load_dwordx2 v[0:1], off, off offset:8 ; 8-byte Folded Reload
+	s_endpgm
+.Lfunc_end0:
+"""
+    good = bad.replace("k_bad", "k_good").replace("""	scratch_store_dwordx2 off, v[88:89], off offset:8 ; 8-byte Folded Spill
+	s_or_saveexec_b64 s[0:1], s[0:1]""", """	s_or_saveexec_b64 s[0:1], s[0:1]
+	scratch_store_dwordx2 off, v[88:89], off offset:8 ; 8-byte Folded Spill""").replace("LBB0", "LBB1").replace("func_end0", "func_end1")
+    script = os.path.join(ROOT, "scripts", "check_spill_slots.py")
+    for name, text, rc in (("bad.s", bad, 1), ("good.s", good, 0)):
+        f = tmp_path / name
+        f.write_text(text)
+        c = subprocess.run([sys.executable, script, str(f)], capture_output=True, text=True)
+        assert c.returncode == rc, (name, c.stdout)
+        assert ("ahead of its exec restore" in c.stdout) == (rc == 1), c.stdout
