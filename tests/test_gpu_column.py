@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(scope="module", params=[(3, 2, 6, 1, 6), (4, 1, 6, 0, 5), (2, 2, 6, 3, 4)], ids=lambda p: "p%d_ne%d_np%d_pi%d_nk%d" % p)
+@pytest.fixture(scope="module", params=[(3, 2, 6, 1, 6), (4, 1, 6, 0, 5), (2, 2, 6, 3, 4), (3, 3, 6, 2, 8)], ids=lambda p: "p%d_ne%d_np%d_pi%d_nk%d" % p)
 def setup(request, oracle):
     from mimsem_amd.device import DeviceMesh, Engine
     pn, ne, nprocs, pi, nk = request.param
@@ -500,7 +500,7 @@ def test_block_inverse_against_the_oracle_inv(oracle, n):
         assert max(rel_l2(got[i].cpu().numpy(), w) for i, w in zip(ok, want)) < 1e-10 * max(1.0, np.linalg.cond(S[ok[0]]) / 1e3)
 
 
-@pytest.mark.parametrize("pn,ne,nk", [(3, 2, 4), (3, 2, 5), (3, 2, 7), (3, 2, 9), (3, 1, 12), (2, 2, 5), (2, 1, 11), (4, 1, 5), (4, 1, 8), (4, 2, 6), (4, 2, 9)],
+@pytest.mark.parametrize("pn,ne,nk", [(3, 2, 4), (3, 2, 5), (3, 2, 7), (3, 2, 9), (3, 1, 12), (2, 2, 5), (2, 1, 11), (3, 3, 6), (4, 1, 5), (4, 1, 8), (4, 2, 6), (4, 2, 9), (4, 3, 6)],
                          ids=lambda v: str(v))
 @pytest.mark.parametrize("flags", [0, 3], ids=["eul", "box"])
 def test_fused_schur_3_walk_at_other_level_counts(oracle, pn, ne, nk, flags):
