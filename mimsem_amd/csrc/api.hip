@@ -943,7 +943,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
 
     const ElemSizes& es = c->es;
     ElemArgs a;
-    a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr;
+    a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr; a.wfence = 0;
     a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
     a.flags = flags; a.scale = scale; a.alpha = alpha;
     a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.tps = (long long)c->nEl*c->es.mp12*2; a.tnode = 0; a.E = c->d_E; a.w = c->d_w;
@@ -1030,6 +1030,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         // parts of a split apply: their partial sums wait for the other part, and the perimeter pass finishes them)
         const bool fin = c->w_fin && !splits && (nlev + a.lch*a.wcpp - 1)/(a.lch*a.wcpp) <= std::max(c->nk, 1);
         a.wfin = fin ? c->d_wfin : nullptr; a.wsslot = c->d_wsslot; a.wcnt = c->d_wcnt;
+        a.wfence = (fin && c->w_partmem == 2 && getenv("MIMSEM_WAVE_FIN_FENCE") && atoi(getenv("MIMSEM_WAVE_FIN_FENCE")) != 0) ? 1 : 0;
         if (splits) {
             // the pending BOUNDARY part and its INTERIOR part must match; nothing else can consume or overwrite the partial sums
             if (part == MIMSEM_PART_BOUNDARY) {

@@ -167,6 +167,7 @@ struct ElemArgs {
     // wave-level fused scatter-add (k_apply_wave)
     const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump; int wcpp;
     const int4* wfin; const int* wsslot; int* wcnt;      // finishing phase (null: the perimeter pass follows)
+    int wfence;                      // finishing phase, experiment: partial sums in PLAIN memory, one agent-scope release fence per wavefront before its arrival
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
     double Wq[5];                    // GLL weights by value (orders <= 4)
     long long* wstamps;              // diagnostic build (MIMSEM_STAMPS): 16 s_memtime stamps per work item, else null
