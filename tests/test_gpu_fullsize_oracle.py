@@ -373,6 +373,33 @@ def test_config5_sampled_columns_match_oracle(cfg5, oracle):
     print("config 5 schur_3 (box) budget:", {k: "%.1e" % max(r[k] for r in rep3) for k in rep3[0]})
 
 
+def test_config5_pivoted_band_lu_at_the_size_limit(cfg5):
+    """mimsem_column_set_pivot_fallback(2) on config 5's columns: 1 024 unknowns per column (the limit of column_pivot.inc), scalar
+    half-bandwidth 31 (Helmholtz system) and 47 (box solve_schur_column_3) -- every column through the band LU with partial pivoting,
+    status 3, the solutions of the block sweep reproduced"""
+    bx, topos, geoms, dm, eng, levs = cfg5
+    nk, n2 = 64, eng.n2e
+    rng = np.random.default_rng(5503)
+    F = _hydrostatic_fields(dm, geoms, eng, nk, 4, rng, noise=1e-2)
+    N, Nm = nk * n2, (nk - 1) * n2
+    Fs = [rng.standard_normal((dm.nEl, n)) * 1e8 for n in (Nm, N, N, N)]
+    t = eng.tensor
+    runs = (lambda: eng.solve_schur_eta(0.5, t(F["thetaL"]), t(F["rho"]), t(F["eta"]), t(F["pi"]), *[t(f) for f in Fs]),
+            lambda: eng.solve_schur_3(0.5, t(F["theta"]), t(F["velz"]), t(F["rho"]), t(F["rt"]), t(F["pi"]), *[t(f) for f in Fs], flags=3))
+    for run in runs:
+        ref = run()
+        assert eng.solve_status()[0] == 0
+        eng.set_pivot_fallback(2)
+        try:
+            out = run()
+            nbad, st, ratio = eng.solve_status()
+        finally:
+            eng.set_pivot_fallback(0)
+        assert nbad == 0 and (st == 3).all() and ratio.max() < 1e-10, (nbad, np.unique(st), float(ratio.max()))
+        for a, b in zip(out, ref):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-9
+
+
 # ---- config 3: p=3, 24x24x6 sphere, shallow water (signed det, no thickness) -------------------------------------------
 def test_config3_upwinded_operators_match_oracle(oracle):
     """Phmat::assemble_up / RotMat_up::assemble (src/Assembly.cpp:499-567, 1784-1853) and the plain src-flavour Umat / RotMat on the
