@@ -288,6 +288,14 @@ int mimsem_sw_operator_precond_apply(mimsem_ctx* ctx, int nlev, double a, double
                                      const double* f0, long long f0_stride, const double* blocks,
                                      const double* x, long long x_stride, double* z, long long z_stride);
 
+/* The same body TOGETHER with the first classical Gram-Schmidt pass of the Arnoldi step it feeds (round 4; one level row):
+ *   w = P (A x);  h[0..k) = V w;  w += alpha V^T h      (V: k rows of length n1 + n2, stride ldv; alpha = -1 orthogonalises)
+ * in four launches instead of five: the 1-form gather of w rides in the dot pass.  Bit-identical to
+ * mimsem_sw_operator_precond_apply + mimsem_krylov_orthogonalize (same sums, same order).  Stands where KSPSolve's GMRES calls
+ * PCApply(MatMult(A, v)) and then KSPGMRESClassicalGramSchmidtOrthogonalization (src/SWEqn_Picard.cpp:751-765). */
+int mimsem_sw_operator_precond_orthogonalize(mimsem_ctx* ctx, double a, double grav, double H, const double* f0, const double* blocks,
+                                             const double* x, double* w, int k, const double* V, long long ldv, double alpha, double* h);
+
 /* ---- vertical / column operators (rows C1..C9), eul/VertOps.h:45-72 ------------------------- */
 enum mimsem_colop {
     MIMSEM_V_CONST = 0, MIMSEM_V_CONST_INV = 1, MIMSEM_V_CONST_RHO = 2, MIMSEM_V_CONST_RHO_INV = 3,

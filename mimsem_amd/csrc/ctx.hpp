@@ -211,7 +211,8 @@ int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H,
                        const double* x, long long xs, double* y, long long ys);
 int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys);
 int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
-                               const double* B, const double* x, long long xs, double* z, long long zs);
+                               const double* B, const double* x, long long xs, double* z, long long zs,
+                               const double** unassembled = nullptr /* nlev == 1: skip the 1-form gather of z, return the element-local results */);
 int launch_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf);
 int launch_halo_unpack(mimsem_ctx* c, const int* idx, int count, int nlev, int mode, const double* buf, double* v, long long vs);
 

@@ -1805,7 +1805,7 @@ int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const doubl
 // z = P (A x): the operator's element pass, the block pass reading the operator result through the gather plan, one gather
 // (three launches; the assembled A x never exists).  Workspace: two element-local buffers + one packed row per level.
 int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
-                               const double* B, const double* x, long long xs, double* z, long long zs) {
+                               const double* B, const double* x, long long xs, double* z, long long zs, const double** unassembled) {
     const ElemSizes& es = c->es;
     if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
     if (es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
@@ -1822,6 +1822,7 @@ int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, d
     default: return MIMSEM_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
+    if (unassembled && nlev == 1) { *unassembled = ye1; return MIMSEM_OK; }      // (mimsem_sw_operator_precond_orthogonalize: the gather rides in its first dot pass)
     return launch_gather_sum(c, 1, nlev, ye1, per, 0, z, zs);
 }
 

@@ -97,6 +97,34 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(long long n, long long c
     __syncthreads();
     if (tid == 0) part[(size_t)row*gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// Round 4: the dots of the first Gram-Schmidt pass with the 1-form GATHER of w folded in.  w's first n1 entries are still element-local
+// (ze: what k_sw_blocks_apply left; plan: the two contributors of every edge slot, the order k_gather_sum adds them in): every block forms
+// the entries of its chunk on the fly, the blocks of row 0 also store them.  Same products, same order as k_gather_sum + k_rowdot_partial.
+__global__ __launch_bounds__(256) void k_rowdot_partial_gather(long long n, long long n1, long long chunk, const double* __restrict__ V, long long ldv,
+                                                               const double* __restrict__ ze, const int* __restrict__ plan,
+                                                               double* __restrict__ w, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.y;
+    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
+    const double* a = V + (size_t)row*ldv;
+    double s = 0.0;
+    for (long long t = lo + tid; t < hi; t += 256) {
+        double wv;
+        if (t < n1) {
+            const int p0 = plan[(size_t)t*2], p1 = plan[(size_t)t*2 + 1];
+            double acc = 0.0;
+            if (p0 >= 0) acc += ze[p0];
+            if (p1 >= 0) acc += ze[p1];
+            wv = acc;
+            if (row == 0) w[t] = wv;
+        } else wv = w[t];
+        s += a[t]*wv;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) part[(size_t)row*gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 // the k rows V_i . w of a Gram-Schmidt pass AND w . w (row k) in one launch: what the second pass needs to normalise without a
 // reduction of its own (|w - V h|^2 = |w|^2 - |h|^2 for an orthonormal V)
 __global__ __launch_bounds__(256) void k_mdot_self_partial(int k, long long n, long long chunk, const double* __restrict__ V, long long ldv,
@@ -340,6 +368,29 @@ int mimsem_krylov_orthogonalize(mimsem_ctx* c, int k, long long n, const double*
     int nb = 0;
     int rc = rowdot_partials(c, k, n, V, ldv, w, 0, &nb);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_maxpy_reduce, dim3((unsigned)((n + 255)/256)), dim3(256), (size_t)k*sizeof(double), c->stream,
+                       k, nb, n, V, ldv, c->d_kry, alpha, w, h, (double*)nullptr);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
+// w = P (A x) ; h = V w ; w += alpha V^T h : the Krylov body of the shallow-water solve and the first Gram-Schmidt pass in FOUR launches
+// (mimsem_sw_operator_precond_apply + mimsem_krylov_orthogonalize: five) -- the 1-form gather of w rides in the dot pass.
+int mimsem_sw_operator_precond_orthogonalize(mimsem_ctx* c, double a, double grav, double H, const double* f0, const double* blocks,
+                                             const double* x, double* w, int k, const double* V, long long ldv, double alpha, double* h) {
+    if (!c || !f0 || !blocks || !x || !w || x == w || k < 0 || (k > 0 && (!V || !h))) return MIMSEM_ERR_ARG;
+    const long long n1 = c->n1, n = (long long)c->n1 + c->n2;
+    if (c->nEl == 0 || n == 0) return MIMSEM_OK;
+    if (k > 0 && ldv < n) return MIMSEM_ERR_ARG;
+    if (k == 0) return launch_sw_operator_precond(c, 1, a, grav, H, f0, 0, blocks, x, n, w, n);
+    const double* ze = nullptr;
+    int rc = launch_sw_operator_precond(c, 1, a, grav, H, f0, 0, blocks, x, n, w, n, &ze);
+    if (rc) return rc;
+    if (!ze) return MIMSEM_ERR_STATE;
+    const int nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+    const long long chunk = (n + nb - 1)/nb;
+    if ((rc = c->ensure_kry((long long)nb*k))) return rc;
+    hipLaunchKernelGGL(k_rowdot_partial_gather, dim3(nb, k), dim3(256), 0, c->stream, n, n1, chunk, V, ldv, ze, c->d_g1, w, c->d_kry);
     hipLaunchKernelGGL(k_maxpy_reduce, dim3((unsigned)((n + 255)/256)), dim3(256), (size_t)k*sizeof(double), c->stream,
                        k, nb, n, V, ldv, c->d_kry, alpha, w, h, (double*)nullptr);
     MIMSEM_HIP_TRY(hipGetLastError());

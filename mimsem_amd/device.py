@@ -423,6 +423,17 @@ class Engine:
                                                       _ptr(blocks), x2.data_ptr(), x2.stride(0), z2.data_ptr(), z2.stride(0)), "sw_operator_precond")
         return z if (x.dim() == 2 or out is not None) else z[0]
 
+    def sw_operator_precond_orthogonalize(self, a, grav, H, f0, blocks, x, V, k, h, out, alpha=-1.0):
+        """out = P (A x); h[:k] = V[:k] out; out += alpha V[:k]^T h -- the Krylov body and the first Gram-Schmidt pass of the Arnoldi step in four
+        launches (mimsem_sw_operator_precond_orthogonalize; bit-identical to sw_operator_precond + orthogonalize, which take five)"""
+        nd = 2 * self.n1e + self.n2e
+        n = self.sizes[1] + self.sizes[2]
+        assert x.numel() == n and out.numel() == n and x.is_contiguous() and out.is_contiguous() and blocks.shape == (self.nEl, nd, nd)
+        assert f0.numel() == self.sizes[0] and V.stride(1) == 1 and V.shape[1] == n and 0 <= k <= V.shape[0] and h.numel() >= k
+        check(self.L.mimsem_sw_operator_precond_orthogonalize(self.ctx, a, grav, H, f0.data_ptr(), _ptr(blocks), x.data_ptr(), out.data_ptr(),
+                                                              k, _ptr(V), V.stride(0), alpha, _ptr(h)), "sw_operator_precond_orthogonalize")
+        return out
+
     def sw_blocks_apply(self, blocks, x, out=None):
         """z = sum_e R_e^T B_e R_e x on packed rows [u | h]; blocks [nEl, ND, ND] stored column-major per element (mimsem_sw_blocks_apply)"""
         nd = 2 * self.n1e + self.n2e

@@ -413,13 +413,17 @@ class GraphedGMRES:
     body(v) -> M^-1 A v must be capturable: fixed shapes, no host synchronisation, every kernel on the current stream
     (`eng.on_current_stream()` rebinds the engine's HIP stream for the capture)."""
 
-    def __init__(self, eng, n, body, restart=30, dtype=torch.float64):
+    def __init__(self, eng, n, body, restart=30, dtype=torch.float64, body_orth=None):
         self.eng, self.n, self.m, self.body = eng, n, restart, body
+        # body_orth(v, V, k, h, out) -> out = M^-1 A v already orthogonalised once against V[:k] (h[:k] = the projections): an operator that can
+        # fold its own last pass into the first Gram-Schmidt pass (SWEqn: the 1-form gather rides in the dots, one launch less per step)
+        self.body_orth = body_orth
         dev = eng.device
         self.V = torch.zeros(restart + 1, n, dtype=dtype, device=dev)
         self.h = torch.zeros(restart + 1, dtype=dtype, device=dev)
         self.h2 = torch.zeros(restart + 1, dtype=dtype, device=dev)
         self.col = torch.zeros(restart + 2, dtype=dtype, device=dev)
+        self.wbuf = torch.zeros(n, dtype=dtype, device=dev) if body_orth is not None else None
         self.col_host = torch.zeros(restart, restart + 2, dtype=dtype).pin_memory()     # row j: Hessenberg column of step j
         self.graphs = [None] * restart
         self.pool = None
@@ -437,6 +441,10 @@ class GraphedGMRES:
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1
+        if self.body_orth is not None and not (self.gs_fused and self.cgs2):
+            w = self.body_orth(V[j], V, k, self.h, self.wbuf)
+            eng.reorthonormalize(V, w, V[j + 1], k, self.h, self.h2, self.col_host[j], self.m + 1, fused=self.gs_fused, flag=self.gs_flag)
+            return
         w = self.body(V[j:j + 1]).reshape(-1)
         if not w.is_contiguous():
             w = w.contiguous()

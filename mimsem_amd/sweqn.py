@@ -278,6 +278,18 @@ class SWEqn:
             return lambda v: self.eng.sw_operator_precond(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, v)
         return lambda v: self.precond_A(self.apply_A(v, dt), dt)
 
+    def _krylov_body_orth(self, dt):
+        """(v, V, k, h, out) -> out = P A v orthogonalised once against V[:k]: the body above with its 1-form gather folded into the first
+        Gram-Schmidt pass (mimsem_sw_operator_precond_orthogonalize, round 4).  OPT-IN (MIMSEM_SW_FUSED_DOTS=1): one launch less per Arnoldi step and
+        SLOWER -- every one of the k row-blocks of the dot pass repeats the gather (192-196 against 205-208 steps/s, profiles/r04_sw_cgs2_ab.txt);
+        None otherwise, and where the fused body does not apply"""
+        if not (self.eng.mesh.n <= 4 and self.coupled_pc and not hasattr(self.eng, "halo")) or os.environ.get("MIMSEM_SW_FUSED_DOTS", "0") != "1":
+            return None
+        if self._pcA is None or self._pcA[0] != dt:
+            self._pcA = (dt, self._coupled_element_blocks(dt))
+        blocks = self._pcA[1]
+        return lambda v, V, k, h, out: self.eng.sw_operator_precond_orthogonalize(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, v, V, k, h, out)
+
     def precond_A(self, r, dt=None):
         """dt given (and order <= 4): the coupled element blocks above; otherwise block diagonal -- the element-block preconditioner
         on M1, the exact element-wise inverse on M2 (WmatInv)"""
@@ -305,7 +317,8 @@ class SWEqn:
             f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot, qi=qi, qj=qi if it == 0 else None)   # iteration 0: uj = ui, hj = hi
             if self.graphs:
                 if self._gA is None or self._gA[0] != (dt, restart):       # the operator is fixed for a given dt: capture once
-                    self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2, self._krylov_body(dt), restart=restart))
+                    self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2, self._krylov_body(dt), restart=restart,
+                                                            body_orth=self._krylov_body_orth(dt)))
                 dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, lambda r: self.precond_A(r, dt), rtol=self.rtol, maxit=1000)
             else:
                 with self.eng.space("uh"):

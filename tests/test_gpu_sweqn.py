@@ -234,6 +234,34 @@ def test_richardson_sweeps_match_composition(sw):
     assert torch.equal(q1, q + updq)
 
 
+def test_sw_body_with_the_gather_folded_into_the_first_gram_schmidt_pass(sw):
+    """Round 4: mimsem_sw_operator_precond_orthogonalize (w = P A x, h = V w, w -= V^T h in four launches: the 1-form gather of w rides in
+    the dot pass) against mimsem_sw_operator_precond_apply + mimsem_krylov_orthogonalize (five): the same bits, for every k"""
+    import torch
+    cs, eng, O, S, uq, hq = sw
+    r = np.random.default_rng(33)
+    dm = eng.mesh
+    n, m, dt = dm.n1 + dm.n2, 9, 360.0
+    x = _t(eng, np.concatenate([r.standard_normal(dm.n1), 20.0 * r.standard_normal(dm.n2)]))
+    import os
+    os.environ["MIMSEM_SW_FUSED_DOTS"] = "1"                       # (opt-in: measured slower than the five launches it replaces)
+    try:
+        body, fused = S._krylov_body(dt), S._krylov_body_orth(dt)
+    finally:
+        del os.environ["MIMSEM_SW_FUSED_DOTS"]
+    assert fused is not None
+    Q, _ = torch.linalg.qr(eng.tensor(r.standard_normal((n, m))))
+    V = Q.T.contiguous()
+    for k in (1, 4, m):
+        wa = body(x).reshape(-1).contiguous()
+        ha = torch.zeros(m, dtype=torch.float64, device=eng.device); hb = torch.zeros_like(ha)
+        eng.orthogonalize(V, wa, ha, k=k)
+        wb = torch.full((n,), 7.0, dtype=torch.float64, device=eng.device)
+        fused(x, V, k, hb, wb)
+        torch.cuda.synchronize()
+        assert torch.equal(wa, wb) and torch.equal(ha[:k], hb[:k]), (k, float((wa - wb).abs().max()))
+
+
 def test_sw_fused_krylov_body_and_reorthonormalize(sw):
     """mimsem_sw_operator_precond_apply == precond(apply) to round-off; mimsem_krylov_reorthonormalize == orthogonalize + normalize"""
     import torch
