@@ -9,12 +9,15 @@ halo reduce (RCCL send/recv over xGMI) that replaces the reference's VecScatter 
 
 At N = 1 the same line also carries "sw": shallow-water time steps/s (the second half of BASELINE's metric; --no-sw skips it)
 and "column": HEVI column Schur solves/s on the same grid (--no-column skips it).
-Prints ONE JSON line (rank 0).  roofline: dominant kernel k_elem_apply<3,UMAT>, HIP-event timed inside the timed
+Prints ONE compact JSON line (rank 0, < 4 KB: compact_record -- the contract's keys, roofline, roofline_cold, cpu_baseline(+_column,
++_sw) and one-number summaries); the full object with every extra goes to bench_extras.json (repo root and gpurun_out/).
+`python bench.py --gpus N` started without WORLD_SIZE launches its own N ranks as a child torch.distributed.run.  roofline: dominant kernel k_elem_apply<3,UMAT>, HIP-event timed inside the timed
 region, against the launch's COMPULSORY bytes (b1_launch_bytes: frac <= 1 by construction; SURVEY 8(d)'s per-unit
 figure rides along as `algorithmic_reference` only).  The headline workload is Infinity-Cache resident
 (`cache_resident: true`); `roofline_cold` repeats the step on 8 independent spheres (829 440 units, ~1 GB working
 set) -- that one is the HBM statement.  cpu_baseline: the oracle's reference-structure (assemble CSR + SpMV) path on
-host cores.
+host cores; cpu_baseline_column: the oracle's solve_schur_column_eta column by column; cpu_baseline_sw: the assemble + MatMult work of one
+shallow-water Picard iteration (Krylov solves excluded: an upper bound of the CPU's steps/s).
 """
 import argparse
 import json
@@ -154,12 +157,33 @@ def measure_pmc_traffic(timeout=240):
     return out
 
 
+def _oracle_patch(pyoracle, pn, ne, nprocs, pi, nk, seed):
+    """one reference rank's patch handed to the CPU checker (cpu_baseline leg only): mesh + sphere geometry + stretched levels"""
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from mimsem_amd.workloads import z_levels
+    rng = np.random.default_rng(seed)
+    cs = CubedSphere(pn, ne, nprocs)
+    coords = sphere_coords(pn, ne)
+    topo = Topo(cs, pi, nk)
+    geom = Geom(topo, cs, coords, nk)
+    geom.set_levels(z_levels(nk, geom.n0, rng))
+    P = pyoracle.Patch(pn, pn, cs.nel, nk)
+    P.set_sphere_geometry(coords[cs.patches[pi].loc0])
+    P.set_levels(geom.levs)
+    return P, rng
+
+
 def cpu_worker(args):
-    """one host core: reference-structure assemble+MatMult on a 12x12-element patch for ~`budget` seconds"""
+    """one host core, three legs of ~budget seconds each share:
+    (1) reference-structure assemble+MatMult of Umat on a 12x12-element patch (+ the reference's own matrix-free Uvec::assemble),
+    (2) solve_schur_column_eta (eul/VertSolve.cpp:677-823 restated: oracle/o_vertops.c) column after column at nk = 30,
+    (3) the operator work of ONE shallow-water Picard iteration (src/SWEqn_Picard.cpp:253-318, 402-621) on the patch:
+        every assemble() of the iteration through the CSR insertion path + its MatMults -- Krylov solves NOT included."""
     budget, seed, barrier = args
     from oracle import pyoracle
-    from tests.helpers import make_patch
-    cs, topo, geom, P, rng = make_patch(pyoracle, PN, 12, 6, 0, nk=2, seed=seed)
+    P, rng = _oracle_patch(pyoracle, PN, 12, 6, 0, 2, seed)
     x = rng.standard_normal(P.n1)
     # calibrate with EVERY worker loaded (round 3 calibrated while the others were still setting up: the slowest then ran 2.6x its budget)
     if barrier is not None:
@@ -178,11 +202,47 @@ def cpu_worker(args):
     for _ in range(mf_reps):
         P.uvec(1, SCALE, x)
     mf_sec = time.perf_counter() - t0
-    return P.nEl * reps, sec, P.nEl * mf_reps, mf_sec
+    res = {"units": P.nEl * reps, "sec": sec, "mf_units": P.nEl * mf_reps, "mf_sec": mf_sec}
+
+    # (3) SW Picard iteration: src flavour (scale 1, no thickness: flag 0), Galewsky-style (q upwinded at both time levels):
+    # diagnose_F: 2 x M1h->assemble(h) + 4 MatMult; diagnose_Phi: 2 x K->assemble(u) + 3 MatMult + 2 M2 MatMult;
+    # 2 x diagnose_q: M0h->assemble(h) + MatMult (+ M0, E01M1 MatMults); 2 x R->assemble(q) + MatMult; M2, 2 M1, 2 M2 MatMults.
+    # bench_assemble_mult(op, ., r) = r x (assemble + MatMult); the extra MatMults are charged as one more assemble-free SpMV each by
+    # timing Umat / Wmat once with their assembly (they ARE assembled once per step in assemble_operator) -- a slight over-count of
+    # four assemblies against ~20 MatMults not counted: the total stays a LOWER bound of the iteration's cost on the CPU.
+    h2 = rng.uniform(1.0, 2.0, P.n2) * 1e3; q0 = rng.standard_normal(P.n0) * 1e-8; x2 = rng.standard_normal(P.n2); x0 = rng.standard_normal(P.n0)
+    legs = (("UHMAT", x, h2, 2), ("WTQUMAT", x, x, 2), ("PHMAT", x0, h2, 2), ("ROTMAT", x, q0, 2), ("UMAT", x, None, 1), ("WMAT", x2, None, 1))
+    def sw_iter(r):
+        tot = 0.0
+        for op, xin, f, cnt in legs:
+            s_, _ = P.bench_assemble_mult(op, xin, cnt * r, lev=0, scale=1.0, flag=0, f1=f)
+            tot += s_
+        return tot
+    t_it = sw_iter(1)
+    sw_reps = max(1, int(0.5 * budget / max(t_it, 1e-6)))
+    sw_sec = sw_iter(sw_reps)
+    res.update({"sw_elements": P.nEl * sw_reps, "sw_sec": sw_sec})
+
+    # (2) column solves: a 2x2-element patch with 30 levels, column after column
+    del P
+    Pc, rc = _oracle_patch(pyoracle, PN, 2, 6, 0, NK, seed)
+    nEl, nk, n2 = Pc.nEl, Pc.nk, Pc.n2e
+    area = Pc.det.mean() * 4.0 / n2; dz = Pc.thick.mean()
+    lev = lambda nl, lo, hi: rc.uniform(lo, hi, (nEl, nl * n2)) * area * dz
+    theta, rho, eta, pi = lev(nk, 280, 320), lev(nk, 0.5, 1.2), lev(nk, 5, 6), lev(nk, 700, 1000)
+    F = [rc.standard_normal((nEl, n * n2)) * 1e8 for n in (nk - 1, nk, nk, nk)]
+    def col(e):
+        Pc.solve_schur_column_eta(e % Pc.nElsX, e // Pc.nElsX, 75.0, theta[e], rho[e], eta[e], pi[e], F[0][e], F[1][e], F[2][e], F[3][e])
+    t0 = time.perf_counter(); col(0); tc = time.perf_counter() - t0
+    ncol = max(2, int(0.5 * budget / max(tc, 1e-6)))
+    t0 = time.perf_counter()
+    for i in range(ncol):
+        col(i % nEl)
+    res.update({"columns": ncol, "col_sec": time.perf_counter() - t0})
+    return res
 
 
-def cpu_baseline(budget=6.0):
-    import multiprocessing as mp
+def granted_cores():
     cores = max(1, min(len(os.sched_getaffinity(0)), 64))
     # the box may grant fewer CPUs than it shows (a cgroup quota: 64 visible cores, 16 granted, on the one-GPU boxes of this pool): more
     # workers than granted CPUs are time-sliced, every one of them then runs a multiple of its budget and "cores" overstates what computed
@@ -197,24 +257,47 @@ def cpu_baseline(budget=6.0):
                 cores = max(1, min(cores, qq // pp))
         except Exception:
             pass
+    return cores
+
+
+def cpu_baseline(budget=6.0, cores=None):
+    """-> (cpu_baseline, cpu_baseline_column, cpu_baseline_sw): the oracle ("port") on the box's granted host cores"""
+    import multiprocessing as mp
+    cores = cores or granted_cores()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         barrier = mgr.Barrier(cores)
         with ctx.Pool(cores) as pool:
-            t0 = time.time()
             res = pool.map(cpu_worker, [(budget, s, barrier) for s in range(cores)], chunksize=1)
-            wall = time.time() - t0
-    units = sum(r[0] for r in res)
-    slowest = max(r[1] for r in res)
-    mf_units = sum(r[2] for r in res)
-    mf_slowest = max(r[3] for r in res)
-    return {"value": units / slowest, "unit": "element operator-applies/s", "cores": cores, "kind": "port",
-            "per_core": units / slowest / cores,
-            "sample": f"Umat assemble(CSR)+MatMult, reference cost structure, one 12x12-element p=3 patch per core, "
-                      f"{units // cores} element-applies per core in {slowest:.1f}s (gcc -O3)",
-            "matrix_free_value": mf_units / mf_slowest,
-            "matrix_free_note": "the reference's own matrix-free variant (Uvec::assemble restated, no matrix, no CSR) on the same cores, "
-                                f"{mf_units // cores} element-applies per core in {mf_slowest:.1f}s"}
+    units = sum(r["units"] for r in res)
+    slowest = max(r["sec"] for r in res)
+    mf_units = sum(r["mf_units"] for r in res)
+    mf_slowest = max(r["mf_sec"] for r in res)
+    b1 = {"value": units / slowest, "unit": "element operator-applies/s", "cores": cores, "kind": "port",
+          "per_core": units / slowest / cores,
+          "sample": f"Umat assemble(CSR)+MatMult, reference cost structure, one 12x12-element p=3 patch per core, "
+                    f"{units // cores} element-applies per core in {slowest:.1f}s (gcc -O3)",
+          "matrix_free_value": mf_units / mf_slowest,
+          "matrix_free_note": "the reference's own matrix-free variant (Uvec::assemble restated, no matrix, no CSR) on the same cores, "
+                              f"{mf_units // cores} element-applies per core in {mf_slowest:.1f}s"}
+    ncol = sum(r["columns"] for r in res); cslow = max(r["col_sec"] for r in res)
+    bc = {"value": ncol / cslow, "unit": "column solves/s", "cores": cores, "kind": "port", "per_core": ncol / cslow / cores,
+          "sample": f"solve_schur_column_eta (eul/VertSolve.cpp:677-823 restated, oracle/o_vertops.c: dense products + dense LU where the "
+                    f"reference has MatMatMult + PCLU), p=3, 30 levels, one column at a time per core, {ncol // cores} columns per core in {cslow:.1f}s"}
+    # one Picard iteration of the 24x24x6 sphere = 3 456 elements' worth of the timed per-element work, spread over the cores
+    sw_el = sum(r["sw_elements"] for r in res); sw_slow = max(r["sw_sec"] for r in res)
+    el_per_s = sw_el / sw_slow                                       # elements of ONE Picard iteration's operator work per second, all cores
+    nel3, nel2 = 24 * 24 * 6, 16 * 16 * 6
+    bs = {"value": el_per_s / nel3 / 2.0, "unit": "SW time-steps/s (upper bound: operator work only)", "cores": cores, "kind": "port",
+          "config3_galewsky_24x24x6_steps_per_s_upper_bound": el_per_s / nel3 / 2.0,
+          "config2_w2_16x16x6_picard_iterations_per_s_upper_bound": el_per_s / nel2,
+          "picard_iteration_operator_work_ms_24x24x6": 1e3 * nel3 / el_per_s,
+          "includes": "per Picard iteration (src/SWEqn_Picard.cpp:253-318, 402-621): 2 Uhmat + 2 WtQUmat + 2 Phmat + 2 RotMat assemblies "
+                      "(coefficient loops, triple products, CSR insertion with per-entry column search) each with one MatMult, + Umat and Wmat once",
+          "excludes": "the four Krylov solves per iteration (ksp M1, 2 x ksp0h, kspA: PETSc GMRES), ~20 further MatMults, E10/E21 products, "
+                      "upwinding of the test/trial functions, halo scatters: the real CPU rate is LOWER than this bound",
+          "sample": f"one 12x12-element p=3 patch per core, {sw_el // cores} element-iterations per core in {sw_slow:.1f}s; 2 Picard iterations per step (config 3)"}
+    return b1, bc, bs
 
 
 def replicate(dm, R):
@@ -412,7 +495,7 @@ def sweep_extras(local_rank, torch):
     from mimsem_amd.geom import Geom
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.topo import Topo
-    from tests.helpers import z_levels
+    from mimsem_amd.workloads import z_levels
     fam_bytes = {"UMAT": 1440, "WMAT": 400, "UHMAT": 1512, "WTQUMAT": 1320, "ROTMAT": 1632, "WHMAT": 472}     # B1 B3 B4 B8 B9 B11
     rng = np.random.default_rng(20241024)
     res = {}
@@ -548,7 +631,7 @@ def local_layout_extras(local_rank, rng, torch):
     from mimsem_amd.geom import Geom
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.topo import Topo
-    from tests.helpers import z_levels
+    from mimsem_amd.workloads import z_levels
     cs = CubedSphere(PN, NE, NPATCH); coords = sphere_coords(PN, NE)
     res = {}
     for paired in (False, True):
@@ -667,6 +750,121 @@ def cold_workload(dm, R, local_rank, rng, torch, steps=20):
                            "FETCH_SIZE x2 + WRITE_SIZE of the family's kernels from this run's PMC passes" % (R, dmc.nEl*NK), "rows": rows}
 
 
+def _g(d, *keys, default=None):
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _r(v, nd=4):
+    """numbers rounded to `nd` significant digits (the compact line is a record, not an archive)"""
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v)) if v == v and abs(v) != float("inf") else None
+    return v
+
+
+def compact_record(out, extras_file=None):
+    """The ONE line the driver parses (round 4: a 20.6 KB line came back as parsed = null): the contract's keys, `roofline`,
+    `roofline_cold`, `cpu_baseline` (+ _column, _sw) and one-number summaries, < 4 KB; the full object goes to `extras_file`."""
+    rec = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    rec["value"] = _r(rec["value"], 6); rec["ms_per_step"] = _r(rec["ms_per_step"], 6)
+    rec["ms_per_step_median"] = _r(out.get("ms_per_step_median"), 6)
+    cfg = out.get("config", {})
+    rec["config"] = {"workload": "Umat (B1) matrix-free apply, p=3 24x24x6 cubed sphere x 30 levels (BASELINE config 4 grid)",
+                     **{k: cfg.get(k) for k in ("order", "elements", "levels", "units_per_step", "patches_per_gpu", "form", "halo_transport") if cfg.get(k) is not None}}
+
+    def roof(r):
+        if not isinstance(r, dict) or "frac" not in r:
+            return r if r is None else {"error": str(r.get("error"))[:160]}
+        w = r.get("whole_operator", {})
+        return {"bound": "hbm", "kernel": r.get("kernel"), "achieved": _r(r.get("achieved")), "peak": r.get("peak"), "unit": "GB/s",
+                "frac": _r(r.get("frac")), "avg_kernel_us": _r(r.get("avg_kernel_us")), "bytes_per_launch": r.get("bytes_per_launch"),
+                "units_per_launch": r.get("units_per_launch"), "traffic": _r(r.get("traffic"), 6), "cache_resident": r.get("cache_resident"),
+                "whole_operator": {"kernels": w.get("kernels"), "avg_us": _r(w.get("avg_us")), "bytes_per_launch": w.get("bytes_per_launch"),
+                                   "frac": _r(w.get("frac")), "traffic_over_compulsory": _r(w.get("traffic_over_compulsory")),
+                                   "copy_of_the_same_bytes_us": _r(w.get("copy_of_the_same_bytes_us"))}}
+    if "roofline" in out:
+        rec["roofline"] = roof(out["roofline"])
+    if "roofline_cold" in out:
+        rec["roofline_cold"] = roof(out["roofline_cold"])
+        if isinstance(rec["roofline_cold"], dict) and "frac" in rec["roofline_cold"]:
+            rec["roofline_cold"]["units_per_launch"] = _g(out, "roofline_cold", "units_per_launch")
+            rec["roofline_cold"]["value"] = _r(_g(out, "roofline_cold", "value"))
+    for key in ("cpu_baseline", "cpu_baseline_column", "cpu_baseline_sw"):
+        c = out.get(key)
+        if isinstance(c, dict):
+            rec[key] = ({k: (_r(c[k]) if not isinstance(c[k], str) else c[k][:150]) for k in ("value", "unit", "cores", "kind", "matrix_free_value", "sample") if k in c}
+                        if "value" in c else {"error": str(c.get("error"))[:160]})
+    fam = _g(out, "families_cold", "rows") or {}
+    if fam:
+        rec["families_cold_frac"] = {k: _r(v.get("frac"), 3) for k, v in fam.items()}
+        rec["families_cold_traffic_over_compulsory"] = {k: _r(v.get("traffic_over_compulsory"), 3) for k, v in fam.items()}
+    col, cb = out.get("column") or {}, out.get("column_box_p4") or {}
+    summ = {"column_solves_per_s": _r(col.get("schur_column_solves_per_s")), "schur_eta_ms": _r(col.get("schur_ms_all_columns")),
+            "schur_eta_unresolved_columns": col.get("schur_unconverged_columns"),
+            "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
+            "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
+            "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
+            "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
+            "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
+            "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall"))}
+    for k in ("weak_scaled", "column_sharded", "horiz_sharded"):
+        v = out.get(k)
+        if isinstance(v, dict):
+            summ[k] = {kk: _r(v[kk]) for kk in ("value", "ms_per_step", "schur_column_solves_per_s", "ms_per_evaluation", "error") if kk in v}
+    rec["summary"] = {k: v for k, v in summ.items() if v is not None}
+    errs = [k for k, v in out.items() if isinstance(v, dict) and "error" in v]
+    if errs:
+        rec["extras_with_errors"] = errs
+    if "extras_watchdog" in out:
+        rec["extras_watchdog"] = out["extras_watchdog"]
+    if extras_file:
+        rec["extras_file"] = extras_file
+    line = json.dumps(rec)
+    if len(line) >= 4000:                                    # never let a long string cost the record: drop the prose first
+        for key in ("cpu_baseline", "cpu_baseline_column", "cpu_baseline_sw"):
+            if isinstance(rec.get(key), dict):
+                rec[key].pop("sample", None)
+        line = json.dumps(rec)
+    return rec, line
+
+
+def write_extras(out):
+    """the full object (every extra, ~20 KB) next to the compact line: bench_extras.json at the repo root and under gpurun_out/"""
+    written = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                json.dump(out, f)
+            written = written or os.path.relpath(os.path.join(d, "bench_extras.json"), ROOT)
+        except OSError:
+            pass
+    return written
+
+
+def emit(out):
+    ef = write_extras(out)
+    _, line = compact_record(out, ef)
+    sys.stdout.write(line + "\n"); sys.stdout.flush()
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE): start N fresh ranks as a CHILD torch.distributed.run -- before this
+    process has made any GPU call, never an exec -- relay its output (rank 0's compact line) and leave with its status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -692,14 +890,15 @@ def main():
                          "working set >> the 256 MiB Infinity Cache, i.e. genuinely HBM-resident; 0 skips it")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))           # (nothing has touched the GPU yet: torch is imported below)
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    import torch
+    import torch.distributed as dist
     # rehearsal of the N > 1 control flow on a one-GPU box: every rank on device 0, gloo transport staged through the host
     # (RCCL refuses two ranks on one device).  Never used by the driver; numbers from such a run mean nothing.
     rehearsal = os.environ.get("MIMSEM_BENCH_REHEARSAL") == "1"
@@ -720,7 +919,7 @@ def main():
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
     from mimsem_amd.topo import Topo
-    from tests.helpers import z_levels
+    from mimsem_amd.workloads import z_levels
 
     cs = CubedSphere(PN, NE, NPATCH)
     coords = sphere_coords(PN, NE)
@@ -894,7 +1093,7 @@ def main():
             out["extras_watchdog"] = {"note": "extras did not finish within %d s: line printed without the unfinished ones; exit status 3" % budget,
                                       "in_flight": in_flight["extra"]}
             if rank == 0:
-                sys.stdout.write(json.dumps(out) + "\n"); sys.stdout.flush()
+                emit(out)
             os._exit(3)               # a hung collective is NOT a clean run: the headline survives, the status says what happened
     budget = int(os.environ.get("MIMSEM_BENCH_EXTRAS_BUDGET", "300"))
     watchdog = None
@@ -1177,13 +1376,17 @@ def main():
         except Exception as ex:          # noqa: BLE001 -- the headline line never depends on the profiler being usable
             out["roofline"]["traffic_note"] = "PMC passes not available in this run (%s: %s): traffic stays null" % (type(ex).__name__, str(ex)[:200])
     if rank == 0 and world == 1 and not a.no_cpu:
-        extra("cpu_baseline", cpu_baseline)
+        def cpu_all():
+            b1, bc, bs = cpu_baseline()
+            out["cpu_baseline_column"] = bc; out["cpu_baseline_sw"] = bs
+            return b1
+        extra("cpu_baseline", cpu_all)
     if watchdog is not None:
         watchdog.cancel()
     if not printed.acquire(blocking=False):
         time.sleep(60)                                   # the watchdog is printing: it ends the process
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

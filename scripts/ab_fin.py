@@ -17,7 +17,7 @@ from mimsem_amd.device import DeviceMesh, Engine  # noqa: E402
 from mimsem_amd.geom import Geom  # noqa: E402
 from mimsem_amd.mesh import CubedSphere, sphere_coords  # noqa: E402
 from mimsem_amd.topo import Topo  # noqa: E402
-from tests.helpers import SCALE, z_levels  # noqa: E402
+from mimsem_amd.workloads import SCALE, z_levels  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 60

@@ -8,7 +8,7 @@ from mimsem_amd.device import DeviceMesh, Engine
 from mimsem_amd.geom import Geom
 from mimsem_amd.mesh import CubedSphere, sphere_coords
 from mimsem_amd.topo import Topo
-from tests.helpers import SCALE, z_levels
+from mimsem_amd.workloads import SCALE, z_levels
 rng = np.random.default_rng(1)
 for ne, nk in ((8, 1), (16, 1), (24, 1), (24, 4), (24, 8), (24, 30)):
     cs = CubedSphere(3, ne, 6); coords = sphere_coords(3, ne)

@@ -9,7 +9,7 @@ from mimsem_amd.device import DeviceMesh, Engine
 from mimsem_amd.geom import Geom
 from mimsem_amd.mesh import CubedSphere, sphere_coords
 from mimsem_amd.topo import Topo
-from tests.helpers import z_levels
+from mimsem_amd.workloads import z_levels
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 def report(tag, eng, call):
     for nref in (1, 2, 3, 4):

@@ -9,7 +9,7 @@ from mimsem_amd.device import DeviceMesh, Engine
 from mimsem_amd.geom import Geom, gll_points
 from mimsem_amd.mesh import CubedSphere, sphere_coords
 from mimsem_amd.topo import Topo
-from tests.helpers import z_levels
+from mimsem_amd.workloads import z_levels
 NK = bench.NK
 cs = CubedSphere(3, 24, 24); coords = sphere_coords(3, 24)
 topos = [Topo(cs, p, NK) for p in range(24)]; geoms = [Geom(t, cs, coords, NK) for t in topos]

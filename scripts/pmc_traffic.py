@@ -17,7 +17,7 @@ from mimsem_amd.device import DeviceMesh, Engine  # noqa: E402
 from mimsem_amd.geom import Geom  # noqa: E402
 from mimsem_amd.mesh import CubedSphere, sphere_coords  # noqa: E402
 from mimsem_amd.topo import Topo  # noqa: E402
-from tests.helpers import z_levels  # noqa: E402
+from mimsem_amd.workloads import z_levels  # noqa: E402
 
 PN, NE, NPATCH, NK = bench.PN, bench.NE, bench.NPATCH, bench.NK
 cs = CubedSphere(PN, NE, NPATCH)

@@ -10,7 +10,7 @@ from mimsem_amd.device import DeviceMesh, Engine
 from mimsem_amd.geom import Geom
 from mimsem_amd.mesh import CubedSphere, sphere_coords
 from mimsem_amd.topo import Topo
-from tests.helpers import z_levels
+from mimsem_amd.workloads import z_levels
 NK = 30
 for ne in (6, 12, 24, 48):
     cs = CubedSphere(3, ne, 6); coords = sphere_coords(3, ne)

@@ -8,7 +8,7 @@ Run once per suite: capture -> grow every workspace through larger requests -> s
 import numpy as np
 import pytest
 
-from tests.helpers import SCALE, z_levels
+from mimsem_amd.workloads import SCALE, z_levels
 
 pytestmark = pytest.mark.gpu
 

@@ -128,7 +128,7 @@ def test_interior_boundary_split_of_an_apply(oracle, op, fl):
     from mimsem_amd.geom import Geom
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.topo import Topo
-    from tests.helpers import SCALE, z_levels
+    from mimsem_amd.workloads import SCALE, z_levels
     cs = CubedSphere(3, 4, 6); coords = sphere_coords(3, 4)
     topos = [Topo(cs, p, 9) for p in range(6)]
     geoms = [Geom(t, cs, coords, 9) for t in topos]
@@ -171,7 +171,7 @@ def test_split_apply_contract():
     from mimsem_amd.geom import Geom
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.topo import Topo
-    from tests.helpers import SCALE, z_levels
+    from mimsem_amd.workloads import SCALE, z_levels
     cs = CubedSphere(3, 4, 6); coords = sphere_coords(3, 4)
     topos = [Topo(cs, p, 9) for p in range(6)]
     geoms = [Geom(t, cs, coords, 9) for t in topos]

@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
         from mimsem_amd.mesh import CubedSphere, sphere_coords
         from mimsem_amd.partition import CHalo, HaloExchanger, build_plans, patches_of_rank
         from mimsem_amd.topo import Topo
-        from tests.helpers import SCALE, z_levels
+        from mimsem_amd.workloads import SCALE, z_levels
         pn, ne, npatch, nk = 3, 4, 24, 3
         cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
         rng = np.random.default_rng(123)                                  # the same global field on every rank
@@ -110,14 +110,41 @@ def test_bench_multi_rank_control_flow_rehearsal():
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, [len(l) for l in lines]        # ONE compact line on stdout
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["patches_per_gpu"] == 12 and d["config"]["units_per_step"] == 103680
     assert d["config"]["halo_transport"] == "dist"                     # the C ABI's halo plans with the host-callback transport (rehearsal)
+    assert "extras_with_errors" not in d, d
+    full = json.load(open(os.path.join(root, d["extras_file"])))      # the full object sits beside it
     for key in ("weak_scaled", "column_sharded", "horiz_sharded"):     # the N > 1 extras with real work per rank ran too
-        assert key in d and "error" not in d[key], d.get(key)
-    assert d["weak_scaled"]["scaling"] == "weak" and d["weak_scaled"]["units_per_rank"] == 829440
+        assert key in full and "error" not in full[key], full.get(key)
+        assert key in d["summary"]
+    assert full["weak_scaled"]["scaling"] == "weak" and full["weak_scaled"]["units_per_rank"] == 829440
+    assert d["summary"]["weak_scaled"]["value"] == pytest.approx(full["weak_scaled"]["value"], rel=1e-3)
+
+
+def test_bench_started_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a user, or a driver without torchrun, starts it): the parent
+    starts the ranks as a CHILD torch.distributed.run before touching the GPU, relays rank 0's compact line and returns its status"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MIMSEM_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-column",
+                          "--no-horiz-sharded"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["config"]["patches_per_gpu"] == 12
+    # the mismatch the old code let through silently
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
 
 
 def test_bench_extras_watchdog_keeps_the_headline_line():

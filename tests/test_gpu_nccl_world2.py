@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
         from mimsem_amd.mesh import CubedSphere, sphere_coords
         from mimsem_amd.partition import HaloExchanger, build_plans, patches_of_rank
         from mimsem_amd.topo import Topo
-        from tests.helpers import SCALE, z_levels
+        from mimsem_amd.workloads import SCALE, z_levels
         pn, ne, npatch, nk = 3, 4, 24, 3
         cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
         xg = np.random.default_rng(123).standard_normal((nk, cs.nDofs1G))

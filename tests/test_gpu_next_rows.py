@@ -3,7 +3,7 @@ checked against a dense assembly of the oracle's element matrices on the whole (
 import numpy as np
 import pytest
 
-from tests.helpers import SCALE, z_levels
+from mimsem_amd.workloads import SCALE, z_levels
 
 pytestmark = pytest.mark.gpu
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import SCALE, z_levels
+from mimsem_amd.workloads import SCALE, z_levels
 
 gpu = pytest.mark.gpu
 
