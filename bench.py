@@ -282,8 +282,9 @@ def cpu_baseline(budget=6.0, cores=None):
                               f"{mf_units // cores} element-applies per core in {mf_slowest:.1f}s"}
     ncol = sum(r["columns"] for r in res); cslow = max(r["col_sec"] for r in res)
     bc = {"value": ncol / cslow, "unit": "column solves/s", "cores": cores, "kind": "port", "per_core": ncol / cslow / cores,
-          "sample": f"solve_schur_column_eta (eul/VertSolve.cpp:677-823 restated, oracle/o_vertops.c: dense products + dense LU where the "
-                    f"reference has MatMatMult + PCLU), p=3, 30 levels, one column at a time per core, {ncol // cores} columns per core in {cslow:.1f}s"}
+          "sample": f"oracle solve_schur_column_eta, p=3, 30 levels, one column at a time per core, {ncol // cores} columns per core in {cslow:.1f}s",
+          "note": "eul/VertSolve.cpp:677-823 restated (oracle/o_vertops.c): dense products + dense LU where the reference has MatMatMult + PCLU on "
+                  "block-sparse MATSEQAIJ matrices"}
     # one Picard iteration of the 24x24x6 sphere = 3 456 elements' worth of the timed per-element work, spread over the cores
     sw_el = sum(r["sw_elements"] for r in res); sw_slow = max(r["sw_sec"] for r in res)
     el_per_s = sw_el / sw_slow                                       # elements of ONE Picard iteration's operator work per second, all cores
@@ -346,16 +347,21 @@ def column_extras(eng, dm, rng, torch):
     t = timeit_rhs(lambda Fc: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *Fc), 5)
     res["schur_column_solves_per_s"] = nEl / t
     res["schur_ms_all_columns"] = t * 1e3
-    # the columns the unpivoted sweep cannot resolve to 1e-10 (status 1), and what the opt-in remedy costs: the same call with
-    # mimsem_column_set_pivot_fallback(1) re-solves exactly those by a band LU with partial pivoting (the reference's PCLU) inside the call
-    res["schur_unconverged_columns"] = int(eng.solve_status()[0])
-    eng.set_pivot_fallback(1)
+    # the default call re-solves the columns its unpivoted block sweep flags (status 1) by the pivoted band LU of csrc/column_pivot.inc inside
+    # the call (the reference's PCLU; on by default since round 5): what is left unresolved, how many were re-solved, and what the remedy
+    # costs -- the same call with mimsem_column_set_pivot_fallback(0)
+    nb, stf, _ = eng.solve_status()
+    res["schur_unconverged_columns"] = int(nb)
+    res["schur_columns_resolved_by_pivoted_lu"] = int((stf == 3).sum())
+    eng.set_pivot_fallback(0)
     try:
         tf = timeit_rhs(lambda Fc: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *Fc), 5)
-        nb, stf, _ = eng.solve_status()
+        nb0 = int(eng.solve_status()[0])
     finally:
-        eng.set_pivot_fallback(0)
-    res["schur_pivot_fallback"] = {"ms_all_columns": tf * 1e3, "columns_resolved_by_pivoted_lu": int((stf == 3).sum()), "unconverged_columns": int(nb)}
+        eng.set_pivot_fallback(1)
+    res["schur_pivot_fallback"] = {"ms_all_columns_with_it": t * 1e3, "ms_all_columns_without_it": tf * 1e3, "cost_frac": t / tf - 1.0,
+                                   "columns_flagged_by_the_block_sweep": nb0, "columns_resolved_by_pivoted_lu": int((stf == 3).sum()),
+                                   "unconverged_columns": int(nb)}
     # what bounds it: FP64 work counted by the SQ counters (profiles/r03_column_pmc.txt: FMA = 2 flop, MUL / ADD = 1, x 64 lanes per wave
     # instruction, all three kernels of the solve) against the 78.6 TFLOP/s vector FP64 peak, and the bytes the solve must move (the four
     # fields and four right-hand sides in, the four updated right-hand sides out, det + thickness per quadrature point) against 8 TB/s
@@ -805,6 +811,7 @@ def compact_record(out, extras_file=None):
     col, cb = out.get("column") or {}, out.get("column_box_p4") or {}
     summ = {"column_solves_per_s": _r(col.get("schur_column_solves_per_s")), "schur_eta_ms": _r(col.get("schur_ms_all_columns")),
             "schur_eta_unresolved_columns": col.get("schur_unconverged_columns"),
+            "schur_eta_columns_by_pivoted_lu": col.get("schur_columns_resolved_by_pivoted_lu"), "schur_eta_pivot_fallback_cost_frac": _r(_g(col, "schur_pivot_fallback", "cost_frac"), 3),
             "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),

@@ -354,18 +354,21 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
  * followed by up to four steps of iterative refinement, and a column stops when its correction is below 1e-10 of its solution.
  * column_status[e] (host, [nEl], may be NULL): 0 = converged, 1 = NOT converged within the allowed steps (conditioning beyond what the
  * unpivoted sweep + refinement resolves to 1e-10: judge d_* of that column by column_ratio), 2 = refinement was switched off,
- * 3 = re-solved by the pivoted fallback (mimsem_column_set_pivot_fallback below; column_ratio: of its refinement step).
+ * 3 = re-solved by the pivoted fallback (mimsem_column_set_pivot_fallback below, on by default) AND verified: every norm finite, normwise
+ *     backward error of the refined solution <= 1e-12; column_ratio: of its refinement step (the conditioning-limited forward indicator).
+ *     A flagged column the fallback cannot verify (NaN / Inf data, a singular system) keeps status 1, its d and a ratio that says why.
  * column_ratio[e] (host, [nEl], may be NULL): |last correction| / |solution| of the column -- how far its refinement got (on rough random
  * columns with cond(L) ~ 1e10 it settles near 1e-9, where LAPACK's pivoted LU leaves the same residual; a ratio >> 1e-8 is a failed solve).
  * *n_unconverged = number of columns with status 1, or -1 when the last solve ran on a path that keeps no status (orders >= 5,
  * MIMSEM_SCHUR_FUSED=rows|wave|0: pivoted Gauss-Jordan inside the blocks + one refinement step).  Synchronises the context's stream. */
 int mimsem_column_solve_status(mimsem_ctx* ctx, int* n_unconverged, int* column_status, double* column_ratio);
-/* The remedy for status 1 (round 4; off by default, MIMSEM_COLUMN_PIVOT_FALLBACK=1 switches it on at context creation): with on != 0 every
- * later mimsem_column_solve_schur_eta / _3 re-solves the columns its unpivoted sweep flags INSIDE the call -- an unblocked band LU with
- * partial pivoting over the whole band, what the reference's PCLU does for every column (eul/VertSolve.cpp:645-653, :806-812), plus one
- * refinement step -- before the back substitution reads the solution.  Such a column reports status 3 and the ratio of that step; it no
- * longer counts in *n_unconverged.  Cost: one extra small launch per solve when nothing is flagged, about a millisecond per flagged
- * column otherwise (at most 64 per call; the rest stay 1).  Columns with more than 1 024 unknowns (nk n2e) are left as they are.
+/* The remedy for status 1 -- ON BY DEFAULT since round 5 (the reference solves every column with PCLU, eul/VertSolve.cpp:645-653, :783-789,
+ * :806-812; MIMSEM_COLUMN_PIVOT_FALLBACK=0 at context creation or on == 0 here switch it off): every mimsem_column_solve_schur_eta / _3
+ * re-solves the columns its unpivoted sweep flags INSIDE the call, before the back substitution reads the solution -- an LU with partial
+ * pivoting over the whole band (one wavefront per flagged column on the block structure, csrc/column_pivot.inc) plus one refinement step.
+ * Such a column reports status 3 (see above) and no longer counts in *n_unconverged.  Cost: one launch whose wavefronts read the
+ * unconverged counter and leave when nothing is flagged; tens of microseconds (order 3) when something is -- the flagged columns run
+ * concurrently, any number of them.  Orders 1..4, up to 1 024 unknowns per column (nk n2e); beyond that columns are left as they are.
  * on == 2: EVERY column goes through the pivoted LU (validation mode: the reference's algorithm for all columns, at its price). */
 int mimsem_column_set_pivot_fallback(mimsem_ctx* ctx, int on);
 /* the assembled block-tridiagonal L_pi itself: out [nEl][nk][3][n2e][n2e] (sub, diag, super)       */

@@ -736,7 +736,9 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     // the register-row form on the config-5 grid, profiles/r03_mfma_p4_ab.txt), off at p <= 3 (24 x 24: 25.3 against 23.8 us);
     // MIMSEM_BLOCKS_MFMA=0 | 1 overrides
     c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") ? atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
-    c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 0;      // (mimsem_column_set_pivot_fallback)
+    if (d->nEl > 0) { c->h_e1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_e1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
+                      c->h_e0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e); }
+    c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 1;      // on by default since round 5 (mimsem_column_set_pivot_fallback)
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
         c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
         c->h_i0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e);

@@ -91,6 +91,8 @@ struct mimsem_ctx {
     struct { bool pending = false; int op = 0, lev0 = 0, nlev = 0; unsigned flags = 0; const double* y = nullptr; long long ys = 0; } split;
     int w_nbgroups = 0, w_nbrec = 0; bool w_split = false;     // interior / boundary split (mimsem_ctx_set_halo_slots): boundary prefix sizes
     std::vector<int> h_i1x, h_i1y, h_i0; std::vector<double> h_J, h_det;      // host copies of the mesh for re-deriving the plan
+    std::vector<int> h_e0;              // element -> 0-form slot lists (node multiplicities, likewise)
+    std::vector<int> h_e1x, h_e1y;      // element -> 1-form slot lists, kept on EVERY context (edge multiplicities of the PCBJACOBI builders, ksp.hip)
     int4* d_wlane = nullptr;            // [w_ngroups][64] {element of the lane, load pair: even slot b, staging positions of x[b] and of x[b+1]
                                         //   (two 16-bit positions each; the dump position where nobody wants the value)}
     int4* d_wplan = nullptr;            // [w_ngroups][64] store pair {dst, result positions of its first and second slot (2 x 16 bit, the
@@ -112,8 +114,8 @@ struct mimsem_ctx {
     double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
     int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
-    int pivot_fallback = 0;     // mimsem_column_set_pivot_fallback: flagged columns are re-solved by a band LU with partial pivoting (column_pivot.inc)
-    double* d_lu = nullptr;     // its workspace: slot counter + band storage of up to 64 flagged columns
+    int pivot_fallback = 1;     // mimsem_column_set_pivot_fallback: flagged columns are re-solved by a band LU with partial pivoting (column_pivot.inc)
+    double* d_lu = nullptr;     // its workspace: per wavefront of the fallback's grid, the rows of U and the multipliers of one column
     long long lu_doubles = 0;
     long long col_doubles = 0;
     double col_param = 0.0;             // scalar argument of the *_ex column operators (dt_fric / dt)

@@ -111,7 +111,7 @@ struct mimsem_ksp {
     // preconditioner
     int pkind = P_NONE; const double* dinv = nullptr; long long dinvs = 0;
     int bform = 1; bool btrans = false; const double* blocks = nullptr; const double* escale = nullptr; long long escales = 0;
-    double* own_blocks = nullptr; double* own_escale = nullptr;
+    double* own_blocks = nullptr; double* own_escale = nullptr; double* own_dinv = nullptr;
     mimsem_ksp_apply_fn pfn = nullptr; void* puser = nullptr;
     // controls
     double rtol = 1.0e-16, atol = 1.0e-50; int maxit = 1000, restart = 30, check_every = 2; bool guess_nonzero = false;
@@ -127,9 +127,10 @@ struct mimsem_ksp {
     int ensure(long long doubles, long long hostd) {
         if (doubles > ws_doubles) {
             if (c->is_capturing()) return MIMSEM_ERR_STATE;
-            if (ws) c->retired.push_back(ws);
-            MIMSEM_HIP_TRY(hipMalloc((void**)&ws, (size_t)doubles*sizeof(double)));
-            ws_doubles = doubles;
+            double* nw = nullptr;                                    // the new buffer first: on failure `ws` still names a live allocation
+            MIMSEM_HIP_TRY(hipMalloc((void**)&nw, (size_t)doubles*sizeof(double)));
+            if (ws) c->retired.push_back(ws);                        // (a captured graph may still hold its address: retired, not freed)
+            ws = nw; ws_doubles = doubles;
         }
         if (hostd > host_doubles) {
             if (host) (void)hipHostFree(host);
@@ -278,8 +279,9 @@ int solve_gmres(mimsem_ksp* k, const double* b, long long bs, double* x, long lo
             MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
             if (*k->flag) {
                 // the Pythagorean norm of the two-launch form cancelled: this object switches to the three-launch form for good and
-                // the cycle restarts from the current iterate (nothing of the failed step is used)
-                k->gs_fused = false; *k->flag = 0; kk = 0; done = false;
+                // the cycle restarts from the iterate the kk = j COMPLETED steps of this cycle give (their Hessenberg columns are valid
+                // and their iterations counted; only the failed step is dropped)
+                k->gs_fused = false; *k->flag = 0; done = false;
                 break;
             }
             for (int i = 0; i <= j; i++) H[(size_t)i*m + j] = col[i];
@@ -335,6 +337,7 @@ void mimsem_ksp_destroy(mimsem_ksp* k) {
     if (k->flag) (void)hipHostFree(k->flag);
     if (k->own_blocks) (void)hipFree(k->own_blocks);
     if (k->own_escale) (void)hipFree(k->own_escale);
+    if (k->own_dinv) (void)hipFree(k->own_dinv);
     delete k;
 }
 int mimsem_ksp_set_operator(mimsem_ksp* k, int op, int geom_lev0, int nlev, double scale, unsigned flags, const double* f, long long fs) {
@@ -346,6 +349,9 @@ int mimsem_ksp_set_operator(mimsem_ksp* k, int op, int geom_lev0, int nlev, doub
     case MIMSEM_OP_PMAT: case MIMSEM_OP_PHMAT: in = out = 0; break;
     default: return MIMSEM_ERR_ARG;
     }
+    // the thickness factor (flag bit 0) reads the context's level tables: they must be there and cover [geom_lev0, geom_lev0 + nlev)
+    if ((flags & 1u) && (!k->c->have_levels || !k->c->d_tI)) return MIMSEM_ERR_STATE;
+    if ((flags & 1u) && geom_lev0 + nlev > k->c->nk) return MIMSEM_ERR_ARG;
     k->akind = A_OP; k->op = op; k->lev0 = geom_lev0; k->nlev = nlev; k->scale = scale; k->flags = flags; k->f = f; k->fs = fs;
     k->form = in; k->n = in == 0 ? k->c->n0 : (in == 1 ? k->c->n1 : k->c->n2);
     (void)out;
@@ -383,46 +389,95 @@ int mimsem_ksp_set_pc_shell(mimsem_ksp* k, mimsem_ksp_apply_fn fn, void* user) {
     k->pkind = P_SHELL; k->pfn = fn; k->puser = user;
     return MIMSEM_OK;
 }
-int mimsem_ksp_set_pc_bjacobi(mimsem_ksp* k) {
-    if (!k || k->akind != A_OP || k->form != 1) return MIMSEM_ERR_STATE;
-    mimsem_ctx* c = k->c;
-    if (c->is_capturing()) return MIMSEM_ERR_STATE;
-    const int n1e = c->es.n1e, nd = 2*n1e, nEl = c->nEl;
-    if ((int)c->h_i1x.size() != nEl*n1e || (int)c->h_i1y.size() != nEl*n1e) return MIMSEM_ERR_STATE;
-    // D_e = 1 / multiplicity of the element's edges
+// edge multiplicities -> D_e = 1 / multiplicity per element-local 1-form dof (`stride` entries per element, the first 2 n1e are edges)
+static int edge_weights(const mimsem_ctx* c, int stride, std::vector<double>& d) {
+    const int n1e = c->es.n1e, nd1 = 2*n1e, nEl = c->nEl;
+    if ((long long)c->h_e1x.size() != (long long)nEl*n1e || (long long)c->h_e1y.size() != (long long)nEl*n1e) return MIMSEM_ERR_STATE;
     std::vector<int> mult(c->n1, 0);
-    for (int v : c->h_i1x) mult[v]++;
-    for (int v : c->h_i1y) mult[v]++;
-    std::vector<double> d((size_t)nEl*nd);
+    for (int v : c->h_e1x) { if (v < 0 || v >= c->n1) return MIMSEM_ERR_ARG; mult[v]++; }
+    for (int v : c->h_e1y) { if (v < 0 || v >= c->n1) return MIMSEM_ERR_ARG; mult[v]++; }
+    d.assign((size_t)nEl*stride, 1.0);
     for (int e = 0; e < nEl; e++)
-        for (int i = 0; i < nd; i++) d[(size_t)e*nd + i] = 1.0/mult[i < n1e ? c->h_i1x[(size_t)e*n1e + i] : c->h_i1y[(size_t)e*n1e + i - n1e]];
-    const long long tot = (long long)nEl*nd*nd;
-    double *em = nullptr, *dd = nullptr;
-    if (k->own_blocks) { (void)hipFree(k->own_blocks); k->own_blocks = nullptr; }
-    if (k->own_escale) { (void)hipFree(k->own_escale); k->own_escale = nullptr; }
-    MIMSEM_HIP_TRY(hipMalloc((void**)&k->own_blocks, (size_t)tot*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&em, (size_t)tot*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&dd, d.size()*8));
+        for (int i = 0; i < nd1; i++) d[(size_t)e*stride + i] = 1.0/mult[i < n1e ? c->h_e1x[(size_t)e*n1e + i] : c->h_e1y[(size_t)e*n1e + i - n1e]];
+    return MIMSEM_OK;
+}
+// 0-forms: with quadrature order == element order the 0-form mass matrices (Pmat, Phmat) are DIAGONAL (l_j(x_q) = delta_jq): the block
+// preconditioner is the inverse of the assembled diagonal, per level -- exact.  Assembled on the host in element order (set-up only,
+// reproducible sums), from the same element matrices the reference hands to MatSetValues.
+static int zero_form_jacobi(mimsem_ksp* k) {
+    mimsem_ctx* c = k->c;
+    const int n0e = c->es.n0e, nEl = c->nEl, n0 = c->n0, nlev = k->nlev;
+    if ((long long)c->h_e0.size() != (long long)nEl*n0e) return MIMSEM_ERR_STATE;
+    if (mimsem_op_elmat_size(c, k->op) != n0e*n0e) return MIMSEM_ERR_UNSUPPORTED;
+    for (int v : c->h_e0) if (v < 0 || v >= n0) return MIMSEM_ERR_ARG;
+    const size_t esz = (size_t)nEl*n0e*n0e;
+    double *em = nullptr, *dinv = nullptr;
+    std::vector<double> hem(esz), diag((size_t)nlev*n0, 0.0);
     int rc = MIMSEM_OK;
     do {
-        if (hipMemcpyAsync(dd, d.data(), d.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
-        // the element's dense block WITHOUT its thickness factor (flag bit 0 off): one inverse per element serves every level
-        const bool vert = (k->flags & 1u) != 0;
-        if ((rc = mimsem_op_element_matrices(c, k->op, k->lev0, k->scale, k->flags & ~1u, k->f, em))) break;
-        hipLaunchKernelGGL(k_em_to_block, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, n1e, em, k->own_blocks);
-        if ((rc = mimsem_block_inverse(c, nEl, nd, k->own_blocks))) break;
-        hipLaunchKernelGGL(k_scale_blocks, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, nd, dd, k->own_blocks);
-        if (vert) {
-            const long long ne = (long long)k->nlev*nEl;
-            if (hipMalloc((void**)&k->own_escale, (size_t)ne*8) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
-            hipLaunchKernelGGL(k_escale, dim3((unsigned)((ne + 255)/256)), dim3(256), 0, c->stream, ne, c->es.mp12,
-                               c->d_tI + (size_t)k->lev0*nEl*c->es.mp12, k->own_escale);
+        if (hipMalloc((void**)&em, esz*8) != hipSuccess || hipMalloc((void**)&dinv, diag.size()*8) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        for (int l = 0; l < nlev && !rc; l++) {
+            if ((rc = mimsem_op_element_matrices(c, k->op, k->lev0 + l, k->scale, k->flags, k->f ? k->f + (size_t)l*k->fs : nullptr, em))) break;
+            if (hipMemcpyAsync(hem.data(), em, esz*8, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+            for (int e = 0; e < nEl; e++)
+                for (int i = 0; i < n0e; i++) diag[(size_t)l*n0 + c->h_e0[(size_t)e*n0e + i]] += hem[((size_t)e*n0e + i)*n0e + i];
         }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        if (rc) break;
+        for (double& v : diag) v = v != 0.0 ? 1.0/v : 1.0;              // (a slot no element touches: identity)
+        if (hipMemcpyAsync(dinv, diag.data(), diag.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = MIMSEM_ERR_HIP;
+    } while (0);
+    (void)hipFree(em);
+    if (rc) { (void)hipFree(dinv); return rc; }
+    if (k->own_dinv) (void)hipFree(k->own_dinv);
+    k->own_dinv = dinv;
+    k->pkind = P_JACOBI; k->dinv = dinv; k->dinvs = n0;
+    return MIMSEM_OK;
+}
+// PCBJACOBI with one block per element, built from the operator of mimsem_ksp_set_operator (PCSetUp).  1-forms: the 2 n1e edges of an
+// element (eul/HorizSolve.cpp:82-85); 2-forms: the element's faces -- the mass matrix is block diagonal, the block inverse is exact
+// (cf. WmatInv, eul/Assembly.cpp:1673-1722); 0-forms (ksp0 of src/SWEqn_Picard.cpp): the mass matrix is diagonal, its inverse exact
+// (zero_form_jacobi above).
+int mimsem_ksp_set_pc_bjacobi(mimsem_ksp* k) {
+    if (!k || k->akind != A_OP || k->form < 0 || k->form > 2) return MIMSEM_ERR_STATE;
+    mimsem_ctx* c = k->c;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    const int form = k->form, n1e = c->es.n1e, nEl = c->nEl;
+    if (form == 0) return zero_form_jacobi(k);
+    const int nd = form == 1 ? 2*n1e : c->es.n2e;
+    const bool vert = (k->flags & 1u) != 0;
+    if (vert && (!c->have_levels || !c->d_tI)) return MIMSEM_ERR_STATE;          // (levels dropped since mimsem_ksp_set_operator)
+    if (vert && k->lev0 + k->nlev > c->nk) return MIMSEM_ERR_ARG;
+    // one inverse per element serves every level: the block WITHOUT its thickness factor (flag bit 0 off) and 1 / mean(thickInv) per
+    // (level, element) beside it.  A single-level solve of a 0- or 2-form operator keeps the factor inside the block (exact inverse).
+    const bool split_thickness = vert && (form == 1 || k->nlev > 1);
+    std::vector<double> d;
+    int rc = form == 1 ? edge_weights(c, nd, d) : MIMSEM_OK;
+    if (rc) return rc;
+    const long long tot = (long long)nEl*nd*nd, ne = (long long)k->nlev*nEl;
+    if (mimsem_op_elmat_size(c, k->op) != (form == 1 ? 4*n1e*n1e : nd*nd)) return MIMSEM_ERR_UNSUPPORTED;
+    double *em = nullptr, *dd = nullptr, *blocks = nullptr, *escale = nullptr;
+    do {                                                              // one exit: every temporary is freed on every path
+        if (hipMalloc((void**)&blocks, (size_t)tot*8) != hipSuccess || (form == 1 && hipMalloc((void**)&em, (size_t)tot*8) != hipSuccess) ||
+            (!d.empty() && hipMalloc((void**)&dd, d.size()*8) != hipSuccess) ||
+            (split_thickness && hipMalloc((void**)&escale, (size_t)ne*8) != hipSuccess)) { rc = MIMSEM_ERR_HIP; break; }
+        if (dd && hipMemcpyAsync(dd, d.data(), d.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        const unsigned fl = split_thickness ? (k->flags & ~1u) : k->flags;
+        if ((rc = mimsem_op_element_matrices(c, k->op, k->lev0, k->scale, fl, k->f, form == 1 ? em : blocks))) break;
+        if (form == 1) hipLaunchKernelGGL(k_em_to_block, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, n1e, em, blocks);
+        if ((rc = mimsem_block_inverse(c, nEl, nd, blocks))) break;
+        if (dd) hipLaunchKernelGGL(k_scale_blocks, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, nd, dd, blocks);
+        if (split_thickness)
+            hipLaunchKernelGGL(k_escale, dim3((unsigned)((ne + 255)/256)), dim3(256), 0, c->stream, ne, c->es.mp12,
+                               c->d_tI + (size_t)k->lev0*nEl*c->es.mp12, escale);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
     } while (0);
     (void)hipFree(em); (void)hipFree(dd);
-    if (rc) return rc;
-    k->pkind = P_BLOCKS; k->bform = 1; k->btrans = true /* symmetric blocks: the coalesced read direction */; k->blocks = k->own_blocks; k->escale = k->own_escale; k->escales = nEl;
+    if (rc) { (void)hipFree(blocks); (void)hipFree(escale); return rc; }        // the handle keeps the preconditioner it had
+    if (k->own_blocks) (void)hipFree(k->own_blocks);
+    if (k->own_escale) (void)hipFree(k->own_escale);
+    k->own_blocks = blocks; k->own_escale = escale;
+    // (1-form blocks are symmetric: the coalesced read direction; a 0- or 2-form block of an upwinded / weighted operator need not be)
+    k->pkind = P_BLOCKS; k->bform = form; k->btrans = form == 1; k->blocks = k->own_blocks; k->escale = k->own_escale; k->escales = nEl;
     return MIMSEM_OK;
 }
 // the coupled [u|h] element blocks of the shallow-water operator, built from the operator given to mimsem_ksp_set_operator_sw
@@ -432,24 +487,15 @@ int mimsem_ksp_set_pc_sw_bjacobi(mimsem_ksp* k) {
     if (c->is_capturing()) return MIMSEM_ERR_STATE;
     const int n = c->es.n, n1e = c->es.n1e, n2e = c->es.n2e, nd1 = 2*n1e, ND = nd1 + n2e, nEl = c->nEl;
     if (ND > 64) return MIMSEM_ERR_UNSUPPORTED;                        // mimsem_sw_blocks_apply: orders 1..4
-    if ((int)c->h_i1x.size() != nEl*n1e || (int)c->h_i1y.size() != nEl*n1e) return MIMSEM_ERR_STATE;
-    std::vector<int> mult(c->n1, 0);
-    for (int v : c->h_i1x) mult[v]++;
-    for (int v : c->h_i1y) mult[v]++;
-    std::vector<double> d((size_t)nEl*ND, 1.0);
-    for (int e = 0; e < nEl; e++)
-        for (int i = 0; i < nd1; i++) d[(size_t)e*ND + i] = 1.0/mult[i < n1e ? c->h_i1x[(size_t)e*n1e + i] : c->h_i1y[(size_t)e*n1e + i - n1e]];
+    std::vector<double> d;
+    int rc = edge_weights(c, ND, d);
+    if (rc) return rc;
     const long long tot = (long long)nEl*ND*ND;
-    double *em1 = nullptr, *rot = nullptr, *em2 = nullptr, *Ae = nullptr, *dd = nullptr;
-    if (k->own_blocks) { (void)hipFree(k->own_blocks); k->own_blocks = nullptr; }
-    MIMSEM_HIP_TRY(hipMalloc((void**)&k->own_blocks, (size_t)tot*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&em1, (size_t)nEl*4*n1e*n1e*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&rot, (size_t)nEl*2*n1e*n1e*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&em2, (size_t)nEl*n2e*n2e*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&Ae, (size_t)tot*8));
-    MIMSEM_HIP_TRY(hipMalloc((void**)&dd, d.size()*8));
-    int rc = MIMSEM_OK;
+    double *em1 = nullptr, *rot = nullptr, *em2 = nullptr, *Ae = nullptr, *dd = nullptr, *blocks = nullptr;
     do {
+        if (hipMalloc((void**)&blocks, (size_t)tot*8) != hipSuccess || hipMalloc((void**)&em1, (size_t)nEl*4*n1e*n1e*8) != hipSuccess ||
+            hipMalloc((void**)&rot, (size_t)nEl*2*n1e*n1e*8) != hipSuccess || hipMalloc((void**)&em2, (size_t)nEl*n2e*n2e*8) != hipSuccess ||
+            hipMalloc((void**)&Ae, (size_t)tot*8) != hipSuccess || hipMalloc((void**)&dd, d.size()*8) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
         if (hipMemcpyAsync(dd, d.data(), d.size()*8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
         // src/ flavour: unit scale, no thickness (mimsem_sw_operator_apply)
         if ((rc = mimsem_op_element_matrices(c, MIMSEM_OP_UMAT, 0, 1.0, 0, nullptr, em1))) break;
@@ -457,11 +503,13 @@ int mimsem_ksp_set_pc_sw_bjacobi(mimsem_ksp* k) {
         if ((rc = mimsem_op_element_matrices(c, MIMSEM_OP_WMAT, 0, 1.0, 0, nullptr, em2))) break;
         hipLaunchKernelGGL(k_sw_block, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, n, n1e, n2e, k->sw_a, k->sw_g, k->sw_H, em1, rot, em2, Ae);
         if ((rc = mimsem_block_inverse(c, nEl, ND, Ae))) break;
-        hipLaunchKernelGGL(k_scale_transpose, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, ND, dd, Ae, k->own_blocks);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
+        hipLaunchKernelGGL(k_scale_transpose, dim3((unsigned)((tot + 255)/256)), dim3(256), 0, c->stream, tot, ND, dd, Ae, blocks);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = MIMSEM_ERR_HIP; break; }
     } while (0);
     (void)hipFree(em1); (void)hipFree(rot); (void)hipFree(em2); (void)hipFree(Ae); (void)hipFree(dd);
-    if (rc) return rc;
+    if (rc) { (void)hipFree(blocks); return rc; }
+    if (k->own_blocks) (void)hipFree(k->own_blocks);
+    k->own_blocks = blocks;
     k->pkind = P_SW; k->blocks = k->own_blocks;
     return MIMSEM_OK;
 }

@@ -667,8 +667,9 @@ class Engine:
         return n.value, st[:self.nEl], ratio[:self.nEl]
 
     def set_pivot_fallback(self, on=True):
-        """later solve_schur_eta / solve_schur_3 calls re-solve the columns their unpivoted sweep flags by a band LU with partial pivoting (what
-        the reference's PCLU does for every column); such columns report status 3 -- mimsem_column_set_pivot_fallback"""
+        """(on by default) solve_schur_eta / solve_schur_3 re-solve the columns their unpivoted sweep flags by an LU with partial pivoting over
+        the band (what the reference's PCLU does for every column); verified re-solves report status 3; 0 switches it off --
+        mimsem_column_set_pivot_fallback"""
         check(self.L.mimsem_column_set_pivot_fallback(self.ctx, int(on)), "column_set_pivot_fallback")      # (2: every column, validation mode)
 
     # ---- Krylov building blocks ----------------------------------------------------------------

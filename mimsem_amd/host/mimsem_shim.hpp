@@ -231,7 +231,7 @@ public:
 //   KSPSetType(ksp1, KSPGMRES); KSPGetPC(ksp1, &pc); PCSetType(pc, PCBJACOBI); PCBJacobiSetTotalBlocks(pc, size*nElsX*nElsX, NULL); ...
 //   KSPSolve(ksp1, b, x);
 // becomes
-//   KSP ksp1(&M1_mesh);  ksp1.setOperators(M1);  ksp1.setTolerances(1.0e-16, 1.0e-50, 1000);  ksp1.setType(KSP::GMRES);  ksp1.setPCBJacobi();
+//   KSP ksp1(&M1_mesh);  ksp1.setOperators(M1);  ksp1.setTolerances(1.0e-16, 1.0e-50, 1000);  ksp1.setType(KSP::GMRES);  ksp1.setPCBJacobi();     (any order)
 //   ksp1.solve(b, x);        // after every M1->assemble(lev, SCALE, true): setOperators(M1) again (the reference re-assembles M1->M in place)
 // The loops run inside libmimsem_hip (mimsem_ksp_*): no host code between the iterations except the convergence test.
 class KSP {
@@ -240,11 +240,17 @@ public:
     explicit KSP(Mesh* m, Type t = GMRES) : mesh(m), type(t) { check(mimsem_ksp_create(mesh->ctx, (int)t, &h), "mimsem_ksp_create"); }
     ~KSP() { mimsem_ksp_destroy(h); }
     KSP(const KSP&) = delete; KSP& operator=(const KSP&) = delete;
-    void setType(Type t) {                                   // KSPSetType (re-creates the object: tolerances are kept)
+    // The setters may come in ANY order, as with PETSc (the reference calls KSPSetOperators before KSPSetType / PCSetType,
+    // eul/HorizSolve.cpp:77-84): the object remembers operator, type and preconditioner choice; the library handle is brought up to date
+    // -- operator re-attached after a type change, preconditioner (re)built from the current operator: PCSetUp -- at the next solve().
+    void setType(Type t) {                                   // KSPSetType (re-creates the library object; operator, tolerances and PC choice are kept)
         if (t == type) return;
-        mimsem_ksp_destroy(h); h = nullptr; type = t; pc_set = false;
+        mimsem_ksp_destroy(h); h = nullptr; type = t;
         check(mimsem_ksp_create(mesh->ctx, (int)t, &h), "mimsem_ksp_create");
         check(mimsem_ksp_set_tolerances(h, rtol, atol, maxit, restart, 2), "mimsem_ksp_set_tolerances");
+        if (guess) check(mimsem_ksp_set_initial_guess_nonzero(h, 1), "mimsem_ksp_set_initial_guess_nonzero");
+        attach_operator();
+        pc_dirty = true;
     }
     void setTolerances(double rtol_, double atol_, int maxit_, int restart_ = 30) {       // KSPSetTolerances (dtol unused, as in the reference)
         rtol = rtol_; atol = atol_; maxit = maxit_; restart = restart_;
@@ -253,29 +259,62 @@ public:
     // KSPSetOperators(ksp, X->M, X->M): the operator in the state its last assemble() left it (one level, like the reference's Mat)
     void setOperators(const OperatorBase& A) {
         if (A.is_up()) fail("KSP::setOperators: the upwinded operators go through setOperatorsShell");
-        check(mimsem_ksp_set_operator(h, A.op_id(), A.level(), 1, A.op_scale(), A.op_flags(), A.op_field(), 0), "mimsem_ksp_set_operator");
-        if (bjacobi) check(mimsem_ksp_set_pc_bjacobi(h), "mimsem_ksp_set_pc_bjacobi");        // PCSetUp on the new matrix
+        akind = A_OP; a_op = A.op_id(); a_lev = A.level(); a_scale = A.op_scale(); a_flags = A.op_flags(); a_field = A.op_field();
+        attach_operator();
+        pc_dirty = true;                                     // PCSetUp on the new matrix, at the next solve
     }
     // the packed [u|h] operator of SWEqn::assemble_operator (src/SWEqn_Picard.cpp:622-725) and its coupled element-block preconditioner
     // (PCBJACOBI: the blocks are built from the operator -- PCSetUp -- unless the caller brings its own)
     void setOperatorsSW(double a, double grav, double H, const double* f0, const double* blocks = nullptr) {
-        check(mimsem_ksp_set_operator_sw(h, 1, a, grav, H, f0, 0), "mimsem_ksp_set_operator_sw");
-        if (blocks) check(mimsem_ksp_set_pc_sw_blocks(h, blocks), "mimsem_ksp_set_pc_sw_blocks");
-        else if (bjacobi) check(mimsem_ksp_set_pc_sw_bjacobi(h), "mimsem_ksp_set_pc_sw_bjacobi");
+        akind = A_SW; sw_a = a; sw_g = grav; sw_H = H; sw_f0 = f0; sw_blocks = blocks;
+        attach_operator();
+        pc_dirty = true;
     }
-    void setOperatorsShell(long long n, mimsem_ksp_apply_fn fn, void* user) { check(mimsem_ksp_set_operator_shell(h, 1, n, fn, user), "mimsem_ksp_set_operator_shell"); }
-    void setPCBJacobi() { bjacobi = true; }                  // PCSetType(pc, PCBJACOBI) + PCBJacobiSetTotalBlocks(one block per element)
-    void setPCNone() { bjacobi = false; check(mimsem_ksp_set_pc_none(h), "mimsem_ksp_set_pc_none"); }
-    void setPCShell(mimsem_ksp_apply_fn fn, void* user) { bjacobi = false; check(mimsem_ksp_set_pc_shell(h, fn, user), "mimsem_ksp_set_pc_shell"); }
-    void setInitialGuessNonzero(bool f) { check(mimsem_ksp_set_initial_guess_nonzero(h, f ? 1 : 0), "mimsem_ksp_set_initial_guess_nonzero"); }
+    void setOperatorsShell(long long n, mimsem_ksp_apply_fn fn, void* user) {
+        akind = A_SHELL; sh_n = n; sh_fn = fn; sh_user = user;
+        attach_operator();
+        pc_dirty = true;
+    }
+    void setPCBJacobi() { pc = PC_BJACOBI; pc_dirty = true; }    // PCSetType(pc, PCBJACOBI) + PCBJacobiSetTotalBlocks(one block per element)
+    void setPCNone() { pc = PC_NONE; pc_dirty = true; }
+    void setPCShell(mimsem_ksp_apply_fn fn, void* user) { pc = PC_SHELL; pc_fn = fn; pc_user = user; pc_dirty = true; }
+    void setInitialGuessNonzero(bool f) { guess = f; check(mimsem_ksp_set_initial_guess_nonzero(h, f ? 1 : 0), "mimsem_ksp_set_initial_guess_nonzero"); }
     void solve(const double* b, double* x) {                 // KSPSolve(ksp, b, x)
+        if (akind == A_NONE) fail("KSP::solve before setOperators");
+        if (pc_dirty) setup_pc();
         check(mimsem_ksp_solve(h, b, 0, x, 0), "mimsem_ksp_solve");
         check(mimsem_ksp_get_info(h, &its, &rnorm, &reason), "mimsem_ksp_get_info");
     }
     int iterations() const { return its; } double residualNorm() const { return rnorm; } int convergedReason() const { return reason; }
 private:
     static void fail(const char* m) { throw std::runtime_error(m); }
-    Mesh* mesh; Type type; mimsem_ksp* h = nullptr; bool bjacobi = false, pc_set = false;
+    enum AKind { A_NONE, A_OP, A_SW, A_SHELL };
+    enum PKind { PC_NONE, PC_BJACOBI, PC_SHELL };
+    void attach_operator() {
+        switch (akind) {
+        case A_OP: check(mimsem_ksp_set_operator(h, a_op, a_lev, 1, a_scale, a_flags, a_field, 0), "mimsem_ksp_set_operator"); break;
+        case A_SW: check(mimsem_ksp_set_operator_sw(h, 1, sw_a, sw_g, sw_H, sw_f0, 0), "mimsem_ksp_set_operator_sw"); break;
+        case A_SHELL: check(mimsem_ksp_set_operator_shell(h, 1, sh_n, sh_fn, sh_user), "mimsem_ksp_set_operator_shell"); break;
+        case A_NONE: break;
+        }
+    }
+    void setup_pc() {                                        // PCSetUp: from the operator the handle holds NOW
+        if (pc == PC_SHELL) check(mimsem_ksp_set_pc_shell(h, pc_fn, pc_user), "mimsem_ksp_set_pc_shell");
+        else if (pc == PC_BJACOBI && akind == A_OP) check(mimsem_ksp_set_pc_bjacobi(h), "mimsem_ksp_set_pc_bjacobi");      // 0-, 1- and 2-form operators
+        else if (pc == PC_BJACOBI && akind == A_SW) {
+            if (sw_blocks) check(mimsem_ksp_set_pc_sw_blocks(h, sw_blocks), "mimsem_ksp_set_pc_sw_blocks");
+            else check(mimsem_ksp_set_pc_sw_bjacobi(h), "mimsem_ksp_set_pc_sw_bjacobi");
+        } else if (pc == PC_BJACOBI) fail("KSP: PCBJACOBI needs an operator the library can take element blocks of (setOperators / setOperatorsSW), not a shell");
+        else if (akind == A_SW && sw_blocks) check(mimsem_ksp_set_pc_sw_blocks(h, sw_blocks), "mimsem_ksp_set_pc_sw_blocks");
+        else check(mimsem_ksp_set_pc_none(h), "mimsem_ksp_set_pc_none");
+        pc_dirty = false;
+    }
+    Mesh* mesh; Type type; mimsem_ksp* h = nullptr;
+    AKind akind = A_NONE; PKind pc = PC_NONE; bool pc_dirty = true, guess = false;
+    int a_op = 0, a_lev = 0; double a_scale = 1.0; unsigned a_flags = 0; const double* a_field = nullptr;
+    double sw_a = 0.0, sw_g = 0.0, sw_H = 0.0; const double* sw_f0 = nullptr; const double* sw_blocks = nullptr;
+    long long sh_n = 0; mimsem_ksp_apply_fn sh_fn = nullptr; void* sh_user = nullptr;
+    mimsem_ksp_apply_fn pc_fn = nullptr; void* pc_user = nullptr;
     double rtol = 1.0e-16, atol = 1.0e-50; int maxit = 1000, restart = 30;
     int its = 0, reason = 0; double rnorm = 0.0;
 };

@@ -133,6 +133,65 @@ int main() {
         if (ksp1.convergedReason() <= 0 || cg.convergedReason() <= 0) { std::printf("not converged: %d %d\n", ksp1.convergedReason(), cg.convergedReason()); fails++; }
         mimsem_free(d_phi); mimsem_free(d_Mphi); mimsem_free(d_dMphi); mimsem_free(d_u);
     }
+    // ---- the reference's own call ORDER (eul/HorizSolve.cpp:77-84: KSPSetOperators, then KSPSetType, then PCSetType(PCBJACOBI)) and the
+    // 2-form / 0-form solves (ksp2 on M2: eul/HorizSolve.cpp:86-96; ksp0 on M0: src/SWEqn_Picard.cpp:84-96).  The preconditioner must be in
+    // place whatever the order (same iteration count as ksp1 above), a type change must keep the operator, and the element blocks of a
+    // 2-form (block-diagonal) and of a 0-form (diagonal, collocated) mass matrix invert it exactly: one or two iterations.
+    {
+        std::vector<double> b1(n1), x1(n1), b2(n2), x2(n2), b0(P->n0), x0(P->n0);
+        for (auto& v : b1) v = S(rng); for (auto& v : b2) v = S(rng); for (auto& v : b0) v = S(rng);
+        double *d_b = mesh.to_device(b1.data(), n1), *d_x = mesh.device_alloc(n1);
+        M1.assemble(lev, SCALE, true);
+        KSP k1(&mesh, KSP::CG);                              // created as something else on purpose
+        k1.setOperators(M1);                                 // KSPSetOperators first ...
+        k1.setTolerances(1.0e-16, 1.0e-50, 1000);
+        k1.setType(KSP::GMRES);                              // ... then the type (re-creates the library object) ...
+        k1.setPCBJacobi();                                   // ... then the preconditioner
+        KSPSolve(k1, d_b, d_x);
+        mesh.to_host(x1.data(), d_x, n1);
+        ksp1.setOperators(M1);
+        KSPSolve(ksp1, d_b, d_x);                            // the order the shim's own tests used so far
+        std::vector<double> A1 = dense_of(ORC_UMAT, 1, nullptr, n1), w1 = b1;
+        dense_solve(A1, w1, n1);
+        report("M1, PETSc order", rel_l2(x1, w1), 1e-10, k1.iterations());
+        if (k1.iterations() != ksp1.iterations() || k1.convergedReason() <= 0) { std::printf("order-dependent solve: %d vs %d iterations\n", k1.iterations(), ksp1.iterations()); fails++; }
+        KSP kn(&mesh, KSP::GMRES);                           // the same solve unpreconditioned needs visibly more iterations
+        kn.setTolerances(1.0e-16, 1.0e-50, 1000);
+        kn.setOperators(M1);
+        KSPSolve(kn, d_b, d_x);
+        if (kn.iterations() <= k1.iterations()) { std::printf("PCBJACOBI did nothing: %d vs %d iterations\n", k1.iterations(), kn.iterations()); fails++; }
+        mimsem_free(d_b); mimsem_free(d_x);
+
+        M2.assemble(lev, SCALE, true);
+        double *d_b2 = mesh.to_device(b2.data(), n2), *d_x2 = mesh.device_alloc(n2);
+        KSP k2(&mesh);
+        k2.setOperators(M2);
+        k2.setTolerances(1.0e-16, 1.0e-50, 1000);
+        k2.setType(KSP::GMRES);
+        k2.setPCBJacobi();
+        KSPSolve(k2, d_b2, d_x2);
+        mesh.to_host(x2.data(), d_x2, n2);
+        std::vector<double> A2 = dense_of(ORC_WMAT, 1, nullptr, n2), w2 = b2;
+        dense_solve(A2, w2, n2);
+        report("M2, BJACOBI", rel_l2(x2, w2), 1e-10, k2.iterations());
+        if (k2.iterations() > 2 || k2.convergedReason() <= 0) { std::printf("2-form element blocks are not the exact inverse: %d iterations\n", k2.iterations()); fails++; }
+        mimsem_free(d_b2); mimsem_free(d_x2);
+
+        Pmat M0(&topo, &geom, &node);
+        M0.assemble(lev, SCALE);
+        double *d_b0 = mesh.to_device(b0.data(), P->n0), *d_x0 = mesh.device_alloc(P->n0);
+        KSP k0(&mesh);
+        k0.setOperators(M0);
+        k0.setTolerances(1.0e-16, 1.0e-50, 1000);
+        k0.setPCBJacobi();
+        KSPSolve(k0, d_b0, d_x0);
+        mesh.to_host(x0.data(), d_x0, P->n0);
+        std::vector<double> A0 = dense_of(ORC_PMAT, 0, nullptr, P->n0), w0 = b0;
+        dense_solve(A0, w0, P->n0);
+        report("M0, BJACOBI", rel_l2(x0, w0), 1e-10, k0.iterations());
+        if (k0.iterations() > 2 || k0.convergedReason() <= 0) { std::printf("0-form element blocks are not the exact inverse: %d iterations\n", k0.iterations()); fails++; }
+        mimsem_free(d_b0); mimsem_free(d_x0);
+    }
     // ---- HorizSolve::diagnose_fluxes(level, u1, u2, h1l, h2l, theta_l, _F, _G, u1l, u2l, theta_in_Wt = false) ----
     {
         std::vector<double> u1(n1), u2(n1), h1(n2), h2(n2), th(n2), Fh(n1), Gh(n1);

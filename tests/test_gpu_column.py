@@ -7,6 +7,7 @@ from tests.helpers import dense_from_band, make_patch, rel_l2, solve_error_budge
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
+HARD = 1e-9       # unconditional ceiling beside the conditioning-aware budget of the Schur solves (round-4 verdict: a budget alone floats)
 
 
 @pytest.fixture(scope="module", params=[(3, 2, 6, 1, 6), (4, 1, 6, 0, 5), (2, 2, 6, 3, 4), (3, 3, 6, 2, 8)], ids=lambda p: "p%d_ne%d_np%d_pi%d_nk%d" % p)
@@ -140,8 +141,9 @@ def test_schur_column_solve(setup):
         assert b["hip_vs_own_system"] < TOL, b
         bound = max(TOL, 4.0 * b["diff_of_exact_solutions"] + b["hip_vs_own_system"] + b["oracle_vs_own_system"])
         assert b["diff"] < bound, b
+        assert b["diff"] < HARD, b                                      # the budget explains a difference, it does not license any: hard ceiling
         for name, got in (("d_u", d_u), ("d_eta", d_eta), ("d_rho", d_rho), ("F_u", dFu), ("F_rho", dFrho), ("F_eta", dFeta), ("F_pi", dFpi)):
-            assert rel_l2(got[e].cpu().numpy(), ref[name]) < max(TOL, 50.0 * bound), (name, b)
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < min(max(TOL, 50.0 * bound), 50.0 * HARD), (name, b)
 
 
 def test_two_sided_thomas_sweep_equals_the_one_sided(setup):
@@ -337,8 +339,9 @@ def test_schur_column_3_pentadiagonal(setup, flags):
         assert b["hip_vs_own_system"] < TOL, b
         bound = max(TOL, 4.0 * b["diff_of_exact_solutions"] + b["hip_vs_own_system"] + b["oracle_vs_own_system"])
         assert b["diff"] < bound, b
+        assert b["diff"] < HARD, b
         for name, got in (("d_u", d_u), ("d_pi", d_pi), ("d_rho", d_rho), ("F_u", dFu), ("F_rho", dFrho), ("F_rt", dFrt), ("F_pi", dFpi)):
-            assert rel_l2(got[e].cpu().numpy(), ref[name]) < max(TOL, 50.0 * bound), (name, b)
+            assert rel_l2(got[e].cpu().numpy(), ref[name]) < min(max(TOL, 50.0 * bound), 50.0 * HARD), (name, b)
 
 
 def test_vertical_incidence(setup):
@@ -587,7 +590,7 @@ def test_pivoted_band_lu_solves_every_column(oracle, pn, ne, nk, kind):
         out, Fs, _ = run()
         nbad, st, ratio = eng.solve_status()
     finally:
-        eng.set_pivot_fallback(0)
+        eng.set_pivot_fallback(1)                                       # (the default)
     assert nbad == 0 and (st == 3).all() and (ratio < 1e-10).all(), (nbad, np.unique(st), float(ratio.max()))
     f_key = 3 if kind == "eta" else 2
     for e in range(nEl):

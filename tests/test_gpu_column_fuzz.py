@@ -55,7 +55,7 @@ def test_fused_column_solves_over_shapes_and_task_splits(oracle, pn, ne, nk, chu
         try:
             c = run(); st = eng.solve_status()[1]
         finally:
-            eng.set_pivot_fallback(0)
+            eng.set_pivot_fallback(1)
         assert (st == 3).all()
         for x, y in zip(a, c):
             assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < TOL2

@@ -144,6 +144,7 @@ def test_column_solve_reports_the_columns_it_cannot_resolve(full):
     n2, nEl = eng.n2e, dm.nEl
     area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
     flagged_total, worst_unflagged, worst_ratio = 0, 0.0, 0.0
+    eng.set_pivot_fallback(0)                                            # the block sweep ALONE (the remedy is on by default since round 5)
     for seed in (77, 1, 2, 3):
         rng = np.random.default_rng(seed)
         lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
@@ -179,11 +180,12 @@ def test_column_solve_reports_the_columns_it_cannot_resolve(full):
         nbad, st, ratio = eng.solve_status()
     finally:
         del os.environ["MIMSEM_NO_REFINE"]
+        eng.set_pivot_fallback(1)
     assert nbad == 0 and (st == 2).all()
 
 
 def test_pivot_fallback_resolves_the_flagged_columns(full):
-    """Round 4: with mimsem_column_set_pivot_fallback(1) the columns the unpivoted sweep flags (the test above) are re-solved inside the
+    """Round 4 (default since round 5): the columns the unpivoted sweep flags (the test above) are re-solved inside the
     call by a band LU with partial pivoting -- the reference's PCLU (eul/VertSolve.cpp:806-812) for exactly the columns that need it:
     no column is left with status 1, the re-solved ones (status 3) satisfy their system as well as LAPACK's pivoted solve of the same
     bands does, and every other column keeps its bits"""
@@ -199,16 +201,16 @@ def test_pivot_fallback_resolves_the_flagged_columns(full):
         F0 = [rng.standard_normal((nEl, n * n2)) * 1e8 for n in (NK - 1, NK, NK, NK)]
         L = eng.helmholtz_blocks(75.0, theta, rho, eta, pi).view(nEl, NK, 3, n2, n2)
         F = [eng.tensor(x) for x in F0]
-        ref = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
-        nbad0, st0, _ = eng.solve_status()
-        assert nbad0 > 0
-        eng.set_pivot_fallback(1)
+        eng.set_pivot_fallback(0)
         try:
-            F = [eng.tensor(x) for x in F0]
-            out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
-            nbad, st, ratio = eng.solve_status()
+            ref = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+            nbad0, st0, _ = eng.solve_status()
         finally:
-            eng.set_pivot_fallback(0)
+            eng.set_pivot_fallback(1)
+        assert nbad0 > 0
+        F = [eng.tensor(x) for x in F0]
+        out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)              # the DEFAULT call (round 5: the remedy is on)
+        nbad, st, ratio = eng.solve_status()
         assert nbad == 0 and set(np.unique(st)) <= {0, 3}, (nbad, np.unique(st))
         assert ((st == 3) == (st0 == 1)).all()                          # exactly the flagged columns were re-solved
         keep = torch.as_tensor(st0 == 0, device=out[0].device)
@@ -226,6 +228,38 @@ def test_pivot_fallback_resolves_the_flagged_columns(full):
             seen += 1
         print("seed %d: %d columns re-solved by the pivoted fallback, largest ratio %.1e" % (seed, int((st == 3).sum()), float(ratio[st == 3].max())))
     assert seen > 0
+
+
+def test_pivot_fallback_never_marks_a_failed_column_solved(full):
+    """round-4 advisor: the fallback marked EVERY column it processed 3 and decremented the counter, whatever came out -- a NaN right-hand
+    side or a singular system read as "solved by the pivoted fallback, ratio 0".  Status 3 now needs a verified solve (finite norms, normwise
+    backward error <= 1e-12): a column with a NaN / Inf in its right-hand side keeps status 1 with a non-finite ratio, and stays counted."""
+    import torch
+    cs, dm, eng, _ = full
+    n2, nEl = eng.n2e, dm.nEl
+    area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    rng = np.random.default_rng(5)
+    lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+    theta, rho, eta, pi = lev(NK, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 5, 6), lev(NK, 700, 1000)
+    F0 = [rng.standard_normal((nEl, n * n2)) * 1e8 for n in (NK - 1, NK, NK, NK)]
+    F = [eng.tensor(x) for x in F0]
+    clean = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+    nb0, st0, _ = eng.solve_status()
+    assert nb0 == 0 and set(np.unique(st0)) <= {0, 3}
+    bad = {7: float("nan"), 1234: float("inf"), nEl - 1: float("nan")}
+    F = [eng.tensor(x) for x in F0]
+    for e, v in bad.items():
+        F[3][e, 11 * n2 + 3] = v                                         # one poisoned entry of F_pi
+    out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *F)
+    nb, st, ratio = eng.solve_status()
+    assert nb == len(bad), (nb, np.nonzero(st == 1)[0])
+    for e in bad:
+        assert st[e] == 1 and not np.isfinite(ratio[e]), (e, st[e], ratio[e])
+    ok = np.ones(nEl, bool); ok[list(bad)] = False
+    assert (st[ok] == st0[ok]).all()
+    keep = torch.as_tensor(ok, device=out[0].device)
+    for a, b in zip(out, clean):
+        assert torch.equal(a[keep], b[keep])                             # the neighbours of a poisoned column keep their bits
 
 
 def test_column_solve_3_satisfies_its_block_pentadiagonal_system(full):

@@ -394,7 +394,7 @@ def test_config5_pivoted_band_lu_at_the_size_limit(cfg5):
             out = run()
             nbad, st, ratio = eng.solve_status()
         finally:
-            eng.set_pivot_fallback(0)
+            eng.set_pivot_fallback(1)
         assert nbad == 0 and (st == 3).all() and ratio.max() < 1e-10, (nbad, np.unique(st), float(ratio.max()))
         for a, b in zip(out, ref):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-9

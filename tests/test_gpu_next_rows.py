@@ -375,3 +375,78 @@ def test_vertical_newton_loop_with_horizontal_transport():
     assert all(bool(torch.isfinite(o).all()) for o in out)
     h = vs.history
     assert h[-1]["exner"] < 0.2 * h[0]["exner"] and h[-1]["rho"] < h[0]["rho"] and h[-1]["exner"] < 1e-3, h
+
+
+def test_c_abi_ksp_bjacobi_on_every_context_and_form(oracle):
+    """round-4 advisor: (a) PCBJACOBI took the edge multiplicities from host copies only the wave-eligible contexts kept -- a p = 5 context
+    or MIMSEM_WAVE=0 got MIMSEM_ERR_STATE; (b) a level window outside the context's levels reached the kernels unchecked; (c) 0- and 2-form
+    operators (ksp0, ksp2 of the reference) were refused.  Each case: the call's return code and the solve against a dense solve."""
+    import os
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.krylov import KSP
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+
+    def build(pn, ne, nk, env=None):
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+            topos = [Topo(cs, p, nk) for p in range(6)]; geoms = [Geom(t, cs, coords, nk) for t in topos]
+            levs = z_levels(nk, geoms[0].n0)
+            for g in geoms:
+                g.set_levels(levs)
+            return cs, Engine(DeviceMesh(topos, geoms, nk=nk, numbering="global"))
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    def dense(eng, op, n, nlev, flags):
+        """column j = the operator applied to e_j (per level)"""
+        I = eng.tensor(np.eye(n))
+        out = []
+        for k in range(nlev):
+            cols = [eng.apply(op, I[j:j + 1].contiguous(), lev0=k, scale=SCALE, flags=flags).cpu().numpy()[0] for j in range(n)]
+            out.append(np.array(cols).T)
+        return out
+
+    rng = np.random.default_rng(12)
+    for pn, ne, env in ((5, 1, None), (3, 2, {"MIMSEM_WAVE": "0"})):
+        cs, eng = build(pn, ne, 2, env)
+        b = rng.standard_normal((2, cs.nDofs1G)) * 1e9
+        ksp = KSP(eng, "cg").set_operator("UMAT", 2, scale=SCALE, flags=1)
+        ksp.set_pc("bjacobi").set_tolerances(rtol=1e-15, atol=1e-300, maxit=400)
+        x = ksp.solve(eng.tensor(b)).cpu().numpy()
+        assert ksp.reason in ("rtol", "atol"), (pn, ksp.reason)
+        its_pc = ksp.iterations
+        for k, A in enumerate(dense(eng, "UMAT", cs.nDofs1G, 2, 1)):
+            ref = np.linalg.solve(A, b[k])
+            assert np.linalg.norm(x[k] - ref) / np.linalg.norm(ref) < 1e-10, (pn, k)
+        ksp = KSP(eng, "cg").set_operator("UMAT", 2, scale=SCALE, flags=1)
+        ksp.set_pc("none").set_tolerances(rtol=1e-15, atol=1e-300, maxit=400)
+        ksp.solve(eng.tensor(b))
+        assert ksp.iterations > its_pc, (pn, its_pc, ksp.iterations)
+        # the level window is checked where it is given
+        L, h = eng.L, KSP(eng, "cg")
+        from mimsem_amd.device import OPS
+        assert L.mimsem_ksp_set_operator(h.h, OPS["UMAT"], 1, 2, SCALE, 1, None, 0) == -1          # levels 1..2 of 2: MIMSEM_ERR_ARG
+        assert L.mimsem_ksp_set_operator(h.h, OPS["UMAT"], 1, 2, SCALE, 0, None, 0) == 0           # without the thickness factor no table is read
+        assert L.mimsem_ksp_set_pc_bjacobi(h.h) == 0
+        # 2-forms: block-diagonal mass matrix, the element blocks are its inverse; 0-forms: diagonal (collocated) mass matrix, likewise
+        for op, n, flags, form in (("WMAT", cs.nDofs2G, 1, 2), ("PMAT", cs.nDofs0G, 0, 0)):
+            bb = rng.standard_normal((1, n)) * 1e9
+            ksp = KSP(eng, "gmres").set_operator(op, 1, lev0=1, scale=SCALE, flags=flags)
+            ksp.set_pc("bjacobi").set_tolerances(rtol=1e-15, atol=1e-300, maxit=50)
+            xx = ksp.solve(eng.tensor(bb)).cpu().numpy()
+            assert ksp.iterations <= 2 and ksp.reason in ("rtol", "atol"), (op, ksp.iterations, ksp.reason)
+            I = eng.tensor(np.eye(n))
+            A = np.array([eng.apply(op, I[j:j + 1].contiguous(), lev0=1, scale=SCALE, flags=flags).cpu().numpy()[0] for j in range(n)]).T
+            ref = np.linalg.solve(A, bb[0])
+            assert np.linalg.norm(xx[0] - ref) / np.linalg.norm(ref) < 1e-10, op
+        del eng
+        torch.cuda.empty_cache()
