@@ -661,6 +661,17 @@ def local_layout_extras(local_rank, rng, torch):
             row[label] = {"applies_per_s": dmp.nEl*nl/wall, "us_per_call_wall": wall*1e6, "kernel_us": (c1 + c2)/cn*1e3}
         res["paired_local" if paired else "reference_local"] = row
         del e
+    # the same patch from a C++ host over the shim (mimsem_amd/host/bench_call.cpp, built by __graft_entry__.build()): the reference's own
+    # per-level loop as written, the same loop recorded in a hipGraph (mimsem_graph_*) and one 30-level call -- a child process
+    exe = os.path.join(ROOT, "mimsem_amd", "host", "bench_call")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            res["cpp_host"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as ex:          # noqa: BLE001
+            res["cpp_host"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return {"workload": "Umat apply on ONE 12x12-element patch (144 elements) of the config-4 sphere in a rank-LOCAL vector layout", "rows": res}
 
 
@@ -817,7 +828,9 @@ def compact_record(out, extras_file=None):
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
             "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
             "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
-            "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall"))}
+            "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall")),
+            "cpp_host_per_level_call_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_us_per_call")),
+            "cpp_host_per_level_call_in_graph_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_in_a_graph_us_per_call"))}
     for k in ("weak_scaled", "column_sharded", "horiz_sharded"):
         v = out.get(k)
         if isinstance(v, dict):

@@ -355,7 +355,7 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
  * column_status[e] (host, [nEl], may be NULL): 0 = converged, 1 = NOT converged within the allowed steps (conditioning beyond what the
  * unpivoted sweep + refinement resolves to 1e-10: judge d_* of that column by column_ratio), 2 = refinement was switched off,
  * 3 = re-solved by the pivoted fallback (mimsem_column_set_pivot_fallback below, on by default) AND verified: every norm finite, normwise
- *     backward error of the refined solution <= 1e-12; column_ratio: of its refinement step (the conditioning-limited forward indicator).
+ *     backward error of the pivoted solve <= 1e-12; column_ratio: of its refinement step (the conditioning-limited forward indicator).
  *     A flagged column the fallback cannot verify (NaN / Inf data, a singular system) keeps status 1, its d and a ratio that says why.
  * column_ratio[e] (host, [nEl], may be NULL): |last correction| / |solution| of the column -- how far its refinement got (on rough random
  * columns with cond(L) ~ 1e10 it settles near 1e-9, where LAPACK's pivoted LU leaves the same residual; a ratio >> 1e-8 is a failed solve).
@@ -588,6 +588,24 @@ int  mimsem_halo_set_transport(mimsem_halo* plan, mimsem_halo_transport_fn fn, v
 int  mimsem_halo_set_loopback(mimsem_halo* plan);
 int  mimsem_halo_begin(mimsem_halo* plan, int mode, int nlev, double* v, long long v_stride);
 int  mimsem_halo_end(mimsem_halo* plan);
+
+/* ---- hipGraph capture of a launch sequence, for hosts that carry no HIP toolchain (the C++ shim, a PETSc application) -------------------
+ * The reference calls its operators one level at a time -- for (kk ...) { M1->assemble(kk, SCALE, true); MatMult(M1->M, x[kk], y[kk]); ... }
+ * (eul/Euler_2.cpp:1427-1457, eul/HorizSolve.cpp:651-699) -- and on one rank's patch (144 elements) such a call is two ~4 us kernels
+ * behind ~10 us of launch cost.  A host that keeps that loop can record it ONCE: mimsem_graph_begin puts the context's stream into
+ * capture (a context on the default stream gets a stream of its own for the duration), every call of this library made on the context
+ * until mimsem_graph_end is recorded instead of executed -- calls that synchronise, copy to pageable host memory or would have to grow a
+ * workspace return MIMSEM_ERR_STATE (run the sequence once un-captured first) -- and mimsem_graph_launch replays the whole sequence with
+ * one submission, in stream order with the context's other work.  Pointers are baked in: the replay reads and writes the same
+ * arrays (VecGetArray of the same Vecs).  Replaces: nothing in the reference (PETSc has no such facility); it is what "capture
+ * launch-bound inner loops in hipGraphs" means for a host behind this C ABI.
+ * Errors: MIMSEM_ERR_STATE (begin while capturing, end without begin, a capture invalidated by an illegal call), MIMSEM_ERR_HIP. */
+typedef struct mimsem_graph mimsem_graph;
+int  mimsem_graph_begin(mimsem_ctx* ctx);
+int  mimsem_graph_end(mimsem_ctx* ctx, mimsem_graph** out);
+int  mimsem_graph_launch(mimsem_graph* graph);
+int  mimsem_graph_num_nodes(const mimsem_graph* graph);
+void mimsem_graph_destroy(mimsem_graph* graph);
 
 #ifdef __cplusplus
 }

@@ -772,10 +772,66 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     delete c;
 }
 
-int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) { if (!c) return MIMSEM_ERR_ARG; c->stream = (hipStream_t)s; return MIMSEM_OK; }
+int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) {
+    if (!c) return MIMSEM_ERR_ARG;
+    if (c->cap_active) return MIMSEM_ERR_STATE;                          // (between mimsem_graph_begin and _end the stream is the capture's)
+    c->stream = (hipStream_t)s;
+    return MIMSEM_OK;
+}
+// ---- hipGraph capture for hosts without a HIP toolchain (include/mimsem_hip.h) -----------------------------------------------------
+struct mimsem_graph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t stream = nullptr; int nodes = 0; };
+int mimsem_graph_begin(mimsem_ctx* c) {
+    if (!c) return MIMSEM_ERR_ARG;
+    if (c->cap_active || c->is_capturing()) return MIMSEM_ERR_STATE;
+    MIMSEM_HIP_TRY(hipSetDevice(c->device));
+    c->cap_swapped = false;
+    if (c->stream == nullptr) {                                          // the legacy default stream cannot capture: a blocking stream of the
+        if (!c->cap_stream) MIMSEM_HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamDefault));   // context's own keeps its order with it
+        c->cap_saved = c->stream; c->stream = c->cap_stream; c->cap_swapped = true;
+    }
+    const hipError_t he = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    if (he != hipSuccess) {
+        if (c->cap_swapped) { c->stream = c->cap_saved; c->cap_swapped = false; }
+        return mimsem::hip_fail(he, "hipStreamBeginCapture");
+    }
+    c->cap_active = true;
+    return MIMSEM_OK;
+}
+int mimsem_graph_end(mimsem_ctx* c, mimsem_graph** out) {
+    if (!c || !out) return MIMSEM_ERR_ARG;
+    if (!c->cap_active) return MIMSEM_ERR_STATE;
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    const hipError_t he = hipStreamEndCapture(c->stream, &g);
+    const hipStream_t used = c->stream;
+    c->cap_active = false;
+    if (c->cap_swapped) { c->stream = c->cap_saved; c->cap_swapped = false; }
+    if (he != hipSuccess || !g) { (void)hipGetLastError(); return he == hipSuccess ? MIMSEM_ERR_STATE : mimsem::hip_fail(he, "hipStreamEndCapture"); }
+    mimsem_graph* gr = new mimsem_graph();
+    gr->g = g; gr->stream = used;
+    size_t nn = 0;
+    if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) gr->nodes = (int)nn;
+    const hipError_t hi = hipGraphInstantiate(&gr->x, g, nullptr, nullptr, 0);
+    if (hi != hipSuccess) { (void)hipGraphDestroy(g); delete gr; return mimsem::hip_fail(hi, "hipGraphInstantiate"); }
+    *out = gr;
+    return MIMSEM_OK;
+}
+int mimsem_graph_launch(mimsem_graph* g) {
+    if (!g || !g->x) return MIMSEM_ERR_ARG;
+    MIMSEM_HIP_TRY(hipGraphLaunch(g->x, g->stream));
+    return MIMSEM_OK;
+}
+int mimsem_graph_num_nodes(const mimsem_graph* g) { return g ? g->nodes : MIMSEM_ERR_ARG; }
+void mimsem_graph_destroy(mimsem_graph* g) {
+    if (!g) return;
+    if (g->x) (void)hipGraphExecDestroy(g->x);
+    if (g->g) (void)hipGraphDestroy(g->g);
+    delete g;
+}
 int mimsem_ctx_sync(mimsem_ctx* c) { if (!c) return MIMSEM_ERR_ARG; MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream)); return MIMSEM_OK; }
 long long mimsem_ctx_workspace_bytes(const mimsem_ctx* c) { return c ? c->bytes : 0; }
 int mimsem_op_level_chunk(const mimsem_ctx* c, int nlev) { return (c && nlev > 0) ? level_chunk(c, nlev) : MIMSEM_ERR_ARG; }

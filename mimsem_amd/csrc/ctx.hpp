@@ -26,6 +26,7 @@ struct ElemSizes {
 struct mimsem_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t cap_stream = nullptr, cap_saved = nullptr; bool cap_active = false, cap_swapped = false;      // mimsem_graph_begin / _end
     ElemSizes es;
     int nEl = 0, nk = 0, n0 = 0, n1 = 0, n2 = 0;
     bool inds2_contig = true;

@@ -191,6 +191,29 @@ private:
     Mesh* mesh; mimsem_halo *rev = nullptr, *fwd = nullptr;
 };
 
+// A recorded launch sequence (mimsem_graph_*): the reference's per-level loops -- for (kk ...) { M1->assemble(kk, SCALE, true);
+// M1->mult(x[kk], y[kk]); } (eul/Euler_2.cpp:1427-1457) -- written once between begin() and end(), replayed by launch() with one
+// submission.  The arrays are the ones named while recording (VecGetArray of the same Vecs); run the loop once un-recorded first so that
+// the library's workspaces have their size.
+class Graph {
+public:
+    explicit Graph(Mesh* m) : mesh(m) {}
+    ~Graph() { mimsem_graph_destroy(g); }
+    Graph(const Graph&) = delete; Graph& operator=(const Graph&) = delete;
+    void begin() { mimsem_graph_destroy(g); g = nullptr; check(mimsem_graph_begin(mesh->ctx), "mimsem_graph_begin"); }
+    void end() { check(mimsem_graph_end(mesh->ctx, &g), "mimsem_graph_end"); }
+    void launch() { check(mimsem_graph_launch(g), "mimsem_graph_launch"); }
+    int nodes() const { return mimsem_graph_num_nodes(g); }
+    // record f() -- the host's own loop -- with the capture closed on every exit path
+    template <class F> void record(F&& f) {
+        begin();
+        try { f(); } catch (...) { mimsem_graph* junk = nullptr; (void)mimsem_graph_end(mesh->ctx, &junk); mimsem_graph_destroy(junk); throw; }
+        end();
+    }
+private:
+    Mesh* mesh; mimsem_graph* g = nullptr;
+};
+
 // common part of every operator class: remembers what assemble() was given, mult() issues the fused launch
 class OperatorBase {
 protected:

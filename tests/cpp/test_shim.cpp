@@ -69,6 +69,54 @@ int main() {
     compare("Uhmat");
 
 
+    // ---- the reference's per-level loop recorded once (Graph::record -> mimsem_graph_*) and replayed: the replay must write the same bits as
+    // the loop itself, see its inputs' CURRENT values, and a call that cannot be recorded must say so and leave the context usable
+    {
+        Wmat M2(&topo, &geom, &edge);
+        std::vector<double> x2((size_t)nk*P->n2), y2((size_t)nk*P->n2), r2((size_t)nk*P->n2), y1((size_t)nk*P->n1), r1((size_t)nk*P->n1), uu((size_t)nk*P->n1);
+        for (auto& v : x2) v = S(rng); for (auto& v : uu) v = S(rng);
+        double *d_x2 = mesh.to_device(x2.data(), x2.size()), *d_y2 = mesh.device_alloc(x2.size()), *d_uu = mesh.to_device(uu.data(), uu.size()), *d_y1 = mesh.device_alloc(uu.size());
+        auto loop = [&]() {
+            for (int kk = 0; kk < nk; kk++) {
+                M1.assemble(kk, SCALE, true); M1.mult(d_uu + (size_t)kk*P->n1, d_y1 + (size_t)kk*P->n1);
+                M2.assemble(kk, SCALE, true); M2.mult(d_x2 + (size_t)kk*P->n2, d_y2 + (size_t)kk*P->n2);
+            }
+        };
+        loop();
+        mesh.to_host(r1.data(), d_y1, r1.size()); mesh.to_host(r2.data(), d_y2, r2.size());
+        Graph g(&mesh);
+        g.record(loop);
+        check(mimsem_memset(mesh.ctx, d_y1, 0, (long long)(r1.size()*8)), "memset"); check(mimsem_memset(mesh.ctx, d_y2, 0, (long long)(r2.size()*8)), "memset");
+        g.launch();
+        mesh.to_host(y1.data(), d_y1, y1.size()); mesh.to_host(y2.data(), d_y2, y2.size());
+        bool same = y1 == r1 && y2 == r2;
+        // new values in the same arrays: the replay reads them
+        for (auto& v : uu) v = S(rng);
+        check(mimsem_memcpy_h2d(mesh.ctx, d_uu, uu.data(), (long long)(uu.size()*8)), "h2d");
+        loop(); mesh.to_host(r1.data(), d_y1, r1.size());
+        check(mimsem_memset(mesh.ctx, d_y1, 0, (long long)(r1.size()*8)), "memset");
+        g.launch(); g.launch();
+        mesh.to_host(y1.data(), d_y1, y1.size());
+        same = same && y1 == r1 && g.nodes() >= 2*nk;
+        std::printf("%-8s %s (%d nodes)\n", "Graph", same ? "bit-exact replay" : "MISMATCH", g.nodes()); if (!same) fails++;
+        // what cannot be recorded is refused, and the context survives: a device-to-host copy inside a recording
+        int rc_bad = MIMSEM_OK;
+        check(mimsem_graph_begin(mesh.ctx), "graph_begin");
+        if (mimsem_graph_begin(mesh.ctx) != MIMSEM_ERR_STATE) fails++;                      // (no nesting)
+        rc_bad = mimsem_ctx_set_stream(mesh.ctx, nullptr);
+        mimsem_graph* junk = nullptr;
+        const int rc_end = mimsem_graph_end(mesh.ctx, &junk);
+        mimsem_graph_destroy(junk);
+        if (rc_bad != MIMSEM_ERR_STATE || rc_end != MIMSEM_OK || mimsem_graph_end(mesh.ctx, &junk) != MIMSEM_ERR_STATE) { std::printf("Graph    state codes %d %d\n", rc_bad, rc_end); fails++; }
+        M1.assemble(1, SCALE, true);                                                     // eager calls work as before
+        M1.mult(d_u, d_y);
+        orc_op_elmats(P, ORC_UMAT, 1, SCALE, 1, nullptr, em.data());
+        std::fill(want.begin(), want.end(), 0.0);
+        orc_op_apply(P, ORC_UMAT, em.data(), u.data(), want.data());
+        compare("Umat'");
+        mimsem_free(d_x2); mimsem_free(d_y2); mimsem_free(d_uu); mimsem_free(d_y1);
+    }
+
     // ---- upwinded test functions: M1->assemble_up(lev, SCALE, tau, ui, uj); MatMult(M1->M, ..) and MatMult(M1->MT, ..)  (eul/Assembly.cpp:156-279)
     {
         double tI = 0.0; for (int j = 0; j < P->n0q; j++) tI += P->thickInv[(size_t)1*P->n0q + j]; tI /= P->n0q;
