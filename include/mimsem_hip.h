@@ -589,6 +589,14 @@ int  mimsem_halo_set_loopback(mimsem_halo* plan);
 int  mimsem_halo_begin(mimsem_halo* plan, int mode, int nlev, double* v, long long v_stride);
 int  mimsem_halo_end(mimsem_halo* plan);
 
+/* Self-test of the half-row block algebra of order 4 (csrc/column_dpp.inc, dpp::RowsH: a 16 x 16 block row split over two lanes, the layout the
+ * order-4 walk of solve_schur_column_3 runs on): for ntask sets of blocks A, B [ntask][16][16] (row-major), vectors x [ntask][16] and
+ * quadrature-point coefficients cq [ntask][25] (all device) it writes, per task, out[825] = { A B + B A (256), A^-1 by the unpivoted
+ * Gauss-Jordan (256; A symmetric positive definite), W^T diag(cq) W (256), A x (16), sum_j W[q][j] x[j] at the 25 points, 16 probe values }.
+ * Test infrastructure of the library itself (tests/test_gpu_rows_half.py compares with numpy); replaces nothing in the reference.
+ * MIMSEM_ERR_UNSUPPORTED unless the context is of order 4.  Synchronises. */
+int  mimsem_selftest_rows_half(mimsem_ctx* ctx, int ntask, const double* A, const double* B, const double* x, const double* cq, double* out);
+
 /* ---- hipGraph capture of a launch sequence, for hosts that carry no HIP toolchain (the C++ shim, a PETSc application) -------------------
  * The reference calls its operators one level at a time -- for (kk ...) { M1->assemble(kk, SCALE, true); MatMult(M1->M, x[kk], y[kk]); ... }
  * (eul/Euler_2.cpp:1427-1457, eul/HorizSolve.cpp:651-699) -- and on one rank's patch (144 elements) such a call is two ~4 us kernels

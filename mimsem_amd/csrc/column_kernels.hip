@@ -2544,6 +2544,58 @@ int mimsem_column_helmholtz_blocks(mimsem_ctx* c, double dt, const double* theta
     return MIMSEM_OK;
 }
 
+// ---- self-test of the half-row block algebra (dpp::RowsH, order 4): every primitive the walks use, on caller-supplied blocks, so that a
+// parity failure of a kernel built on it can be told from a failure of the algebra (tests/test_gpu_rows_half.py checks against numpy) ----
+namespace {
+__global__ __launch_bounds__(64) void k_rows_half_selftest(int ntask, const double* A, const double* B, const double* x, const double* cq,
+                                                          const double* Eg, const double* Wg, const double* Earg, double* out) {
+    using R = dpp::RowsH;
+    constexpr int N2 = R::N2, NC = R::NC, NP = R::NP, MP12 = R::MP12, OUT = 3*256 + 16 + 25 + 16;
+    const int lane = threadIdx.x, r = lane%16, c0 = R::c0(lane);
+    const int t = min((int)blockIdx.x*R::TPW + R::task(lane), ntask - 1);
+    typename R::Lane Ln;
+    R::init_lane(Ln, Eg, Wg, lane);
+    double E[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) E[i] = Earg[i];
+    double a[NC], b[NC], c[NC], ai[NC], as[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) { a[j] = A[((size_t)t*N2 + r)*N2 + c0 + j]; b[j] = B[((size_t)t*N2 + r)*N2 + c0 + j]; ai[j] = a[j]; }
+    const double xv = x[(size_t)t*N2 + r];
+    double cc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) cc[p] = cq[(size_t)t*MP12 + min(r + 16*p, MP12 - 1)];
+    R::mul(c, a, b);
+    R::mul_add(c, b, a);                                 // C = A B + B A
+    const double y = R::matvec(a, xv, lane);
+    R::inverse(ai, lane);
+    double fq[NP];
+    R::interp(fq, Ln, xv);
+    R::assemble(as, Ln, E, cc);
+    double* o = out + (size_t)t*OUT;
+#pragma unroll
+    for (int j = 0; j < NC; j++) { o[r*N2 + c0 + j] = c[j]; o[256 + r*N2 + c0 + j] = ai[j]; o[512 + r*N2 + c0 + j] = as[j]; }
+    o[768 + r] = y;
+#pragma unroll
+    for (int p = 0; p < NP; p++) if (r + 16*p < MP12) o[784 + r + 16*p] = fq[p];
+    o[809 + r] = dpp::getH<3>(xv, (lane >> 4) & 1) + 100.0*dpp::xsum(lane < 16 || (lane >= 32 && lane < 48) ? 1.0 : 2.0);      // x[8h + 3] + 100 (1 + 2)
+}
+}  // namespace
+int mimsem_selftest_rows_half(mimsem_ctx* c, int ntask, const double* A, const double* B, const double* x, const double* cq, double* out) {
+    if (!c || ntask < 1 || !A || !B || !x || !cq || !out) return MIMSEM_ERR_ARG;
+    if (c->es.n != 4) return MIMSEM_ERR_UNSUPPORTED;
+    struct { double E[20]; } e;
+    for (int i = 0; i < 20; i++) e.E[i] = i < (int)c->tab.E.size() ? c->tab.E[i] : 0.0;
+    double* dE = nullptr;
+    MIMSEM_HIP_TRY(hipMalloc((void**)&dE, sizeof(e)));
+    MIMSEM_HIP_TRY(hipMemcpyAsync(dE, &e, sizeof(e), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_rows_half_selftest, dim3((unsigned)((ntask + 1)/2)), dim3(64), 0, c->stream, ntask, A, B, x, cq, c->d_E, c->d_W, dE, out);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(dE);
+    return MIMSEM_OK;
+}
+
 int mimsem_column_set_pivot_fallback(mimsem_ctx* c, int on) {
     if (!c) return MIMSEM_ERR_ARG;
     c->pivot_fallback = on == 2 ? 2 : (on ? 1 : 0);

@@ -33,6 +33,34 @@ def test_no_dpp_hazard_in_the_generated_isa(tmp_path):
     assert int(c.stdout.strip().split("\n")[-1].split()[0]) > 100, c.stdout[-300:]
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_order4_walk_of_schur_3_runs_without_scratch(tmp_path):
+    """Round 5: k_s3_sweep<4> on the half-row block layout (dpp::RowsH: 16 VGPRs per block) must fit the register file -- round 4's 16-lane
+    form ran with ~700 spilled dwords per lane (5.9 GB of scratch traffic per launch, and the spill pattern behind its wrong bands).
+    From the code-object metadata: no scratch memory at all for both flavours of the half-row kernel; the order-3 walks stay spill-free."""
+    import re
+    asm = tmp_path / "column_kernels.s"
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-function",
+                        "-Wno-unused-variable", os.path.join(ROOT, "mimsem_amd", "csrc", "column_kernels.hip"), "-o", str(asm)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = asm.read_text()
+    md = s[s.index("amdgpu_metadata"):]
+    seen = {}
+    for e in md.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", e).group(1)
+        if "k_s3_sweepILi" in name:
+            g = lambda k: int(re.search(k + r":\s+(\d+)", e).group(1))
+            seen[name] = (g(r"\.vgpr_spill_count"), g(r"\.private_segment_fixed_size"), g(r"\.vgpr_count"))
+    half = {k: v for k, v in seen.items() if re.search(r"ILi4ELb[01]ELb1E", k)}       # k_s3_sweep<4, BOX, HALF = true>
+    assert len(half) == 2, sorted(seen)
+    for k, (spill, scratch, vgpr) in half.items():
+        assert scratch == 0 and spill <= 8 and vgpr <= 512, (k, spill, scratch, vgpr)       # (a handful of "spills" into AGPRs cost no memory traffic)
+    for k, (spill, scratch, vgpr) in seen.items():
+        if "ILi3E" in k:
+            assert scratch == 0, (k, spill, scratch)
+
+
 def test_spill_checker_sees_the_pattern_it_was_written_for(tmp_path):
     """scripts/check_spill_slots.py on two hand-written kernels: a spill store at the top of a structuriser "Flow" block (entered by
     s_cbranch_execz with the else-lanes still disabled) ahead of the s_or_saveexec that re-enables them -- the code hipcc produced in
