@@ -49,10 +49,49 @@ class SWEqn:
         self.chunk = int(os.environ.get("MIMSEM_SW_CHUNK", "10"))
         self.fused_sweeps = os.environ.get("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
         self.warm_start = os.environ.get("MIMSEM_SW_WARM_START", "1") == "1"
+        # Initial guesses of the nested solves from the counterpart solves of the previous steps (round 5 experiment, OFF): every solve of a
+        # step has a counterpart a step ago -- the same diagnostic, the same Picard iteration.  MIMSEM_SW_EXTRAPOLATE=2 starts from the linear
+        # extrapolation 2 x(n-1) - x(n-2) of the last two counterparts, 1 from the last one, 0 (default) from what round 4 did (the last
+        # solution of the same diagnostic; zero for the [u|h] system).  Measured (profiles/r05_sw_extrapolate_ab.txt): the Picard increments
+        # of successive steps are NOT close -- |P (b - A x0)| / |P b| = 0.5 ... 1.8 for the extrapolated guess of the [u|h] solve on the
+        # Galewsky run (dt = 360 s resolves the grid-scale gravity waves with 2.5 steps per period: the increments oscillate) -- GMRES needs
+        # its 25-26 iterations either way and the step is 0-6 % slower.  Kept as the record of the experiment.
+        self.extrapolate = int(os.environ.get("MIMSEM_SW_EXTRAPOLATE", "0"))
+        # Polynomial preconditioning of the [u|h] solve (round 5): d Richardson steps on the coupled element blocks as ONE application of the
+        # preconditioner, P_d = sum_{i<d} (I - P A)^i P -- an Arnoldi step then costs d operator passes but ONE orthogonalisation (4 launches +
+        # a host synchronisation, ~28 of the ~43 us of a step), and GMRES needs ~1/d of the iterations where I - P A contracts.
+        # MIMSEM_SW_POLY=d (1 = round 4's plain P; default 2).  Measured (scripts/ab_sw_poly.sh, profiles/r05_sw_poly_ab.txt): GMRES iterations
+        # 26 -> 16 / 13 / 11 for d = 2 / 3 / 4, config 3 211.9 -> 222.7 / 222.1 / 220.3 steps/s, config 2 16.1 -> 16.1 / 16.4 / 16.1; error norms
+        # and conservation drifts unchanged to 12 digits.  The iterations fall more slowly than 1/d (I - P A is not a strong contraction on the
+        # gravity-wave part of the spectrum), so the operator passes grow 26 -> 32 / 39 / 44 while the orthogonalisations shrink: d = 2 it is.
+        self.poly = max(1, int(os.environ.get("MIMSEM_SW_POLY", "2")))
+        self._hist = {}
         self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
         self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
+    def _guess_for(self, key, shape):
+        """initial guess of the solve `key` from the solutions its counterparts had in the last two steps (None: start from P^-1 b / zero)"""
+        if not self.warm_start or self.extrapolate <= 0:
+            return None
+        h = self._hist.get(key)
+        if not h or h[-1].shape != shape:
+            return None
+        if self.extrapolate >= 2 and len(h) == 2 and h[0].shape == shape:
+            return torch.add(h[1], h[1]).sub_(h[0])
+        return h[-1]
+
+    @staticmethod
+    def _base(key):
+        """"F0", "F1" -> "F" (what self.its and the round-4 guesses are keyed by); "M1" stays"""
+        return key if key == "M1" else key.rstrip("0123456789")
+
+    def _remember(self, key, x):
+        if self.extrapolate > 0:
+            h = self._hist.setdefault(key, [])
+            h.append(x)
+            del h[:-2]
+
     def M1(self, u): return self.eng.apply("UMAT", u)
     def M2(self, h): return self.eng.apply("WMAT", h)
     def M1h(self, h, u, out=None, alpha=1.0, accum=False):
@@ -91,15 +130,20 @@ class SWEqn:
                                                   sweep=lambda x, rhs, upd: self.eng.block_richardson_sweep("UMAT", cm, x, rhs, upd=upd))
                 else:
                     self._rM1 = GraphedRichardson(self.eng, tuple(b.shape), lambda x, rhs: self.precond_M1(rhs - self.M1(x)), chunk=self.chunk)
-            x0 = self._guess.get(key) if self.warm_start else None      # the previous solution of the same diagnostic: a nearby system
-            res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol, x0=x0 if (x0 is not None and x0.shape == b.shape) else None)
+            if self.extrapolate > 0:
+                x0 = self._guess_for(key, b.shape)
+            else:
+                x0 = self._guess.get(self._base(key)) if self.warm_start else None      # (round 4) the previous solution of the same diagnostic: a nearby system
+                x0 = x0 if (x0 is not None and x0.shape == b.shape) else None
+            res = self._rM1.solve(b, self.precond_M1, rtol=self.rtol, x0=x0)
             if res is not None:
-                self.its[key] = res[1]
-                self._guess[key] = res[0]
+                self.its[self._base(key)] = res[1]
+                self._guess[self._base(key)] = res[0]
+                self._remember(key, res[0])
                 return res[0]
         with self.eng.space(1):
             x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
-        self.its[key] = its
+        self.its[self._base(key)] = its
         return x
 
     # ---- diagnostics ------------------------------------------------------------------------------------------
@@ -112,7 +156,7 @@ class SWEqn:
         """:236-250: w = M0^-1 E01 M1 u"""
         return self.E("E01", self.M1(u)) / self.m0
 
-    def diagnose_F(self, ui, uj, hi, hj):
+    def diagnose_F(self, ui, uj, hi, hj, key="F"):
         """:253-284: F = M1^-1 (1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj)"""
         loc = getattr(self.eng, "eng", self.eng)                   # local partial sums, one halo reduction
         hu = loc.apply("UHMAT", ui, f=hi, alpha=1.0 / 3.0)
@@ -120,7 +164,7 @@ class SWEqn:
         loc.apply("UHMAT", ui, f=hj, alpha=1.0 / 6.0, flags=2, out=hu)
         loc.apply("UHMAT", uj, f=hj, alpha=1.0 / 3.0, flags=2, out=hu)
         self.eng.complete(1, hu)
-        return self.solve_M1(hu, "F")
+        return self.solve_M1(hu, key)
 
     def diagnose_Phi(self, ui, uj, hi, hj):
         """:289-320 (integral form): 1/3 K(ui) ui + 1/3 K(ui) uj + 1/3 K(uj) uj + g/2 M2 (hi + hj)"""
@@ -132,7 +176,7 @@ class SWEqn:
         self.eng.apply("WMAT", hi + hj, alpha=self.grav / 2.0, flags=2, out=Phi)
         return Phi
 
-    def diagnose_q(self, dt, u, h):
+    def diagnose_q(self, dt, u, h, key="q"):
         """:322-341: M0h q = M0 f + E01 M1 u ; M0h upwinded (Phmat::assemble_up) when dt > 1e-6"""
         if self._m0fg is None:
             self._m0fg = self.m0 * self.fg
@@ -162,11 +206,12 @@ class SWEqn:
                     if self._rq[2] is bh:
                         if self._rq[3] is not None:
                             torch.reciprocal(m0h, out=self._rq[3])
-                        x0 = self._guess.get("q") if self.warm_start else None
+                        x0 = self._guess_for(key, rhs.shape) if self.extrapolate > 0 else (self._guess.get("q") if self.warm_start else None)
                         res = self._rq[1].solve(rhs, lambda r: r / m0h, rtol=self.rtol, x0=x0)
                         if res is not None:
                             self.its["q"] = res[1]
                             self._guess["q"] = res[0]
+                            self._remember(key, res[0])
                             return res[0]
                 q, its, _ = g.solve(A, rhs, lambda r: r / m0h, rtol=self.rtol, maxit=1000)
                 self.its["q"] = its
@@ -181,21 +226,21 @@ class SWEqn:
     def pack(self, u, h): return torch.cat([u, h], dim=1)
     def unpack(self, x): return x[:, :self.n1].contiguous(), x[:, self.n1:].contiguous()
 
-    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None):
+    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None, it=0):
         """:402-607.  qi / qj: potential vorticities already diagnosed from (ui, hi) / (uj, hj) -- the reference re-solves for qi in
         every Picard iteration although (ui, hi) is the fixed start-of-step state; solve() passes the first result back in."""
-        F = self.diagnose_F(ui, uj, hi, hj)
+        F = self.diagnose_F(ui, uj, hi, hj, key="F%d" % it)          # (keys: the counterpart of a solve is the same Picard iteration of the last step)
         Phi = self.diagnose_Phi(ui, uj, hi, hj)
         if bot is not None:
             Phi = Phi + self.grav * self.M2(bot)
         fu = self.E("E12", Phi)
         if q_exact:
             um, hm = torch.add(ui, uj).mul_(0.5), torch.add(hi, hj).mul_(0.5)
-            q = self.diagnose_q(0.0, um, hm)
+            q = self.diagnose_q(0.0, um, hm, key="qm%d" % it)
             self.eng.apply("ROTMAT", F, f=q, flags=2, out=fu)                                    # fu += R(q) F
         else:
-            qi = self.diagnose_q(dt, ui, hi) if qi is None else qi
-            qj = self.diagnose_q(dt, uj, hj) if qj is None else qj
+            qi = self.diagnose_q(dt, ui, hi, key="qi") if qi is None else qi
+            qj = self.diagnose_q(dt, uj, hj, key="qj%d" % it) if qj is None else qj
             self.eng.apply_up("ROTMAT_UP", F, qi, ui, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)      # fu += 1/2 R_up(qi, ui) F
             self.eng.apply_up("ROTMAT_UP", F, qj, uj, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)
         # the mass terms are linear: M1 (uj - ui) and M2 (hj - hi + dt E21 F) -- two applies instead of five; both halves of the packed
@@ -269,14 +314,32 @@ class SWEqn:
         C = d[:, :, None] * getattr(self.eng, "eng", self.eng).block_inverse(Ae) * d[:, None, :]
         return C.transpose(1, 2).contiguous()                     # column-major per element
 
+    def _krylov_body1(self, dt):
+        """v -> P A v with the plain (degree-1) preconditioner"""
+        keep, self.poly = self.poly, 1
+        try:
+            return self._krylov_body(dt)
+        finally:
+            self.poly = keep
+
     def _krylov_body(self, dt):
         """v -> P A v for the graph-captured Arnoldi step: one fused call (three launches) when the coupled blocks are in use"""
         if self.eng.mesh.n <= 4 and self.coupled_pc and not hasattr(self.eng, "halo"):
             if self._pcA is None or self._pcA[0] != dt:
                 self._pcA = (dt, self._coupled_element_blocks(dt))
             blocks = self._pcA[1]
-            return lambda v: self.eng.sw_operator_precond(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, v)
-        return lambda v: self.precond_A(self.apply_A(v, dt), dt)
+            body1 = lambda v: self.eng.sw_operator_precond(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, v)
+        else:
+            body1 = lambda v: self.precond_A(self.apply_A(v, dt), dt)
+        if self.poly <= 1:
+            return body1
+
+        def body(v):                                                  # P_d A v = (I - (I - P A)^d) v: w <- v, d times w <- w - P A w; v - w
+            w = v
+            for _ in range(self.poly):
+                w = w - body1(w)
+            return v - w
+        return body
 
     def _krylov_body_orth(self, dt):
         """(v, V, k, h, out) -> out = P A v orthogonalised once against V[:k]: the body above with its 1-form gather folded into the first
@@ -312,14 +375,27 @@ class SWEqn:
         uj, hj = un, hn
         x = self.pack(uj, hj)
         it, hist = 0, []
-        qi = None if q_exact else self.diagnose_q(dt, ui, hi)             # depends on the start-of-step state only
+        qi = None if q_exact else self.diagnose_q(dt, ui, hi, key="qi")   # depends on the start-of-step state only
         while True:
-            f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot, qi=qi, qj=qi if it == 0 else None)   # iteration 0: uj = ui, hj = hi
+            f = self.assemble_residual(ui, hi, uj, hj, dt, q_exact, bot, qi=qi, qj=qi if it == 0 else None, it=it)   # iteration 0: uj = ui, hj = hi
             if self.graphs:
                 if self._gA is None or self._gA[0] != (dt, restart):       # the operator is fixed for a given dt: capture once
                     self._gA = ((dt, restart), GraphedGMRES(self.eng, self.n1 + self.n2, self._krylov_body(dt), restart=restart,
                                                             body_orth=self._krylov_body_orth(dt)))
-                dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, lambda r: self.precond_A(r, dt), rtol=self.rtol, maxit=1000)
+                # the increment of Picard iteration `it` is close to the one the same iteration produced a step ago (smooth flow)
+                dx0 = self._guess_for("A%d" % it, f.shape) if it < 8 else None
+                pc = lambda r: self.precond_A(r, dt)
+                if self.poly > 1:
+                    body1 = self._krylov_body1(dt)
+
+                    def pc(r, p1=pc):                                 # P_d r = sum_{i<d} (I - P A)^i P r
+                        z = p1(r); acc = z
+                        for _ in range(self.poly - 1):
+                            z = z - body1(z); acc = acc + z
+                        return acc
+                dx, its, res = self._gA[1].solve(lambda v: self.apply_A(v, dt), -f, pc, x0=dx0, rtol=self.rtol, maxit=1000)
+                if it < 8:
+                    self._remember("A%d" % it, dx)
             else:
                 with self.eng.space("uh"):
                     dx, its, res = gmres(lambda v: self.apply_A(v, dt), -f, precond=lambda r: self.precond_A(r, dt), rtol=self.rtol,

@@ -15,13 +15,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_no_dpp_hazard_in_the_generated_isa(tmp_path):
-    asm = tmp_path / "column_kernels.s"
+@pytest.fixture(scope="module")
+def column_asm(tmp_path_factory):
+    """column_kernels.hip compiled ONCE to gfx950 ISA (device side only: ~50 s) for every check of this module"""
+    asm = tmp_path_factory.mktemp("isa") / "column_kernels.s"
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-function",
                         "-Wno-unused-variable", os.path.join(ROOT, "mimsem_amd", "csrc", "column_kernels.hip"), "-o", str(asm)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    return asm
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_no_dpp_hazard_in_the_generated_isa(column_asm):
+    asm = column_asm
     c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_dpp_hazards.py"), str(asm)], capture_output=True, text=True)
     assert c.returncode == 0, c.stdout[-2000:]
     n = int(c.stdout.split()[0])
@@ -34,17 +41,12 @@ def test_no_dpp_hazard_in_the_generated_isa(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_order4_walk_of_schur_3_runs_without_scratch(tmp_path):
+def test_order4_walk_of_schur_3_runs_without_scratch(column_asm):
     """Round 5: k_s3_sweep<4> on the half-row block layout (dpp::RowsH: 16 VGPRs per block) must fit the register file -- round 4's 16-lane
     form ran with ~700 spilled dwords per lane (5.9 GB of scratch traffic per launch, and the spill pattern behind its wrong bands).
     From the code-object metadata: no scratch memory at all for both flavours of the half-row kernel; the order-3 walks stay spill-free."""
     import re
-    asm = tmp_path / "column_kernels.s"
-    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-function",
-                        "-Wno-unused-variable", os.path.join(ROOT, "mimsem_amd", "csrc", "column_kernels.hip"), "-o", str(asm)],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    s = asm.read_text()
+    s = column_asm.read_text()
     md = s[s.index("amdgpu_metadata"):]
     seen = {}
     for e in md.split("  - .agpr_count")[1:]:
