@@ -353,6 +353,7 @@ def column_extras(eng, dm, rng, torch):
     nb, stf, _ = eng.solve_status()
     res["schur_unconverged_columns"] = int(nb)
     res["schur_columns_resolved_by_pivoted_lu"] = int((stf == 3).sum())
+    res["schur_columns_accepted_on_backward_error"] = int((stf == 4).sum())
     eng.set_pivot_fallback(0)
     try:
         tf = timeit_rhs(lambda Fc: eng.solve_schur_eta(75.0, theta, rho, eta, pi, *Fc), 5)
@@ -360,7 +361,7 @@ def column_extras(eng, dm, rng, torch):
     finally:
         eng.set_pivot_fallback(1)
     res["schur_pivot_fallback"] = {"ms_all_columns_with_it": t * 1e3, "ms_all_columns_without_it": tf * 1e3, "cost_frac": t / tf - 1.0,
-                                   "columns_flagged_by_the_block_sweep": nb0, "columns_resolved_by_pivoted_lu": int((stf == 3).sum()),
+                                   "columns_flagged_by_the_block_sweep": nb0, "columns_resolved_by_pivoted_lu": int((stf == 3).sum()), "columns_accepted_on_backward_error": int((stf == 4).sum()),
                                    "unconverged_columns": int(nb)}
     # what bounds it: FP64 work counted by the SQ counters (profiles/r03_column_pmc.txt: FMA = 2 flop, MUL / ADD = 1, x 64 lanes per wave
     # instruction, all three kernels of the solve) against the 78.6 TFLOP/s vector FP64 peak, and the bytes the solve must move (the four
@@ -822,7 +823,7 @@ def compact_record(out, extras_file=None):
     col, cb = out.get("column") or {}, out.get("column_box_p4") or {}
     summ = {"column_solves_per_s": _r(col.get("schur_column_solves_per_s")), "schur_eta_ms": _r(col.get("schur_ms_all_columns")),
             "schur_eta_unresolved_columns": col.get("schur_unconverged_columns"),
-            "schur_eta_columns_by_pivoted_lu": col.get("schur_columns_resolved_by_pivoted_lu"), "schur_eta_pivot_fallback_cost_frac": _r(_g(col, "schur_pivot_fallback", "cost_frac"), 3),
+            "schur_eta_columns_by_pivoted_lu": col.get("schur_columns_resolved_by_pivoted_lu"), "schur_eta_columns_accepted_on_backward_error": col.get("schur_columns_accepted_on_backward_error"), "schur_eta_pivot_fallback_cost_frac": _r(_g(col, "schur_pivot_fallback", "cost_frac"), 3),
             "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),

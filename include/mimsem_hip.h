@@ -357,6 +357,9 @@ int mimsem_column_solve_schur_eta(mimsem_ctx* ctx, double dt,
  * 3 = re-solved by the pivoted fallback (mimsem_column_set_pivot_fallback below, on by default) AND verified: every norm finite, normwise
  *     backward error of the pivoted solve <= 1e-12; column_ratio: of its refinement step (the conditioning-limited forward indicator).
  *     A flagged column the fallback cannot verify (NaN / Inf data, a singular system) keeps status 1, its d and a ratio that says why.
+ * 4 = flagged for its CONDITIONING only: the block sweep's own solution has the normwise backward error of a pivoted LU (<= 1e-14 in the
+ *     Frobenius norm; measured by the fallback's triage before any re-solve) and stands unchanged; column_ratio stays above 1e-10 -- the
+ *     forward error no solver in double precision can bring down at cond ~ 1e10 (the reference's PCLU included).  Not counted in *n_unconverged.
  * column_ratio[e] (host, [nEl], may be NULL): |last correction| / |solution| of the column -- how far its refinement got (on rough random
  * columns with cond(L) ~ 1e10 it settles near 1e-9, where LAPACK's pivoted LU leaves the same residual; a ratio >> 1e-8 is a failed solve).
  * *n_unconverged = number of columns with status 1, or -1 when the last solve ran on a path that keeps no status (orders >= 5,
@@ -366,7 +369,8 @@ int mimsem_column_solve_status(mimsem_ctx* ctx, int* n_unconverged, int* column_
  * :806-812; MIMSEM_COLUMN_PIVOT_FALLBACK=0 at context creation or on == 0 here switch it off): every mimsem_column_solve_schur_eta / _3
  * re-solves the columns its unpivoted sweep flags INSIDE the call, before the back substitution reads the solution -- an LU with partial
  * pivoting over the whole band (one wavefront per flagged column on the block structure, csrc/column_pivot.inc) plus one refinement step.
- * Such a column reports status 3 (see above) and no longer counts in *n_unconverged.  Cost: one launch whose wavefronts read the
+ * The triage first measures the backward error of the solution the column already has: at a pivoted LU's level the column is accepted as
+ * it is (status 4); otherwise it is re-solved (status 3).  Either way it no longer counts in *n_unconverged.  Cost: one launch whose wavefronts read the
  * unconverged counter and leave when nothing is flagged; tens of microseconds (order 3) when something is -- the flagged columns run
  * concurrently, any number of them.  Orders 1..4, up to 1 024 unknowns per column (nk n2e); beyond that columns are left as they are.
  * on == 2: EVERY column goes through the pivoted LU (validation mode: the reference's algorithm for all columns, at its price). */

@@ -660,7 +660,7 @@ class Engine:
 
     def solve_status(self):
         """(columns whose refinement did not converge in the last solve_schur_eta, or -1 when that path keeps no status; per-column status
-        array: 0 converged, 1 not converged, 2 refinement off, 3 solved by the pivoted fallback (set_pivot_fallback); per-column |last correction| / |solution|) -- mimsem_column_solve_status"""
+        array: 0 converged, 1 not converged, 2 refinement off, 3 re-solved by the pivoted fallback, 4 flagged for its conditioning only and accepted on its backward error (set_pivot_fallback); per-column |last correction| / |solution|) -- mimsem_column_solve_status"""
         n = C.c_int(-1)
         st = np.zeros(max(self.nEl, 1), dtype=np.int32); ratio = np.zeros(max(self.nEl, 1))
         check(self.L.mimsem_column_solve_status(self.ctx, C.byref(n), st.ctypes.data, ratio.ctypes.data), "column_solve_status")
