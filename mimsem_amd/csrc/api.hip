@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include "ctx.hpp"
 
@@ -129,7 +130,13 @@ struct WavePlan {
     std::vector<int4> lane, plan;
     std::vector<int2> sing;
     std::vector<int4> fin;
+    // round 5, tile mode: four consecutive wave-groups = one workgroup = a tile; the partial sums of the slots two groups of a tile share
+    // meet in the workgroup's LDS instead of the workspace (tfin: [ntiles][WTF] {slot, LDS position of part A, of part B, 0}, -1 padded)
+    int ntiles = 0, tpmax = 0, ninner = 0;
+    std::vector<int4> tfin;
 };
+constexpr int WTF = MIMSEM_WTF;      // finishing entries a tile can hold (4 x 4 elements at p = 3: 24 inner slots)
+constexpr int WTP = MIMSEM_WTP;      // doubles of a tile's LDS row (pairs of partial sums)
 // Round 3: the partial sums are laid out per SIDE -- the (<= WMP) perimeter slots two wave-groups share, in ascending slot order; row
 // of a level = [side][part A (lower group) | part B][WMP] -- so that whichever group reaches a side second can finish its slots inside
 // the same launch (elem_wave.inc, finishing phase): no second kernel, no second trip of the partial sums through HBM.  A complete
@@ -137,7 +144,7 @@ struct WavePlan {
 // group's sides (the other part of that entry is written as 0).  The perimeter records (k_wave_perim: split applies, MIMSEM_WAVE_FIN=0)
 // address the same layout.
 int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const int* ix, const int* iy, const int* i0, bool singles, bool mixed,
-                    const char* marked /* [n1] halo slots or null */, WavePlan& P) {
+                    const char* marked /* [n1] halo slots or null */, WavePlan& P, bool tile = false) {
     const int nd = 2*n1e, lpe = 64/G, mp1 = order + 1;
     const int RS = mp1 + (mp1 & 1), XT = n1e + mp1*RS, sxe0 = XT + 2*(lpe - n1e), SXE = sxe0 + (sxe0 & 1);     // as k_apply_wave
     const unsigned NACC = (unsigned)(G*nd), ZERO = NACC + 128, DUMPX = (unsigned)XT;
@@ -192,6 +199,50 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         for (int g : bnd) perm2.insert(perm2.end(), P.perm.begin() + (size_t)g*G, P.perm.begin() + (size_t)(g + 1)*G);
         for (int g : inn) perm2.insert(perm2.end(), P.perm.begin() + (size_t)g*G, P.perm.begin() + (size_t)(g + 1)*G);
         P.perm.swap(perm2); P.nbgroups = (int)bnd.size();
+    }
+    // ---- tile mode (round 5): wave-groups in fours, each four = the wavefronts of one workgroup.  Grown over the group adjacency (shared
+    // perimeter slots) with one step of look-ahead so that the fours come out as 2 x 2 squares of groups where the mesh allows (a square
+    // keeps 4 sides inside, a line of four only 3); a four that cannot be filled is padded with empty groups.
+    tile = tile && mixed && !singles && !marked;
+    if (tile) {
+        std::vector<int> g0(nEl, -1);
+        for (int g = 0; g < P.ngroups; g++) for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e >= 0) g0[e] = g; }
+        std::vector<std::vector<std::pair<int, int>>> adj(P.ngroups);       // (neighbour group, shared slots)
+        {
+            std::vector<std::pair<std::pair<int, int>, int>> pr;
+            for (int sl = 0; sl < n1; sl++) if (cnt[sl] == 2) {
+                const int a = g0[own[(size_t)sl*2]], b = g0[own[(size_t)sl*2 + 1]];
+                if (a != b) { pr.push_back({{a, b}, 1}); pr.push_back({{b, a}, 1}); }
+            }
+            std::sort(pr.begin(), pr.end());
+            for (size_t i = 0; i < pr.size();) { size_t j = i; while (j < pr.size() && pr[j].first == pr[i].first) j++;
+                adj[pr[i].first.first].push_back({pr[i].first.second, (int)(j - i)}); i = j; }
+        }
+        std::vector<char> done(P.ngroups, 0);
+        auto shared_with = [&](const std::vector<int>& t, int h) { int w = 0; for (int m : t) for (auto& e : adj[m]) if (e.first == h) w += e.second; return w; };
+        std::vector<int> perm2;
+        for (int seed = 0; seed < P.ngroups; seed++) {
+            if (done[seed]) continue;
+            std::vector<int> t{seed}; done[seed] = 1;
+            while ((int)t.size() < 4) {
+                int best = -1, bw = 0, bl = -1;
+                for (int m : t) for (auto& e : adj[m]) {
+                    const int h = e.first;
+                    if (done[h]) continue;
+                    const int w = shared_with(t, h);
+                    int look = 0;                                       // the most a fourth / next group could share with the tile grown by h
+                    if ((int)t.size() < 3) { std::vector<int> t2(t); t2.push_back(h);
+                        for (int m2 : t2) for (auto& e2 : adj[m2]) if (!done[e2.first] && e2.first != h) look = std::max(look, shared_with(t2, e2.first)); }
+                    if (w > bw || (w == bw && look > bl) || (w == bw && look == bl && h < best)) { best = h; bw = w; bl = look; }
+                }
+                if (best < 0) break;
+                t.push_back(best); done[best] = 1;
+            }
+            for (int m : t) perm2.insert(perm2.end(), P.perm.begin() + (size_t)m*G, P.perm.begin() + (size_t)(m + 1)*G);
+            for (int k = (int)t.size(); k < 4; k++) perm2.insert(perm2.end(), (size_t)G, -1);
+            P.ntiles++;
+        }
+        P.perm.swap(perm2); P.ngroups = 4*P.ntiles;
     }
     std::vector<int> grp(nEl, -1);
     for (int g = 0; g < P.ngroups; g++) for (int k = 0; k < G; k++) { const int e = P.perm[(size_t)g*G + k]; if (e >= 0) grp[e] = g; }
@@ -308,10 +359,18 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
         // round 2's dense layout (the default: the perimeter pass finishes every slot): the routed slots of a group in pairs, one after
         // the other in the row -- 26 values in three cache lines per group and level
         P.npart = 0;
+        std::vector<int> tpos(std::max(P.ntiles, 1), 0), tpart;             // doubles used in a tile's LDS row; LDS positions of an inner slot's two parts
+        if (tile) { tpart.assign((size_t)n1*2, -1); P.tfin.assign((size_t)P.ntiles*WTF, int4{-1, 0, 0, 0}); }
+        std::vector<int> tcount(std::max(P.ntiles, 1), 0);
         for (int g = 0; g < P.ngroups; g++) {
             if (routed_of[g].empty()) continue;
             mark_group(g, slots);
-            const std::vector<int>& routed = routed_of[g];
+            std::vector<int> routed, inner;
+            for (int s : routed_of[g]) {
+                bool in = false;
+                if (tile && cnt[s] == 2) { const int a = grp[own[(size_t)s*2]], b = grp[own[(size_t)s*2 + 1]]; in = a != b && a/4 == b/4; }
+                (in ? inner : routed).push_back(s);
+            }
             for (size_t i = 0; i < routed.size(); i += 2) {
                 const int s0 = routed[i], s1 = i + 1 < routed.size() ? routed[i + 1] : -1;
                 const int pi = P.npart; P.npart += 2; P.npwritten += 2;
@@ -319,8 +378,33 @@ int build_wave_plan(int order, int n1, int nEl, int n1e, int n0e, int G, const i
                 reg(s0, pi); reg(s1, pi + 1);
                 entries[g].push_back(int4{-(pi + 2), apack(s0), apack(s1), 0});
             }
+            // the slots this group shares with another group of its tile: pairs of partial sums into the tile's LDS row (w = position + 1;
+            // x = INT_MIN: the lane's global store goes to the dump tail)
+            const int T = g/4;
+            for (size_t i = 0; i < inner.size(); i += 2) {
+                const int s0 = inner[i], s1 = i + 1 < inner.size() ? inner[i + 1] : -1;
+                const int tp = tpos[T]; tpos[T] += 2;
+                if (tpos[T] > WTP) return MIMSEM_ERR_UNSUPPORTED;
+                auto reg = [&](int s, int pos) {
+                    if (s < 0) return;
+                    if (tpart[(size_t)s*2] < 0) { tpart[(size_t)s*2] = pos; return; }
+                    if (tcount[T] >= WTF) return;                         // (checked below)
+                    P.tfin[(size_t)T*WTF + tcount[T]] = int4{s, tpart[(size_t)s*2], pos, 0};       // part A = the lower group, as in the perimeter pass
+                    tcount[T]++; P.ninner++;
+                };
+                reg(s0, tp); reg(s1, tp + 1);
+                entries[g].push_back(int4{INT_MIN, apack(s0), apack(s1), tp + 1});
+            }
             if (entries[g].size() > 64) return MIMSEM_ERR_UNSUPPORTED;
             for (int s : slots) use[s] = Use();
+        }
+        if (tile) {
+            for (int T = 0; T < P.ntiles; T++) { if (tcount[T] >= WTF) return MIMSEM_ERR_UNSUPPORTED; P.tpmax = std::max(P.tpmax, tpos[T]); }
+            for (int s = 0; s < n1; s++) if (tpart[(size_t)s*2] >= 0) {       // every inner slot must have found its second part
+                bool found = false;
+                for (int k = 0; k < WTF && !found; k++) { const int4& r = P.tfin[(size_t)(grp[own[(size_t)s*2]]/4)*WTF + k]; found = r.x == s; }
+                if (!found) return MIMSEM_ERR_STATE;
+            }
         }
     }
     for (int g = 0; g < P.ngroups && !mixed; g++) {
@@ -509,9 +593,17 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     // dense layout with mixed pairs + the perimeter pass (measured faster: DESIGN 4.6)
     const bool want_fin = getenv("MIMSEM_WAVE_FIN") && atoi(getenv("MIMSEM_WAVE_FIN")) != 0;
     const bool mixed = !want_fin && !(getenv("MIMSEM_WAVE_MIXED") && atoi(getenv("MIMSEM_WAVE_MIXED")) == 0);
-    int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, mixed, marked, P);
+    // round 5: TILE mode -- four wave-groups per workgroup, the partial sums of the slots they share meet in LDS behind ONE barrier per work
+    // item instead of travelling through the workspace to the perimeter pass (MIMSEM_WAVE_TILE=0 | 1; orders 3 and 4, no halo split)
+    const bool want_tile = (es.n == 3 || es.n == 4) && !marked && getenv("MIMSEM_WAVE_TILE") && atoi(getenv("MIMSEM_WAVE_TILE")) != 0;
+    int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, mixed, marked, P, want_tile);
+    if (rc && want_tile) {                                             // a numbering the tiles do not fit: the plain plan
+        P = WavePlan();
+        rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, mixed, marked, P, false);
+    }
     if (rc) return rc;
-    void* old[] = {c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt};
+    void* old[] = {c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin};
+    c->d_wtfin = nullptr; c->w_ntiles = 0;
     for (void* p : old) if (p) c->retired.push_back(p);
     c->d_wlane = nullptr; c->d_wplan = nullptr; c->d_wprec = nullptr; c->d_wnode = nullptr; c->d_wsing = nullptr; c->d_wG = nullptr; c->d_wR = nullptr;
     c->d_wfin = nullptr; c->d_wsslot = nullptr; c->d_wcnt = nullptr;
@@ -527,6 +619,7 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     if (P.nsing && (rc = upload(&c->d_wsing, P.sing.data(), P.sing.size(), c))) return rc;
     if ((rc = upload(&c->d_wfin, P.fin.data(), P.fin.size(), c))) return rc;
     if ((rc = upload(&c->d_wsslot, P.sslot.data(), P.sslot.size(), c))) return rc;
+    if (P.ntiles > 0) { if ((rc = upload(&c->d_wtfin, P.tfin.data(), P.tfin.size(), c))) return rc; c->w_ntiles = P.ntiles; c->w_ninner = P.ninner; }
     {   // arrival counters of the finishing phase: one per (side, work item of a group), zero between launches
         const size_t n = (size_t)std::max(P.nsides, 1)*(size_t)std::max(c->nk, 1);
         MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_wcnt, n*sizeof(int)));
@@ -564,7 +657,8 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     if (const char* ev = getenv("MIMSEM_WAVE2")) c->wave2_mode = atoi(ev);
     if (getenv("MIMSEM_VERBOSE"))
         fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials in %d sides) of %d; "
-                        "in-kernel finishing %s\n", P.ngroups, 64/lpe, P.nbgroups, P.nps, P.npwritten, P.nsides, c->n1, c->w_fin ? "on" : "off");
+                        "in-kernel finishing %s; tiles %d (%d inner slots finished in LDS, widest LDS row %d doubles)\n", P.ngroups, 64/lpe, P.nbgroups, P.nps,
+                P.npwritten, P.nsides, c->n1, c->w_fin ? "on" : "off", P.ntiles, P.ninner, P.tpmax);
     return MIMSEM_OK;
 }
 
@@ -767,7 +861,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -1084,9 +1178,16 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         a.lch = wave_level_chunk(c, nlev);
         a.wcpp = wave_chunks_per_item(c, nlev, a.lch, g1 - g0);
         a.swz = c->wave_order;
+        a.wtfin = nullptr; a.wtile = 0;
+        if (c->w_ntiles > 0) {                                           // tile mode (never together with a halo split: setup_wave)
+            if (splits) return MIMSEM_ERR_STATE;
+            a.wtfin = c->d_wtfin; a.wtile = WTF;
+            a.wcpp = std::min(a.wcpp, MIMSEM_WTLEV/8);                   // the tile's LDS rows hold MIMSEM_WTLEV levels
+            a.swz &= ~2;                                                 // group-minor work items: the four waves of a workgroup = the four groups of a tile
+        }
         // the whole operator in ONE launch: each side of the perimeter is finished by the group that reaches it second (not for the
         // parts of a split apply: their partial sums wait for the other part, and the perimeter pass finishes them)
-        const bool fin = c->w_fin && !splits && (nlev + a.lch*a.wcpp - 1)/(a.lch*a.wcpp) <= std::max(c->nk, 1);
+        const bool fin = c->w_fin && !splits && !a.wtfin && (nlev + a.lch*a.wcpp - 1)/(a.lch*a.wcpp) <= std::max(c->nk, 1);
         a.wfin = fin ? c->d_wfin : nullptr; a.wsslot = c->d_wsslot; a.wcnt = c->d_wcnt;
         a.wfence = (fin && c->w_partmem == 2 && getenv("MIMSEM_WAVE_FIN_FENCE") && atoi(getenv("MIMSEM_WAVE_FIN_FENCE")) != 0) ? 1 : 0;
         if (splits) {

@@ -96,6 +96,7 @@ struct mimsem_ctx {
     std::vector<int> h_e1x, h_e1y;      // element -> 1-form slot lists, kept on EVERY context (edge multiplicities of the PCBJACOBI builders, ksp.hip)
     int4* d_wlane = nullptr;            // [w_ngroups][64] {element of the lane, load pair: even slot b, staging positions of x[b] and of x[b+1]
                                         //   (two 16-bit positions each; the dump position where nobody wants the value)}
+    int4* d_wtfin = nullptr; int w_ntiles = 0, w_ninner = 0;      // tile mode (round 5): [w_ntiles][64] {slot, LDS position of part A, of part B, 0}
     int4* d_wplan = nullptr;            // [w_ngroups][64] store pair {dst, result positions of its first and second slot (2 x 16 bit, the
                                         //   strip's zero for a missing contributor), 0}: dst >= 0: y[dst], y[dst+1]; dst <= -2: partial sums
                                         //   -(dst+2), +1 of the workspace row (unused lanes: its dump tail)
@@ -147,6 +148,9 @@ struct mimsem_ctx {
     int ensure_kry(long long doubles);
 };
 
+// tile mode of the wave-level kernel (round 5): finishing entries per tile, doubles of a tile's LDS row, levels the LDS rows hold
+constexpr int MIMSEM_WTF = 64, MIMSEM_WTP = 64, MIMSEM_WTLEV = 32;
+
 // kernels (elem_kernels.hip / column_kernels.hip) ---------------------------------------------------
 struct ElemArgs {
     int nEl, nlev, lev0, total;
@@ -170,6 +174,7 @@ struct ElemArgs {
     // wave-level fused scatter-add (k_apply_wave)
     const int4* wlane; const int4* wplan; const int2* wsing; const int* wnode; const double* wG; const double* wR; int wgroups; int wg0; int wdump; int wcpp;
     const int4* wfin; const int* wsslot; int* wcnt;      // finishing phase (null: the perimeter pass follows)
+    const int4* wtfin; int wtile;                        // tile mode: finishing entries per tile (stride wtile), or null
     int wfence;                      // finishing phase, experiment: partial sums in PLAIN memory, one agent-scope release fence per wavefront before its arrival
     double Etab[20];                 // edge-basis table E[mp1][n] by value (orders <= 4): SGPRs, no load in the kernel
     double Wq[5];                    // GLL weights by value (orders <= 4)

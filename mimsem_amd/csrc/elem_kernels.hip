@@ -1515,9 +1515,15 @@ static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)((items + WNW - 1)/WNW);
     if (grid == 0) return MIMSEM_OK;
+    constexpr bool TILEABLE = (N == 3 || N == 4) && WNW == 4;
+    const bool tile = a.wtfin != nullptr;
+    if (tile && (!TILEABLE || a.wgroups%4 != 0 || a.wg0 != 0 || a.lch*a.wcpp > MIMSEM_WTLEV)) return MIMSEM_ERR_STATE;
+#define MIMSEM_WL1(OPV, LCT, ACC, TL) \
+        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC, TL>), dim3(grid), dim3(64*WNW), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
+        else hipLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC, TL>), dim3(grid), dim3(64*WNW), 0, c->stream, a)
 #define MIMSEM_WL(OPV, LCT, ACC) \
-        if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
-        else hipLaunchKernelGGL((k_apply_wave<N, OPV, LCT, ACC>), dim3(grid), dim3(64*WNW), 0, c->stream, a)
+        if constexpr (TILEABLE) { if (tile) { MIMSEM_WL1(OPV, LCT, ACC, true); } else { MIMSEM_WL1(OPV, LCT, ACC, false); } } \
+        else { MIMSEM_WL1(OPV, LCT, ACC, false); }
 #define MIMSEM_WCASE(OPV) case OPV: \
         if (a.lch == 1) { if (a.accum) { MIMSEM_WL(OPV, 1, true); } else { MIMSEM_WL(OPV, 1, false); } } \
         else            { if (a.accum) { MIMSEM_WL(OPV, WLC, true); } else { MIMSEM_WL(OPV, WLC, false); } } \
@@ -1529,6 +1535,7 @@ static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     }
 #undef MIMSEM_WCASE
 #undef MIMSEM_WL
+#undef MIMSEM_WL1
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

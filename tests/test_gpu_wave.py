@@ -51,6 +51,11 @@ def engines(request):
         wave.fin = Engine(dm)
     finally:
         del os.environ["MIMSEM_WAVE_FIN"]
+    os.environ["MIMSEM_WAVE_TILE"] = "1"                 # opt-in (round 5): four wave-groups per workgroup, their shared slots summed in LDS
+    try:
+        wave.tile = Engine(dm)
+    finally:
+        del os.environ["MIMSEM_WAVE_TILE"]
     assert two.L.mimsem_op_wave_stats(two.ctx, NK, st) == 0
     return pn, dm, wave, two, (cs, topos, geoms)
 
@@ -102,6 +107,40 @@ def test_finishing_phase_equals_perimeter_pass(engines, op, fl):
     for it in range(12):
         x = wave.tensor(r.standard_normal((nl, dm.n1)) * (1.0 + it))
         for lev0, nlev in ((0, nl), (1, 3), (4, 1), (0, 8)):
+            fs = None if ft is None else ft[:nlev]
+            a = wave.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
+            b = per.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
+            assert torch.equal(a, b), (op, it, lev0, nlev, int((a != b).sum()))
+        base = wave.tensor(r.standard_normal((nl, dm.n1)))
+        ya.copy_(base); yb.copy_(base)
+        wave.apply(op, x, f=None if ft is None else ft[:nl], lev0=0, scale=SCALE, flags=fl | 2, alpha=0.25, out=ya)
+        per.apply(op, x, f=None if ft is None else ft[:nl], lev0=0, scale=SCALE, flags=fl | 2, alpha=0.25, out=yb)
+        assert torch.equal(ya, yb), (op, it, "accumulate", int((ya != yb).sum()))
+
+
+@pytest.mark.parametrize("op,fl", CASES, ids=["%s_%d" % c for c in CASES])
+def test_tile_mode_equals_perimeter_pass(engines, op, fl):
+    """Round 5 experiment (MIMSEM_WAVE_TILE=1): the four wavefronts of a workgroup take the four wave-groups of a tile; the
+    partial sums of the slots those groups share meet in the workgroup's LDS behind ONE barrier per work item and go straight into y,
+    the perimeter pass finishes the tile's outer perimeter only.  Bit for bit the default form (a sum of two parts either way), for
+    whole and ragged level ranges, single levels, the accumulate form and inputs that change from launch to launch."""
+    import torch
+    pn, dm, per, two, _ = engines
+    wave = per.tile
+    st, st0 = (C.c_int * 5)(), (C.c_int * 5)()
+    assert wave.L.mimsem_op_wave_stats(wave.ctx, NK, st) == 1 and per.L.mimsem_op_wave_stats(per.ctx, NK, st0) == 1
+    if pn in (3, 4):
+        assert st[3] < st0[3], (list(st), list(st0))                    # fewer slots left to the perimeter pass: the tiles exist
+    r = np.random.default_rng(31)
+    nl = NK - 1 if op == "UTMAT" else NK
+    f = {"UHMAT": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6, "UTMAT_H": r.uniform(0.5, 1.5, (NK, dm.n2)) * 1e6,
+         "ROTMAT": r.standard_normal((NK, dm.n0)) * 1e-4}.get(op)
+    ft = None if f is None else wave.tensor(f)
+    ya, yb = wave.zeros(nl, dm.n1), per.zeros(nl, dm.n1)
+    for it in range(4):
+        x = wave.tensor(r.standard_normal((nl, dm.n1)) * (1.0 + it))
+        for lev0, nlev in ((0, nl), (1, 3), (4, 1), (0, 8), (2, 9)):
+            nlev = min(nlev, nl - lev0)
             fs = None if ft is None else ft[:nlev]
             a = wave.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
             b = per.apply(op, x[:nlev], f=fs, lev0=lev0, scale=SCALE, flags=fl)
