@@ -323,6 +323,69 @@ __global__ __launch_bounds__(64) void k_block_inverse(long long nb, int n, int T
 }
 
 
+// Round 5: ONE WAVEFRONT per block for 16 < n <= 64 (the 24 x 24 / 40 x 40 element blocks of M1 and the 33 x 33 / 56 x 56 coupled [u|h]
+// blocks of the shallow-water preconditioner at p = 3 / 4; the 25 .. 49-wide 2-form blocks of p = 5 .. 7).  The thread-per-block kernel
+// above walks n^3 entries through LDS with ONE lane working per block: 2.9 ms for the 3 456 blocks of SWEqn's PCSetUp (round-4 verdict).
+// Here lane = row of the elimination (and column of the row swap / scaling), the block in LDS with an ODD row stride (conflict-free row
+// and column walks), the same algorithm in the same order -- full pivoting with LinAlg.cpp:186-269's tie-breaking (the LAST entry of the
+// row-major scan that attains the maximum), normalise, eliminate, un-permute the columns -- so the same pivots and the same operations
+// per entry as the kernel above: identical bits.
+__global__ __launch_bounds__(64) void k_block_inverse_wave(long long nb, int n, double* blocks, int* errcount) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, ns = n | 1;
+    double* A = lds;                                   // A[i*ns + j]
+    int* ipiv = (int*)(lds + (size_t)n*ns);            // [n]; then indxr[n], indxc[n]
+    int* indxr = ipiv + n; int* indxc = indxr + n;
+    const long long b = blockIdx.x;
+    if (b >= nb) return;
+    double* src = blocks + b*n*n;
+    for (int idx = lane; idx < n*n; idx += 64) A[(idx/n)*ns + idx%n] = src[idx];
+    if (lane < n) ipiv[lane] = 0;
+    __syncthreads();
+    int err = 0;
+    for (int i = 0; i < n; i++) {
+        // pivot search: my row, then the wavefront.  Sequential semantics of the reference: the last (j, k) in row-major order with |a| == max
+        double big = -1.0; int kk = 0;
+        if (lane < n && ipiv[lane] != 1)
+            for (int k = 0; k < n; k++) {
+                const int pk = ipiv[k];
+                if (pk == 0) { const double v = fabs(A[lane*ns + k]); if (v >= big) { big = v; kk = k; } }
+                else if (pk > 1) err = 1;
+            }
+        double vmax = big;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
+        int jsel = (big == vmax && big >= 0.0) ? lane : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) jsel = max(jsel, __shfl_xor(jsel, off));
+        if (jsel < 0) { err = 2; jsel = 0; }           // (nothing left to pivot on / NaN: reported like a vanishing pivot)
+        const int irow = jsel, icol = __shfl(kk, jsel);
+        __syncthreads();
+        if (lane == 0) { ++ipiv[icol]; indxr[i] = irow; indxc[i] = icol; }
+        if (irow != icol && lane < n) { const double t0 = A[irow*ns + lane]; A[irow*ns + lane] = A[icol*ns + lane]; A[icol*ns + lane] = t0; }
+        __syncthreads();
+        const double piv = A[icol*ns + icol];
+        if (fabs(piv) < 1.0e-12) err = 2;
+        const double pivinv = 1.0/piv;
+        __syncthreads();
+        if (lane < n) A[icol*ns + lane] = (lane == icol ? 1.0 : A[icol*ns + lane])*pivinv;
+        __syncthreads();
+        if (lane < n && lane != icol) {
+            const double dum = A[lane*ns + icol];
+            A[lane*ns + icol] = 0.0;
+            for (int l = 0; l < n; l++) A[lane*ns + l] -= A[icol*ns + l]*dum;
+        }
+        __syncthreads();
+    }
+    for (int l = n - 1; l >= 0; l--) {
+        const int ir = indxr[l], ic = indxc[l];
+        if (ir != ic && lane < n) { const double t0 = A[lane*ns + ir]; A[lane*ns + ir] = A[lane*ns + ic]; A[lane*ns + ic] = t0; }
+        __syncthreads();
+    }
+    for (int idx = lane; idx < n*n; idx += 64) src[idx] = A[(idx/n)*ns + idx%n];
+    if (errcount) { const unsigned long long any = __ballot(err != 0); if (lane == 0 && any) atomicAdd(errcount, 1); }
+}
+
 // Cooperative variant for the block sizes of p <= 4 (n = 1, 4, 9, 16): ONE LANE PER ROW, the row lives in
 // registers, LPM lanes per matrix (4 matrices per wavefront at n = 9/16).  Same algorithm and tie-breaking as
 // LinAlg.cpp:186-269: the pivot is the LAST entry (row-major scan of the not-yet-pivoted rows x columns)
@@ -506,6 +569,12 @@ int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double
     case 9:  return getenv("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks, err) : launch_inverse_reg<9>(c, nblocks, blocks, err);
     case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks, err);
     default: break;                  // 25, 36, 49: thread-per-matrix in LDS below
+    }
+    if (n > 16 && n <= 64 && !(getenv("MIMSEM_INV_THREAD") && atoi(getenv("MIMSEM_INV_THREAD")) != 0)) {      // one wavefront per block (round 5)
+        const size_t lds = (size_t)n*(n | 1)*sizeof(double) + (size_t)3*n*sizeof(int);
+        hipLaunchKernelGGL(k_block_inverse_wave, dim3((unsigned)nblocks), dim3(64), lds, c->stream, nblocks, n, blocks, err);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
     }
     // matrices per workgroup: as many as fit a 144 KiB LDS budget (64 for n<=16, fewer for the 25..49-wide blocks of p>=5)
     int T = 64;

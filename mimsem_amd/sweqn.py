@@ -348,6 +348,8 @@ class SWEqn:
         None otherwise, and where the fused body does not apply"""
         if not (self.eng.mesh.n <= 4 and self.coupled_pc and not hasattr(self.eng, "halo")) or os.environ.get("MIMSEM_SW_FUSED_DOTS", "0") != "1":
             return None
+        if self.poly > 1:
+            return None                                               # (the fused form is the plain preconditioner's)
         if self._pcA is None or self._pcA[0] != dt:
             self._pcA = (dt, self._coupled_element_blocks(dt))
         blocks = self._pcA[1]

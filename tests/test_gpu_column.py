@@ -466,7 +466,7 @@ def test_vertical_newton_loop_matches_oracle(setup):
         assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < TOL, name
 
 
-@pytest.mark.parametrize("n", [1, 4, 9, 16, 24, 33])
+@pytest.mark.parametrize("n", [1, 4, 9, 16, 24, 33, 40, 56, 64])
 def test_block_inverse_against_the_oracle_inv(oracle, n):
     """A5 as an entry point (mimsem_block_inverse: the PCBJACOBI blocks and WmatInv / the column inverses run through it): the batched
     Gauss-Jordan against the oracle's restatement of LinAlg::Inv (eul/LinAlg.cpp:186-269, pinned bit-for-bit against the compiled
@@ -492,6 +492,16 @@ def test_block_inverse_against_the_oracle_inv(oracle, n):
         err = np.array([rel_l2(got[i], want[i]) for i in range(nb)])
         assert (err < 1e-10 * np.maximum(1.0, cond / 1e3)).all(), (name, float(err.max()), float(cond.max()))
         assert max(np.abs(got[i] @ B[i] - np.eye(n)).max() for i in range(nb)) < 1e-9 * cond.max()
+        if n > 16:
+            # round 5: one wavefront per block (k_block_inverse_wave) -- the same pivots, the same operations per entry as the
+            # thread-per-block kernel it replaces (MIMSEM_INV_THREAD=1): the same bits
+            import os
+            os.environ["MIMSEM_INV_THREAD"] = "1"
+            try:
+                old, _ = eng.block_inverse_status(eng.tensor(B))
+            finally:
+                del os.environ["MIMSEM_INV_THREAD"]
+            assert torch.equal(old.cpu(), torch.as_tensor(got)), name
     if n > 1:
         S = spd.copy()
         S[11, :, -1] = S[11, :, 0]; S[11, -1, :] = S[11, 0, :]             # two equal rows and columns: exactly singular

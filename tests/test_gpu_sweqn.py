@@ -246,7 +246,11 @@ def test_sw_body_with_the_gather_folded_into_the_first_gram_schmidt_pass(sw):
     import os
     os.environ["MIMSEM_SW_FUSED_DOTS"] = "1"                       # (opt-in: measured slower than the five launches it replaces)
     try:
-        body, fused = S._krylov_body(dt), S._krylov_body_orth(dt)
+        keep, S.poly = S.poly, 1                                    # (the fused form exists for the plain preconditioner, not the polynomial one)
+        try:
+            body, fused = S._krylov_body1(dt), S._krylov_body_orth(dt)
+        finally:
+            S.poly = keep
     finally:
         del os.environ["MIMSEM_SW_FUSED_DOTS"]
     assert fused is not None
@@ -271,7 +275,7 @@ def test_sw_fused_krylov_body_and_reorthonormalize(sw):
     x = _t(eng, np.concatenate([r.standard_normal(dm.n1), 20.0 * r.standard_normal(dm.n2)]))
     dt = 360.0
     ref = S.precond_A(S.apply_A(x, dt), dt)
-    got = S._krylov_body(dt)(x)
+    got = S._krylov_body1(dt)(x)                                  # (the plain degree-1 body: P A x)
     assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
     # the second Gram-Schmidt pass as it occurs: V orthonormal, w already orthogonalised once (what is left in span V is round-off
     # sized -- here made 1e-9 so that the pass does something).  Two-launch form (|w - V h2|^2 = w.w - h2.h2) against the separate
