@@ -484,6 +484,12 @@ int mimsem_interface_average(mimsem_ctx* ctx, int nk, long long n, const double*
 int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
                             const double* p, long long ldp, const double* Ap, long long ldap,
                             double* x, long long ldx, double* r, long long ldr);
+/* The vector algebra of one step of a Chebyshev semi-iteration on a preconditioned operator B = P A whose spectrum is (close to) a real
+ * interval -- KSPCHEBYSHEV in PETSc's terms; here the [u|h] system of SWEqn::solve (src/SWEqn_Picard.cpp:751-765: KSPSolve(kspA, f, dx)),
+ * whose coupled element-block preconditioner leaves P A with Ritz values in [0.35, 1.18] and |Im| < 0.05 -- in ONE pass:
+ * x += d;  r -= Bd;  d = a d + b r (the updated r), row by row.  No inner products: a and b follow from the spectral bounds alone. */
+int mimsem_krylov_chebyshev_update(mimsem_ctx* ctx, int nrows, long long n, double a, double b, const double* Bd, long long ldBd,
+                                   double* x, long long ldx, double* r, long long ldr, double* d, long long ldd);
 int mimsem_krylov_cg_direction(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,
                                const double* z, long long ldz, double* p, long long ldp);
 

@@ -333,6 +333,30 @@ int mimsem_krylov_cg_update(mimsem_ctx* c, int nrows, long long n, const double*
     return MIMSEM_OK;
 }
 
+// one step of the Chebyshev semi-iteration's vector algebra in ONE pass: x += d;  r -= Bd;  d = a d + b r (the updated r)
+namespace {
+__global__ __launch_bounds__(256) void k_chebyshev_update(long long n, double a, double b, const double* __restrict__ Bd, long long ldb,
+                                                          double* __restrict__ x, long long ldx, double* __restrict__ r, long long ldr,
+                                                          double* __restrict__ d, long long ldd) {
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = blockIdx.y;
+    const double dv = d[row*ldd + i];
+    x[row*ldx + i] += dv;
+    const double rv = r[row*ldr + i] - Bd[row*ldb + i];
+    r[row*ldr + i] = rv;
+    d[row*ldd + i] = fma(a, dv, b*rv);
+}
+}  // namespace
+int mimsem_krylov_chebyshev_update(mimsem_ctx* c, int nrows, long long n, double a, double b, const double* Bd, long long ldb,
+                                   double* x, long long ldx, double* r, long long ldr, double* d, long long ldd) {
+    if (!c || !Bd || !x || !r || !d || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_chebyshev_update, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, a, b, Bd, ldb, x, ldx, r, ldr, d, ldd);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 int mimsem_krylov_cg_direction(mimsem_ctx* c, int nrows, long long n, const double* num, const double* den,
                                const double* z, long long ldz, double* p, long long ldp) {
     if (!c || !num || !den || !z || !p || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;

@@ -737,6 +737,11 @@ class Engine:
         check(self.L.mimsem_krylov_cg_update(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(p), p.stride(0),
                                              _ptr(Ap), Ap.stride(0), _ptr(x), x.stride(0), _ptr(r), r.stride(0)), "cg_update")
 
+    def chebyshev_update(self, a, b, Bd, x, r, d):
+        """x += d ; r -= Bd ; d = a d + b r  row-wise, in place (one launch: mimsem_krylov_chebyshev_update)"""
+        check(self.L.mimsem_krylov_chebyshev_update(self.ctx, x.shape[0], x.shape[1], float(a), float(b), _ptr(Bd), Bd.stride(0),
+                                                    _ptr(x), x.stride(0), _ptr(r), r.stride(0), _ptr(d), d.stride(0)), "chebyshev_update")
+
     def cg_direction(self, num, den, z, p):
         """p = z + (num/den) p  row-wise, in place"""
         check(self.L.mimsem_krylov_cg_direction(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(z), z.stride(0),

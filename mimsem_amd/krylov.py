@@ -622,6 +622,85 @@ class GraphedRichardson:
         return None
 
 
+def arnoldi_ritz(body, n, m, device, seed=1):
+    """Ritz values of B = P A from m Arnoldi steps on a random start vector (set-up time: host algebra on the small Hessenberg)"""
+    import numpy as np
+    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    V = torch.zeros(m + 1, n, dtype=torch.float64, device=device); H = np.zeros((m + 1, m))
+    v = torch.randn(n, dtype=torch.float64, device=device, generator=gen); V[0] = v / torch.linalg.vector_norm(v)
+    k = m
+    for j in range(m):
+        w = body(V[j:j + 1].contiguous()).reshape(-1)
+        for _ in range(2):
+            hh = V[:j + 1] @ w; w = w - hh @ V[:j + 1]; H[:j + 1, j] += hh.cpu().numpy()
+        H[j + 1, j] = float(torch.linalg.vector_norm(w))
+        if H[j + 1, j] < 1e-14 * abs(H[0, 0]):
+            k = j + 1
+            break
+        V[j + 1] = w / H[j + 1, j]
+    return np.linalg.eigvals(H[:k, :k])
+
+
+class GraphedChebyshev:
+    """B x = c, B = P A with a spectrum that is (close to) a real interval [lmin, lmax]: the Chebyshev semi-iteration (Saad, Alg. 12.1)
+    with a FIXED number of steps -- known in advance from the interval and the tolerance -- captured with the preconditioning of the
+    right-hand side and the final norms in ONE hipGraph: a solve is one replay and one read of two scalars.  Per step: body(d) = P A d
+    (three launches for the shallow-water operator) and one fused vector update (mimsem_krylov_chebyshev_update); no inner products, no
+    host round trip -- against eight launches and a synchronisation per Arnoldi step of the GMRES it replaces.  solve() returns None when
+    the recurrence residual misses the tolerance (the caller falls back to its Krylov solver from the iterate reached)."""
+
+    def __init__(self, eng, shape, body, precond, lmin, lmax, rtol=1e-14, margin=(0.9, 1.05), dtype=torch.float64):
+        import math
+        self.eng, self.body, self.precond = eng, body, precond
+        self.lmin, self.lmax = margin[0] * lmin, margin[1] * lmax
+        self.theta, self.delta = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
+        kap = self.lmax / self.lmin
+        q = (math.sqrt(kap) - 1.0) / (math.sqrt(kap) + 1.0)
+        self.rate = q
+        self.steps = max(2, int(math.ceil(math.log(0.5 * rtol) / math.log(q))) + 1)
+        self.rtol = rtol
+        self.b = torch.zeros(shape, dtype=dtype, device=eng.device)       # the raw right-hand side (un-preconditioned)
+        self.x = torch.zeros(shape, dtype=dtype, device=eng.device)
+        self.r = torch.zeros(shape, dtype=dtype, device=eng.device)
+        self.d = torch.zeros(shape, dtype=dtype, device=eng.device)
+        self.nrm = torch.zeros(2, dtype=dtype, device=eng.device)         # |r|^2, |P b|^2
+        self.graph = None
+        self.graph_steps = 0
+
+    def _run(self):
+        sigma1 = self.theta / self.delta
+        rho = 1.0 / sigma1
+        c = self.precond(self.b)
+        self.r.copy_(c)
+        self.x.zero_()
+        torch.mul(c, 1.0 / self.theta, out=self.d)
+        self.eng.rowdot(c.reshape(1, -1), c.reshape(1, -1), out=self.nrm[1:2])
+        for _ in range(self.steps):
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            Bd = self.body(self.d)
+            self.eng.chebyshev_update(rho_new * rho, 2.0 * rho_new / self.delta, Bd, self.x, self.r, self.d)     # x += d; r -= B d; d = rho' rho d + (2 rho'/delta) r
+            rho = rho_new
+        self.eng.rowdot(self.r.reshape(1, -1), self.r.reshape(1, -1), out=self.nrm[0:1])
+
+    def solve(self, b):
+        if self.graph is None or self.graph_steps != self.steps:
+            self.b.copy_(b)
+            self.graph, _ = self.eng.capture(self._run)
+            self.graph_steps = self.steps
+        self.b.copy_(b)
+        self.graph.replay()
+        r2, c2 = self.nrm.tolist()
+        if c2 == 0.0:
+            return self.x.clone(), self.steps, 0.0
+        rel = (r2 / c2) ** 0.5
+        if not (rel <= self.rtol):                        # (NaN fails too)
+            if rel == rel and rel < 1e3 * self.rtol and self.steps < 200:
+                import math
+                self.steps += max(1, int(math.ceil(math.log(self.rtol / rel) / math.log(self.rate))) + 1)     # the bound was a little short: longer next time
+            return None if not (rel == rel) else (self.x.clone(), -self.steps, rel)
+        return self.x.clone(), self.steps, rel
+
+
 def lanczos_bounds(apply_A, precond, b, its=25):
     """Extreme eigenvalues of P A (A SPD, P SPD) for every row system of b, from the Lanczos tridiagonal that `its` steps of
     preconditioned CG generate (T_kk = 1/a_k + b_{k-1}/a_{k-1}, T_{k,k+1} = sqrt(b_k)/a_k): Ritz values converge to the ends of
