@@ -284,6 +284,14 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nle
 /* z = P (A x) for the left-preconditioned Krylov iteration on the shallow-water operator: mimsem_sw_operator_apply followed by
  * mimsem_sw_blocks_apply in three launches instead of four -- the block pass reads the operator's element-local results through
  * the gather plan, the assembled A x is never written. */
+/* One step of the Chebyshev semi-iteration on the preconditioned shallow-water operator B = P A (mimsem_sw_operator_precond_apply's P A) in
+ * the SAME three launches, its vector algebra riding in the block pass (2-form rows) and the gather (1-form slots):
+ *   x += d;   r -= P A d;   d = ca d + cb r        on the packed [u | h] rows; d is updated in place.
+ * With the coefficients of the step from the spectral interval of P A (mimsem_krylov_chebyshev_update's comment) a solve of
+ * KSPSolve(kspA, f, dx) (src/SWEqn_Picard.cpp:751-765) is ~30 of these calls and no inner product.  x, r, d distinct; orders 1..4. */
+int mimsem_sw_operator_precond_chebyshev(mimsem_ctx* ctx, int nlev, double a, double grav, double H, const double* f0, long long f0_stride,
+                                         const double* blocks, double ca, double cb, double* x, long long x_stride,
+                                         double* r, long long r_stride, double* d, long long d_stride);
 int mimsem_sw_operator_precond_apply(mimsem_ctx* ctx, int nlev, double a, double grav, double H,
                                      const double* f0, long long f0_stride, const double* blocks,
                                      const double* x, long long x_stride, double* z, long long z_stride);

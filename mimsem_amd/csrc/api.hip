@@ -1405,6 +1405,17 @@ int mimsem_sw_operator_precond_apply(mimsem_ctx* c, int nlev, double a, double g
     return launch_sw_operator_precond(c, nlev, a, grav, H, f0, f0s, blocks, x, xs, z, zs);
 }
 
+int mimsem_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                                         const double* blocks, double ca, double cb, double* x, long long xs, double* r, long long rs,
+                                         double* d, long long ds) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!f0 || !blocks || !x || !r || !d || x == r || x == d || r == d) return MIMSEM_ERR_ARG;
+    const long long n = (long long)c->n1 + c->n2;
+    if (nlev > 1 && (xs < n || rs < n || ds < n)) return MIMSEM_ERR_ARG;
+    return launch_sw_operator_precond_chebyshev(c, nlev, a, grav, H, f0, f0s, blocks, ca, cb, x, xs, r, rs, d, ds);
+}
+
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
     if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null

@@ -192,6 +192,9 @@ struct GatherEpilogue {
     double alpha = 1.0, beta = 0.0;  // mode 3 (Chebyshev semi-iteration)
     double* p = nullptr; long long ps = 0;
     const double* escale = nullptr; long long ess = 0;      // block pass: per (level, element) factor of the element blocks
+    // mode 4 (round 5): the vector algebra of a Chebyshev step on B = P A with acc = (B d)[s]:  x += d;  r -= acc;  d = alpha d + beta r.
+    // d lives in p (in/out), r in cr
+    double* cr = nullptr; long long crs = 0;
 };
 int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, const GatherEpilogue& g,
                            double* x, long long xs);
@@ -218,6 +221,8 @@ int launch_interp_quad(mimsem_ctx* c, int form, int global, int nlev, const doub
 int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                        const double* x, long long xs, double* y, long long ys);
 int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys);
+int launch_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                                         const double* B, double ca, double cb, double* x, long long xs, double* r, long long rs, double* d, long long ds);
 int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                                const double* B, const double* x, long long xs, double* z, long long zs,
                                const double** unassembled = nullptr /* nlev == 1: skip the 1-form gather of z, return the element-local results */);

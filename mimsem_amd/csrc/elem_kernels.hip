@@ -605,7 +605,13 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
 #pragma unroll
         for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
         const double d = (g.mode == 1) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
-        if (g.mode == 3) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p
+        if (g.mode == 4) {           // Chebyshev step on B = P A, acc = (B d)[s]: x += d; r -= acc; d = alpha d + beta r
+            double* dp = g.p + (size_t)lev*g.ps + s; double* rp = g.cr + (size_t)lev*g.crs + s;
+            const double dv = *dp, rv = *rp - acc;
+            x[(size_t)lev*xs + s] += dv;
+            *rp = rv;
+            *dp = fma(g.alpha, dv, g.beta*rv);
+        } else if (g.mode == 3) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p
             double* pp = g.p + (size_t)lev*g.ps + s;
             const double pn = d + g.beta*(*pp);
             *pp = pn;
@@ -1131,7 +1137,10 @@ template <int N>
 __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long long n1,
         const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2, const double* __restrict__ B,
         const double* __restrict__ x, long long xs, double* __restrict__ ye, long long yes, double* __restrict__ y, long long ys,
-        const double* __restrict__ ye_in, long long yis, const int* __restrict__ plan /* edge entries of x = gather of ye_in (or null) */) {
+        const double* __restrict__ ye_in, long long yis, const int* __restrict__ plan /* edge entries of x = gather of ye_in (or null) */,
+        double ca = 0.0, double cb = 0.0, double* cr = nullptr, long long crs = 0, double* cd = nullptr, long long cds = 0
+        /* cd != null (round 5): the 2-form rows finish a Chebyshev step instead of storing their result s = (B d)[slot]:
+           y[slot] += d[slot];  r[slot] -= s;  d[slot] = ca d[slot] + cb r[slot]   (y = the iterate) */) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e + D::n2e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
@@ -1162,7 +1171,13 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
 #pragma unroll
     for (int c = 0; c < ND; c++) s += Be[(size_t)c*ND]*s_x[el][c];
     if (r < 2*D::n1e) ye[(size_t)lev*yes + (size_t)e*2*D::n1e + r] = s;
-    else y[(size_t)lev*ys + slot] = s;
+    else if (cd) {
+        double* dp = cd + (size_t)lev*cds + slot; double* rp = cr + (size_t)lev*crs + slot;
+        const double dv = *dp, rv = *rp - s;
+        y[(size_t)lev*ys + slot] += dv;
+        *rp = rv;
+        *dp = fma(ca, dv, cb*rv);
+    } else y[(size_t)lev*ys + slot] = s;
 }
 
 __global__ __launch_bounds__(256) void k_halo_pack(const int* __restrict__ idx, int count, int nlev,
@@ -1780,14 +1795,15 @@ int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H,
 
 template <int N>
 static int sw_blocks_n(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* ye, long long yes, double* y, long long ys,
-                       const double* ye_in = nullptr, long long yis = 0) {
+                       const double* ye_in = nullptr, long long yis = 0, double ca = 0.0, double cb = 0.0, double* cr = nullptr, long long crs = 0,
+                       double* cd = nullptr, long long cds = 0) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e + D::n2e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
     const long long total = (long long)c->nEl*nlev;
     const unsigned grid = (unsigned)((total + EPB - 1)/EPB);
     hipLaunchKernelGGL((k_sw_blocks_apply<N>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, (long long)c->n1,
-                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys, ye_in, yis, c->d_g1);
+                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys, ye_in, yis, c->d_g1, ca, cb, cr, crs, cd, cds);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
@@ -1831,6 +1847,33 @@ int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, d
     if (rc) return rc;
     if (unassembled && nlev == 1) { *unassembled = ye1; return MIMSEM_OK; }      // (mimsem_sw_operator_precond_orthogonalize: the gather rides in its first dot pass)
     return launch_gather_sum(c, 1, nlev, ye1, per, 0, z, zs);
+}
+
+// One step of the Chebyshev semi-iteration on B = P A in THREE launches (round 5): the operator's element pass on d, the block pass (its
+// 2-form rows finish the step for the h part), the gather with the step's epilogue for the u part:  x += d;  r -= P A d;  d = ca d + cb r.
+// d is read by the first launch only and updated in place by the other two.
+int launch_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
+                                         const double* B, double ca, double cb, double* x, long long xs, double* r, long long rs, double* d, long long ds) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    if (es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
+    const long long per = (long long)c->nEl*2*es.n1e, nrow = (long long)c->n1 + c->n2;
+    int rc = c->ensure_ye(2*per*nlev + nrow*nlev);
+    if (rc) return rc;
+    double* ye0 = c->d_ye; double* ye1 = c->d_ye + per*nlev; double* yt = c->d_ye + 2*per*nlev;
+    const double ag = a*grav, aH = a*H;
+    const long long n1 = c->n1;
+    switch (es.n) {
+#define MIMSEM_SWC(N) case N: rc = sw_operator_n<N>(c, nlev, a, ag, aH, f0, f0s, d, ds, d + n1, ds, ye0, per, yt + n1, nrow); \
+                      if (!rc) rc = sw_blocks_n<N>(c, nlev, B, yt, nrow, ye1, per, x, xs, ye0, per, ca, cb, r, rs, d, ds); break;
+    MIMSEM_SWC(1) MIMSEM_SWC(2) MIMSEM_SWC(3) MIMSEM_SWC(4)
+#undef MIMSEM_SWC
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    GatherEpilogue g{4, nullptr, 0, nullptr, 0, nullptr, 0};
+    g.alpha = ca; g.beta = cb; g.p = d; g.ps = ds; g.cr = r; g.crs = rs;
+    return launch_gather_epilogue(c, 1, nlev, ye1, per, g, x, xs);
 }
 
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,

@@ -423,6 +423,16 @@ class Engine:
                                                       _ptr(blocks), x2.data_ptr(), x2.stride(0), z2.data_ptr(), z2.stride(0)), "sw_operator_precond")
         return z if (x.dim() == 2 or out is not None) else z[0]
 
+    def sw_operator_precond_chebyshev(self, a, grav, H, f0, blocks, ca, cb, x, r, d):
+        """one Chebyshev step on B = P A in three launches (mimsem_sw_operator_precond_chebyshev): x += d; r -= P A d; d = ca d + cb r, in place"""
+        nd = 2 * self.n1e + self.n2e
+        assert x.dim() == 2 and x.shape == r.shape == d.shape and x.shape[1] == self.sizes[1] + self.sizes[2] and blocks.shape == (self.nEl, nd, nd)
+        f2 = f0 if f0.dim() == 2 else f0.unsqueeze(0)
+        assert f2.shape[1] == self.sizes[0] and f2.shape[0] in (1, x.shape[0])
+        check(self.L.mimsem_sw_operator_precond_chebyshev(self.ctx, x.shape[0], a, grav, H, f2.data_ptr(), 0 if f2.shape[0] == 1 else f2.stride(0),
+                                                          _ptr(blocks), float(ca), float(cb), _ptr(x), x.stride(0), _ptr(r), r.stride(0),
+                                                          _ptr(d), d.stride(0)), "sw_operator_precond_chebyshev")
+
     def sw_operator_precond_orthogonalize(self, a, grav, H, f0, blocks, x, V, k, h, out, alpha=-1.0):
         """out = P (A x); h[:k] = V[:k] out; out += alpha V[:k]^T h -- the Krylov body and the first Gram-Schmidt pass of the Arnoldi step in four
         launches (mimsem_sw_operator_precond_orthogonalize; bit-identical to sw_operator_precond + orthogonalize, which take five)"""

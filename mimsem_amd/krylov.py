@@ -649,9 +649,11 @@ class GraphedChebyshev:
     host round trip -- against eight launches and a synchronisation per Arnoldi step of the GMRES it replaces.  solve() returns None when
     the recurrence residual misses the tolerance (the caller falls back to its Krylov solver from the iterate reached)."""
 
-    def __init__(self, eng, shape, body, precond, lmin, lmax, rtol=1e-14, margin=(0.9, 1.05), dtype=torch.float64):
+    def __init__(self, eng, shape, body, precond, lmin, lmax, rtol=1e-14, margin=(0.9, 1.05), dtype=torch.float64, step=None):
+        """step(ca, cb, x, r, d) (optional): the whole step x += d; r -= B d; d = ca d + cb r as ONE fused engine call (the shallow-water
+        operator has one: mimsem_sw_operator_precond_chebyshev, three launches) instead of body(d) + the update kernel (four)"""
         import math
-        self.eng, self.body, self.precond = eng, body, precond
+        self.eng, self.body, self.precond, self.step = eng, body, precond, step
         self.lmin, self.lmax = margin[0] * lmin, margin[1] * lmax
         self.theta, self.delta = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
         kap = self.lmax / self.lmin
@@ -677,8 +679,11 @@ class GraphedChebyshev:
         self.eng.rowdot(c.reshape(1, -1), c.reshape(1, -1), out=self.nrm[1:2])
         for _ in range(self.steps):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
-            Bd = self.body(self.d)
-            self.eng.chebyshev_update(rho_new * rho, 2.0 * rho_new / self.delta, Bd, self.x, self.r, self.d)     # x += d; r -= B d; d = rho' rho d + (2 rho'/delta) r
+            if self.step is not None:
+                self.step(rho_new * rho, 2.0 * rho_new / self.delta, self.x, self.r, self.d)
+            else:
+                Bd = self.body(self.d)
+                self.eng.chebyshev_update(rho_new * rho, 2.0 * rho_new / self.delta, Bd, self.x, self.r, self.d)     # x += d; r -= B d; d = rho' rho d + (2 rho'/delta) r
             rho = rho_new
         self.eng.rowdot(self.r.reshape(1, -1), self.r.reshape(1, -1), out=self.nrm[0:1])
 

@@ -130,6 +130,16 @@ class SWEqn:
     def solve_M1(self, b, key="M1"):
         """KSPSolve(ksp, b, x) on M1 (:84-92).  Single rank: hipGraph-captured preconditioned Richardson sweeps (P^-1 M1 is within
         ~10 % of the identity); otherwise / if they do not contract: SPD => preconditioned CG reaches the same solution"""
+        if self.graphs and self.cheb and self.eng.mesh.n <= 5 and self.fused_sweeps and not hasattr(self.eng, "halo") and \
+                os.environ.get("MIMSEM_SW_CHEB_M1", "1") == "1":
+            # round 5: a FIXED-length Chebyshev semi-iteration on the fused block sweep (krylov.ChebyshevMass: 3 launches per step, spectrum of
+            # P M1 from 25 Lanczos steps once), the whole solve with its two norms in ONE hipGraph replay -- ~15 steps where the Richardson
+            # sweeps below take 20 and a host read per chunk of 10
+            res = self._solve_M1_chebyshev(b)
+            if res is not None:
+                self.its[self._base(key)] = res[1]
+                self._guess[self._base(key)] = res[0]
+                return res[0]
         if self.graphs and self.richardson:
             if self._rM1 is None or self._rM1.x.shape != b.shape:
                 if self.eng.mesh.n <= 5 and self.fused_sweeps:
@@ -153,6 +163,39 @@ class SWEqn:
             x, its = pcg_engine(self.eng, self.M1, b, self.precond_M1, rtol=self.rtol, maxit=1000, check_every=2)
         self.its[self._base(key)] = its
         return x
+
+    def _solve_M1_chebyshev(self, b):
+        from .krylov import ChebyshevMass, lanczos_bounds
+        st = getattr(self, "_cM1", None)
+        if st is None or st["b"].shape != b.shape:
+            cm = self.m1_pre.transpose(1, 2).contiguous()
+            g = torch.Generator(device="cpu"); g.manual_seed(4321)
+            rb = torch.randn(b.shape, generator=g, dtype=torch.float64).to(self.eng.device)
+            lmin, lmax = lanczos_bounds(self.M1, self.precond_M1, rb, its=25)
+            ch = ChebyshevMass(self.eng, lambda x, rhs, p, al, be, upd: self.eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd),
+                               lmin, lmax, rtol=self.rtol)
+            st = {"ch": ch, "b": torch.zeros_like(b), "x": torch.zeros_like(b), "nrm": torch.zeros(2, dtype=torch.float64, device=self.eng.device),
+                  "graph": None, "bad": 0}
+
+            def run():
+                c = self.precond_M1(st["b"])
+                self.eng.rowdot(c.reshape(1, -1), c.reshape(1, -1), out=st["nrm"][1:2])
+                st["x"].copy_(ch.solve(st["b"], want_residual=True))
+                self.eng.rowdot(ch.upd.reshape(1, -1), ch.upd.reshape(1, -1), out=st["nrm"][0:1])      # the last preconditioned residual P (b - M1 x)
+            st["run"] = run
+            self._cM1 = st
+        if st["bad"] >= 2:
+            return None
+        st["b"].copy_(b)
+        if st["graph"] is None:
+            st["graph"], _ = self.eng.capture(st["run"])
+        st["graph"].replay()
+        z2, c2 = st["nrm"].tolist()
+        # (the residual the last sweep saw belongs to the iterate BEFORE its update: one more contraction lies between it and the result)
+        if c2 > 0.0 and not (z2 ** 0.5 <= 30.0 * self.rtol * c2 ** 0.5):
+            st["bad"] += 1
+            return None
+        return st["x"].clone(), st["ch"].steps
 
     # ---- diagnostics ------------------------------------------------------------------------------------------
     def coriolis(self):
@@ -401,7 +444,11 @@ class SWEqn:
                         ev = arnoldi_ritz(body1, self.n1 + self.n2, 40, self.eng.device)
                         lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
                         ok = lmin > 0.02 and imax <= 0.15 * (lmax - lmin)          # a real, positive interval (else: the GMRES)
-                        self._cA = (dt, GraphedChebyshev(self.eng, tuple(f.shape), body1, lambda r: self.precond_A(r, dt), lmin, lmax, rtol=self.rtol)
+                        step = None
+                        if os.environ.get("MIMSEM_SW_CHEB_FUSED", "1") == "1" and not hasattr(self.eng, "halo"):
+                            blocks = self._pcA[1]                                   # (set by _krylov_body1: the coupled element blocks of this dt)
+                            step = lambda ca, cb, x, r, d: self.eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, ca, cb, x, r, d)
+                        self._cA = (dt, GraphedChebyshev(self.eng, tuple(f.shape), body1, lambda r: self.precond_A(r, dt), lmin, lmax, rtol=self.rtol, step=step)
                                     if ok else None, (lmin, lmax, imax))
                     if self._cA[1] is not None:
                         res_c = self._cA[1].solve(-f)

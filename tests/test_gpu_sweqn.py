@@ -430,3 +430,51 @@ def test_config2_williamson2_errors_converge_with_resolution():
     # refinements) from a lost or mis-scaled term, whose O(1) error would show as order ~0 in the finer pair
     assert min(ov) >= 1.9 and min(oh) >= 2.2 and abs(ov[0] - ov[1]) < 0.3 and abs(oh[0] - oh[1]) < 0.4, (errs, ov, oh)
     assert errs[24][0] < 1.5e-4 and errs[24][1] < 3.5e-5, errs
+
+
+def test_sw_chebyshev_step_and_solve(sw):
+    """Round 5: the [u|h] solve without a Krylov method.  (a) mimsem_sw_operator_precond_chebyshev (x += d; r -= P A d; d = ca d + cb r in the
+    three launches of the Krylov body) against the body + mimsem_krylov_chebyshev_update + plain tensor algebra; (b) the spectrum of P A under
+    the coupled element blocks is real to a few per cent (the premise); (c) krylov.GraphedChebyshev -- fixed step count from the interval, one
+    graph replay -- reaches the GMRES solution to the tolerance both were given"""
+    import torch
+    from mimsem_amd.krylov import GraphedChebyshev, GraphedGMRES, arnoldi_ritz
+    from mimsem_amd.sweqn import H_MEAN, ROS_ALPHA
+    cs, eng, O, S, uq, hq = sw
+    r = np.random.default_rng(41)
+    dm = eng.mesh
+    n, dt = dm.n1 + dm.n2, 360.0
+    body = S._krylov_body1(dt)
+    blocks = S._pcA[1]
+    mk = lambda: _t(eng, np.concatenate([r.standard_normal(dm.n1), 20.0 * r.standard_normal(dm.n2)]))
+    x, res, d = mk(), mk(), mk()
+    ca, cb = 0.37, 1.9
+    Bd = body(d)
+    x_ref, r_ref = x + d, res - Bd
+    d_ref = ca * d + cb * r_ref
+    x1, r1, d1 = x.clone(), res.clone(), d.clone()
+    eng.chebyshev_update(ca, cb, Bd, x1, r1, d1)
+    for got, want in ((x1, x_ref), (r1, r_ref), (d1, d_ref)):
+        assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 1e-15
+    x2, r2, d2 = x.clone(), res.clone(), d.clone()
+    eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, S.grav, H_MEAN, S.fg, blocks, ca, cb, x2, r2, d2)
+    for got, want, name in ((x2, x_ref, "x"), (r2, r_ref, "r"), (d2, d_ref, "d")):
+        assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 1e-14, name
+    ev = arnoldi_ritz(body, n, 30, eng.device)
+    lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
+    assert 0.1 < lmin < 1.0 < lmax < 2.0 and imax < 0.15 * (lmax - lmin), (lmin, lmax, imax)
+    b = mk()
+    pc = lambda v: S.precond_A(v, dt)
+    step = lambda a_, b_, xx, rr, dd: eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, S.grav, H_MEAN, S.fg, blocks, a_, b_, xx, rr, dd)
+    sols = []
+    for st in (None, step):
+        ch = GraphedChebyshev(eng, tuple(b.shape), body, pc, lmin, lmax, rtol=1e-13, step=st)
+        out = ch.solve(b)
+        assert out is not None and out[1] > 0 and out[2] <= 1e-13, out[1:]
+        true = float(torch.linalg.vector_norm(pc(b - S.apply_A(out[0], dt))) / torch.linalg.vector_norm(pc(b)))
+        assert true < 3e-13, true                                       # the recurrence residual is the true one to round-off
+        sols.append(out[0])
+    assert rel_l2(sols[0].cpu().numpy(), sols[1].cpu().numpy()) < 1e-12
+    g = GraphedGMRES(eng, n, body, restart=60)
+    xg, its, _ = g.solve(lambda v: S.apply_A(v, dt), b, pc, rtol=1e-13, maxit=200)
+    assert rel_l2(sols[1].cpu().numpy(), xg.cpu().numpy()) < 1e-11
