@@ -61,6 +61,8 @@ _SIGS = {
     "mimsem_sw_blocks_apply": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_op_richardson_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
                                              c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_op_chebyshev_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint,
+                                            c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_block_richardson_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint,
                                                 c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_block_chebyshev_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll, c_dp, c_dp, c_ll,

@@ -1371,6 +1371,20 @@ int mimsem_op_richardson_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, d
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, x, xs, 1.0, &g);
 }
 
+// the Chebyshev form of mimsem_op_richardson_sweep: z = dinv (b - Op x);  p = z + beta p;  x += alpha p  (two launches)
+int mimsem_op_chebyshev_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, double tau, unsigned flags,
+                              const double* f, long long fs, const double* u, long long us,
+                              const double* b, long long bs, const double* dinv, long long ds, double alpha, double beta,
+                              double* p, long long ps, double* x, long long xs, double* upd, long long upds) {
+    if (!c || !b || !dinv || !x || !p || (flags & MIMSEM_FLAG_ACCUM)) return MIMSEM_ERR_ARG;
+    int in, cf, outsp;
+    if (op_spaces(op, &in, &cf, &outsp) || outsp == 2 || in != outsp) return MIMSEM_ERR_ARG;     // square operators on gathered spaces
+    if (is_up_op(op) && !u) return MIMSEM_ERR_ARG;
+    GatherEpilogue g{5, b, bs, dinv, ds, upd, upds};
+    g.alpha = alpha; g.beta = beta; g.p = p; g.ps = ps;
+    return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, u, us, tau, x, xs, x, xs, 1.0, &g);
+}
+
 int mimsem_block_richardson_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
                                   const double* f, long long fs, const double* blocks,
                                   const double* b, long long bs, double* x, long long xs, double* upd, long long upds) {

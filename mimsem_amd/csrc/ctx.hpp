@@ -185,7 +185,7 @@ struct ElemArgs {
 
 // pass 2 with an epilogue (the Richardson sweeps): what happens to the gathered sum `acc` of a slot
 struct GatherEpilogue {
-    int mode;                        // 1: d = dinv*(b - acc) ; 2, 3: d = acc.   1, 2: x += d.   3: p = d + beta p ; x += alpha p.   upd = d if given
+    int mode;                        // 1, 5: d = dinv*(b - acc) ; 2, 3: d = acc.   1, 2: x += d.   3, 5: p = d + beta p ; x += alpha p.   upd = d if given
     const double* b; long long bs;
     const double* dinv; long long ds;
     double* upd; long long us;

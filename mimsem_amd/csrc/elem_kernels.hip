@@ -604,14 +604,14 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
-        const double d = (g.mode == 1) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
+        const double d = (g.mode == 1 || g.mode == 5) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
         if (g.mode == 4) {           // Chebyshev step on B = P A, acc = (B d)[s]: x += d; r -= acc; d = alpha d + beta r
             double* dp = g.p + (size_t)lev*g.ps + s; double* rp = g.cr + (size_t)lev*g.crs + s;
             const double dv = *dp, rv = *rp - acc;
             x[(size_t)lev*xs + s] += dv;
             *rp = rv;
             *dp = fma(g.alpha, dv, g.beta*rv);
-        } else if (g.mode == 3) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p
+        } else if (g.mode == 3 || g.mode == 5) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p (5: z = dinv (b - acc))
             double* pp = g.p + (size_t)lev*g.ps + s;
             const double pn = d + g.beta*(*pp);
             *pp = pn;

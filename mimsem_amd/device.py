@@ -261,6 +261,18 @@ class Engine:
                                                 _ptr(upd), upd.stride(0) if upd is not None else 0), "richardson_sweep(%s)" % op)
         return x
 
+    def chebyshev_sweep(self, op, x, b, dinv, p, alpha, beta, f=None, u=None, tau=0.0, lev0=0, scale=1.0, flags=0, upd=None):
+        """z = dinv * (b - Op x); p = z + beta p; x += alpha p in place (mimsem_op_chebyshev_sweep: two launches); upd receives z"""
+        sin, sf, sout = self._SPACES[op]
+        nlev = x.shape[0]
+        assert sin == sout and x.dim() == 2 and x.shape == b.shape == dinv.shape == p.shape and x.shape[1] == self.sizes[sin]
+        assert upd is None or upd.shape == x.shape
+        check(self.L.mimsem_op_chebyshev_sweep(self.ctx, OPS[op], lev0, nlev, scale, tau, flags,
+                                               _ptr(f), f.stride(0) if f is not None else 0, _ptr(u), u.stride(0) if u is not None else 0,
+                                               _ptr(b), b.stride(0), _ptr(dinv), dinv.stride(0), float(alpha), float(beta), _ptr(p), p.stride(0),
+                                               _ptr(x), x.stride(0), _ptr(upd), upd.stride(0) if upd is not None else 0), "chebyshev_sweep(%s)" % op)
+        return x
+
     def block_richardson_sweep(self, op, blocks, x, b, f=None, lev0=0, scale=1.0, flags=0, upd=None):
         """x += sum_e R_e^T B_e R_e (b - Op x) in place on 1-forms; blocks [nEl, 2 n1e, 2 n1e] column-major per element
         (mimsem_block_richardson_sweep: element pass, block pass with on-the-fly gathered residual, gather with update)"""

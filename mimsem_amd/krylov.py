@@ -641,6 +641,26 @@ def arnoldi_ritz(body, n, m, device, seed=1):
     return np.linalg.eigvals(H[:k, :k])
 
 
+def chebyshev_ellipse_coefs(d, c2, steps):
+    """(alpha_k, beta_k) of the Chebyshev iteration p_k = z_k + beta_k p_{k-1}, x += alpha_k p_k for a spectrum inside an ellipse with centre d
+    and foci d +- c (Manteuffel 1977); c2 = c^2 may be NEGATIVE (foci d +- i |c|: a spectrum stretched along the imaginary direction, e.g. an
+    advective operator) -- the recurrence stays real.  c2 > 0 with a real interval [d - c, d + c] gives ChebyshevMass' coefficients."""
+    al = 1.0 / d
+    coef = [(al, 0.0)]
+    for k in range(1, steps):
+        be = (0.5 if k == 1 else 0.25) * c2 * al * al
+        al = 1.0 / (d - be / al)
+        coef.append((al, be))
+    return coef
+
+
+def chebyshev_ellipse_rate(d, a_re, a_im):
+    """asymptotic convergence factor for an ellipse with centre d > 0 and semi-axes a_re (real direction), a_im (imaginary direction)"""
+    import math
+    c2 = a_re * a_re - a_im * a_im
+    return (a_re + a_im) / (d + math.sqrt(max(d * d - c2, 0.0)))
+
+
 class GraphedChebyshev:
     """B x = c, B = P A with a spectrum that is (close to) a real interval [lmin, lmax]: the Chebyshev semi-iteration (Saad, Alg. 12.1)
     with a FIXED number of steps -- known in advance from the interval and the tolerance -- captured with the preconditioning of the

@@ -73,6 +73,13 @@ class SWEqn:
         # finished by the GMRES from the iterate reached.  MIMSEM_SW_CHEB=0 selects the GMRES alone.
         self.cheb = os.environ.get("MIMSEM_SW_CHEB", "1") == "1"
         self._cA = None
+        # ... and with every nested solve of a Picard iteration of FIXED length (Chebyshev for the [u|h] system, the 1-form mass and the
+        # upwinded lumped 0-form mass) the WHOLE iteration -- residual assembly, its solves, the [u|h] solve, the update, every check norm --
+        # is ONE hipGraph: one replay and one read of a handful of scalars per Picard iteration, no Python between the ~450 launches
+        # (MIMSEM_SW_GRAPH_ITER=0: the nested solves each in their own graph, Python in between, as before).
+        self.graph_iter = os.environ.get("MIMSEM_SW_GRAPH_ITER", "1") == "1"
+        self._inline = None                 # the _PicardGraph that is recording / warming up: nested solves run inline and log their check norms
+        self._pg = None
         self._hist = {}
         self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
         self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
@@ -130,6 +137,8 @@ class SWEqn:
     def solve_M1(self, b, key="M1"):
         """KSPSolve(ksp, b, x) on M1 (:84-92).  Single rank: hipGraph-captured preconditioned Richardson sweeps (P^-1 M1 is within
         ~10 % of the identity); otherwise / if they do not contract: SPD => preconditioned CG reaches the same solution"""
+        if self._inline is not None:
+            return self._inline.m1(b)
         if self.graphs and self.cheb and self.eng.mesh.n <= 5 and self.fused_sweeps and not hasattr(self.eng, "halo") and \
                 os.environ.get("MIMSEM_SW_CHEB_M1", "1") == "1":
             # round 5: a FIXED-length Chebyshev semi-iteration on the fused block sweep (krylov.ChebyshevMass: 3 launches per step, spectrum of
@@ -233,6 +242,8 @@ class SWEqn:
             self._m0fg = self.m0 * self.fg
         rhs = self._m0fg + self.E("E01", self.M1(u))
         m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
+        if dt > 1.0e-6 and self._inline is not None:
+            return self._inline.q(rhs, m0h, h, u, dt)
         if dt > 1.0e-6:
             A = lambda q: self.eng.apply_up("PHMAT_UP", q, h, u, fac=UP_TAU, dt=dt)
             if self.graphs:
@@ -424,6 +435,10 @@ class SWEqn:
 
     def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
         """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
+        if self.graphs and self.cheb and self.graph_iter and bot is None and self.eng.mesh.n <= 4 and self.coupled_pc and self.fused_sweeps:
+            out = self._solve_graphed(un, hn, dt, nits, q_exact, verbose)
+            if out is not None:
+                return out
         ui, hi = un, hn                                                    # (read only: the iterate lives in x)
         uj, hj = un, hn
         x = self.pack(uj, hj)
@@ -492,6 +507,42 @@ class SWEqn:
         self.step += 1
         self.history = hist
         return uj, hj
+
+    def _solve_graphed(self, un, hn, dt, nits, q_exact, verbose):
+        """SWEqn::solve with one hipGraph replay per Picard iteration (_PicardGraph); None when the graphed path is not available or one of
+        its fixed-length solves missed its tolerance (the caller then runs the step on the adaptive path from the same start state)"""
+        pg = self._pg
+        if pg is None or pg.key != (dt, bool(q_exact), tuple(un.shape)):
+            if pg is not None and pg.key[0] == dt and pg.broken:
+                return None
+            try:
+                pg = self._pg = _PicardGraph(self, dt, bool(q_exact), un, hn)
+            except _NoGraph:
+                self._pg = _PicardGraph.__new__(_PicardGraph); self._pg.key = (dt, bool(q_exact), tuple(un.shape)); self._pg.broken = True
+                return None
+        if pg.broken:
+            return None
+        pg.ui.copy_(un); pg.hi.copy_(hn)
+        pg.x[:, :self.n1].copy_(un); pg.x[:, self.n1:].copy_(hn)
+        it, hist = 0, []
+        while True:
+            vals = pg.replay(first=(it == 0))
+            ok, norm = pg.verify(vals, first=(it == 0))
+            if not ok:
+                pg.fails += 1
+                if pg.fails >= 2:
+                    pg.broken = True
+                return None
+            hist.append(norm)
+            if verbose:
+                print("iteration: %d\t|dx|/|x|: %.6e  (graphed)" % (it, norm))
+            it += 1
+            if not (norm > 1.0e-14 and it < nits):
+                break
+        self.its.update(pg.its)
+        self.step += 1
+        self.history = hist
+        return pg.x[:, :self.n1].clone(), pg.x[:, self.n1:].clone()
 
     # ---- conservation diagnostics (int0 :1202-1238, int2 :1240-1274, intE :1276-1323, writeConservation :1325-1359) ------------
     def conservation(self, u, h, bot=None):
@@ -572,6 +623,150 @@ class SWEqn:
     def init2(self, hq):
         """hq: [nq] -> 2-form h = M2^-1 WtQ hq (M2 is element-block diagonal: exact inverse)"""
         return self.eng.blocks_apply(2, self.m2_inv, self.eng.apply("WTQ", hq.reshape(1, -1).contiguous()))
+
+
+class _NoGraph(Exception):
+    pass
+
+
+class _PicardGraph:
+    """One Picard iteration of SWEqn::solve (src/SWEqn_Picard.cpp:751-765 with assemble_residual :402-607) as ONE hipGraph.  Every nested solve
+    has a FIXED length -- Chebyshev semi-iterations whose step counts follow from spectral regions estimated once per dt: the [u|h] system
+    (real interval, GraphedChebyshev), the 1-form mass (real interval, ChebyshevMass on the fused block sweep), the upwinded lumped 0-form
+    mass (a vertical segment 1 +- i sigma: ellipse with imaginary foci, mimsem_op_chebyshev_sweep) -- so nothing inside needs the host.  Each
+    solve logs {|last preconditioned residual|^2, |P b|^2} into a slot of one small device vector; after the replay the host reads that
+    vector ONCE, checks every solve against its tolerance and takes |dx| / |x| for the Picard loop.  Two graphs: the first iteration of a step
+    (also diagnoses q of the start-of-step state; uj = ui) and the later ones."""
+    NSLOT = 16
+
+    def __init__(self, S, dt, q_exact, un, hn):
+        from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds
+        self.S, self.dt, self.q_exact = S, dt, q_exact
+        self.key = (dt, q_exact, tuple(un.shape))
+        self.broken, self.fails = False, 0
+        eng = S.eng
+        dev = eng.device
+        n1, n2, n0 = S.n1, S.n2, eng.sizes[0]
+        self.ui, self.hi = torch.zeros_like(un), torch.zeros_like(hn)
+        self.x = torch.zeros(un.shape[0], n1 + n2, dtype=torch.float64, device=dev)
+        self.qi = torch.zeros(un.shape[0], n0, dtype=torch.float64, device=dev)
+        self.chk = torch.zeros(2 * self.NSLOT, dtype=torch.float64, device=dev)
+        self.graphs = {}
+        self.its = {}
+        # ---- [u|h]: real interval of P A
+        body1 = S._krylov_body1(dt)
+        ev = arnoldi_ritz(body1, n1 + n2, 40, dev)
+        lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
+        if not (lmin > 0.02 and imax <= 0.15 * (lmax - lmin)):
+            raise _NoGraph()
+        blocks = S._pcA[1]
+        step = lambda ca, cb, x, r, d: eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, S.grav, H_MEAN, S.fg, blocks, ca, cb, x, r, d)
+        self.chA = GraphedChebyshev(eng, (un.shape[0], n1 + n2), body1, lambda r: S.precond_A(r, dt), lmin, lmax, rtol=S.rtol, step=step)
+        self.its["A"] = self.chA.steps
+        # ---- M1: real interval of P M1
+        cm = S.m1_pre.transpose(1, 2).contiguous()
+        g = torch.Generator(device="cpu"); g.manual_seed(4321)
+        rb = torch.randn(un.shape, generator=g, dtype=torch.float64).to(dev)
+        l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
+        self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol)
+        self.its["F"] = self.chM.steps
+        # ---- the upwinded lumped 0-form mass under its diagonal: 1 +- i sigma (the upwinding is a skew perturbation of the identity)
+        self.qcoef = None
+        if not q_exact:
+            m0h = eng.pvec(0, 1, 1.0, h2=hn)
+            tau = 1.0 / (1.0 / (UP_TAU * dt))
+            evq = arnoldi_ritz(lambda v: eng.apply_up("PHMAT_UP", v, hn, un, fac=UP_TAU, dt=dt) / m0h, n0, 40, dev)
+            d0 = 0.5 * float(evq.real.max() + evq.real.min())
+            a_re = 0.5 * float(evq.real.max() - evq.real.min()) * 1.5 + 0.01
+            a_im = float(abs(evq.imag).max()) * 1.2 + 0.01
+            rate = chebyshev_ellipse_rate(d0, a_re, a_im)
+            if not (d0 > 0.2 and rate < 0.6):
+                raise _NoGraph()
+            nq = max(2, int(math.ceil(math.log(0.5 * S.rtol) / math.log(rate))) + 1)
+            self.qcoef = chebyshev_ellipse_coefs(d0, a_re * a_re - a_im * a_im, nq)
+            self.qtau = tau
+            self.qp = torch.zeros(un.shape[0], n0, dtype=torch.float64, device=dev)
+            self.qupd = torch.zeros_like(self.qp)
+            self.its["q"] = nq
+        self.slot = 0
+        self.names = {}
+
+    # -- the inline solves (called from SWEqn.solve_M1 / diagnose_q while this object records or warms up)
+    def _log(self, name, res, ref):
+        k = self.slot; self.slot += 1
+        assert k < self.NSLOT
+        self.names[k] = name
+        eng = self.S.eng
+        eng.rowdot(res.reshape(1, -1), res.reshape(1, -1), out=self.chk[2 * k:2 * k + 1])
+        eng.rowdot(ref.reshape(1, -1), ref.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2])
+
+    def m1(self, b):
+        x = self.chM.solve(b, want_residual=True)
+        self._log("M1", self.chM.upd, self.S.precond_M1(b))
+        return x
+
+    def q(self, rhs, m0h, h, u, dt):
+        eng = self.S.eng
+        dinv = torch.reciprocal(m0h)
+        x = torch.zeros_like(rhs)
+        self.qp.zero_()
+        last = len(self.qcoef) - 1
+        for k, (al, be) in enumerate(self.qcoef):
+            eng.chebyshev_sweep("PHMAT_UP", x, rhs, dinv, self.qp, al, be, f=h, u=u, tau=self.qtau, upd=self.qupd if k == last else None)
+        self._log("q", self.qupd, rhs * dinv)
+        return x
+
+    def _body(self, first):
+        S, n1 = self.S, self.S.n1
+        self.slot = 0
+        uj, hj = self.x[:, :n1].contiguous(), self.x[:, n1:].contiguous()
+        if first and not self.q_exact:
+            self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
+        f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, None, qi=None if self.q_exact else self.qi,
+                                qj=(None if self.q_exact else (self.qi if first else None)), it=0 if first else 1)
+        ch = self.chA
+        torch.neg(f, out=ch.b)
+        ch._run()
+        k = self.slot; self.slot += 1
+        self.names[k] = "A"
+        self.chk[2 * k:2 * k + 2].copy_(ch.nrm)
+        self.x.add_(ch.x)
+        k = self.slot; self.slot += 1
+        self.names[k] = "picard"
+        S.eng.rowdot(ch.x.reshape(1, -1), ch.x.reshape(1, -1), out=self.chk[2 * k:2 * k + 1])
+        S.eng.rowdot(self.x.reshape(1, -1), self.x.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2])
+        self.nslots = self.slot
+
+    def replay(self, first):
+        S = self.S
+        if first not in self.graphs:
+            keep = self.x.clone()
+            S._inline = self
+            try:
+                self.graphs[first] = (S.eng.capture(lambda: self._body(first))[0], dict(self.names), self.nslots)
+            finally:
+                S._inline = None
+            self.x.copy_(keep)
+        g, _, _ = self.graphs[first]
+        g.replay()
+        return self.chk.tolist()
+
+    def verify(self, vals, first):
+        _, names, nslots = self.graphs[first]
+        ok, norm = True, float("nan")
+        for k in range(nslots):
+            res2, ref2 = vals[2 * k], vals[2 * k + 1]
+            if names[k] == "picard":
+                norm = (res2 / ref2) ** 0.5 if ref2 > 0.0 else 0.0
+                ok = ok and norm == norm
+                continue
+            # M1 / q log the residual the LAST sweep saw (one more contraction lies between it and the result): a factor 30 of slack; the
+            # [u|h] system logs the recurrence residual of the result itself
+            tol = self.S.rtol * (30.0 if names[k] in ("M1", "q") else 3.0)
+            rel = (res2 / ref2) ** 0.5 if ref2 > 0.0 else 0.0
+            if not (rel <= tol):
+                ok = False
+        return ok, norm
 
 
 def williamson2(xq, alpha=0.25 * math.pi):

@@ -1,0 +1,15 @@
+#!/bin/bash
+# A/B of the whole-Picard-iteration hipGraph (mimsem_amd/sweqn.py _PicardGraph, MIMSEM_SW_GRAPH_ITER = 1) against the nested solves in their own
+# graphs with Python in between (0) -> steps/s, iteration counts, error norms, drifts on configs 2 and 3
+R=$GRAFT_REPO_ROOT; cd $R
+for e in 0 1 0 1; do
+  MIMSEM_SW_GRAPH_ITER=$e python3 bench.py --no-families --no-column --no-sweep --cold 0 --no-pmc --no-cpu > /dev/null 2> /dev/null
+  python3 - <<PY
+import json
+d = json.load(open("bench_extras.json"))["sw"]
+for k, v in d.items():
+    print("graph_iter=$e", k, "steps/s %.1f" % v["steps_per_s"], "picard/step %.1f" % v["picard_iterations_per_step"], "its", v["krylov_iterations_last"],
+          "drift", {a: "%.3e" % b for a, b in v["relative_drift_over_timed_steps"].items()},
+          "errs", None if not v["williamson2_error_norms_L1_L2_Linf"] else {a: ["%.12e" % x for x in b] for a, b in v["williamson2_error_norms_L1_L2_Linf"].items()})
+PY
+done
