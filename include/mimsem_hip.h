@@ -622,6 +622,20 @@ int  mimsem_halo_end(mimsem_halo* plan);
  * MIMSEM_ERR_UNSUPPORTED unless the context is of order 4.  Synchronises. */
 int  mimsem_selftest_rows_half(mimsem_ctx* ctx, int ntask, const double* A, const double* B, const double* x, const double* cq, double* out);
 
+/* Round 5: fixed-length solves from C / C++.  Under its element-block preconditioner the 1-form mass matrix, and under the coupled [u|h]
+ * element blocks the shallow-water operator of SWEqn::solve (src/SWEqn_Picard.cpp:751-765), have a REAL, narrow spectrum; a Chebyshev
+ * semi-iteration with a step count known in advance (mimsem_block_chebyshev_sweep, mimsem_sw_operator_precond_chebyshev,
+ * mimsem_op_chebyshev_sweep) then replaces KSPSolve's GMRES -- no inner product, no host round trip, recordable in a hipGraph
+ * (mimsem_graph_*).  What the host needs from the KSP object PCSetUp built:
+ * mimsem_ksp_get_pc_blocks: the device blocks of mimsem_ksp_set_pc_bjacobi (1- or 2-form operators; *elem_scale: the per (level, element)
+ *   factor, or NULL) or of mimsem_ksp_set_pc_sw_bjacobi / _sw_blocks (the coupled blocks, *elem_scale = NULL), owned by the KSP object;
+ *   *nd = rows of a block.  MIMSEM_ERR_STATE for any other preconditioner.
+ * mimsem_ksp_ritz: m Arnoldi steps of P A (operator and preconditioner of the object as set) on a fixed pseudo-random start vector and the
+ *   eigenvalues of the m x m Hessenberg matrix (shifted QR on the host): the smallest / largest real part and the largest |imaginary part|
+ *   of the Ritz values -- the interval (or ellipse) the Chebyshev coefficients are computed from.  Set-up cost: m operator applications. */
+int  mimsem_ksp_get_pc_blocks(const mimsem_ksp* ksp, const double** blocks, const double** elem_scale, int* nd);
+int  mimsem_ksp_ritz(mimsem_ksp* ksp, int m, double* re_min, double* re_max, double* im_max);
+
 /* ---- hipGraph capture of a launch sequence, for hosts that carry no HIP toolchain (the C++ shim, a PETSc application) -------------------
  * The reference calls its operators one level at a time -- for (kk ...) { M1->assemble(kk, SCALE, true); MatMult(M1->M, x[kk], y[kk]); ... }
  * (eul/Euler_2.cpp:1427-1457, eul/HorizSolve.cpp:651-699) -- and on one rank's patch (144 elements) such a call is two ~4 us kernels

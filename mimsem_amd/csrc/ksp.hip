@@ -17,6 +17,7 @@
 #include <vector>
 #include <hip/hip_runtime.h>
 #include "ctx.hpp"
+#include "hqr_host.hpp"
 #include "../../include/mimsem_hip.h"
 
 #define KTRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -534,6 +535,65 @@ int mimsem_ksp_solve(mimsem_ksp* k, const double* b, long long bs, double* x, lo
     }
     return k->type == MIMSEM_KSP_CG ? solve_cg(k, b, bs, x, xs) : solve_gmres(k, b, bs, x, xs);
 }
+// ---- round 5: what a host needs to run FIXED-LENGTH (Chebyshev) solves itself: the blocks PCSetUp built, and the region of the spectrum ----
+int mimsem_ksp_get_pc_blocks(const mimsem_ksp* k, const double** blocks, const double** elem_scale, int* nd) {
+    if (!k || !blocks) return MIMSEM_ERR_ARG;
+    if (k->pkind != P_BLOCKS && k->pkind != P_SW) return MIMSEM_ERR_STATE;
+    *blocks = k->blocks;
+    if (elem_scale) *elem_scale = k->pkind == P_BLOCKS ? k->escale : nullptr;
+    if (nd) {
+        const ElemSizes& es = k->c->es;
+        *nd = k->pkind == P_SW ? 2*es.n1e + es.n2e : (k->bform == 1 ? 2*es.n1e : (k->bform == 0 ? es.n0e : es.n2e));
+    }
+    return MIMSEM_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_pseudo_random(long long n, double* __restrict__ v) {
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long x = (unsigned long long)i*0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;      // splitmix64: a fixed start vector for every run
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    v[i] = (double)(x >> 11)*(1.0/9007199254740992.0) - 0.5;
+}
+}  // namespace
+
+// Ritz values of P A from m Arnoldi steps on a fixed start vector: the region of the spectrum a fixed-length Chebyshev solve needs
+int mimsem_ksp_ritz(mimsem_ksp* k, int m, double* re_min, double* re_max, double* im_max) {
+    if (!k || m < 2 || m > 200 || k->akind == A_NONE || !re_min || !re_max || !im_max) return MIMSEM_ERR_ARG;
+    mimsem_ctx* c = k->c; const int nr = k->nlev; const long long n = k->n, N = nr*n;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    KTRY(k->ensure((long long)(m + 1)*N + 4*N + 3*(long long)(m + 2), (long long)(m + 2) + 4));
+    double *V = k->ws, *w = V + (long long)(m + 1)*N, *t = w + N, *h = t + 3*N, *h2 = h + (m + 2);
+    double* col = k->host;
+    hipLaunchKernelGGL(k_pseudo_random, dim3((unsigned)((N + 255)/256)), dim3(256), 0, c->stream, N, w);
+    KTRY(mimsem_krylov_rowdot(c, 1, N, w, N, w, N, h2));
+    KTRY(to_host(c, col, h2, 1));
+    if (!(col[0] > 0.0)) return MIMSEM_ERR_STATE;
+    KTRY(combine(c, 1, N, 1.0/std::sqrt(col[0]), w, N, 0.0, nullptr, 0, V, N));
+    std::vector<double> H((size_t)m*m, 0.0);
+    int kk = 0;
+    for (int j = 0; j < m; j++) {
+        KTRY(k->PA(V + (long long)j*N, n, t, w, n));
+        *k->flag = 0;
+        KTRY(mimsem_krylov_orthogonalize(c, j + 1, N, V, N, -1.0, w, h));
+        KTRY(mimsem_krylov_reorthonormalize_ex(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, 0, k->flag));
+        MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i <= j; i++) H[(size_t)i*m + j] = col[i];
+        kk = j + 1;
+        if (!(col[m + 1] == col[m + 1])) return MIMSEM_ERR_STATE;                  // NaN
+        if (j + 1 < m) H[(size_t)(j + 1)*m + j] = col[m + 1];
+        if (col[m + 1] <= 1e-14*std::fabs(H[0])) break;                           // invariant subspace: the Ritz values are eigenvalues
+    }
+    std::vector<double> a((size_t)kk*kk), wr, wi;
+    for (int i = 0; i < kk; i++) for (int j = 0; j < kk; j++) a[(size_t)i*kk + j] = H[(size_t)i*m + j];
+    if (hessenberg_eigenvalues(a, kk, wr, wi) != 0) return MIMSEM_ERR_STATE;
+    double lo = wr[0], hi = wr[0], im = 0.0;
+    for (int i = 0; i < kk; i++) { lo = std::min(lo, wr[i]); hi = std::max(hi, wr[i]); im = std::max(im, std::fabs(wi[i])); }
+    *re_min = lo; *re_max = hi; *im_max = im;
+    return MIMSEM_OK;
+}
+
 int mimsem_ksp_get_info(const mimsem_ksp* k, int* its, double* rnorm, int* reason) {
     if (!k) return MIMSEM_ERR_ARG;
     if (its) *its = k->its;
