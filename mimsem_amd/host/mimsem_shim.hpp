@@ -105,7 +105,13 @@ public:
         d.inds0 = i0.data(); d.inds1x = ix.data(); d.inds1y = iy.data(); d.inds2 = nullptr;
         d.det = g->det.data(); d.J = g->J.data(); d.thick = th.data(); d.thickInv = ti.data();
         d.indsq = iqa.data(); d.nq = (int)n0q;
-        nEl_ = nEl; n2e = n*n;
+        nEl_ = nEl; n2e = n*n; n0 = d.n0; n1 = d.n1; n2 = d.n2; nk_ = d.nk;
+        check(mimsem_ctx_create(&d, device, &ctx), "mimsem_ctx_create");
+    }
+    // any set of patches the host numbered itself (several cubed-sphere faces on one GPU: the whole sphere of the src/ drivers): the
+    // element -> slot tables and the metric as mimsem_mesh_desc takes them.  topo / geom stay null: only classes built from a Mesh* apply.
+    explicit Mesh(const mimsem_mesh_desc& d, int device = 0) : topo(nullptr), geom(nullptr) {
+        nEl_ = d.nEl; n2e = d.elOrd*d.elOrd; n0 = d.n0; n1 = d.n1; n2 = d.n2; nk_ = d.nk;
         check(mimsem_ctx_create(&d, device, &ctx), "mimsem_ctx_create");
     }
     ~Mesh() { mimsem_ctx_destroy(ctx); }
@@ -145,7 +151,7 @@ public:
     void interp2_l(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 2, 0, 1, x, 0, out, 0), "interp2_l"); }
     void interp2_g(const double* x, double* out) const { check(mimsem_interp_quad(ctx, 2, MIMSEM_INTERP_GLOBAL, 1, x, 0, out, 0), "interp2_g"); }
     const Topo* topo; const Geom* geom; mimsem_ctx* ctx = nullptr;
-    int nEl_ = 0, n2e = 0;
+    int nEl_ = 0, n2e = 0, n0 = 0, n1 = 0, n2 = 0, nk_ = 1;
 private:
     static std::map<std::pair<const Topo*, const Geom*>, std::unique_ptr<Mesh>>& registry() {
         static std::map<std::pair<const Topo*, const Geom*>, std::unique_ptr<Mesh>> r;
@@ -162,11 +168,11 @@ class VecScatterHalo {
 public:
     VecScatterHalo(Mesh* m, int form, const std::vector<int>& ranks, const std::vector<int>& ghost_idx, const std::vector<int>& ghost_off,
                    const std::vector<int>& mirror_idx, const std::vector<int>& mirror_off) : mesh(m) {
-        const int nslots = form == 1 ? m->topo->n1 : m->topo->n0, nn = (int)ranks.size();
+        const int nslots = form == 1 ? m->n1 : m->n0, nn = (int)ranks.size();
         check(mimsem_halo_create(m->ctx, nn, ranks.data(), ghost_idx.data(), ghost_off.data(), mirror_idx.data(), mirror_off.data(),
-                                 nslots, m->geom->nk, &rev), "mimsem_halo_create(reverse)");
+                                 nslots, m->nk_, &rev), "mimsem_halo_create(reverse)");
         check(mimsem_halo_create(m->ctx, nn, ranks.data(), mirror_idx.data(), mirror_off.data(), ghost_idx.data(), ghost_off.data(),
-                                 nslots, m->geom->nk, &fwd), "mimsem_halo_create(forward)");
+                                 nslots, m->nk_, &fwd), "mimsem_halo_create(forward)");
         if (form == 1) {                       // the slots that travel: their element groups go first in the operators' plans
             std::vector<int> shared(ghost_idx); shared.insert(shared.end(), mirror_idx.begin(), mirror_idx.end());
             check(mimsem_ctx_set_halo_slots(m->ctx, 1, shared.data(), (int)shared.size()), "mimsem_ctx_set_halo_slots");
@@ -300,6 +306,7 @@ public:
     }
     void setPCBJacobi() { pc = PC_BJACOBI; pc_dirty = true; }    // PCSetType(pc, PCBJACOBI) + PCBJacobiSetTotalBlocks(one block per element)
     void setPCNone() { pc = PC_NONE; pc_dirty = true; }
+    void setPCJacobi(const double* dinv) { pc = PC_JACOBI; pc_dinv = dinv; pc_dirty = true; }     // PCJACOBI with the caller's inverse diagonal (device)
     void setPCShell(mimsem_ksp_apply_fn fn, void* user) { pc = PC_SHELL; pc_fn = fn; pc_user = user; pc_dirty = true; }
     void setInitialGuessNonzero(bool f) { guess = f; check(mimsem_ksp_set_initial_guess_nonzero(h, f ? 1 : 0), "mimsem_ksp_set_initial_guess_nonzero"); }
     void solve(const double* b, double* x) {                 // KSPSolve(ksp, b, x)
@@ -309,10 +316,22 @@ public:
         check(mimsem_ksp_get_info(h, &its, &rnorm, &reason), "mimsem_ksp_get_info");
     }
     int iterations() const { return its; } double residualNorm() const { return rnorm; } int convergedReason() const { return reason; }
+    // For hosts that replace KSPSolve by a fixed-length Chebyshev iteration (src::SWEqn in mimsem_sweqn.hpp): the region of the spectrum of
+    // P A from m Arnoldi steps (mimsem_ksp_ritz), and the element blocks PCSetUp built (device; owned by this object, valid until the next set-up)
+    void ritz(int m, double* re_min, double* re_max, double* im_max) {
+        if (akind == A_NONE) fail("KSP::ritz before setOperators");
+        if (pc_dirty) setup_pc();
+        check(mimsem_ksp_ritz(h, m, re_min, re_max, im_max), "mimsem_ksp_ritz");
+    }
+    void pcBlocks(const double** blocks, const double** elem_scale = nullptr, int* nd = nullptr) {
+        if (akind == A_NONE) fail("KSP::pcBlocks before setOperators");
+        if (pc_dirty) setup_pc();
+        check(mimsem_ksp_get_pc_blocks(h, blocks, elem_scale, nd), "mimsem_ksp_get_pc_blocks");
+    }
 private:
     static void fail(const char* m) { throw std::runtime_error(m); }
     enum AKind { A_NONE, A_OP, A_SW, A_SHELL };
-    enum PKind { PC_NONE, PC_BJACOBI, PC_SHELL };
+    enum PKind { PC_NONE, PC_BJACOBI, PC_SHELL, PC_JACOBI };
     void attach_operator() {
         switch (akind) {
         case A_OP: check(mimsem_ksp_set_operator(h, a_op, a_lev, 1, a_scale, a_flags, a_field, 0), "mimsem_ksp_set_operator"); break;
@@ -323,6 +342,7 @@ private:
     }
     void setup_pc() {                                        // PCSetUp: from the operator the handle holds NOW
         if (pc == PC_SHELL) check(mimsem_ksp_set_pc_shell(h, pc_fn, pc_user), "mimsem_ksp_set_pc_shell");
+        else if (pc == PC_JACOBI) check(mimsem_ksp_set_pc_jacobi(h, pc_dinv, 0), "mimsem_ksp_set_pc_jacobi");
         else if (pc == PC_BJACOBI && akind == A_OP) check(mimsem_ksp_set_pc_bjacobi(h), "mimsem_ksp_set_pc_bjacobi");      // 0-, 1- and 2-form operators
         else if (pc == PC_BJACOBI && akind == A_SW) {
             if (sw_blocks) check(mimsem_ksp_set_pc_sw_blocks(h, sw_blocks), "mimsem_ksp_set_pc_sw_blocks");
@@ -337,7 +357,7 @@ private:
     int a_op = 0, a_lev = 0; double a_scale = 1.0; unsigned a_flags = 0; const double* a_field = nullptr;
     double sw_a = 0.0, sw_g = 0.0, sw_H = 0.0; const double* sw_f0 = nullptr; const double* sw_blocks = nullptr;
     long long sh_n = 0; mimsem_ksp_apply_fn sh_fn = nullptr; void* sh_user = nullptr;
-    mimsem_ksp_apply_fn pc_fn = nullptr; void* pc_user = nullptr;
+    mimsem_ksp_apply_fn pc_fn = nullptr; void* pc_user = nullptr; const double* pc_dinv = nullptr;
     double rtol = 1.0e-16, atol = 1.0e-50; int maxit = 1000, restart = 30;
     int its = 0, reason = 0; double rnorm = 0.0;
 };
@@ -502,7 +522,7 @@ struct E21mat { explicit E21mat(Topo* t) : mesh(Mesh::of_topo(t)) {} explicit E2
 struct L2Vecs {
     L2Vecs(int nk_, Topo* t, Geom* g) : L2Vecs(nk_, Mesh::of(t, g)) {}              // eul/L2Vecs.h: L2Vecs(int _nk, Topo*, Geom*)
     L2Vecs(int nk_, Mesh* m) : nk(nk_), mesh(m) {
-        n2 = m->topo->n2; nEl = m->nEl_; n2e = m->n2e;
+        n2 = m->n2; nEl = m->nEl_; n2e = m->n2e;
         vh = m->device_alloc((size_t)nk*n2); vz = m->device_alloc((size_t)nEl*nk*n2e);
     }
     ~L2Vecs() { mimsem_free(vh); mimsem_free(vz); }
