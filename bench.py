@@ -580,8 +580,30 @@ def sw_extras(local_rank, torch):
                      "relative_drift_over_timed_steps": {k: (c1[k] - c0[k]) / abs(c0[k]) for k in ("mass", "energy", "enstrophy")},
                      "williamson2_error_norms_L1_L2_Linf": errs, "days": (nsteps + 3) * dt / 86400.0,
                      "krylov_iterations_last": dict(S.its), "elements": dm.nEl, "dofs": dm.n1 + dm.n2}
+        # the same steps with the HOST in C++ (mimsem_amd/host/sw_call.cpp over mimsem_sweqn.hpp: no Python, no torch -- what a C++ driver like
+        # src/Galewsky.cpp gets), from the state reached here
+        res[name]["cpp_host"] = sw_cpp_host(dm, S.fg[0].cpu().numpy(), u[0].cpu().numpy(), h[0].cpu().numpy(), dt, nsteps, nits, q_exact)
         del S, eng
     return res
+
+
+def sw_cpp_host(dm, fg, u, h, dt, nsteps, nits, q_exact):
+    import subprocess
+    import tempfile
+    from mimsem_amd.workloads import write_sw_case
+    exe = os.path.join(ROOT, "mimsem_amd", "host", "sw_call")
+    if not os.path.exists(exe):
+        return {"error": "mimsem_amd/host/sw_call not built (__graft_entry__.build())"}
+    with tempfile.TemporaryDirectory() as tmp:
+        case = os.path.join(tmp, "case.bin")
+        write_sw_case(case, dm, fg, u, h, dt, max(nsteps, 20), min(nits, 50), q_exact)
+        try:
+            out = subprocess.run([exe, case, "3"], capture_output=True, text=True, timeout=300)
+            if out.returncode != 0:
+                return {"error": (out.stderr or out.stdout)[-300:]}
+            return json.loads(out.stdout)
+        except Exception as e:                     # noqa: BLE001 -- an extra must not take the bench line down
+            return {"error": repr(e)[:300]}
 
 
 FAMILIES = (("B1", "UMAT", 1, None, 1), ("B3", "WMAT", 2, None, 1), ("B4", "UHMAT", 1, 2, 1), ("B8", "WTQUMAT", 1, 1, 0),
@@ -829,6 +851,8 @@ def compact_record(out, extras_file=None):
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
             "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
             "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
+            "sw_steps_per_s_config3_cpp_host": _r(_g(out, "sw", "config3_galewsky_24x24x6", "cpp_host", "graph", "steps_per_s")),
+            "sw_steps_per_s_config2_cpp_host": _r(_g(out, "sw", "config2_w2_16x16x6", "cpp_host", "graph", "steps_per_s")),
             "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall")),
             "cpp_host_per_level_call_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_us_per_call")),
             "cpp_host_per_level_call_in_graph_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_in_a_graph_us_per_call"))}

@@ -159,6 +159,9 @@ int  mimsem_ctx_set_profiling(mimsem_ctx* ctx, int on);
 int  mimsem_ctx_profile_read(mimsem_ctx* ctx, double* ms_pass1, double* ms_pass2, long long* launches);
 
 /* plain device memory helpers so a C/C++ host (PETSc VecGetArray side) needs no HIP headers */
+/* A stream of the context's own (non-blocking), for hosts without HIP headers that want their launches out of the legacy default stream;
+ * mimsem_ctx_set_stream still overrides it.  MIMSEM_ERR_STATE while a graph is being recorded. */
+int  mimsem_ctx_use_own_stream(mimsem_ctx* ctx);
 int  mimsem_malloc(void** dev, long long bytes);
 int  mimsem_free(void* dev);
 int  mimsem_memcpy_h2d(mimsem_ctx* ctx, void* dev, const void* host, long long bytes);

@@ -32,6 +32,7 @@ _SIGS = {
     "mimsem_ctx_create": (C.c_int, [C.POINTER(MeshDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "mimsem_ctx_destroy": (None, [C.c_void_p]),
     "mimsem_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mimsem_ctx_use_own_stream": (C.c_int, [C.c_void_p]),
     "mimsem_ctx_sync": (C.c_int, [C.c_void_p]),
     "mimsem_ctx_set_levels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_ctx_workspace_bytes": (c_ll, [C.c_void_p]),

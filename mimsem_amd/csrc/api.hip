@@ -867,6 +867,8 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     for (void* p : c->retired) (void)hipFree(p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     delete c;
 }
 
@@ -874,6 +876,16 @@ int mimsem_ctx_set_stream(mimsem_ctx* c, void* s) {
     if (!c) return MIMSEM_ERR_ARG;
     if (c->cap_active) return MIMSEM_ERR_STATE;                          // (between mimsem_graph_begin and _end the stream is the capture's)
     c->stream = (hipStream_t)s;
+    return MIMSEM_OK;
+}
+// a stream of the context's own for hosts that cannot create one (no HIP headers): non-blocking, so nothing this context launches orders itself
+// against the legacy default stream any more
+int mimsem_ctx_use_own_stream(mimsem_ctx* c) {
+    if (!c) return MIMSEM_ERR_ARG;
+    if (c->cap_active) return MIMSEM_ERR_STATE;
+    MIMSEM_HIP_TRY(hipSetDevice(c->device));
+    if (!c->own_stream) MIMSEM_HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     return MIMSEM_OK;
 }
 // ---- hipGraph capture for hosts without a HIP toolchain (include/mimsem_hip.h) -----------------------------------------------------
@@ -940,6 +952,8 @@ int mimsem_op_wave_stats(const mimsem_ctx* c, int nlev, int out[5]) {
 
 int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thickInv) {
     if (!c) return MIMSEM_ERR_ARG;
+    if (c->is_capturing()) return MIMSEM_ERR_STATE;
+    MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));        // (a non-blocking stream does not order itself against the synchronous copies below)
     const size_t cnt = (size_t)c->nk*c->nEl*c->es.mp12;
     std::vector<double> th(cnt, 1.0), ti(cnt, 1.0);
     if (thick) std::memcpy(th.data(), thick, cnt*sizeof(double));
@@ -1009,12 +1023,35 @@ int mimsem_memcpy_h2d(mimsem_ctx* c, void* dev, const void* host, long long byte
 }
 int mimsem_memcpy_d2h(mimsem_ctx* c, void* host, const void* dev, long long bytes) {
     if (!c || !dev || !host || bytes < 0) return MIMSEM_ERR_ARG;
+    if (bytes > 0 && bytes <= 4096 && !c->is_capturing()) {                   // a handful of scalars (check norms, counters): through pinned memory
+        if (!c->h_pin) MIMSEM_HIP_TRY(hipHostMalloc(&c->h_pin, 4096, hipHostMallocDefault));
+        MIMSEM_HIP_TRY(hipMemcpyAsync(c->h_pin, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+        MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(host, c->h_pin, (size_t)bytes);
+        return MIMSEM_OK;
+    }
     MIMSEM_HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     return MIMSEM_OK;
 }
+namespace {
+__global__ __launch_bounds__(256) void k_fill64(long long n, unsigned long long v, unsigned long long* __restrict__ out) {
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+}  // namespace
+// (8-byte-aligned fills go through a kernel: inside a recorded graph a memset NODE costs tens of microseconds on this runtime, a kernel node
+// two or three -- the fixed-length solves of the shallow-water step clear five vectors per Picard iteration)
 int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
     if (!c || !dev || bytes < 0) return MIMSEM_ERR_ARG;
+    if (bytes == 0) return MIMSEM_OK;
+    if (bytes % 8 == 0 && ((uintptr_t)dev & 7u) == 0 && !(getenv("MIMSEM_MEMSET_NODE") && atoi(getenv("MIMSEM_MEMSET_NODE")) != 0)) {
+        const unsigned long long v = 0x0101010101010101ull*(unsigned long long)(unsigned char)byte;
+        const long long n = bytes/8;
+        hipLaunchKernelGGL(k_fill64, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, n, v, (unsigned long long*)dev);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     MIMSEM_HIP_TRY(hipMemsetAsync(dev, byte, (size_t)bytes, c->stream));
     return MIMSEM_OK;
 }

@@ -27,6 +27,8 @@ struct mimsem_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t cap_stream = nullptr, cap_saved = nullptr; bool cap_active = false, cap_swapped = false;      // mimsem_graph_begin / _end
+    hipStream_t own_stream = nullptr;          // mimsem_ctx_use_own_stream
+    void* h_pin = nullptr;                     // 4 KB of pinned host memory: small read-backs (mimsem_memcpy_d2h) skip the pageable-copy path
     ElemSizes es;
     int nEl = 0, nk = 0, n0 = 0, n1 = 0, n2 = 0;
     bool inds2_contig = true;

@@ -11,6 +11,7 @@
 //                 tolerance sends THAT Picard iteration through the krylov mode again from the saved state.
 // Header-only, C++17, no HIP toolchain needed (everything goes through include/mimsem_hip.h).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <utility>
 #include "mimsem_shim.hpp"
@@ -54,6 +55,7 @@ public:
     std::vector<double> history;         // |dx| / |x| of the iterations of the last solve()
     int fallbacks = 0;                   // Picard iterations the fixed mode handed to the krylov mode
     int steps_A = 0, steps_M1 = 0, steps_q = 0;
+    double us_submit = 0.0, us_wait = 0.0; long replays = 0;      // host time inside the graph submissions / waiting for the check norms
 
     // fg: the Coriolis 0-form (SWEqn::coriolis, src/SWEqn_Picard.cpp:95-140), device, n0 entries; it must outlive the object
     SWEqn(Mesh* m, const double* fg_dev) : mesh(m), fg(fg_dev), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
@@ -287,7 +289,10 @@ private:
         double v[2*NSLOT];
         if (fixed_length && can_fix) {
             inline_fixed = true;
-            if (use_graph && have_graph[g]) gr[g].launch();
+            const auto t0 = std::chrono::steady_clock::now();
+            auto t1 = t0;
+            const bool replay = use_graph && have_graph[g];
+            if (replay) { gr[g].launch(); t1 = std::chrono::steady_clock::now(); }
             else {
                 body(first);                                   // eagerly the first time (the library's workspaces get their sizes) ...
                 for (int k = 0; k < slot; k++) kinds_of[g][k] = kinds[k];
@@ -296,6 +301,11 @@ private:
             }
             inline_fixed = false;
             mesh->to_host(v, chk, 2*NSLOT);
+            if (replay) {
+                const auto t2 = std::chrono::steady_clock::now();
+                us_submit += std::chrono::duration<double, std::micro>(t1 - t0).count(); us_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
+                replays++;
+            }
             double norm = 0.0; bool ok = true;
             for (int k = 0; k < nslots_of[g]; k++) {
                 const double r2 = v[2*k], ref2 = v[2*k + 1], rel = ref2 > 0.0 ? std::sqrt(r2/ref2) : 0.0;

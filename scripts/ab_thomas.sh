@@ -1,9 +1,9 @@
 #!/bin/bash
 # The Helmholtz solve inside solve_schur_column_eta (3 456 columns x 30 levels): one-sided sweep (MIMSEM_THOMAS2=0) against the two-sided
-# sweep (default); wall clock per solve and rocprofv3 kernel averages of the three kernels of the solve.
+# sweep at one wavefront per SIMD (MIMSEM_THOMAS_WPS=1, round 3) and at two (default, round 5); wall clock per solve and rocprofv3 kernel averages of the three kernels of the solve.
 out=gpurun_out/ab_thomas.log; : > $out
 cd /tmp && export TMPDIR=/tmp
-for v in "MIMSEM_THOMAS2=0" "DEFAULT=1"; do
+for v in "MIMSEM_THOMAS2=0" "MIMSEM_THOMAS_WPS=1" "DEFAULT=1"; do
   echo "== $v" >> $GRAFT_REPO_ROOT/$out
   d=$GRAFT_REPO_ROOT/gpurun_out/prof_thomas_$(echo $v | tr -c 'A-Za-z0-9' '_')
   env $v python3 $GRAFT_REPO_ROOT/scripts/prof_column.py 2>/dev/null | tail -1 >> $GRAFT_REPO_ROOT/$out

@@ -9,14 +9,10 @@
 #include <cstdlib>
 #include <vector>
 #include "../../mimsem_amd/host/mimsem_sweqn.hpp"
+#include "../../mimsem_amd/host/sw_io.hpp"
 
 using namespace mimsem_host;
 
-template <class T> static std::vector<T> rd(FILE* f, size_t n) {
-    std::vector<T> v(n);
-    if (n && std::fread(v.data(), sizeof(T), n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); }
-    return v;
-}
 static double rel_l2(const std::vector<double>& a, const std::vector<double>& b) {
     double num = 0, den = 0;
     for (size_t i = 0; i < a.size(); i++) { num += (a[i] - b[i])*(a[i] - b[i]); den += b[i]*b[i]; }
@@ -25,25 +21,15 @@ static double rel_l2(const std::vector<double>& a, const std::vector<double>& b)
 
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: test_sw in.bin out.bin\n"); return 2; }
-    FILE* f = std::fopen(argv[1], "rb");
-    if (!f) { std::perror(argv[1]); return 2; }
-    auto hd = rd<int>(f, 12);            // elOrd quadOrd nEl nk n0 n1 n2 nq nsteps nits q_exact reserved
-    const int n = hd[0], m = hd[1], nEl = hd[2], n0 = hd[4], n1 = hd[5], n2 = hd[6], nsteps = hd[8], nits = hd[9];
-    const bool q_exact = hd[10] != 0;
-    const size_t mp12 = (size_t)(m + 1)*(m + 1);
-    auto i0 = rd<int>(f, (size_t)nEl*(n + 1)*(n + 1)), ix = rd<int>(f, (size_t)nEl*(n + 1)*n), iy = rd<int>(f, (size_t)nEl*(n + 1)*n);
-    auto i2 = rd<int>(f, (size_t)nEl*n*n), iq = rd<int>(f, nEl*mp12);
-    auto det = rd<double>(f, nEl*mp12), J = rd<double>(f, nEl*mp12*4), th = rd<double>(f, (size_t)hd[3]*nEl*mp12), ti = rd<double>(f, (size_t)hd[3]*nEl*mp12);
-    auto fg = rd<double>(f, n0), u0 = rd<double>(f, n1), h0 = rd<double>(f, n2), dtv = rd<double>(f, 1);
-    std::fclose(f);
-    const double dt = dtv[0];
-    mimsem_mesh_desc d{};
-    d.elOrd = n; d.quadOrd = m; d.nEl = nEl; d.nk = hd[3]; d.n0 = n0; d.n1 = n1; d.n2 = n2; d.nq = hd[7];
-    d.inds0 = i0.data(); d.inds1x = ix.data(); d.inds1y = iy.data(); d.inds2 = i2.data(); d.indsq = iq.data();
-    d.det = det.data(); d.J = J.data(); d.thick = th.data(); d.thickInv = ti.data();
     int fails = 0;
     std::vector<double> out[3][2];
+    int n1 = 0, n2 = 0;
     try {
+        const SWCase cs = read_sw_case(argv[1]);
+        const mimsem_mesh_desc d = cs.desc();
+        const std::vector<double>&fg = cs.fg, &u0 = cs.u, &h0 = cs.h;
+        const int n0 = cs.n0, nsteps = cs.nsteps, nits = cs.nits; const bool q_exact = cs.q_exact; const double dt = cs.dt;
+        n1 = cs.n1; n2 = cs.n2;
         Mesh mesh(d);
         double* dfg = mesh.to_device(fg.data(), n0);
         for (int mode = 0; mode < 3; mode++) {

@@ -63,6 +63,24 @@ def test_order4_walk_of_schur_3_runs_without_scratch(column_asm):
             assert scratch == 0, (k, spill, scratch)
 
 
+def test_penta_solve_on_lane_major_bands_keeps_its_blocks_in_registers(column_asm):
+    """Round 5: with run-time band strides every element of a block load carries its own 64-bit address; at order 4 those address registers
+    pushed the two-sided block-pentadiagonal solve to 577 spilled dwords per lane (order 3: 114).  On the lane-major bands the fused path
+    writes, the strides are compile-time constants (k_penta_dpp<N2, TWO, LM = true>): no scratch at order 3, and at order 4 only the few
+    blocks parked across the refinement's outer loop."""
+    import re
+    s = column_asm.read_text()
+    md = s[s.index("amdgpu_metadata"):]
+    seen = {}
+    for e in md.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", e).group(1)
+        m = re.search(r"k_penta_dppILi(\d+)ELb1ELb1E", name)
+        if m:
+            seen[int(m.group(1))] = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", e).group(1))
+    assert set(seen) == {1, 4, 9, 16}, seen
+    assert seen[1] == seen[4] == seen[9] == 0 and seen[16] <= 1024, seen
+
+
 def test_spill_checker_sees_the_pattern_it_was_written_for(tmp_path):
     """scripts/check_spill_slots.py on two hand-written kernels: a spill store at the top of a structuriser "Flow" block (entered by
     s_cbranch_execz with the else-lanes still disabled) ahead of the s_or_saveexec that re-enables them -- the code hipcc produced in

@@ -54,6 +54,7 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
     from mimsem_amd.geom import Geom
     from mimsem_amd.mesh import CubedSphere, sphere_coords
     from mimsem_amd.topo import Topo
+    from mimsem_amd.workloads import write_sw_case
     from oracle import sw_oracle
     from tests.helpers import rel_l2
     pn, ne, nsteps = 3, 2, 2
@@ -70,12 +71,7 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
     hq = H0 - (6371220.0 * 7.292e-5 * U0 + 0.5 * U0 * U0) * np.sin(th) ** 2 / 9.80616 + 40.0 * np.cos(th) * np.sin(lam)
     u0, h0 = O.init1(uq), O.init2(hq)
     fin, fout = str(tmp_path / "sw_in.bin"), str(tmp_path / "sw_out.bin")
-    with open(fin, "wb") as f:
-        np.array([dm.n, dm.m, dm.nEl, 1, dm.n0, dm.n1, dm.n2, dm.nq, nsteps, nits, int(q_exact), 0], dtype=np.int32).tofile(f)
-        for a in (dm.inds0, dm.inds1x, dm.inds1y, dm.inds2, dm.indsq):
-            np.ascontiguousarray(a, dtype=np.int32).tofile(f)
-        for a in (dm.det, dm.J, dm.thick, dm.thickInv, O.fg, u0, h0, np.array([dt])):
-            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    write_sw_case(fin, dm, O.fg, u0, h0, dt, nsteps, nits, q_exact)
     out = subprocess.run([_build(str(tmp_path), "test_sw"), fin, fout], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "ALL OK" in out.stdout
