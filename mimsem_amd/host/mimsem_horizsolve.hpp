@@ -1,0 +1,178 @@
+// mimsem_horizsolve.hpp -- the right-hand sides of the horizontal dynamics (row N2) driven from C++ over the C ABI: the counterpart of the
+// reference's HorizSolve (eul/HorizSolve.cpp: grad :208-228, curl :233-254, laplacian :256-283, diagnose_fluxes :285-327, advection_rhs_ec
+// :380-417, diagnose_Phi :419-470, diagnose_q :472-493, momentum_rhs_ec :637-786) for a host that holds its fields in device memory.
+// The reference loops `for (kk ...)` around a per-level assemble + MatMult + KSPSolve; here EVERY LEVEL goes through each operator in one
+// call (level rows `n` doubles apart), and the ksp1 solves of all levels are ONE batched CG (mimsem_ksp_*: one block per element as in
+// PCBJACOBI, the thickness of a level as a per-(level, element) factor).
+// Field layout: horizontal, one row per level -- 1-forms [nk][n1], 2-forms [nk][n2], 0-forms [nk][n0]; interface quantities (velz, dudz,
+// dwdx, Fz) [nk-1][.].  Header-only, C++17, no HIP toolchain needed.
+#pragma once
+#include <cmath>
+#include "mimsem_shim.hpp"
+
+namespace mimsem_host {
+
+class HorizSolve {
+public:
+    static constexpr double SCALE = 1.0e8, OMEGA = 7.29212e-5, RAD_EARTH = 6371220.0;      // eul/HorizSolve.cpp:21-25
+    double del2; bool do_visc; double rtol = 1.0e-14;
+    int last_its = 0;
+
+    // fg: the Coriolis 0-form per level (HorizSolve::coriolis :124-161), device [nk][n0]; nDofs0G: the GLOBAL node count (viscosity() :112-120)
+    HorizSolve(Mesh* m, const double* fg_dev, long long nDofs0G = 0, bool visc = true) : mesh(m), fg(fg_dev) {
+        nk = m->nk_; n0 = m->n0; n1 = m->n1; n2 = m->n2; do_visc = visc;
+        const double dx = std::sqrt(4.0*M_PI*RAD_EARTH*RAD_EARTH/(double)(nDofs0G > 0 ? nDofs0G : n0));
+        del2 = -std::sqrt(0.072*std::pow(dx, 3.2));
+        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1}) *p = mesh->device_alloc((size_t)nk*n1);
+        for (double** p : {&a2, &b2, &c2}) *p = mesh->device_alloc((size_t)nk*n2);
+        for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
+        scal = mesh->device_alloc(2);
+        check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, nullptr, 0, m0, n0), "mimsem_pvec");                       // M0 is diagonal (collocated 0-forms)
+        // ksp1 (:77-96): the 1-form mass of every level, one element block each
+        check(mimsem_ksp_create(mesh->ctx, MIMSEM_KSP_CG, &ksp1), "mimsem_ksp_create");
+        check(mimsem_ksp_set_operator(ksp1, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0), "mimsem_ksp_set_operator");
+        check(mimsem_ksp_set_pc_bjacobi(ksp1), "mimsem_ksp_set_pc_bjacobi");
+        check(mimsem_ksp_set_tolerances(ksp1, rtol, 1.0e-50, 1000, 0, 2), "mimsem_ksp_set_tolerances");
+    }
+    ~HorizSolve() {
+        mimsem_ksp_destroy(ksp1);
+        for (double* p : {a1, b1, c1, d1, e1, g1, a2, b2, c2, m0, a0, b0, scal}) mimsem_free(p);
+    }
+    HorizSolve(const HorizSolve&) = delete; HorizSolve& operator=(const HorizSolve&) = delete;
+
+    // u = M1^-1 E12 M2 phi  (:208-228)
+    void grad(const double* phi, double* u) {
+        ap(MIMSEM_OP_WMAT, MIMSEM_FLAG_VERT, nullptr, 0, phi, n2, a2, n2, 1.0);
+        inc(2, a2, n2, g1, n1);
+        solve_M1(g1, u);
+    }
+    // w = M0^-1 E01 M1 u (+ f)  (:233-254)
+    void curl(const double* u, double* w, bool add_f = false) {
+        ap(MIMSEM_OP_UMAT, MIMSEM_FLAG_VERT, nullptr, 0, u, n1, g1, n1, 1.0);
+        inc(3, g1, n1, w, n0);
+        comb(n0, 1.0, w, 2, m0, add_f ? 1.0 : 0.0, add_f ? fg : nullptr, w);
+    }
+    // del2 (grad(E21 u) + E10 curl(u))  (:256-283)
+    void laplacian(const double* u, double* out) {
+        inc(1, u, n1, c2, n2);
+        grad(c2, out);
+        curl(u, b0);
+        inc(0, b0, n0, e1, n1);
+        comb(n1, del2, e1, 0, nullptr, del2, out, out);
+    }
+    // F = M1^-1 (hu),  G = M1^-1 F(theta) F  (:285-327, theta_in_Wt = false)
+    void diagnose_fluxes(const double* u1, const double* u2, const double* h1, const double* h2, const double* theta, double* F, double* G) {
+        uvec_hu4(u1, u2, h1, h2, d1);
+        solve_M1(d1, F);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT, theta, n2, F, n1, d1, n1, 1.0);
+        solve_M1(d1, G);
+    }
+    // :380-417: dF, dG [nk][n2] (horizontal layout; the caller's HorizToVert is mimsem_l2_transpose), Fk, Gk [nk][n1]
+    void advection_rhs_ec(const double* u1, const double* u2, const double* h1, const double* h2, const double* theta, double* dF, double* dG,
+                          double* Fk, double* Gk) {
+        diagnose_fluxes(u1, u2, h1, h2, theta, Fk, Gk);
+        inc(1, Fk, n1, b2, n2);
+        ap(MIMSEM_OP_WMAT, MIMSEM_FLAG_VERT, nullptr, 0, b2, n2, dF, n2, 1.0);
+        inc(1, Gk, n1, c2, n2);
+        ap(MIMSEM_OP_WMAT, MIMSEM_FLAG_VERT, nullptr, 0, c2, n2, dG, n2, 0.5);
+        ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, theta, n2, b2, n2, dG, n2, 0.5);
+        grad(theta, c1);
+        ap(MIMSEM_OP_WTQUMAT, MIMSEM_FLAG_ACCUM, c1, n1, Fk, n1, dG, n2, 1.0);                              // K incl. its 0.5 factor
+    }
+    // :419-470
+    void diagnose_Phi(const double* u1, const double* u2, const double* velz1, const double* velz2, double* Phi) {
+        ap(MIMSEM_OP_WTQUMAT, 0, u1, n1, u1, n1, Phi, n2, 1.0/3.0);
+        ap(MIMSEM_OP_WTQUMAT, MIMSEM_FLAG_ACCUM, u1, n1, u2, n1, Phi, n2, 1.0/3.0);
+        ap(MIMSEM_OP_WTQUMAT, MIMSEM_FLAG_ACCUM, u2, n1, u2, n1, Phi, n2, 1.0/3.0);
+        // 0.5 (interface k-1) + 0.5 (interface k), the missing boundary interfaces left out (:451-459)
+        check(mimsem_interface_average(mesh->ctx, nk, n2, velz1, n2, b2, n2), "mimsem_interface_average");
+        check(mimsem_interface_average(mesh->ctx, nk, n2, velz2, n2, c2, n2), "mimsem_interface_average");
+        ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_ACCUM, b2, n2, b2, n2, Phi, n2, 1.0/6.0);
+        ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_ACCUM, b2, n2, c2, n2, Phi, n2, 1.0/6.0);
+        ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_ACCUM, c2, n2, c2, n2, Phi, n2, 1.0/6.0);
+    }
+    // (M0h(rho)) q = E01 M1 u + M0 f; M0h is diagonal  (:472-493)
+    void diagnose_q(const double* rho, const double* u, double* q) {
+        ap(MIMSEM_OP_UMAT, MIMSEM_FLAG_VERT, nullptr, 0, u, n1, g1, n1, 1.0);
+        inc(3, g1, n1, q, n0);
+        comb(n0, 1.0, m0, 1, fg, 1.0, q, q);
+        check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, rho, n2, b0, n0), "mimsem_pvec");
+        comb(n0, 1.0, q, 2, b0, 0.0, nullptr, q);
+    }
+    // :637-786 for every level at once: fu [nk][n1].  Optional: Fx (the mass flux, else diagnosed), Fz (vertical mass flux on the interfaces,
+    // else the mean vertical velocity), dwdx1 / dwdx2, Fk (then k2i() is the kinetic-to-internal exchange :697-701)
+    void momentum_rhs_ec(const double* theta, const double* dudz1, const double* dudz2, const double* velz1, const double* velz2, const double* Pi,
+                         const double* velx1, const double* velx2, const double* rho1, const double* rho2, double* fu,
+                         const double* Fx = nullptr, const double* Fz = nullptr, const double* dwdx1 = nullptr, const double* dwdx2 = nullptr,
+                         const double* Fk = nullptr) {
+        mimsem_ctx* c = mesh->ctx;
+        diagnose_Phi(velx1, velx2, velz1, velz2, a2);
+        inc(2, a2, n2, fu, n1);
+        grad(Pi, a1);                                                                                         // dPi
+        grad(theta, b1);                                                                                      // dTheta
+        comb(n1, 0.5, velx1, 0, nullptr, 0.5, velx2, c1);                                                     // uh
+        comb(n2, 0.5, rho1, 0, nullptr, 0.5, rho2, b2);
+        diagnose_q(b2, c1, a0);
+        if (!Fx) { uvec_hu4(velx1, velx2, rho1, rho2, d1); solve_M1(d1, e1); Fx = e1; }
+        ap(MIMSEM_OP_ROTMAT, MIMSEM_FLAG_ACCUM, a0, n0, Fx, n1, fu, n1, 1.0);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, theta, n2, a1, n1, fu, n1, 0.5);            // pressure gradient force
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, Pi, n2, b1, n1, fu, n1, -0.5);
+        ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_VERT, Pi, n2, theta, n2, a2, n2, 1.0);
+        inc(2, a2, n2, d1, n1);                                                                               // dp
+        comb(n1, 0.5, d1, 0, nullptr, 1.0, fu, fu);
+        have_k2i = Fk != nullptr;
+        if (Fk) check(mimsem_krylov_rowdot(c, 1, (long long)nk*n1, Fk, (long long)nk*n1, d1, (long long)nk*n1, scal), "mimsem_krylov_rowdot");
+        // second vorticity term: interface i feeds levels i and i+1 (:704-746)
+        if (nk > 1) {
+            combr(nk - 1, n1, 0.5, dudz1, 0, nullptr, 0.5, dudz2, a1);                                        // dz
+            if (dwdx1) { combr(nk - 1, n1, -0.5, dwdx1, 0, nullptr, 1.0, a1, a1); combr(nk - 1, n1, -0.5, dwdx2, 0, nullptr, 1.0, a1, a1); }
+            const double* v = Fz;
+            if (!v) { combr(nk - 1, n2, 0.5, velz1, 0, nullptr, 0.5, velz2, a2); v = a2; }
+            check(mimsem_op_apply(c, MIMSEM_OP_UTQWMAT, 0, nk - 1, SCALE, 0, a1, n1, v, n2, b1, n1, 1.0), "UTQWMAT");     // UtQWmat::assemble(u1, scale): no thickness
+            combr(nk - 1, n1, 0.5, b1, 0, nullptr, 1.0, fu + n1, fu + n1);
+            combr(nk - 1, n1, 0.5, b1, 0, nullptr, 1.0, fu, fu);
+        }
+        if (do_visc) {
+            laplacian(c1, a1);
+            laplacian(a1, b1);
+            ap(MIMSEM_OP_UMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, nullptr, 0, b1, n1, fu, n1, 1.0);
+        }
+    }
+    // horizontal kinetic-to-internal energy exchange of the last momentum_rhs_ec that was given Fk (synchronises)
+    double k2i() {
+        if (!have_k2i) return 0.0;
+        double v = 0.0;
+        mesh->to_host(&v, scal, 1);
+        return v/SCALE;
+    }
+    // KSPSolve(ksp1, b, x) for all levels
+    void solve_M1(const double* b, double* x) {
+        check(mimsem_ksp_solve(ksp1, b, n1, x, n1), "mimsem_ksp_solve");
+        double rn; int reason;
+        check(mimsem_ksp_get_info(ksp1, &last_its, &rn, &reason), "mimsem_ksp_get_info");
+        if (reason < 0) throw std::runtime_error("HorizSolve: the 1-form mass solve did not converge");
+    }
+
+private:
+    Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
+    int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
+    double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
+           *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;
+    void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {
+        check(mimsem_op_apply(mesh->ctx, op, 0, nk, SCALE, flags, f, fs, x, xs, y, ys, alpha), "mimsem_op_apply");
+    }
+    void inc(int which, const double* x, long long xs, double* y, long long ys) { check(mimsem_incidence_apply(mesh->ctx, which, nk, x, xs, y, ys), "mimsem_incidence_apply"); }
+    void combr(int rows, long long n, double a, const double* A, int op, const double* B, double b, const double* C, double* out) {
+        check(mimsem_vec_combine(mesh->ctx, rows, n, a, A, n, op, B, n, b, C, n, out, n), "mimsem_vec_combine");
+    }
+    void comb(long long n, double a, const double* A, int op, const double* B, double b, const double* C, double* out) { combr(nk, n, a, A, op, B, b, C, out); }
+    // the four m1->assemble_hu(level, SCALE, u, h, false, fac) calls (:300-305, :675-682)
+    void uvec_hu4(const double* ua, const double* ub, const double* ha, const double* hb, double* hu) {
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT, ha, n2, ua, n1, hu, n1, 1.0/3.0);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, hb, n2, ua, n1, hu, n1, 1.0/6.0);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, ha, n2, ub, n1, hu, n1, 1.0/6.0);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, hb, n2, ub, n1, hu, n1, 1.0/3.0);
+    }
+};
+
+}  // namespace mimsem_host

@@ -43,3 +43,48 @@ inline SWCase read_sw_case(const char* path) {
     return c;
 }
 }  // namespace mimsem_host
+
+// ---- named arrays on disk (tests/cpp/test_horiz.cpp): "MSEMARR1", int32 count, then per array {int32 name length, name, int32 type
+// (0 = int32, 1 = float64), int64 entries, data}; written by mimsem_amd/workloads.py::write_arrays --------------------------------------
+#include <cstring>
+#include <map>
+namespace mimsem_host {
+struct ArrayFile {
+    std::map<std::string, std::vector<int>> i;
+    std::map<std::string, std::vector<double>> d;
+    const std::vector<int>& ints(const std::string& k) const { auto it = i.find(k); if (it == i.end()) throw std::runtime_error("no int array " + k); return it->second; }
+    const std::vector<double>& reals(const std::string& k) const { auto it = d.find(k); if (it == d.end()) throw std::runtime_error("no real array " + k); return it->second; }
+    bool has(const std::string& k) const { return d.count(k) || i.count(k); }
+};
+inline ArrayFile read_arrays(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    auto need = [&](void* p, size_t sz, size_t n) { if (n && std::fread(p, sz, n, f) != n) { std::fclose(f); throw std::runtime_error(std::string("short read: ") + path); } };
+    char magic[8]; int count = 0;
+    need(magic, 1, 8); need(&count, 4, 1);
+    if (std::memcmp(magic, "MSEMARR1", 8) != 0 || count < 0 || count > 4096) { std::fclose(f); throw std::runtime_error("not an array file"); }
+    ArrayFile a;
+    for (int k = 0; k < count; k++) {
+        int nl = 0, type = 0; long long n = 0;
+        need(&nl, 4, 1);
+        if (nl < 1 || nl > 255) { std::fclose(f); throw std::runtime_error("bad name length"); }
+        std::string name((size_t)nl, ' ');
+        need(&name[0], 1, (size_t)nl); need(&type, 4, 1); need(&n, 8, 1);
+        if (n < 0 || (type != 0 && type != 1)) { std::fclose(f); throw std::runtime_error("bad array header"); }
+        if (type == 0) { auto& v = a.i[name]; v.resize((size_t)n); need(v.data(), 4, (size_t)n); }
+        else { auto& v = a.d[name]; v.resize((size_t)n); need(v.data(), 8, (size_t)n); }
+    }
+    std::fclose(f);
+    return a;
+}
+// the mesh tables of a DeviceMesh stored under their mimsem_mesh_desc names + "sizes" = {elOrd quadOrd nEl nk n0 n1 n2 nq}
+inline mimsem_mesh_desc desc_of(const ArrayFile& a) {
+    const auto& s = a.ints("sizes");
+    mimsem_mesh_desc d{};
+    d.elOrd = s.at(0); d.quadOrd = s.at(1); d.nEl = s.at(2); d.nk = s.at(3); d.n0 = s.at(4); d.n1 = s.at(5); d.n2 = s.at(6); d.nq = s.at(7);
+    d.inds0 = a.ints("inds0").data(); d.inds1x = a.ints("inds1x").data(); d.inds1y = a.ints("inds1y").data(); d.inds2 = a.ints("inds2").data();
+    d.indsq = a.ints("indsq").data(); d.det = a.reals("det").data(); d.J = a.reals("J").data(); d.thick = a.reals("thick").data();
+    d.thickInv = a.reals("thickInv").data();
+    return d;
+}
+}  // namespace mimsem_host

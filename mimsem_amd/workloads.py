@@ -26,3 +26,28 @@ def write_sw_case(path, dm, fg, u, h, dt, nsteps, nits, q_exact):
             np.ascontiguousarray(a, dtype=np.int32).tofile(f)
         for a in (dm.det, dm.J, dm.thick[:1], dm.thickInv[:1], fg, u, h, np.array([dt])):
             np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+
+
+def write_arrays(path, arrays):
+    """named int32 / float64 arrays for the C++ hosts (mimsem_amd/host/sw_io.hpp::read_arrays)"""
+    import struct
+
+    import numpy as np
+    with open(path, "wb") as f:
+        f.write(b"MSEMARR1"); f.write(struct.pack("<i", len(arrays)))
+        for name, a in arrays.items():
+            a = np.asarray(a)
+            kind = 0 if np.issubdtype(a.dtype, np.integer) else 1
+            a = np.ascontiguousarray(a, dtype=np.int32 if kind == 0 else np.float64)
+            nb = name.encode()
+            f.write(struct.pack("<i", len(nb))); f.write(nb); f.write(struct.pack("<iq", kind, a.size))
+            a.tofile(f)
+
+
+def mesh_arrays(dm):
+    """the tables of a DeviceMesh under their mimsem_mesh_desc names (sw_io.hpp::desc_of)"""
+    import numpy as np
+    d = {"sizes": np.array([dm.n, dm.m, dm.nEl, dm.nk, dm.n0, dm.n1, dm.n2, dm.nq], dtype=np.int32)}
+    for k in ("inds0", "inds1x", "inds1y", "inds2", "indsq", "det", "J", "thick", "thickInv"):
+        d[k] = getattr(dm, k)
+    return d

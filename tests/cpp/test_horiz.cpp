@@ -1,0 +1,47 @@
+// tests/cpp/test_horiz.cpp -- the right-hand sides of the horizontal dynamics (row N2) driven from C++: mimsem_host::HorizSolve
+// (mimsem_amd/host/mimsem_horizsolve.hpp, the counterpart of eul/HorizSolve.cpp:208-786) on the mesh and fields the pytest wrapper wrote,
+// every level in one call.  Results go back to the wrapper, which compares them with the dense restatement oracle/horiz_oracle.py
+// (per-level dense matrices, LU for the KSP solves) -- the same check the Python host gets in tests/test_gpu_next_rows.py.
+//   usage: test_horiz <in.arr> <out.bin>
+#include <cstdio>
+#include <vector>
+#include "../../mimsem_amd/host/mimsem_horizsolve.hpp"
+#include "../../mimsem_amd/host/sw_io.hpp"
+
+using namespace mimsem_host;
+
+int main(int argc, char** argv) {
+    if (argc < 3) { std::fprintf(stderr, "usage: test_horiz in.arr out.bin\n"); return 2; }
+    try {
+        const ArrayFile a = read_arrays(argv[1]);
+        const mimsem_mesh_desc d = desc_of(a);
+        Mesh mesh(d);
+        const int nk = d.nk, n0 = d.n0, n1 = d.n1, n2 = d.n2;
+        auto dev = [&](const char* k) { const auto& v = a.reals(k); return mesh.to_device(v.data(), v.size()); };
+        double *fg = dev("fg"), *u1 = dev("u1"), *u2 = dev("u2"), *h1 = dev("h1"), *h2 = dev("h2"), *th = dev("theta"), *Pi = dev("Pi");
+        double *velz = dev("velz1"), *velz2 = dev("velz2"), *dudz = dev("dudz1"), *dudz2 = dev("dudz2"), *Fz = dev("Fz");
+        HorizSolve hs(&mesh, fg);
+        std::printf("del2 = %.12e\n", hs.del2);
+        const size_t s1 = (size_t)nk*n1, s2 = (size_t)nk*n2, s0 = (size_t)nk*n0;
+        double *dF = mesh.device_alloc(s2), *dG = mesh.device_alloc(s2), *Fk = mesh.device_alloc(s1), *Gk = mesh.device_alloc(s1);
+        double *Phi = mesh.device_alloc(s2), *q = mesh.device_alloc(s0), *fuA = mesh.device_alloc(s1), *fuB = mesh.device_alloc(s1);
+        hs.advection_rhs_ec(u1, u2, h1, h2, th, dF, dG, Fk, Gk);
+        std::printf("M1 solve: %d iterations\n", hs.last_its);
+        hs.diagnose_Phi(u1, u2, velz, velz2, Phi);
+        hs.diagnose_q(h1, u1, q);
+        hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuA, nullptr, nullptr, nullptr, nullptr, Fk);
+        const double k2iA = hs.k2i();
+        hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuB, Fk, Fz, nullptr, nullptr, Fk);
+        const double k2iB = hs.k2i();
+        FILE* g = std::fopen(argv[2], "wb");
+        if (!g) { std::perror(argv[2]); return 2; }
+        auto put = [&](const double* p, size_t n) { std::vector<double> h(n); mesh.to_host(h.data(), p, n); std::fwrite(h.data(), 8, n, g); };
+        put(dF, s2); put(dG, s2); put(Fk, s1); put(Gk, s1); put(Phi, s2); put(q, s0); put(fuA, s1); put(fuB, s1);
+        const double tail[3] = {k2iA, k2iB, hs.del2};
+        std::fwrite(tail, 8, 3, g);
+        std::fclose(g);
+        for (double* p : {fg, u1, u2, h1, h2, th, Pi, velz, velz2, dudz, dudz2, Fz, dF, dG, Fk, Gk, Phi, q, fuA, fuB}) mimsem_free(p);
+    } catch (const std::exception& e) { std::printf("FAIL: %s\n", e.what()); return 1; }
+    std::printf("DONE\n");
+    return 0;
+}

@@ -25,6 +25,7 @@ def test_shim_compiles_and_links(tmp_path, oracle):
     assert os.path.exists(_build(str(tmp_path)))
     assert os.path.exists(_build(str(tmp_path), "test_ksp"))
     assert os.path.exists(_build(str(tmp_path), "test_sw"))
+    assert os.path.exists(_build(str(tmp_path), "test_horiz"))
 
 
 @pytest.mark.gpu
@@ -81,3 +82,68 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
     res = np.fromfile(fout, dtype=np.float64).reshape(3, dm.n1 + dm.n2)
     for mode in range(3):
         assert rel_l2(res[mode, :dm.n1], ur) < 1e-9 and rel_l2(res[mode, dm.n1:], hr) < 1e-9, mode
+
+
+@pytest.mark.gpu
+def test_horizsolve_driven_from_cpp(tmp_path, oracle):
+    """N2 from C++: HorizSolve::advection_rhs_ec / diagnose_Phi / diagnose_q / momentum_rhs_ec (eul/HorizSolve.cpp:380-786) written over the C
+    ABI (mimsem_amd/host/mimsem_horizsolve.hpp), all levels per call, against the dense restatement oracle/horiz_oracle.py -- the fields,
+    mesh and tolerances of tests/test_gpu_next_rows.py::test_horizsolve_right_hand_sides"""
+    import numpy as np
+    from mimsem_amd.device import DeviceMesh
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.topo import Topo
+    from mimsem_amd.workloads import mesh_arrays, write_arrays, z_levels
+    from oracle import horiz_oracle as ho
+    pn, ne, nk = 3, 2, 3
+    cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
+    topos = [Topo(cs, p, nk) for p in range(6)]
+    geoms = [Geom(t, cs, coords, nk) for t in topos]
+    levs = z_levels(nk, geoms[0].n0)
+    for g in geoms:
+        g.set_levels(levs)
+    dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+    gd = ho.GlobalDense(cs, topos, geoms, coords, levs)
+    H = ho.HorizOracle(gd)
+    r = np.random.default_rng(31)
+    area = np.mean([P.det.mean() for P in gd.P]) * 4.0 / (pn * pn); dz = np.mean([P.thick.mean() for P in gd.P]); ln = np.sqrt(area)
+    N0, N1, N2 = dm.n0, gd.N1, gd.N2
+    u1 = r.standard_normal((nk, N1)) * 20.0 * ln * dz; u2 = u1 * (1 + 0.05 * r.standard_normal((nk, N1)))
+    h1 = r.uniform(0.8, 1.2, (nk, N2)) * area * dz; h2 = h1 * (1 + 0.01 * r.standard_normal((nk, N2)))
+    th = r.uniform(290, 310, (nk, N2)) * area * dz; Pi = r.uniform(900, 1000, (nk, N2)) * area * dz
+    velz = r.standard_normal((nk - 1, N2)) * area; velz2 = velz * (1 + 0.05 * r.standard_normal(velz.shape))
+    dudz = r.standard_normal((nk - 1, N1)) * 1e-3 * ln; dudz2 = dudz * 1.1
+    Fz = velz * 0.7
+    fg = np.broadcast_to(H.fg, (nk, N0)) if np.ndim(H.fg) == 1 else H.fg
+    arrays = mesh_arrays(dm)
+    arrays.update(fg=fg, u1=u1, u2=u2, h1=h1, h2=h2, theta=th, Pi=Pi, velz1=velz, velz2=velz2, dudz1=dudz, dudz2=dudz2, Fz=Fz)
+    fin, fout = str(tmp_path / "horiz_in.arr"), str(tmp_path / "horiz_out.bin")
+    write_arrays(fin, arrays)
+    out = subprocess.run([_build(str(tmp_path), "test_horiz"), fin, fout], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "DONE" in out.stdout
+    res = np.fromfile(fout, dtype=np.float64)
+    pos = [0]
+
+    def take(rows, n):
+        a = res[pos[0]:pos[0] + rows * n].reshape(rows, n); pos[0] += rows * n
+        return a
+    gF, gG, gFk, gGk, gPhi, gq, fuA, fuB = take(nk, N2), take(nk, N2), take(nk, N1), take(nk, N1), take(nk, N2), take(nk, N0), take(nk, N1), take(nk, N1)
+    k2iA, k2iB, del2 = res[pos[0]:pos[0] + 3]
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert abs(del2 - H.del2) < 1e-6 * abs(H.del2)
+    dF, dG, Fk, Gk = H.advection_rhs_ec(u1, u2, h1, h2, th)
+    assert rel(gFk, Fk) < 1e-10 and rel(gGk, Gk) < 1e-10
+    assert rel(gF, dF) < 1e-9 and rel(gG, dG) < 1e-9
+    for lev in range(nk):
+        assert rel(gPhi[lev], H.diagnose_Phi(lev, u1[lev], u2[lev], velz, velz2)) < 1e-10
+        assert rel(gq[lev], H.diagnose_q(lev, h1[lev], u1[lev])) < 1e-10
+    for got, k2i_got, use_F in ((fuA, k2iA, False), (fuB, k2iB, True)):
+        k2i = 0.0
+        for lev in range(nk):
+            want, k = H.momentum_rhs_ec(lev, th[lev], dudz, dudz2, velz, velz2, Pi[lev], u1[lev], u2[lev], h1[lev], h2[lev],
+                                        Fx=Fk[lev] if use_F else None, Fz=Fz if use_F else None, Fk=Fk[lev])
+            k2i += k
+            assert rel(got[lev], want) < 1e-8, (lev, use_F)
+        assert abs(k2i_got - k2i) < 1e-8 * abs(k2i)
