@@ -849,6 +849,8 @@ def compact_record(out, extras_file=None):
             "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
+            "horiz_rhs_ms": _r(_g(out, "horiz_rhs", "ms_per_evaluation_hipgraph")),
+            "horiz_rhs_ms_cpp_host": _r(_g(out, "horiz_rhs", "cpp_host", "ms_per_evaluation")),
             "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
             "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
             "sw_steps_per_s_config3_cpp_host": _r(_g(out, "sw", "config3_galewsky_24x24x6", "cpp_host", "graph", "steps_per_s")),
@@ -923,7 +925,8 @@ def main():
     ap.add_argument("--box", action="store_true", help="(default at N = 1, with the families) BASELINE config 5 grid (p=4, 32x32 periodic box x 64 levels) Umat apply")
     ap.add_argument("--pcie", action="store_true", help="extra: the same step with the input copied host->device and the result device->host "
                                                         "through the C ABI (the conservative MATSHELL binding of INTEGRATION.md section 2)")
-    ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation)")
+    ap.add_argument("--horiz", action="store_true", help="extra: HorizSolve momentum_rhs_ec + advection_rhs_ec over all 30 levels (ms per evaluation; on by default at N = 1)")
+    ap.add_argument("--no-horiz", action="store_true", help="skip the HorizSolve right-hand-side extra (~3 s)")
     ap.add_argument("--sweep", action="store_true", help="extra: SURVEY 8(d) batch-size sweep of six operator families (384 ... 1e6 element-level pairs)")
     ap.add_argument("--no-column", action="store_true", help="skip the column-solves/s extra (reported by default at N = 1, ~3 s)")
     ap.add_argument("--no-sw", action="store_true", help="skip the shallow-water time-steps/s extra (reported by default at N = 1, ~20 s)")
@@ -1179,7 +1182,7 @@ def main():
         out["pcie_inclusive"] = {"value": units_rank / elp, "ms_per_step": 1e3 * elp, "bytes_each_way": nbytes,
                                  "GBs_each_way": nbytes / elp / 1e9 * 2 / 2,
                                  "note": "pageable host memory, synchronous hipMemcpy through mimsem_memcpy_h2d/_d2h; never the headline value"}
-    if a.horiz and rank == 0 and world == 1:
+    def horiz_extras():
         from mimsem_amd.horizsolve import HorizSolve
         xqg = np.zeros((dm.nq, 3))
         for g in geoms:
@@ -1208,9 +1211,35 @@ def main():
             graph.replay()
         torch.cuda.synchronize(); elg = (time.perf_counter() - t1) / 20
         hs.m1.fixed_its = 0
-        out["horiz_rhs"] = {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels per evaluation",
-                            "ms_per_evaluation_eager": 1e3 * el, "ms_per_evaluation_hipgraph": 1e3 * elg, "evaluations_per_s": 1.0 / elg,
-                            "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
+        res = {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels per evaluation",
+               "ms_per_evaluation_eager": 1e3 * el, "ms_per_evaluation_hipgraph": 1e3 * elg, "evaluations_per_s": 1.0 / elg,
+               "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
+        # the same evaluation with the HOST in C++ (mimsem_amd/host/horiz_call.cpp over mimsem_horizsolve.hpp; the ksp1 solves are the
+        # library's batched CG with its convergence test on the host: not recorded as a graph)
+        import subprocess
+        import tempfile
+        from mimsem_amd.workloads import mesh_arrays, write_arrays
+        exe = os.path.join(ROOT, "mimsem_amd", "host", "horiz_call")
+        if os.path.exists(exe):
+            with tempfile.TemporaryDirectory() as tmp:
+                case = os.path.join(tmp, "case.arr")
+                arr = mesh_arrays(dm)
+                cpu = lambda t: t.cpu().numpy()
+                arr.update(fg=cpu(hs.fg) if hs.fg.shape[0] == NK else np.broadcast_to(cpu(hs.fg), (NK, dm.n0)), u1=cpu(u1), u2=cpu(u2), h1=cpu(h1),
+                           h2=cpu(h2), theta=cpu(th), Pi=cpu(Pi), velz=cpu(vz), dudz=cpu(dudz))
+                write_arrays(case, arr)
+                try:
+                    r = subprocess.run([exe, case, "10"], capture_output=True, text=True, timeout=300)
+                    res["cpp_host"] = json.loads(r.stdout) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+                    if "fu_l2" in res["cpp_host"]:
+                        res["cpp_host"]["fu_l2_rel_diff_to_python_host"] = abs(res["cpp_host"]["fu_l2"] - float(torch.linalg.vector_norm(ref))) / float(torch.linalg.vector_norm(ref))
+                except Exception as e:                     # noqa: BLE001
+                    res["cpp_host"] = {"error": repr(e)[:300]}
+        else:
+            res["cpp_host"] = {"error": "mimsem_amd/host/horiz_call not built (__graft_entry__.build())"}
+        return res
+    if (a.horiz or not a.no_horiz) and rank == 0 and world == 1:      # row N2: the right-hand sides of the horizontal dynamics, on by default at N = 1
+        extra("horiz_rhs", horiz_extras)
     if (a.sw or not a.no_sw) and rank == 0 and world == 1:        # the second half of BASELINE's metric: on by default at N = 1
         extra("sw", lambda: sw_extras(local_rank, torch))
     if (a.sweep or not a.no_sweep) and rank == 0 and world == 1:
