@@ -8,6 +8,7 @@
 // dwdx, Fz) [nk-1][.].  Header-only, C++17, no HIP toolchain needed.
 #pragma once
 #include <cmath>
+#include <utility>
 #include "mimsem_shim.hpp"
 
 namespace mimsem_host {
@@ -17,6 +18,12 @@ public:
     static constexpr double SCALE = 1.0e8, OMEGA = 7.29212e-5, RAD_EARTH = 6371220.0;      // eul/HorizSolve.cpp:21-25
     double del2; bool do_visc; double rtol = 1.0e-14;
     int last_its = 0;
+    // The ksp1 solves as a Chebyshev semi-iteration of FIXED length on the fused block sweep (mimsem_block_chebyshev_sweep): the spectrum of
+    // P M1 belongs to the mesh and its layer thicknesses, so its interval is estimated once (mimsem_ksp_ritz on the object PCSetUp built) and
+    // the step count for `rtol` follows -- no inner product, no host round trip: a whole right-hand-side evaluation can be recorded in a
+    // Graph.  The first `verify_first` solves compare the last preconditioned residual with |P b| on the host (a miss falls back to the CG
+    // for good); use_fixed_length(false) keeps the CG of the reference's structure.
+    int verify_first = 3; int cheb_steps = 0; bool fixed_length = false;
 
     // fg: the Coriolis 0-form per level (HorizSolve::coriolis :124-161), device [nk][n0]; nDofs0G: the GLOBAL node count (viscosity() :112-120)
     HorizSolve(Mesh* m, const double* fg_dev, long long nDofs0G = 0, bool visc = true) : mesh(m), fg(fg_dev) {
@@ -26,17 +33,33 @@ public:
         for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1}) *p = mesh->device_alloc((size_t)nk*n1);
         for (double** p : {&a2, &b2, &c2}) *p = mesh->device_alloc((size_t)nk*n2);
         for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
-        scal = mesh->device_alloc(2);
+        scal = mesh->device_alloc(4);
         check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, nullptr, 0, m0, n0), "mimsem_pvec");                       // M0 is diagonal (collocated 0-forms)
         // ksp1 (:77-96): the 1-form mass of every level, one element block each
         check(mimsem_ksp_create(mesh->ctx, MIMSEM_KSP_CG, &ksp1), "mimsem_ksp_create");
         check(mimsem_ksp_set_operator(ksp1, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0), "mimsem_ksp_set_operator");
         check(mimsem_ksp_set_pc_bjacobi(ksp1), "mimsem_ksp_set_pc_bjacobi");
         check(mimsem_ksp_set_tolerances(ksp1, rtol, 1.0e-50, 1000, 0, 2), "mimsem_ksp_set_tolerances");
+        p1 = mesh->device_alloc((size_t)nk*n1); upd1 = mesh->device_alloc((size_t)nk*n1); pb1 = mesh->device_alloc((size_t)nk*n1);
+        use_fixed_length(true);
+    }
+    void use_fixed_length(bool on) {
+        fixed_length = false;
+        if (!on) return;
+        double lo, hi, im;
+        check(mimsem_ksp_ritz(ksp1, 25, &lo, &hi, &im), "mimsem_ksp_ritz");
+        if (!(lo > 0.02) || mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) return;
+        const double l1 = 0.90*lo, l2 = 1.05*hi, sg = (std::sqrt(l2/l1) - 1.0)/(std::sqrt(l2/l1) + 1.0), d = 0.5*(l1 + l2), c2 = 0.25*(l2 - l1)*(l2 - l1);
+        cheb_steps = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/sg)));
+        coef.clear();
+        double al = 1.0/d;
+        coef.emplace_back(al, 0.0);
+        for (int k = 1; k < cheb_steps; k++) { const double be = (k == 1 ? 0.5 : 0.25)*c2*al*al; al = 1.0/(d - be/al); coef.emplace_back(al, be); }
+        verified = 0; fixed_length = true;
     }
     ~HorizSolve() {
         mimsem_ksp_destroy(ksp1);
-        for (double* p : {a1, b1, c1, d1, e1, g1, a2, b2, c2, m0, a0, b0, scal}) mimsem_free(p);
+        for (double* p : {a1, b1, c1, d1, e1, g1, a2, b2, c2, m0, a0, b0, scal, p1, upd1, pb1}) mimsem_free(p);
     }
     HorizSolve(const HorizSolve&) = delete; HorizSolve& operator=(const HorizSolve&) = delete;
 
@@ -147,6 +170,26 @@ public:
     }
     // KSPSolve(ksp1, b, x) for all levels
     void solve_M1(const double* b, double* x) {
+        if (fixed_length) {
+            mimsem_ctx* c = mesh->ctx;
+            const long long tot = (long long)nk*n1;
+            const bool verify = verified < verify_first;
+            check(mimsem_memset(c, x, 0, tot*8), "mimsem_memset"); check(mimsem_memset(c, p1, 0, tot*8), "mimsem_memset");
+            for (size_t k = 0; k < coef.size(); k++)
+                check(mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
+                                                   coef[k].first, coef[k].second, p1, n1, x, n1, verify && k + 1 == coef.size() ? upd1 : nullptr, n1),
+                      "mimsem_block_chebyshev_sweep");
+            last_its = cheb_steps;
+            if (!verify) return;
+            check(mimsem_elem_blocks_apply(c, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, b, n1, pb1, n1, 1.0), "mimsem_elem_blocks_apply");
+            check(mimsem_krylov_rowdot(c, 1, tot, upd1, tot, upd1, tot, scal + 2), "mimsem_krylov_rowdot");
+            check(mimsem_krylov_rowdot(c, 1, tot, pb1, tot, pb1, tot, scal + 3), "mimsem_krylov_rowdot");
+            double v[2];
+            mesh->to_host(v, scal + 2, 2);
+            // (the residual the LAST sweep saw: one more contraction lies between it and the result)
+            if (v[1] == 0.0 || std::sqrt(v[0]/v[1]) <= 30.0*rtol) { verified++; return; }
+            fixed_length = false;                                   // the interval was too optimistic: the CG from here on
+        }
         check(mimsem_ksp_solve(ksp1, b, n1, x, n1), "mimsem_ksp_solve");
         double rn; int reason;
         check(mimsem_ksp_get_info(ksp1, &last_its, &rn, &reason), "mimsem_ksp_get_info");
@@ -156,6 +199,8 @@ public:
 private:
     Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
+    const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int verified = 0;
+    double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr;
     double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
            *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;
     void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {

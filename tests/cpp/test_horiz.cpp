@@ -2,7 +2,7 @@
 // (mimsem_amd/host/mimsem_horizsolve.hpp, the counterpart of eul/HorizSolve.cpp:208-786) on the mesh and fields the pytest wrapper wrote,
 // every level in one call.  Results go back to the wrapper, which compares them with the dense restatement oracle/horiz_oracle.py
 // (per-level dense matrices, LU for the KSP solves) -- the same check the Python host gets in tests/test_gpu_next_rows.py.
-//   usage: test_horiz <in.arr> <out.bin>
+//   usage: test_horiz <in.arr> <out.bin> [ksp]
 #include <cstdio>
 #include <vector>
 #include "../../mimsem_amd/host/mimsem_horizsolve.hpp"
@@ -21,7 +21,8 @@ int main(int argc, char** argv) {
         double *fg = dev("fg"), *u1 = dev("u1"), *u2 = dev("u2"), *h1 = dev("h1"), *h2 = dev("h2"), *th = dev("theta"), *Pi = dev("Pi");
         double *velz = dev("velz1"), *velz2 = dev("velz2"), *dudz = dev("dudz1"), *dudz2 = dev("dudz2"), *Fz = dev("Fz");
         HorizSolve hs(&mesh, fg);
-        std::printf("del2 = %.12e\n", hs.del2);
+        if (argc > 3 && argv[3][0] == 'k') hs.use_fixed_length(false);          // "ksp": the CG of the reference's structure
+        std::printf("del2 = %.12e   M1 solves: %s (%d steps)\n", hs.del2, hs.fixed_length ? "fixed-length Chebyshev" : "CG", hs.cheb_steps);
         const size_t s1 = (size_t)nk*n1, s2 = (size_t)nk*n2, s0 = (size_t)nk*n0;
         double *dF = mesh.device_alloc(s2), *dG = mesh.device_alloc(s2), *Fk = mesh.device_alloc(s1), *Gk = mesh.device_alloc(s1);
         double *Phi = mesh.device_alloc(s2), *q = mesh.device_alloc(s0), *fuA = mesh.device_alloc(s1), *fuB = mesh.device_alloc(s1);

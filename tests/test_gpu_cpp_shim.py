@@ -85,7 +85,8 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
 
 
 @pytest.mark.gpu
-def test_horizsolve_driven_from_cpp(tmp_path, oracle):
+@pytest.mark.parametrize("m1", ["chebyshev", "ksp"])
+def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
     """N2 from C++: HorizSolve::advection_rhs_ec / diagnose_Phi / diagnose_q / momentum_rhs_ec (eul/HorizSolve.cpp:380-786) written over the C
     ABI (mimsem_amd/host/mimsem_horizsolve.hpp), all levels per call, against the dense restatement oracle/horiz_oracle.py -- the fields,
     mesh and tolerances of tests/test_gpu_next_rows.py::test_horizsolve_right_hand_sides"""
@@ -120,9 +121,10 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle):
     arrays.update(fg=fg, u1=u1, u2=u2, h1=h1, h2=h2, theta=th, Pi=Pi, velz1=velz, velz2=velz2, dudz1=dudz, dudz2=dudz2, Fz=Fz)
     fin, fout = str(tmp_path / "horiz_in.arr"), str(tmp_path / "horiz_out.bin")
     write_arrays(fin, arrays)
-    out = subprocess.run([_build(str(tmp_path), "test_horiz"), fin, fout], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([_build(str(tmp_path), "test_horiz"), fin, fout] + (["ksp"] if m1 == "ksp" else []), capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "DONE" in out.stdout
+    assert ("fixed-length Chebyshev" in out.stdout) == (m1 == "chebyshev")
     res = np.fromfile(fout, dtype=np.float64)
     pos = [0]
 
