@@ -84,7 +84,7 @@ public:
     // SWEqn::solve (src/SWEqn_Picard.cpp:727-791): un, hn (device) are advanced in place by one time step; `save` (field output) is the
     // host's business and ignored here
     void solve(double* un, double* hn, double dt_, bool /*save*/, int nits, bool q_exact = false, const double* bot = nullptr) {
-        if (dt_ != dt || q_exact != qx || bot != bt) setup(dt_, q_exact, bot, un, hn);
+        if (dt_ != dt || q_exact != qx || bot != bt || fixed_length != set_fixed) setup(dt_, q_exact, bot, un, hn);
         copy(n1, un, ui); copy(n2, hn, hi);
         copy(n1, un, x); copy(n2, hn, x + n1);
         history.clear();
@@ -148,7 +148,7 @@ private:
     MassOp M1;
     Graph gr[2]; bool have_graph[2] = {false, false}; bool warm[2] = {false, false};
     int n0 = 0, n1 = 0, n2 = 0; long long N = 0;
-    double dt = -1.0; bool qx = false; const double* bt = nullptr;
+    double dt = -1.0; bool qx = false; const double* bt = nullptr; bool set_fixed = true; int misses = 0;
     double *ui = nullptr, *uj = nullptr, *hu = nullptr, *F = nullptr, *fu = nullptr, *t1 = nullptr, *p1 = nullptr, *upd1 = nullptr, *um = nullptr;
     double *hi = nullptr, *hj = nullptr, *Phi = nullptr, *t2 = nullptr, *t2b = nullptr, *hm = nullptr;
     double *m0 = nullptr, *m0fg = nullptr, *m0h = nullptr, *dinv = nullptr, *ones0 = nullptr, *rhs0 = nullptr, *t0 = nullptr, *qi = nullptr, *qj = nullptr,
@@ -195,7 +195,7 @@ private:
     // once per (dt, q_exact, bot): the [u|h] operator with its coupled element blocks (assemble_operator, :622-725) and the spectral
     // regions the fixed-length solves are built on
     void setup(double dt_, bool q_exact, const double* bot, const double* un, const double* hn) {
-        dt = dt_; qx = q_exact; bt = bot;
+        dt = dt_; qx = q_exact; bt = bot; set_fixed = fixed_length; misses = 0;
         have_graph[0] = have_graph[1] = false; warm[0] = warm[1] = false;
         const double a = ROS_ALPHA*dt;
         kspA.setOperatorsSW(a, grav, H_MEAN, fg); kspA.setPCBJacobi();
@@ -315,6 +315,7 @@ private:
                 if (!(rel <= rtol*(kinds_of[g][k] == K_MASS ? 30.0 : 3.0))) ok = false;
             }
             if (ok) {
+                misses = 0;
                 if (use_graph && !have_graph[g] && warm[g]) {  // ... and recorded for every later call (recording executes nothing)
                     inline_fixed = true;
                     try { gr[g].record([&] { body(first); }); } catch (...) { inline_fixed = false; throw; }
@@ -324,6 +325,7 @@ private:
                 return norm;
             }
             fallbacks++;
+            if (++misses >= 3) can_fix = false;                // three iterations in a row: the spectral regions no longer hold -- the KSP objects from here on
             copy(N, xsave, x);
         }
         body(first);

@@ -89,6 +89,20 @@ class KSP:
         self.iterations, self.rnorm, self.reason = its.value, rn.value, self.REASONS.get(rs.value, rs.value)
         return x2.view(b.shape)
 
+    def ritz(self, m=40):
+        """mimsem_ksp_ritz: (min Re, max Re, max |Im|) of the Ritz values of P A after m Arnoldi steps inside the library"""
+        C = self._C
+        lo, hi, im = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.eng.L.mimsem_ksp_ritz(self.h, m, C.byref(lo), C.byref(hi), C.byref(im)), "ksp_ritz")
+        return lo.value, hi.value, im.value
+
+    def pc_blocks(self):
+        """mimsem_ksp_get_pc_blocks: (device address of the blocks PCSetUp built, address of the per-(level, element) factors or None, rows of a block)"""
+        C = self._C
+        b, e, nd = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._check(self.eng.L.mimsem_ksp_get_pc_blocks(self.h, C.byref(b), C.byref(e), C.byref(nd)), "ksp_get_pc_blocks")
+        return b.value, e.value, nd.value
+
 
 def pcg(apply_A, b, minv=None, x0=None, rtol=1e-14, maxit=300, check_every=10, allreduce=None, precond=None):
     """Solve A x = b for a batch of systems (rows of b).  apply_A(x)->A x on [nlev, n] tensors.

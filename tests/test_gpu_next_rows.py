@@ -91,6 +91,47 @@ def test_c_abi_ksp_mass_solves(sphere):
     assert float(torch.linalg.vector_norm(x_c - x_p) / torch.linalg.vector_norm(x_p)) < 1e-12
 
 
+def test_c_abi_ksp_ritz_and_pc_blocks(sphere):
+    """mimsem_ksp_ritz (round 5): the Ritz values of P M1 after m Arnoldi steps inside the library against the eigenvalues of the dense
+    P M1 -- P applied column by column through mimsem_elem_blocks_apply on the blocks mimsem_ksp_get_pc_blocks hands out.  Ritz values lie
+    inside the spectrum's hull and reach its ends (that is what the fixed-length Chebyshev solves of the C++ hosts rely on)."""
+    import ctypes as C
+    import torch
+    from mimsem_amd.krylov import KSP
+    cs, eng, mats, rng = sphere
+    n1 = cs.nDofs1G
+    ksp = KSP(eng, "cg").set_operator("UMAT", eng.nk, scale=SCALE, flags=1)
+    ksp.set_pc("bjacobi")
+    blocks, escale, nd = ksp.pc_blocks()
+    assert blocks and escale and nd == 2 * eng.n1e                      # thickness flag + 1-forms: one inverse per element and a per-level factor
+    # dense P per level: the preconditioner applied to the identity
+    eye = torch.eye(n1, dtype=torch.float64, device=eng.device)
+    lam = []
+    for k, (M1, _) in enumerate(mats):
+        Pk = np.zeros((n1, n1))
+        for j0 in range(0, n1, 64):
+            cols = eye[j0:j0 + 64].contiguous()                          # rows = unit vectors; one "level" each, all with the factors of level k
+            out = torch.zeros_like(cols)
+            for r in range(cols.shape[0]):
+                rc = eng.L.mimsem_elem_blocks_apply(eng.ctx, 1, 1, 0, C.c_void_p(blocks), 0, C.c_void_p(escale + 8 * k * eng.nEl), eng.nEl,
+                                                    C.c_void_p(cols[r].data_ptr()), n1, C.c_void_p(out[r].data_ptr()), n1, 1.0)
+                assert rc == 0
+            Pk[:, j0:j0 + 64] = out.cpu().numpy().T
+        ev = np.linalg.eigvals(Pk @ M1)
+        assert np.abs(ev.imag).max() < 1e-8 * np.abs(ev.real).max()       # P and M1 symmetric positive definite
+        lam.append(ev.real)
+    lam = np.concatenate(lam)
+    lo, hi, im = ksp.ritz(25)
+    assert im < 1e-6
+    assert lam.min() * (1 - 1e-8) <= lo <= lam.min() * 1.10 and lam.max() * 0.95 <= hi <= lam.max() * (1 + 1e-8), (lo, hi, lam.min(), lam.max())
+    # a non-symmetric case: the packed shallow-water operator under its coupled blocks has (nearly) real Ritz values in (0, 2)
+    kA = KSP(eng, "gmres")
+    with pytest.raises(Exception):
+        kA.ritz(10)                                                       # no operator yet
+    lo2, hi2, im2 = ksp.ritz(2)                                           # the shortest recurrence still gives values inside the hull
+    assert lam.min() * (1 - 1e-8) <= lo2 <= hi2 <= lam.max() * (1 + 1e-8)
+
+
 def test_chebyshev_mass_solver(sphere):
     """the default mass solver on one rank: fixed-length Chebyshev semi-iteration on the fused block sweep
     (mimsem_block_chebyshev_sweep) -- one sweep against its composition, the Lanczos spectral bounds, the solve against PCG"""
