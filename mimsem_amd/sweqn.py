@@ -288,7 +288,7 @@ class SWEqn:
     def pack(self, u, h): return torch.cat([u, h], dim=1)
     def unpack(self, x): return x[:, :self.n1].contiguous(), x[:, self.n1:].contiguous()
 
-    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None, it=0):
+    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None, it=0, before_q=None):
         """:402-607.  qi / qj: potential vorticities already diagnosed from (ui, hi) / (uj, hj) -- the reference re-solves for qi in
         every Picard iteration although (ui, hi) is the fixed start-of-step state; solve() passes the first result back in."""
         F = self.diagnose_F(ui, uj, hi, hj, key="F%d" % it)          # (keys: the counterpart of a solve is the same Picard iteration of the last step)
@@ -301,6 +301,8 @@ class SWEqn:
             q = self.diagnose_q(0.0, um, hm, key="qm%d" % it)
             self.eng.apply("ROTMAT", F, f=q, flags=2, out=fu)                                    # fu += R(q) F
         else:
+            if before_q is not None:
+                before_q()                     # (qi / qj were diagnosed on a parallel branch of the recorded graph: join it here)
             qi = self.diagnose_q(dt, ui, hi, key="qi") if qi is None else qi
             qj = self.diagnose_q(dt, uj, hj, key="qj%d" % it) if qj is None else qj
             self.eng.apply_up("ROTMAT_UP", F, qi, ui, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)      # fu += 1/2 R_up(qi, ui) F
@@ -690,6 +692,13 @@ class _PicardGraph:
             self.its["q"] = nq
         self.slot = 0
         self.names = {}
+        # MIMSEM_SW_FORK=1: the q solve as a parallel branch of the recorded iteration (second stream + second context of the same mesh)
+        self.fork = (not q_exact) and os.environ.get("MIMSEM_SW_FORK", "0") == "1"
+        if self.fork:
+            from .device import Engine
+            self.eng_q = Engine(eng.mesh, device=eng.device.index or 0)
+            self.sq = torch.cuda.Stream(device=eng.device)
+            self.qj = torch.zeros_like(self.qi)
 
     # -- the inline solves (called from SWEqn.solve_M1 / diagnose_q while this object records or warms up)
     def _log(self, name, res, ref):
@@ -716,14 +725,36 @@ class _PicardGraph:
         self._log("q", self.qupd, rhs * dinv)
         return x
 
+    def _q_on_a_branch(self, first, uj, hj):
+        """the potential vorticity of this iteration (from (ui, hi) in the first, (uj, hj) in the later ones) on a SECOND stream and a second
+        context of the same mesh (own workspaces): ~45 of an iteration's ~225 graph nodes that depend on nothing the mass flux F and the
+        Bernoulli function need -- a parallel branch of the recorded graph, joined before the rotational term reads q"""
+        S = self.S
+        main = torch.cuda.current_stream(S.eng.device)
+        self.sq.wait_stream(main)
+        eng_main, S.eng = S.eng, self.eng_q
+        try:
+            with torch.cuda.stream(self.sq), self.eng_q.on_current_stream():
+                if first:
+                    self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
+                else:
+                    self.qj.copy_(S.diagnose_q(self.dt, uj, hj, key="qj1"))
+        finally:
+            S.eng = eng_main
+        return lambda: main.wait_stream(self.sq)
+
     def _body(self, first):
         S, n1 = self.S, self.S.n1
         self.slot = 0
         uj, hj = self.x[:, :n1].contiguous(), self.x[:, n1:].contiguous()
-        if first and not self.q_exact:
+        join = None
+        if self.fork and not self.q_exact:
+            join = self._q_on_a_branch(first, uj, hj)
+        elif first and not self.q_exact:
             self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
+        qj = None if self.q_exact else (self.qi if first else (self.qj if self.fork else None))
         f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, None, qi=None if self.q_exact else self.qi,
-                                qj=(None if self.q_exact else (self.qi if first else None)), it=0 if first else 1)
+                                qj=qj, it=0 if first else 1, before_q=join)
         ch = self.chA
         torch.neg(f, out=ch.b)
         ch._run()
