@@ -1,7 +1,7 @@
 // sw_io.hpp -- a shallow-water case on disk for the C++ hosts (tests/cpp/test_sw.cpp, mimsem_amd/host/sw_call.cpp): the mesh tables of
 // mimsem_mesh_desc, the Coriolis 0-form and a start state, written by mimsem_amd/workloads.py::write_sw_case.
 //   int32 [12]: elOrd quadOrd nEl nk n0 n1 n2 nq nsteps nits q_exact reserved;  int32 tables inds0 inds1x inds1y inds2 indsq;
-//   float64: det J thick thickInv fg[n0] u[n1] h[n2] dt
+//   float64: det J thick thickInv fg[n0] u[n1] h[n2] dt  [bot[n2] when the header's last entry is 1]
 #pragma once
 #include <cstdio>
 #include <stdexcept>
@@ -13,7 +13,7 @@ namespace mimsem_host {
 struct SWCase {
     int n = 0, m = 0, nEl = 0, nk = 1, n0 = 0, n1 = 0, n2 = 0, nq = 0, nsteps = 0, nits = 0; bool q_exact = false; double dt = 0.0;
     std::vector<int> i0, ix, iy, i2, iq;
-    std::vector<double> det, J, th, ti, fg, u, h;
+    std::vector<double> det, J, th, ti, fg, u, h, bot;          // bot: empty = no topography
     mimsem_mesh_desc desc() const {
         mimsem_mesh_desc d{};
         d.elOrd = n; d.quadOrd = m; d.nEl = nEl; d.nk = nk; d.n0 = n0; d.n1 = n1; d.n2 = n2; d.nq = nq;
@@ -39,6 +39,7 @@ inline SWCase read_sw_case(const char* path) {
     rd(c.det, e*mp12); rd(c.J, e*mp12*4); rd(c.th, (size_t)c.nk*e*mp12); rd(c.ti, (size_t)c.nk*e*mp12);
     rd(c.fg, (size_t)c.n0); rd(c.u, (size_t)c.n1); rd(c.h, (size_t)c.n2); rd(dt, 1);
     c.dt = dt[0];
+    if (hd[11] == 1) rd(c.bot, (size_t)c.n2);
     std::fclose(f);
     return c;
 }

@@ -16,15 +16,16 @@ def z_levels(nk, n0q, rng=None, ztop=30000.0, mu=15.0):
     return levs
 
 
-def write_sw_case(path, dm, fg, u, h, dt, nsteps, nits, q_exact):
+def write_sw_case(path, dm, fg, u, h, dt, nsteps, nits, q_exact, bot=None):
     """A shallow-water case for the C++ hosts (mimsem_amd/host/sw_io.hpp: tests/cpp/test_sw.cpp, mimsem_amd/host/sw_call.cpp): the tables of
-    a DeviceMesh (nk = 1) as mimsem_mesh_desc takes them, the Coriolis 0-form, a start state (host arrays) and the step parameters."""
+    a DeviceMesh (nk = 1) as mimsem_mesh_desc takes them, the Coriolis 0-form, a start state (host arrays), the step parameters and
+    (optional) the bottom topography 2-form."""
     import numpy as np
     with open(path, "wb") as f:
-        np.array([dm.n, dm.m, dm.nEl, 1, dm.n0, dm.n1, dm.n2, dm.nq, nsteps, nits, int(q_exact), 0], dtype=np.int32).tofile(f)
+        np.array([dm.n, dm.m, dm.nEl, 1, dm.n0, dm.n1, dm.n2, dm.nq, nsteps, nits, int(q_exact), 0 if bot is None else 1], dtype=np.int32).tofile(f)
         for a in (dm.inds0, dm.inds1x, dm.inds1y, dm.inds2, dm.indsq):
             np.ascontiguousarray(a, dtype=np.int32).tofile(f)
-        for a in (dm.det, dm.J, dm.thick[:1], dm.thickInv[:1], fg, u, h, np.array([dt])):
+        for a in (dm.det, dm.J, dm.thick[:1], dm.thickInv[:1], fg, u, h, np.array([dt])) + (() if bot is None else (bot,)):
             np.ascontiguousarray(a, dtype=np.float64).tofile(f)
 
 

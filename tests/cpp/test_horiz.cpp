@@ -20,12 +20,13 @@ int main(int argc, char** argv) {
         auto dev = [&](const char* k) { const auto& v = a.reals(k); return mesh.to_device(v.data(), v.size()); };
         double *fg = dev("fg"), *u1 = dev("u1"), *u2 = dev("u2"), *h1 = dev("h1"), *h2 = dev("h2"), *th = dev("theta"), *Pi = dev("Pi");
         double *velz = dev("velz1"), *velz2 = dev("velz2"), *dudz = dev("dudz1"), *dudz2 = dev("dudz2"), *Fz = dev("Fz");
+        double *dwdx1 = dev("dwdx1"), *dwdx2 = dev("dwdx2");
         HorizSolve hs(&mesh, fg);
         if (argc > 3 && argv[3][0] == 'k') hs.use_fixed_length(false);          // "ksp": the CG of the reference's structure
         std::printf("del2 = %.12e   M1 solves: %s (%d steps)\n", hs.del2, hs.fixed_length ? "fixed-length Chebyshev" : "CG", hs.cheb_steps);
         const size_t s1 = (size_t)nk*n1, s2 = (size_t)nk*n2, s0 = (size_t)nk*n0;
         double *dF = mesh.device_alloc(s2), *dG = mesh.device_alloc(s2), *Fk = mesh.device_alloc(s1), *Gk = mesh.device_alloc(s1);
-        double *Phi = mesh.device_alloc(s2), *q = mesh.device_alloc(s0), *fuA = mesh.device_alloc(s1), *fuB = mesh.device_alloc(s1);
+        double *Phi = mesh.device_alloc(s2), *q = mesh.device_alloc(s0), *fuA = mesh.device_alloc(s1), *fuB = mesh.device_alloc(s1), *fuC = mesh.device_alloc(s1);
         hs.advection_rhs_ec(u1, u2, h1, h2, th, dF, dG, Fk, Gk);
         std::printf("M1 solve: %d iterations\n", hs.last_its);
         hs.diagnose_Phi(u1, u2, velz, velz2, Phi);
@@ -34,14 +35,15 @@ int main(int argc, char** argv) {
         const double k2iA = hs.k2i();
         hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuB, Fk, Fz, nullptr, nullptr, Fk);
         const double k2iB = hs.k2i();
+        hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuC, Fk, Fz, dwdx1, dwdx2, Fk);      // + the horizontal gradient of w (:704-712)
         FILE* g = std::fopen(argv[2], "wb");
         if (!g) { std::perror(argv[2]); return 2; }
         auto put = [&](const double* p, size_t n) { std::vector<double> h(n); mesh.to_host(h.data(), p, n); std::fwrite(h.data(), 8, n, g); };
-        put(dF, s2); put(dG, s2); put(Fk, s1); put(Gk, s1); put(Phi, s2); put(q, s0); put(fuA, s1); put(fuB, s1);
+        put(dF, s2); put(dG, s2); put(Fk, s1); put(Gk, s1); put(Phi, s2); put(q, s0); put(fuA, s1); put(fuB, s1); put(fuC, s1);
         const double tail[3] = {k2iA, k2iB, hs.del2};
         std::fwrite(tail, 8, 3, g);
         std::fclose(g);
-        for (double* p : {fg, u1, u2, h1, h2, th, Pi, velz, velz2, dudz, dudz2, Fz, dF, dG, Fk, Gk, Phi, q, fuA, fuB}) mimsem_free(p);
+        for (double* p : {fg, u1, u2, h1, h2, th, Pi, velz, velz2, dudz, dudz2, Fz, dwdx1, dwdx2, dF, dG, Fk, Gk, Phi, q, fuA, fuB, fuC}) mimsem_free(p);
     } catch (const std::exception& e) { std::printf("FAIL: %s\n", e.what()); return 1; }
     std::printf("DONE\n");
     return 0;

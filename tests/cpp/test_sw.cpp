@@ -36,8 +36,9 @@ int main(int argc, char** argv) {
             src::SWEqn sw(&mesh, dfg);
             sw.fixed_length = mode > 0; sw.use_graph = mode == 2;
             double *un = mesh.to_device(u0.data(), n1), *hn = mesh.to_device(h0.data(), n2);
+            double* bot = cs.bot.empty() ? nullptr : mesh.to_device(cs.bot.data(), n2);          // bottom topography (src/SWEqn_Picard.cpp:727 `bot`)
             for (int s = 0; s < nsteps; s++) {
-                sw.solve(un, hn, dt, false, nits, q_exact);
+                sw.solve(un, hn, dt, false, nits, q_exact, bot);
                 std::printf("mode %d step %d:", mode, s);
                 for (double v : sw.history) std::printf(" %.6e", v);
                 std::printf("\n");
@@ -46,7 +47,7 @@ int main(int argc, char** argv) {
             mesh.to_host(out[mode][0].data(), un, n1); mesh.to_host(out[mode][1].data(), hn, n2);
             std::printf("mode %d: Chebyshev steps [u|h] %d, M1 %d, q %d; iterations handed to the KSP objects: %d\n", mode, sw.steps_A, sw.steps_M1, sw.steps_q, sw.fallbacks);
             if (mode > 0 && sw.fallbacks) { std::printf("FAIL: the fixed-length solves missed their tolerance\n"); fails++; }
-            mimsem_free(un); mimsem_free(hn);
+            mimsem_free(un); mimsem_free(hn); if (bot) mimsem_free(bot);
         }
         mimsem_free(dfg);
     } catch (const std::exception& e) { std::printf("FAIL: %s\n", e.what()); return 1; }

@@ -45,8 +45,9 @@ def test_ksp_call_sites_match_dense_solves(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q_exact,nits,dt", [(False, 2, 360.0), (True, 4, 600.0)], ids=["galewsky_style", "williamson2_style"])
-def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
+@pytest.mark.parametrize("q_exact,nits,dt,topo", [(False, 2, 360.0, False), (True, 4, 600.0, False), (False, 3, 300.0, True)],
+                         ids=["galewsky_style", "williamson2_style", "with_topography"])
+def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo):
     """SWEqn::solve (src/SWEqn_Picard.cpp:727-791) orchestrated in C++ (mimsem_amd/host/mimsem_sweqn.hpp: KSP objects, fixed-length
     Chebyshev solves, the same as one hipGraph per Picard iteration) on the cubed sphere of tests/test_gpu_sweqn.py, against the numpy
     oracle's step (oracle/sw_oracle.py: dense matrices, LU for every KSPSolve).  Tolerance 1e-9 as for the Python host."""
@@ -71,14 +72,16 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt):
     uq = np.stack([U0 * np.cos(th) + 3.0 * np.sin(2 * lam) * np.cos(th), 2.0 * np.cos(lam) * np.cos(th) ** 2], axis=1)
     hq = H0 - (6371220.0 * 7.292e-5 * U0 + 0.5 * U0 * U0) * np.sin(th) ** 2 / 9.80616 + 40.0 * np.cos(th) * np.sin(lam)
     u0, h0 = O.init1(uq), O.init2(hq)
+    # an isolated mountain (2-form dofs), the `bot` argument of SWEqn::solve (src/SWEqn_Picard.cpp:727; Phi += g M2 bot, :301-303)
+    bot = O.init2(300.0 * np.exp(-((lam - 0.5) ** 2 + (th - 0.4) ** 2) / 0.1)) if topo else None
     fin, fout = str(tmp_path / "sw_in.bin"), str(tmp_path / "sw_out.bin")
-    write_sw_case(fin, dm, O.fg, u0, h0, dt, nsteps, nits, q_exact)
+    write_sw_case(fin, dm, O.fg, u0, h0, dt, nsteps, nits, q_exact, bot=bot)
     out = subprocess.run([_build(str(tmp_path), "test_sw"), fin, fout], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "ALL OK" in out.stdout
     ur, hr = u0, h0
     for _ in range(nsteps):
-        ur, hr = O.solve(ur, hr, dt, nits=nits, q_exact=q_exact)
+        ur, hr = O.solve(ur, hr, dt, nits=nits, q_exact=q_exact, bot=bot)
     res = np.fromfile(fout, dtype=np.float64).reshape(3, dm.n1 + dm.n2)
     for mode in range(3):
         assert rel_l2(res[mode, :dm.n1], ur) < 1e-9 and rel_l2(res[mode, dm.n1:], hr) < 1e-9, mode
@@ -116,9 +119,10 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
     velz = r.standard_normal((nk - 1, N2)) * area; velz2 = velz * (1 + 0.05 * r.standard_normal(velz.shape))
     dudz = r.standard_normal((nk - 1, N1)) * 1e-3 * ln; dudz2 = dudz * 1.1
     Fz = velz * 0.7
+    dwdx = r.standard_normal((nk - 1, N1)) * 2e-4 * ln; dwdx2 = dwdx * 0.9
     fg = np.broadcast_to(H.fg, (nk, N0)) if np.ndim(H.fg) == 1 else H.fg
     arrays = mesh_arrays(dm)
-    arrays.update(fg=fg, u1=u1, u2=u2, h1=h1, h2=h2, theta=th, Pi=Pi, velz1=velz, velz2=velz2, dudz1=dudz, dudz2=dudz2, Fz=Fz)
+    arrays.update(fg=fg, u1=u1, u2=u2, h1=h1, h2=h2, theta=th, Pi=Pi, velz1=velz, velz2=velz2, dudz1=dudz, dudz2=dudz2, Fz=Fz, dwdx1=dwdx, dwdx2=dwdx2)
     fin, fout = str(tmp_path / "horiz_in.arr"), str(tmp_path / "horiz_out.bin")
     write_arrays(fin, arrays)
     out = subprocess.run([_build(str(tmp_path), "test_horiz"), fin, fout] + (["ksp"] if m1 == "ksp" else []), capture_output=True, text=True, timeout=600)
@@ -131,7 +135,8 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
     def take(rows, n):
         a = res[pos[0]:pos[0] + rows * n].reshape(rows, n); pos[0] += rows * n
         return a
-    gF, gG, gFk, gGk, gPhi, gq, fuA, fuB = take(nk, N2), take(nk, N2), take(nk, N1), take(nk, N1), take(nk, N2), take(nk, N0), take(nk, N1), take(nk, N1)
+    gF, gG, gFk, gGk, gPhi, gq, fuA, fuB, fuC = (take(nk, N2), take(nk, N2), take(nk, N1), take(nk, N1), take(nk, N2), take(nk, N0), take(nk, N1),
+                                                  take(nk, N1), take(nk, N1))
     k2iA, k2iB, del2 = res[pos[0]:pos[0] + 3]
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert abs(del2 - H.del2) < 1e-6 * abs(H.del2)
@@ -141,11 +146,14 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
     for lev in range(nk):
         assert rel(gPhi[lev], H.diagnose_Phi(lev, u1[lev], u2[lev], velz, velz2)) < 1e-10
         assert rel(gq[lev], H.diagnose_q(lev, h1[lev], u1[lev])) < 1e-10
-    for got, k2i_got, use_F in ((fuA, k2iA, False), (fuB, k2iB, True)):
+    for got, k2i_got, use_F, use_w in ((fuA, k2iA, False, False), (fuB, k2iB, True, False), (fuC, None, True, True)):
         k2i = 0.0
         for lev in range(nk):
             want, k = H.momentum_rhs_ec(lev, th[lev], dudz, dudz2, velz, velz2, Pi[lev], u1[lev], u2[lev], h1[lev], h2[lev],
-                                        Fx=Fk[lev] if use_F else None, Fz=Fz if use_F else None, Fk=Fk[lev])
+                                        Fx=Fk[lev] if use_F else None, Fz=Fz if use_F else None, Fk=Fk[lev],
+                                        dwdx1=dwdx if use_w else None, dwdx2=dwdx2 if use_w else None)
             k2i += k
-            assert rel(got[lev], want) < 1e-8, (lev, use_F)
-        assert abs(k2i_got - k2i) < 1e-8 * abs(k2i)
+            assert rel(got[lev], want) < 1e-8, (lev, use_F, use_w)
+        if k2i_got is not None:
+            assert abs(k2i_got - k2i) < 1e-8 * abs(k2i)
+    assert rel(fuC, fuB) > 1e-6                      # the dwdx term is not lost in the noise of the comparison

@@ -333,15 +333,18 @@ def test_horizsolve_right_hand_sides(oracle):
     for lev in range(nk):
         assert rel(hs.diagnose_Phi(t(u1), t(u2), t(velz), t(velz2))[lev].cpu().numpy(), H.diagnose_Phi(lev, u1[lev], u2[lev], velz, velz2)) < 1e-10
         assert rel(hs.diagnose_q(t(h1), t(u1))[lev].cpu().numpy(), H.diagnose_q(lev, h1[lev], u1[lev])) < 1e-10
-    for kwargs in (dict(), dict(use_F=True)):
+    dwdx = r.standard_normal((nk - 1, N1)) * 2e-4 * ln; dwdx2 = dwdx * 0.9          # horizontal gradient of the vertical velocity on the interfaces (:704-712)
+    for kwargs in (dict(), dict(use_F=True), dict(use_F=True, dwdx=True)):
         Fx = Fk if kwargs.get("use_F") else None
         Fz = (velz * 0.7) if kwargs.get("use_F") else None
+        w1, w2 = (dwdx, dwdx2) if kwargs.get("dwdx") else (None, None)
         got = hs.momentum_rhs_ec(t(th), t(dudz), t(dudz2), t(velz), t(velz2), t(Pi), t(u1), t(u2), t(h1), t(h2),
-                                 Fx=None if Fx is None else t(Fx), Fz=None if Fz is None else t(Fz), Fk=t(Fk)).cpu().numpy()
+                                 Fx=None if Fx is None else t(Fx), Fz=None if Fz is None else t(Fz), Fk=t(Fk),
+                                 dwdx1=None if w1 is None else t(w1), dwdx2=None if w2 is None else t(w2)).cpu().numpy()
         k2i = 0.0
         for lev in range(nk):
             want, k = H.momentum_rhs_ec(lev, th[lev], dudz, dudz2, velz, velz2, Pi[lev], u1[lev], u2[lev], h1[lev], h2[lev],
-                                        Fx=None if Fx is None else Fx[lev], Fz=Fz, Fk=Fk[lev])
+                                        Fx=None if Fx is None else Fx[lev], Fz=Fz, Fk=Fk[lev], dwdx1=w1, dwdx2=w2)
             k2i += k
             assert rel(got[lev], want) < 1e-8, (lev, kwargs)
         assert abs(hs.k2i - k2i) < 1e-8 * abs(k2i)

@@ -84,6 +84,22 @@ def test_sw_time_step(sw, q_exact, nits, dt):
     assert rel_l2(ue[0].cpu().numpy(), ud[0].cpu().numpy()) < 1e-11 and rel_l2(he[0].cpu().numpy(), hd[0].cpu().numpy()) < 1e-11
 
 
+def test_sw_time_step_with_topography(sw):
+    """SWEqn::solve with its `bot` argument (src/SWEqn_Picard.cpp:727, :301-303: Phi += g M2 bot) -- an isolated mountain, three Picard
+    iterations with the upwinded potential vorticity -- against the oracle's step"""
+    cs, eng, O, S, uq, hq = sw
+    th = np.arcsin(O.xq[:, 2] / 6371220.0); lam = np.arctan2(O.xq[:, 1], O.xq[:, 0])
+    bot = O.init2(300.0 * np.exp(-((lam - 0.5) ** 2 + (th - 0.4) ** 2) / 0.1))
+    u0, h0 = O.init1(uq), O.init2(hq)
+    ur, hr = O.solve(u0, h0, 300.0, nits=3, q_exact=False, bot=bot)
+    ud, hd = S.solve(_t(eng, u0), _t(eng, h0), 300.0, nits=3, q_exact=False, bot=_t(eng, bot))
+    assert rel_l2(ud[0].cpu().numpy(), ur) < 1e-9 and rel_l2(hd[0].cpu().numpy(), hr) < 1e-9
+    assert np.allclose(S.history, O.history, rtol=1e-4, atol=1e-13)
+    # the mountain matters: without it the step differs by far more than the tolerance
+    u_flat, _ = O.solve(u0, h0, 300.0, nits=3, q_exact=False)
+    assert rel_l2(u_flat, ur) > 1e-6
+
+
 def test_sw_conservation_diagnostics(sw):
     """int2 / int0 / intE / enstrophy of SWEqn::writeConservation (src/SWEqn_Picard.cpp:1202-1359): the device evaluates them as
     bilinear forms of the engine operators, the oracle point by point as the reference does"""
