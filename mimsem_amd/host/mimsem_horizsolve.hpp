@@ -30,18 +30,19 @@ public:
         nk = m->nk_; n0 = m->n0; n1 = m->n1; n2 = m->n2; do_visc = visc;
         const double dx = std::sqrt(4.0*M_PI*RAD_EARTH*RAD_EARTH/(double)(nDofs0G > 0 ? nDofs0G : n0));
         del2 = -std::sqrt(0.072*std::pow(dx, 3.2));
-        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1}) *p = mesh->device_alloc((size_t)nk*n1);
-        for (double** p : {&a2, &b2, &c2}) *p = mesh->device_alloc((size_t)nk*n2);
-        for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
-        scal = mesh->device_alloc(4);
-        check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, nullptr, 0, m0, n0), "mimsem_pvec");                       // M0 is diagonal (collocated 0-forms)
-        // ksp1 (:77-96): the 1-form mass of every level, one element block each
-        check(mimsem_ksp_create(mesh->ctx, MIMSEM_KSP_CG, &ksp1), "mimsem_ksp_create");
-        check(mimsem_ksp_set_operator(ksp1, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0), "mimsem_ksp_set_operator");
-        check(mimsem_ksp_set_pc_bjacobi(ksp1), "mimsem_ksp_set_pc_bjacobi");
-        check(mimsem_ksp_set_tolerances(ksp1, rtol, 1.0e-50, 1000, 0, 2), "mimsem_ksp_set_tolerances");
-        p1 = mesh->device_alloc((size_t)nk*n1); upd1 = mesh->device_alloc((size_t)nk*n1); pb1 = mesh->device_alloc((size_t)nk*n1);
-        use_fixed_length(true);
+        try {
+            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1, &upd1, &pb1}) *p = mesh->device_alloc((size_t)nk*n1);
+            for (double** p : {&a2, &b2, &c2}) *p = mesh->device_alloc((size_t)nk*n2);
+            for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
+            scal = mesh->device_alloc(4);
+            check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, nullptr, 0, m0, n0), "mimsem_pvec");                   // M0 is diagonal (collocated 0-forms)
+            // ksp1 (:77-96): the 1-form mass of every level, one element block each
+            check(mimsem_ksp_create(mesh->ctx, MIMSEM_KSP_CG, &ksp1), "mimsem_ksp_create");
+            check(mimsem_ksp_set_operator(ksp1, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0), "mimsem_ksp_set_operator");
+            check(mimsem_ksp_set_pc_bjacobi(ksp1), "mimsem_ksp_set_pc_bjacobi");
+            check(mimsem_ksp_set_tolerances(ksp1, rtol, 1.0e-50, 1000, 0, 2), "mimsem_ksp_set_tolerances");
+            use_fixed_length(true);
+        } catch (...) { release(); throw; }                  // (a constructor that throws runs no destructor)
     }
     void use_fixed_length(bool on) {
         fixed_length = false;
@@ -57,10 +58,7 @@ public:
         for (int k = 1; k < cheb_steps; k++) { const double be = (k == 1 ? 0.5 : 0.25)*c2*al*al; al = 1.0/(d - be/al); coef.emplace_back(al, be); }
         verified = 0; fixed_length = true;
     }
-    ~HorizSolve() {
-        mimsem_ksp_destroy(ksp1);
-        for (double* p : {a1, b1, c1, d1, e1, g1, a2, b2, c2, m0, a0, b0, scal, p1, upd1, pb1}) mimsem_free(p);
-    }
+    ~HorizSolve() { release(); }
     HorizSolve(const HorizSolve&) = delete; HorizSolve& operator=(const HorizSolve&) = delete;
 
     // u = M1^-1 E12 M2 phi  (:208-228)
@@ -197,6 +195,10 @@ public:
     }
 
 private:
+    void release() {
+        mimsem_ksp_destroy(ksp1); ksp1 = nullptr;
+        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &upd1, &pb1}) { if (*p) mimsem_free(*p); *p = nullptr; }
+    }
     Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
     const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int verified = 0;

@@ -60,25 +60,24 @@ public:
     // fg: the Coriolis 0-form (SWEqn::coriolis, src/SWEqn_Picard.cpp:95-140), device, n0 entries; it must outlive the object
     SWEqn(Mesh* m, const double* fg_dev) : mesh(m), fg(fg_dev), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
-        for (double** p : {&ui, &uj, &hu, &F, &fu, &t1, &p1, &upd1, &um}) *p = mesh->device_alloc(n1);
-        for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
-        for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &t0, &qi, &qj, &p0, &upd0}) *p = mesh->device_alloc(n0);
-        for (double** p : {&x, &xsave, &res, &bA, &rA, &dA, &dx}) *p = mesh->device_alloc((size_t)N);
-        chk = mesh->device_alloc(2*NSLOT);
-        mimsem_ctx* c = mesh->ctx;
-        check(mimsem_pvec(c, 0, 1, 1.0, nullptr, 0, m0, 0), "mimsem_pvec");                                   // M0 is diagonal (collocated 0-forms)
-        combine(n0, 1.0, m0, 1, fg, 0.0, nullptr, m0fg);                                                      // M0 f
-        combine(n0, 1.0, m0, 2, m0, 0.0, nullptr, ones0);
-        // ksp1: the 1-form mass matrix with one exact block per element (src/SWEqn_Picard.cpp:84-92)
-        M1.assemble();
-        ksp1.setOperators(M1); ksp1.setPCBJacobi(); ksp1.setTolerances(rtol, 1.0e-50, 1000);
-        ksp0.setTolerances(rtol, 1.0e-50, 1000, 30);
-        kspA.setTolerances(rtol, 1.0e-50, 1000, 30);
+        try {
+            for (double** p : {&ui, &uj, &hu, &F, &fu, &t1, &p1, &upd1, &um}) *p = mesh->device_alloc(n1);
+            for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
+            for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &t0, &qi, &qj, &p0, &upd0}) *p = mesh->device_alloc(n0);
+            for (double** p : {&x, &xsave, &res, &bA, &rA, &dA, &dx}) *p = mesh->device_alloc((size_t)N);
+            chk = mesh->device_alloc(2*NSLOT);
+            mimsem_ctx* c = mesh->ctx;
+            check(mimsem_pvec(c, 0, 1, 1.0, nullptr, 0, m0, 0), "mimsem_pvec");                                   // M0 is diagonal (collocated 0-forms)
+            combine(n0, 1.0, m0, 1, fg, 0.0, nullptr, m0fg);                                                      // M0 f
+            combine(n0, 1.0, m0, 2, m0, 0.0, nullptr, ones0);
+            // ksp1: the 1-form mass matrix with one exact block per element (src/SWEqn_Picard.cpp:84-92)
+            M1.assemble();
+            ksp1.setOperators(M1); ksp1.setPCBJacobi(); ksp1.setTolerances(rtol, 1.0e-50, 1000);
+            ksp0.setTolerances(rtol, 1.0e-50, 1000, 30);
+            kspA.setTolerances(rtol, 1.0e-50, 1000, 30);
+        } catch (...) { release(); throw; }              // (a constructor that throws runs no destructor)
     }
-    ~SWEqn() {
-        for (double* p : {ui, uj, hu, F, fu, t1, p1, upd1, um, hi, hj, Phi, t2, t2b, hm, m0, m0fg, m0h, dinv, ones0, rhs0, t0, qi, qj, p0, upd0,
-                          x, xsave, res, bA, rA, dA, dx, chk}) mimsem_free(p);
-    }
+    ~SWEqn() { release(); }
     SWEqn(const SWEqn&) = delete; SWEqn& operator=(const SWEqn&) = delete;
 
     // SWEqn::solve (src/SWEqn_Picard.cpp:727-791): un, hn (device) are advanced in place by one time step; `save` (field output) is the
@@ -139,6 +138,10 @@ public:
     }
 
 private:
+    void release() {
+        for (double** p : {&ui, &uj, &hu, &F, &fu, &t1, &p1, &upd1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &t0, &qi, &qj,
+                           &p0, &upd0, &x, &xsave, &res, &bA, &rA, &dA, &dx, &chk}) { if (*p) mimsem_free(*p); *p = nullptr; }
+    }
     static constexpr int NSLOT = 16;
     enum LogKind { K_MASS = 1, K_A = 2, K_PICARD = 3 };
     Mesh* mesh; const double* fg;
