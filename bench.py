@@ -414,6 +414,23 @@ def column_extras(eng, dm, rng, torch):
     torch.cuda.synchronize(); tn = (time.perf_counter() - t0) / 4
     res["vertical_newton_iteration_ms"] = tn * 1e3
     res["vertical_newton_norms_last"] = vs.history[-1]
+    # the linear solve of that Newton iteration alone, on the state it was given (a hydrostatic column with 1e-4 noise: what the UMJS14 run
+    # hands to solve_schur_column_eta) -- beside schur_ms_all_columns above, whose uniformly random fields make a handful of columns need
+    # every refinement step (the tail of the Thomas launch)
+    vs.keep_solve_args = True
+    vs.solve_schur_eta(*st, zv, maxit=1, tol=0.0)
+    vs.keep_solve_args = False
+    if getattr(vs, "last_solve_args", None) is not None:
+        dtm, thm, rhm, etm, pim, Fm = vs.last_solve_args
+        sets = [[f.clone() for f in Fm] for _ in range(9)]
+        eng.solve_schur_eta(dtm, thm, rhm, etm, pim, *sets[0]); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(8):
+            eng.solve_schur_eta(dtm, thm, rhm, etm, pim, *sets[i + 1])
+        torch.cuda.synchronize(); tm = (time.perf_counter() - t0) / 8
+        nbm, stm, _ = eng.solve_status()
+        res["schur_model_state"] = {"ms_all_columns": tm * 1e3, "column_solves_per_s": nEl / tm, "unconverged_columns": int(nbm),
+                                    "columns_by_status": {str(k): int((stm == k).sum()) for k in (0, 1, 3, 4)},
+                                    "state": "hydrostatic column (theta = 300 K + 4 K/km), 1e-4 relative noise, one Newton iteration in"}
     t = timeit(lambda: eng.colop_apply("CONST_RHO", theta, f1=rho, nout_slots=nk), 20)
     res["vertops_assemble_apply_columns_per_s"] = nEl / t
     vh = eng.tensor(rng.standard_normal((nk, dm.n2)))
@@ -852,6 +869,7 @@ def compact_record(out, extras_file=None):
     summ = {"column_solves_per_s": _r(col.get("schur_column_solves_per_s")), "schur_eta_ms": _r(col.get("schur_ms_all_columns")),
             "schur_eta_unresolved_columns": col.get("schur_unconverged_columns"),
             "schur_eta_columns_by_pivoted_lu": col.get("schur_columns_resolved_by_pivoted_lu"), "schur_eta_columns_accepted_on_backward_error": col.get("schur_columns_accepted_on_backward_error"), "schur_eta_pivot_fallback_cost_frac": _r(_g(col, "schur_pivot_fallback", "cost_frac"), 3),
+            "schur_eta_ms_model_state": _r(_g(out, "column", "schur_model_state", "ms_all_columns")),
             "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),

@@ -189,6 +189,8 @@ class VertSolve:
                 dt, self.rayleigh or 0.0, theta_l2_h, exner_h, velz_i, velz_j, rho_i, rho_j, zv, rt_i, rt_j, rho_h, rt_h, exner_j,
                 add_w=udwdx, add_rho=add_rho, add_rt=add_rt)
             self._k2i = k2i
+            if getattr(self, "keep_solve_args", False):     # (bench: the linear solve of this iteration again, alone, on the state it was given)
+                self.last_solve_args = (dt, th_w3.clone(), rho_h.clone(), eta.clone(), exner_h.clone(), [F_w.clone(), F_rho.clone(), F_eta.clone(), F_exner.clone()])
             d_w, d_rho, d_eta, d_exner = eng.solve_schur_eta(dt, th_w3, rho_h, eta, exner_h, F_w, F_rho, F_eta, F_exner)   # :1855
             velz_h, rho_h, rt_h, exner_h, nrm = eng.newton_update(d_w, d_rho, d_eta, d_exner, velz_i, rho_i, rt_i, exner_i,
                                                                   velz_j, rho_j, rt_j, exner_j)
