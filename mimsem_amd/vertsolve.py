@@ -196,10 +196,12 @@ class VertSolve:
                                                                   velz_j, rho_j, rt_j, exner_j)
             cs = nrm.sum(dim=2)                                                     # [8, nEl]: column sums of squares
             nv = torch.sqrt(cs[0::2] / cs[1::2]).amax(dim=1)                        # MaxNorm :228 for exner, w, rho, eta
-            nv = eng.allreduce(nv, op="max").tolist()                               # MPI_Allreduce(MAX) :1915-1918
+            nv = eng.allreduce(nv, op="max")                                        # MPI_Allreduce(MAX) :1915-1918
+            # (the theta diagnosis does not depend on the norms: launched BEFORE the host waits for them, it runs under the read-back)
+            theta_h, theta_l2_h = eng.diag_theta_blend(rho_j, rt_j, blend2=theta_i, blendL=theta_l2_i, wa=0.5, wb=0.5)     # :1896-1912
+            nv = nv.tolist()
             norms = dict(exner=nv[0], w=nv[1], rho=nv[2], eta=nv[3])
             self.history.append(norms)
-            theta_h, theta_l2_h = eng.diag_theta_blend(rho_j, rt_j, blend2=theta_i, blendL=theta_l2_i, wa=0.5, wb=0.5)     # :1896-1912
             if verbose:
                 print("\t%d:\t|d_exner|/|exner|: %.6e\t|d_w|/|w|: %.6e\t|d_rho|/|rho|: %.6e\t|d_eta|/|eta|: %.6e"
                       % (itt, norms["exner"], norms["w"], norms["rho"], norms["eta"]))
