@@ -414,6 +414,23 @@ def column_extras(eng, dm, rng, torch):
     torch.cuda.synchronize(); tn = (time.perf_counter() - t0) / 4
     res["vertical_newton_iteration_ms"] = tn * 1e3
     res["vertical_newton_norms_last"] = vs.history[-1]
+    # the same iterations with the HOST in C++ (mimsem_amd/host/vert_call.cpp over mimsem_vertsolve.hpp), from the same start state
+    exe = os.path.join(ROOT, "mimsem_amd", "host", "vert_call")
+    if os.path.exists(exe):
+        import subprocess
+        import tempfile
+        from mimsem_amd.workloads import mesh_arrays, write_arrays
+        with tempfile.TemporaryDirectory() as tmp:
+            case = os.path.join(tmp, "case.arr")
+            arr = mesh_arrays(dm)
+            cpu = lambda tt: tt.cpu().numpy()
+            arr.update(dt=np.array([75.0]), zv=cpu(zv), velz=cpu(st[0]), rho=cpu(st[1]), rt=cpu(st[2]), exner=cpu(st[3]))
+            write_arrays(case, arr)
+            try:
+                r_ = subprocess.run([exe, case, "4"], capture_output=True, text=True, timeout=300)
+                res["vertical_newton_cpp_host"] = json.loads(r_.stdout) if r_.returncode == 0 else {"error": (r_.stderr or r_.stdout)[-300:]}
+            except Exception as e_:                    # noqa: BLE001
+                res["vertical_newton_cpp_host"] = {"error": repr(e_)[:300]}
     # the linear solve of that Newton iteration alone, on the state it was given (a hydrostatic column with 1e-4 noise: what the UMJS14 run
     # hands to solve_schur_column_eta) -- beside schur_ms_all_columns above, whose uniformly random fields make a handful of columns need
     # every refinement step (the tail of the Thomas launch)
@@ -871,6 +888,7 @@ def compact_record(out, extras_file=None):
             "schur_eta_columns_by_pivoted_lu": col.get("schur_columns_resolved_by_pivoted_lu"), "schur_eta_columns_accepted_on_backward_error": col.get("schur_columns_accepted_on_backward_error"), "schur_eta_pivot_fallback_cost_frac": _r(_g(col, "schur_pivot_fallback", "cost_frac"), 3),
             "schur_eta_ms_model_state": _r(_g(out, "column", "schur_model_state", "ms_all_columns")),
             "schur3_ms": _r(col.get("schur3_ms_all_columns")), "newton_iteration_ms": _r(col.get("vertical_newton_iteration_ms")),
+            "newton_iteration_ms_cpp_host": _r(_g(out, "column", "vertical_newton_cpp_host", "ms_per_newton_iteration")),
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
             "horiz_rhs_ms": _r(_g(out, "horiz_rhs", "ms_per_evaluation_hipgraph")),

@@ -26,6 +26,7 @@ def test_shim_compiles_and_links(tmp_path, oracle):
     assert os.path.exists(_build(str(tmp_path), "test_ksp"))
     assert os.path.exists(_build(str(tmp_path), "test_sw"))
     assert os.path.exists(_build(str(tmp_path), "test_horiz"))
+    assert os.path.exists(_build(str(tmp_path), "test_vert"))
 
 
 @pytest.mark.gpu
@@ -157,3 +158,64 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
         if k2i_got is not None:
             assert abs(k2i_got - k2i) < 1e-8 * abs(k2i)
     assert rel(fuC, fuB) > 1e-6                      # the dwdx term is not lost in the noise of the comparison
+
+
+@pytest.mark.gpu
+def test_vertical_newton_loop_driven_from_cpp(tmp_path, oracle):
+    """The caller of the column path from C++: VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) as mimsem_host::VertSolveEta
+    (mimsem_amd/host/mimsem_vertsolve.hpp) on the library's fused entry points, against the column-by-column numpy restatement
+    oracle/vert_oracle.py -- the patch, state, forcing and tolerances of tests/test_gpu_column.py::test_vertical_newton_loop_matches_oracle"""
+    import numpy as np
+    from mimsem_amd.device import DeviceMesh
+    from mimsem_amd.workloads import mesh_arrays, write_arrays
+    from oracle import vert_oracle
+    from tests.helpers import make_patch, rel_l2
+    VSCALE = 1.0e8
+    pn, ne, nprocs, pi, nk = 3, 2, 6, 1, 6
+    cs, topo, geom, P, rng = make_patch(oracle, pn, ne, nprocs, pi, nk=nk, seed=7 * pn + nk)
+    dm = DeviceMesh([topo], [geom], nk=nk, numbering="local")
+    r = np.random.default_rng(29)
+    nEl, n2 = P.nEl, P.n2e
+    dt = 0.5
+    levs = geom.levs
+    W, Q = P.arr("W", (P.mp12, n2)), P.arr("Q", (P.mp12,))
+    inds0 = geom.all_inds0_l()
+    zv = np.zeros((nEl, nk * n2))
+    for e in range(nEl):
+        for k in range(nk):
+            gz = 9.80616 * (levs[k, inds0[e]] + levs[k + 1, inds0[e]])
+            zv[e, k * n2:(k + 1) * n2] = W.T @ (VSCALE * 0.5 * Q * gz)
+    wd = np.diff(P.arr("qx", (P.mp1,)))
+    wj = np.outer(wd, wd).ravel()
+    detm = P.det.mean(axis=1)
+    thm = np.stack([[P.thick[k, inds0[e]].mean() for k in range(nk)] for e in range(nEl)])
+    rho_v, th_v = np.linspace(1.2, 0.5, nk), np.linspace(290.0, 330.0, nk)
+    pi_v = 1004.5 * (287.0 * rho_v * th_v / 1.0e5) ** (287.0 / 717.5)
+    col = lambda v: (v[None, :, None] * wj[None, None, :] * detm[:, None, None] * thm[:, :, None]).reshape(nEl, nk * n2)
+    pert = lambda: 1.0 + 1e-4 * r.standard_normal((nEl, nk * n2))
+    rho, rt, exner = col(rho_v) * pert(), col(rho_v * th_v) * pert(), col(pi_v) * pert()
+    velz = np.zeros((nEl, (nk - 1) * n2))
+    lat = np.ascontiguousarray(P.sq[:, 1][P.elinds("q")])
+    udwdx = 1e-3 * r.standard_normal((nEl, (nk - 1) * n2)) * float(np.abs(zv).mean()) / 9.80616 / 1.5e4
+    arrays = mesh_arrays(dm)
+    arrays.update(dt=np.array([dt]), zv=zv, velz=velz, rho=rho, rt=rt, exner=exner, lat=lat, udwdx=udwdx)
+    fin, fout = str(tmp_path / "vert_in.arr"), str(tmp_path / "vert_out.bin")
+    write_arrays(fin, arrays)
+    out = subprocess.run([_build(str(tmp_path), "test_vert"), fin, fout], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "DONE" in out.stdout
+    res = np.fromfile(fout, dtype=np.float64)
+    pos = [0]
+
+    def take(shape):
+        n = int(np.prod(shape)); a = res[pos[0]:pos[0] + n].reshape(shape); pos[0] += n
+        return a
+    for its, kw in ((3, dict()), (2, dict(hs_forcing=True, udwdx=udwdx))):
+        got = [take(velz.shape), take(rho.shape), take(rt.shape), take(exner.shape)]
+        hist = take((its, 4))
+        want = vert_oracle.solve_schur_eta(P, dt, velz, rho, rt, exner, zv, its, **kw)
+        for a, b, name in zip(got, want[:4], ("velz", "rho", "rt", "exner")):
+            assert np.all(np.isfinite(b)) and rel_l2(a, b) < 1e-10, (name, kw.keys())
+        for hd, ho in zip(hist, want[4]):
+            for j, k in enumerate(("exner", "w", "rho", "eta")):
+                assert abs(hd[j] - ho[k]) <= 1e-5 * ho[k] + 1e-15, (k, hd[j], ho[k])
