@@ -421,6 +421,10 @@ int mimsem_column_newton_update(mimsem_ctx* ctx, const double* d_w, const double
         const double* velz_i, const double* rho_i, const double* rt_i, const double* exner_i,
         double* velz_j, double* rho_j, double* rt_j, double* exner_j,
         double* velz_h, double* rho_h, double* rt_h, double* exner_h, double* norm_squares);
+/* VertSolve::MaxNorm (:228) for the four pairs of mimsem_column_newton_update's norm_squares: out4 (device) = max over the columns of
+ * sqrt(sum d^2 / sum x^2) for (exner, w, rho, eta) -- the rank-local operand of the MPI_Allreduce(MAX) of :1915-1918.  ratio_ws: device
+ * workspace of 4 nEl doubles (the per-column ratios stay there).  Two launches; a NaN ratio wins the maximum. */
+int mimsem_column_max_norms(mimsem_ctx* ctx, const double* norm_squares, double* ratio_ws, double* out4);
 /* diagTheta2 and / or diagTheta_L2 (:289-352) in one launch, optionally blended: out = wa * theta(rho, rt) + wb * blend
  * (the half-time averages theta_h = 0.5 theta_j + 0.5 theta_i of :1896-1912).  theta2 / thetaL: either may be null. */
 int mimsem_column_diag_theta_blend(mimsem_ctx* ctx, const double* rho, const double* rt, double* theta2, const double* blend2,

@@ -100,6 +100,7 @@ _SIGS = {
     "mimsem_column_diag_theta": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]),
     "mimsem_column_newton_residual": (C.c_int, [C.c_void_p, C.c_double, C.c_double] + [c_dp]*22),
     "mimsem_column_newton_update": (C.c_int, [C.c_void_p] + [c_dp]*17),
+    "mimsem_column_max_norms": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp]),
     "mimsem_column_diag_theta_blend": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double]),
     "mimsem_column_solve_schur_eta": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*12),
     "mimsem_column_helmholtz_blocks": (C.c_int, [C.c_void_p, C.c_double] + [c_dp]*5),

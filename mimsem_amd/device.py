@@ -659,6 +659,14 @@ class Engine:
                                                  _ptr(velz_h), _ptr(rho_h), _ptr(rt_h), _ptr(exner_h), _ptr(nrm)), "newton_update")
         return velz_h, rho_h, rt_h, exner_h, nrm
 
+    def max_norms(self, nrm):
+        """mimsem_column_max_norms: VertSolve::MaxNorm for the four pairs of newton_update's norm squares -> device tensor [4] (exner, w, rho, eta)"""
+        assert nrm.shape == (8, self.nEl, self.nk * self.n2e) and nrm.is_contiguous()
+        ws = torch.empty(4, self.nEl, dtype=torch.float64, device=self.device)
+        out = torch.empty(4, dtype=torch.float64, device=self.device)
+        check(self.L.mimsem_column_max_norms(self.ctx, _ptr(nrm), _ptr(ws), _ptr(out)), "column_max_norms")
+        return out
+
     def helmholtz_blocks(self, dt, theta, rho, eta, pi):
         for a, nm in ((theta, "theta"), (rho, "rho"), (eta, "eta"), (pi, "pi")):
             self._col(a, self.nk, nm)

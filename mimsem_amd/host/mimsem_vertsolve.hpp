@@ -3,7 +3,7 @@
 // per iteration mimsem_column_newton_residual (assemble_residual_ec with diagnose_F_z / diagnose_Phi_z, the EOS and entropy residuals:
 // :237-286, :432-502, :1806-1851), mimsem_column_solve_schur_eta (:677-823: the linear solve), mimsem_column_newton_update (:1858-1912) and
 // mimsem_column_diag_theta_blend (diagTheta2 / diagTheta_L2 :289-352 with the half-time blend) -- and the max-norms of VertSolve::MaxNorm
-// (:228) with the reference's stopping test.  All state in the "vertical" layout of L2Vecs::vz: [nEl][slots*n2e], velz on the nk-1
+// (:228: mimsem_column_max_norms) with the reference's stopping test.  All state in the "vertical" layout of L2Vecs::vz: [nEl][slots*n2e], velz on the nk-1
 // interfaces, theta on nk+1, the rest on the nk levels.  Orders 1..3 (the fused entries' range).  Header-only, C++17, no HIP toolchain.
 #pragma once
 #include <algorithm>
@@ -53,7 +53,6 @@ public:
         copy(exner_h, exner, nl); copy(velz_h, velz, ni); copy(rho_h, rho, nl); copy(rt_h, rt, nl);
         history.clear();
         int it = 0;
-        std::vector<double> hs((size_t)8*nEl);
         for (it = 1; it <= maxit; it++) {
             const double *a_rho = nullptr, *a_rt = nullptr;
             if (horiz_forcing) { horiz_forcing(rho, rho_j, theta_l2_h, add_rho, add_rt); a_rho = add_rho; a_rt = add_rt; }
@@ -69,20 +68,11 @@ public:
             check(mimsem_column_newton_update(c, d_w, d_rho, d_eta, d_exner, velz, rho, rt, exner, velz_j, rho_j, rt_j, exner_j,
                                               velz_h, rho_h, rt_h, exner_h, nrm), "newton_update");
             // MaxNorm (:228): per column sqrt(sum d^2 / sum x^2), the maximum over the columns (the rank-local part of the MPI_Allreduce(MAX), :1915-1918)
-            const long long rowlen = (long long)nk*n2;
-            for (long long r0 = 0; r0 < 8LL*nEl; r0 += 32768) {
-                const int rows = (int)std::min<long long>(32768, 8LL*nEl - r0);
-                check(mimsem_krylov_rowdot(c, rows, rowlen, nrm + r0*rowlen, rowlen, ones, 0, sums + r0), "krylov_rowdot");
-            }
+            check(mimsem_column_max_norms(c, nrm, sums, sums + 4*(size_t)nEl), "column_max_norms");
             // (the theta diagnosis does not depend on the norms: launched before the host waits for them)
             check(mimsem_column_diag_theta_blend(c, rho_j, rt_j, theta_h, theta_i, theta_l2_h, theta_l2_i, 0.5, 0.5), "diag_theta_blend");  // :1896-1912
-            mesh->to_host(hs.data(), sums, hs.size());
-            double mx[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < 4; q++)
-                for (int e = 0; e < nEl; e++) {
-                    const double v = std::sqrt(hs[(size_t)(2*q)*nEl + e]/hs[(size_t)(2*q + 1)*nEl + e]);
-                    mx[q] = v > mx[q] || v != v ? v : mx[q];
-                }
+            double mx[4];
+            mesh->to_host(mx, sums + 4*(size_t)nEl, 4);
             history.push_back({mx[0], mx[1], mx[2], mx[3]});
             if (mx[0] < tol && mx[2] < tol) break;
         }

@@ -194,8 +194,11 @@ class VertSolve:
             d_w, d_rho, d_eta, d_exner = eng.solve_schur_eta(dt, th_w3, rho_h, eta, exner_h, F_w, F_rho, F_eta, F_exner)   # :1855
             velz_h, rho_h, rt_h, exner_h, nrm = eng.newton_update(d_w, d_rho, d_eta, d_exner, velz_i, rho_i, rt_i, exner_i,
                                                                   velz_j, rho_j, rt_j, exner_j)
-            cs = nrm.sum(dim=2)                                                     # [8, nEl]: column sums of squares
-            nv = torch.sqrt(cs[0::2] / cs[1::2]).amax(dim=1)                        # MaxNorm :228 for exner, w, rho, eta
+            if hasattr(eng, "max_norms"):
+                nv = eng.max_norms(nrm)                                             # MaxNorm :228 for exner, w, rho, eta (two launches)
+            else:
+                cs = nrm.sum(dim=2)                                                 # [8, nEl]: column sums of squares
+                nv = torch.sqrt(cs[0::2] / cs[1::2]).amax(dim=1)
             nv = eng.allreduce(nv, op="max")                                        # MPI_Allreduce(MAX) :1915-1918
             # (the theta diagnosis does not depend on the norms: launched BEFORE the host waits for them, it runs under the read-back)
             theta_h, theta_l2_h = eng.diag_theta_blend(rho_j, rt_j, blend2=theta_i, blendL=theta_l2_i, wa=0.5, wb=0.5)     # :1896-1912
