@@ -466,6 +466,22 @@ def test_vertical_newton_loop_matches_oracle(setup):
         assert np.all(np.isfinite(b)) and rel_l2(a.cpu().numpy(), b) < TOL, name
 
 
+def test_max_norms_against_the_composed_reduction(setup):
+    """mimsem_column_max_norms (VertSolve::MaxNorm, eul/VertSolve.cpp:228, on the squares newton_update leaves) against the torch composition
+    it replaced; a NaN ratio wins the maximum, as a comparison on the host would see it"""
+    import torch
+    eng, P = setup
+    r = np.random.default_rng(5)
+    nrm = eng.tensor(r.uniform(0.1, 2.0, (8, P.nEl, P.nk * P.n2e)))
+    got = eng.max_norms(nrm).cpu().numpy()
+    cs = nrm.sum(dim=2)
+    want = torch.sqrt(cs[0::2] / cs[1::2]).amax(dim=1).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-13, atol=0.0)
+    nrm[2, P.nEl // 2] = float("nan")
+    got = eng.max_norms(nrm).cpu().numpy()
+    assert np.isnan(got[1]) and np.allclose(got[[0, 2, 3]], want[[0, 2, 3]], rtol=1e-13)
+
+
 @pytest.mark.parametrize("n", [1, 4, 9, 16, 24, 33, 40, 56, 64])
 def test_block_inverse_against_the_oracle_inv(oracle, n):
     """A5 as an entry point (mimsem_block_inverse: the PCBJACOBI blocks and WmatInv / the column inverses run through it): the batched
