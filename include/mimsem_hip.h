@@ -401,7 +401,7 @@ int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
 /* VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) is a Newton loop around solve_schur_column_eta; per iteration and column the
  * reference runs assemble_residual_ec with diagnose_F_z / diagnose_Phi_z (:237-286, :432-502: ~12 VertOps assemblies, ~25 MatMult), the
  * EOS residual, the entropy residual and the entropy variables (:1806-1851), and after the solve the update and the EOS (:1858-1912).
- * The three entry points below do that for EVERY column in four launches (orders 1..3; MIMSEM_ERR_UNSUPPORTED above).  All arrays are
+ * The three entry points below do that for EVERY column in four launches (orders 1..4 since round 4; MIMSEM_ERR_UNSUPPORTED above).  All arrays are
  * "vertical" vectors [nEl][slots*n2e]: velz*, F_w, d_w, add_w on the nk-1 interfaces, theta2 / blend2 on nk+1, the rest on the nk levels.
  *
  * mimsem_column_newton_residual: theta = theta_l2_h, Pi = exner_h (the time-centred fields), velz / rho / rt at times i and j, zv from

@@ -4,7 +4,7 @@
 // :237-286, :432-502, :1806-1851), mimsem_column_solve_schur_eta (:677-823: the linear solve), mimsem_column_newton_update (:1858-1912) and
 // mimsem_column_diag_theta_blend (diagTheta2 / diagTheta_L2 :289-352 with the half-time blend) -- and the max-norms of VertSolve::MaxNorm
 // (:228: mimsem_column_max_norms) with the reference's stopping test.  All state in the "vertical" layout of L2Vecs::vz: [nEl][slots*n2e], velz on the nk-1
-// interfaces, theta on nk+1, the rest on the nk levels.  Orders 1..3 (the fused entries' range).  Header-only, C++17, no HIP toolchain.
+// interfaces, theta on nk+1, the rest on the nk levels.  Orders 1..4 (the fused entries' range).  Header-only, C++17, no HIP toolchain.
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -16,7 +16,7 @@ class VertSolve:
         self.nk, self.n2e = eng.nk, eng.n2e
         self.k2i_z = 0.0
         self._blocks = {}
-        # orders 1..3: residual assembly / update of the Newton loop through the fused entry points (mimsem_column_newton_*: four
+        # orders 1..4: residual assembly / update of the Newton loop through the fused entry points (mimsem_column_newton_*: four
         # launches per iteration instead of ~150 single-operator calls); MIMSEM_NEWTON_FUSED=0 keeps the composed form below
         self.fused = os.environ.get("MIMSEM_NEWTON_FUSED", "1") != "0"
 
@@ -168,7 +168,7 @@ class VertSolve:
         return velz_j, rho_j, rt_j, exner_j
 
     def _solve_schur_eta_fused(self, velz_i, rho_i, rt_i, exner_i, zv, horiz_forcing, udwdx, hs_lat, maxit, tol, verbose):
-        """the same Newton loop on the fused entry points (orders 1..3): per iteration mimsem_column_newton_residual (2 launches),
+        """the same Newton loop on the fused entry points (orders 1..4): per iteration mimsem_column_newton_residual (2 launches),
         mimsem_column_solve_schur_eta (3), mimsem_column_newton_update (1), mimsem_column_diag_theta_blend (1) and one reduction of
         the norm partials; every statement of the composed loop above has its counterpart inside those kernels"""
         eng, dt = self.eng, self.dt
