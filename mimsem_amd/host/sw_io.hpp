@@ -4,6 +4,8 @@
 //   float64: det J thick thickInv fg[n0] u[n1] h[n2] dt  [bot[n2] when the header's last entry is 1]
 #pragma once
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -47,8 +49,6 @@ inline SWCase read_sw_case(const char* path) {
 
 // ---- named arrays on disk (tests/cpp/test_horiz.cpp): "MSEMARR1", int32 count, then per array {int32 name length, name, int32 type
 // (0 = int32, 1 = float64), int64 entries, data}; written by mimsem_amd/workloads.py::write_arrays --------------------------------------
-#include <cstring>
-#include <map>
 namespace mimsem_host {
 struct ArrayFile {
     std::map<std::string, std::vector<int>> i;
