@@ -43,6 +43,9 @@ int main(int argc, char** argv) {
                 for (double v : sw.history) std::printf(" %.6e", v);
                 std::printf("\n");
             }
+            // ... and one step with HALF the time step: the [u|h] operator, its blocks, the spectral regions and the recorded graphs belong to a dt
+            // (SWEqn::solve re-assembles A when dt changes, src/SWEqn_Picard.cpp:732-734) -- the set-up must notice
+            sw.solve(un, hn, 0.5*dt, false, nits, q_exact, bot);
             out[mode][0].resize(n1); out[mode][1].resize(n2);
             mesh.to_host(out[mode][0].data(), un, n1); mesh.to_host(out[mode][1].data(), hn, n2);
             std::printf("mode %d: Chebyshev steps [u|h] %d, M1 %d, q %d; iterations handed to the KSP objects: %d\n", mode, sw.steps_A, sw.steps_M1, sw.steps_q, sw.fallbacks);
