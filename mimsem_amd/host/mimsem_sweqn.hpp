@@ -61,10 +61,15 @@ public:
     SWEqn(Mesh* m, const double* fg_dev) : mesh(m), fg(fg_dev), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
         try {
-            for (double** p : {&ui, &uj, &hu, &F, &fu, &t1, &p1, &upd1, &um}) *p = mesh->device_alloc(n1);
+            for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um}) *p = mesh->device_alloc(n1);
             for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
-            for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &t0, &qi, &qj, &p0, &upd0}) *p = mesh->device_alloc(n0);
-            for (double** p : {&x, &xsave, &res, &bA, &rA, &dA, &dx}) *p = mesh->device_alloc((size_t)N);
+            for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj, &p0}) *p = mesh->device_alloc(n0);
+            for (double** p : {&xsave, &res, &bA, &rA, &dA}) *p = mesh->device_alloc((size_t)N);
+            // the two vectors of a check (last residual | its reference) sit side by side: ONE two-row dot per check instead of two
+            // (the second row starts at an even offset: 16-byte aligned like every other vector here)
+            pair1 = mesh->device_alloc(2*even(n1)); upd1 = pair1; t1 = pair1 + even(n1);
+            pair0 = mesh->device_alloc(2*even(n0)); upd0 = pair0; t0 = pair0 + even(n0);
+            pairx = mesh->device_alloc(2*even(N)); dx = pairx; x = pairx + even(N);
             chk = mesh->device_alloc(2*NSLOT);
             mimsem_ctx* c = mesh->ctx;
             check(mimsem_pvec(c, 0, 1, 1.0, nullptr, 0, m0, 0), "mimsem_pvec");                                   // M0 is diagonal (collocated 0-forms)
@@ -139,8 +144,9 @@ public:
 
 private:
     void release() {
-        for (double** p : {&ui, &uj, &hu, &F, &fu, &t1, &p1, &upd1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &t0, &qi, &qj,
-                           &p0, &upd0, &x, &xsave, &res, &bA, &rA, &dA, &dx, &chk}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj,
+                           &p0, &xsave, &res, &bA, &rA, &dA, &chk, &pair1, &pair0, &pairx}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        t1 = upd1 = t0 = upd0 = x = dx = nullptr;
     }
     static constexpr int NSLOT = 16;
     enum LogKind { K_MASS = 1, K_A = 2, K_PICARD = 3 };
@@ -157,12 +163,14 @@ private:
     double *m0 = nullptr, *m0fg = nullptr, *m0h = nullptr, *dinv = nullptr, *ones0 = nullptr, *rhs0 = nullptr, *t0 = nullptr, *qi = nullptr, *qj = nullptr,
            *p0 = nullptr, *upd0 = nullptr;
     double *x = nullptr, *xsave = nullptr, *res = nullptr, *bA = nullptr, *rA = nullptr, *dA = nullptr, *dx = nullptr, *chk = nullptr;
+    double *pair1 = nullptr, *pair0 = nullptr, *pairx = nullptr;
     const double *blocksA = nullptr, *blocks1 = nullptr, *escale1 = nullptr;
     std::vector<std::pair<double, double>> coefM, qcoef; double thetaA = 1.0, deltaA = 1.0;
     bool inline_fixed = false, can_fix = false;
     int slot = 0; int kinds[NSLOT] = {0}; int kinds_of[2][NSLOT] = {{0}}; int nslots_of[2] = {0, 0};
     const double *q_h = nullptr, *q_u = nullptr; double q_tau = 0.0;
 
+    static size_t even(long long n) { return (size_t)((n + 1) & ~1LL); }
     void combine(long long n, double a, const double* A, int op, const double* B, double b, const double* C, double* out) {
         check(mimsem_vec_combine(mesh->ctx, 1, n, a, A, 0, op, B, 0, b, C, 0, out, 0), "mimsem_vec_combine");
     }
@@ -171,8 +179,11 @@ private:
     void log(int kind, const double* r, const double* ref, long long n) {
         if (slot >= NSLOT) throw std::runtime_error("SWEqn: check-norm slots exhausted");
         kinds[slot] = kind;
-        check(mimsem_krylov_rowdot(mesh->ctx, 1, n, r, n, r, n, chk + 2*slot), "mimsem_krylov_rowdot");
-        check(mimsem_krylov_rowdot(mesh->ctx, 1, n, ref, n, ref, n, chk + 2*slot + 1), "mimsem_krylov_rowdot");
+        if (ref == r + even(n)) check(mimsem_krylov_rowdot(mesh->ctx, 2, n, r, (long long)even(n), r, (long long)even(n), chk + 2*slot), "mimsem_krylov_rowdot");     // (side by side: both norms in one call)
+        else {
+            check(mimsem_krylov_rowdot(mesh->ctx, 1, n, r, n, r, n, chk + 2*slot), "mimsem_krylov_rowdot");
+            check(mimsem_krylov_rowdot(mesh->ctx, 1, n, ref, n, ref, n, chk + 2*slot + 1), "mimsem_krylov_rowdot");
+        }
         slot++;
     }
     static int apply_m0h_up(void* user, int, const double* xin, long long, double* y, long long) {
