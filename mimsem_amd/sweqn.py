@@ -672,6 +672,10 @@ class _PicardGraph:
         l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
         self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol)
         self.its["F"] = self.chM.steps
+        # the two vectors of a check (last preconditioned residual | P b) sit side by side: ONE two-row dot per check instead of two
+        self.pairM = torch.zeros(2, un.shape[1], dtype=torch.float64, device=dev) if un.shape[0] == 1 else None
+        if self.pairM is not None:
+            self.chM.p = torch.zeros_like(un); self.chM.upd = self.pairM[0:1]
         # ---- the upwinded lumped 0-form mass under its diagonal: 1 +- i sigma (the upwinding is a skew perturbation of the identity)
         self.qcoef = None
         if not q_exact:
@@ -688,7 +692,8 @@ class _PicardGraph:
             self.qcoef = chebyshev_ellipse_coefs(d0, a_re * a_re - a_im * a_im, nq)
             self.qtau = tau
             self.qp = torch.zeros(un.shape[0], n0, dtype=torch.float64, device=dev)
-            self.qupd = torch.zeros_like(self.qp)
+            self.pair0 = torch.zeros(2, n0, dtype=torch.float64, device=dev) if un.shape[0] == 1 else None
+            self.qupd = self.pair0[0:1] if self.pair0 is not None else torch.zeros_like(self.qp)
             self.its["q"] = nq
         self.slot = 0
         self.names = {}
@@ -709,9 +714,19 @@ class _PicardGraph:
         eng.rowdot(res.reshape(1, -1), res.reshape(1, -1), out=self.chk[2 * k:2 * k + 1])
         eng.rowdot(ref.reshape(1, -1), ref.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2])
 
+    def _log_pair(self, name, pair):
+        k = self.slot; self.slot += 1
+        assert k < self.NSLOT
+        self.names[k] = name
+        self.S.eng.rowdot(pair, pair, out=self.chk[2 * k:2 * k + 2])
+
     def m1(self, b):
         x = self.chM.solve(b, want_residual=True)
-        self._log("M1", self.chM.upd, self.S.precond_M1(b))
+        if self.pairM is not None and self.chM.upd.data_ptr() == self.pairM.data_ptr():
+            self.S.precond_M1(b, out=self.pairM[1:2])
+            self._log_pair("M1", self.pairM)
+        else:
+            self._log("M1", self.chM.upd, self.S.precond_M1(b))
         return x
 
     def q(self, rhs, m0h, h, u, dt):
@@ -722,7 +737,11 @@ class _PicardGraph:
         last = len(self.qcoef) - 1
         for k, (al, be) in enumerate(self.qcoef):
             eng.chebyshev_sweep("PHMAT_UP", x, rhs, dinv, self.qp, al, be, f=h, u=u, tau=self.qtau, upd=self.qupd if k == last else None)
-        self._log("q", self.qupd, rhs * dinv)
+        if self.pair0 is not None:
+            torch.mul(rhs, dinv, out=self.pair0[1:2])
+            self._log_pair("q", self.pair0)
+        else:
+            self._log("q", self.qupd, rhs * dinv)
         return x
 
     def _q_on_a_branch(self, first, uj, hj):
