@@ -162,7 +162,8 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
 
 
 @pytest.mark.gpu
-def test_vertical_newton_loop_driven_from_cpp(tmp_path, oracle):
+@pytest.mark.parametrize("patch", [(3, 2, 6, 1, 6), (4, 1, 6, 0, 5), (2, 2, 6, 3, 4)], ids=lambda p: "p%d_ne%d_np%d_pi%d_nk%d" % p)
+def test_vertical_newton_loop_driven_from_cpp(tmp_path, oracle, patch):
     """The caller of the column path from C++: VertSolve::solve_schur_eta (eul/VertSolve.cpp:1721-1973) as mimsem_host::VertSolveEta
     (mimsem_amd/host/mimsem_vertsolve.hpp) on the library's fused entry points, against the column-by-column numpy restatement
     oracle/vert_oracle.py -- the patch, state, forcing and tolerances of tests/test_gpu_column.py::test_vertical_newton_loop_matches_oracle"""
@@ -172,7 +173,7 @@ def test_vertical_newton_loop_driven_from_cpp(tmp_path, oracle):
     from oracle import vert_oracle
     from tests.helpers import make_patch, rel_l2
     VSCALE = 1.0e8
-    pn, ne, nprocs, pi, nk = 3, 2, 6, 1, 6
+    pn, ne, nprocs, pi, nk = patch
     cs, topo, geom, P, rng = make_patch(oracle, pn, ne, nprocs, pi, nk=nk, seed=7 * pn + nk)
     dm = DeviceMesh([topo], [geom], nk=nk, numbering="local")
     r = np.random.default_rng(29)
