@@ -46,9 +46,10 @@ def test_ksp_call_sites_match_dense_solves(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("q_exact,nits,dt,topo", [(False, 2, 360.0, False), (True, 4, 600.0, False), (False, 3, 300.0, True)],
-                         ids=["galewsky_style", "williamson2_style", "with_topography"])
-def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo):
+@pytest.mark.parametrize("q_exact,nits,dt,topo,pn", [(False, 2, 360.0, False, 3), (True, 4, 600.0, False, 3), (False, 3, 300.0, True, 3),
+                                                       (False, 2, 360.0, False, 2), (False, 2, 360.0, False, 4)],
+                         ids=["galewsky_style", "williamson2_style", "with_topography", "order_2", "order_4"])
+def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo, pn):
     """SWEqn::solve (src/SWEqn_Picard.cpp:727-791) orchestrated in C++ (mimsem_amd/host/mimsem_sweqn.hpp: KSP objects, fixed-length
     Chebyshev solves, the same as one hipGraph per Picard iteration) on the cubed sphere of tests/test_gpu_sweqn.py, against the numpy
     oracle's step (oracle/sw_oracle.py: dense matrices, LU for every KSPSolve).  Tolerance 1e-9 as for the Python host."""
@@ -60,7 +61,7 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo):
     from mimsem_amd.workloads import write_sw_case
     from oracle import sw_oracle
     from tests.helpers import rel_l2
-    pn, ne, nsteps = 3, 2, 2
+    ne, nsteps = 2, 2
     cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
     topos = [Topo(cs, p, 1) for p in range(6)]
     geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
