@@ -91,8 +91,8 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo, pn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m1", ["chebyshev", "ksp"])
-def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
+@pytest.mark.parametrize("m1,pn", [("chebyshev", 3), ("ksp", 3), ("chebyshev", 2), ("chebyshev", 4)], ids=["chebyshev", "ksp", "order_2", "order_4"])
+def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1, pn):
     """N2 from C++: HorizSolve::advection_rhs_ec / diagnose_Phi / diagnose_q / momentum_rhs_ec (eul/HorizSolve.cpp:380-786) written over the C
     ABI (mimsem_amd/host/mimsem_horizsolve.hpp), all levels per call, against the dense restatement oracle/horiz_oracle.py -- the fields,
     mesh and tolerances of tests/test_gpu_next_rows.py::test_horizsolve_right_hand_sides"""
@@ -103,7 +103,7 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1):
     from mimsem_amd.topo import Topo
     from mimsem_amd.workloads import mesh_arrays, write_arrays, z_levels
     from oracle import horiz_oracle as ho
-    pn, ne, nk = 3, 2, 3
+    ne, nk = 2, 3
     cs = CubedSphere(pn, ne, 6); coords = sphere_coords(pn, ne)
     topos = [Topo(cs, p, nk) for p in range(6)]
     geoms = [Geom(t, cs, coords, nk) for t in topos]
