@@ -173,10 +173,15 @@ public:
             const long long tot = (long long)nk*n1;
             const bool verify = verified < verify_first;
             check(mimsem_memset(c, x, 0, tot*8), "mimsem_memset"); check(mimsem_memset(c, p1, 0, tot*8), "mimsem_memset");
-            for (size_t k = 0; k < coef.size(); k++)
-                check(mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
-                                                   coef[k].first, coef[k].second, p1, n1, x, n1, verify && k + 1 == coef.size() ? upd1 : nullptr, n1),
-                      "mimsem_block_chebyshev_sweep");
+            bool unsupported = false;
+            for (size_t k = 0; k < coef.size() && !unsupported; k++) {
+                const int rc = mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
+                                                            coef[k].first, coef[k].second, p1, n1, x, n1, verify && k + 1 == coef.size() ? upd1 : nullptr, n1);
+                if (k == 0 && rc == MIMSEM_ERR_UNSUPPORTED) unsupported = true;         // (an order the fused sweep does not cover: the CG below)
+                else check(rc, "mimsem_block_chebyshev_sweep");
+            }
+            if (unsupported) fixed_length = false;
+            else {
             last_its = cheb_steps;
             if (!verify) return;
             check(mimsem_elem_blocks_apply(c, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, b, n1, pb1, n1, 1.0), "mimsem_elem_blocks_apply");
@@ -187,6 +192,7 @@ public:
             // (the residual the LAST sweep saw: one more contraction lies between it and the result)
             if (v[1] == 0.0 || std::sqrt(v[0]/v[1]) <= 30.0*rtol) { verified++; return; }
             fixed_length = false;                                   // the interval was too optimistic: the CG from here on
+            }
         }
         check(mimsem_ksp_solve(ksp1, b, n1, x, n1), "mimsem_ksp_solve");
         double rn; int reason;

@@ -91,7 +91,8 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo, pn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m1,pn", [("chebyshev", 3), ("ksp", 3), ("chebyshev", 2), ("chebyshev", 4)], ids=["chebyshev", "ksp", "order_2", "order_4"])
+@pytest.mark.parametrize("m1,pn", [("chebyshev", 3), ("ksp", 3), ("chebyshev", 2), ("chebyshev", 4), ("any", 5)],
+                         ids=["chebyshev", "ksp", "order_2", "order_4", "order_5"])
 def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1, pn):
     """N2 from C++: HorizSolve::advection_rhs_ec / diagnose_Phi / diagnose_q / momentum_rhs_ec (eul/HorizSolve.cpp:380-786) written over the C
     ABI (mimsem_amd/host/mimsem_horizsolve.hpp), all levels per call, against the dense restatement oracle/horiz_oracle.py -- the fields,
@@ -131,7 +132,8 @@ def test_horizsolve_driven_from_cpp(tmp_path, oracle, m1, pn):
     out = subprocess.run([_build(str(tmp_path), "test_horiz"), fin, fout] + (["ksp"] if m1 == "ksp" else []), capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "DONE" in out.stdout
-    assert ("fixed-length Chebyshev" in out.stdout) == (m1 == "chebyshev")
+    if m1 != "any":                                  # (order 5: whichever mass solve the library supports there; the results must agree either way)
+        assert ("fixed-length Chebyshev" in out.stdout) == (m1 == "chebyshev")
     res = np.fromfile(fout, dtype=np.float64)
     pos = [0]
 
