@@ -186,6 +186,12 @@ private:
         }
         slot++;
     }
+    static int pc_block_diagonal(void* user, int, const double* r, long long, double* z, long long) {
+        SWEqn* s = (SWEqn*)user;
+        mimsem_ctx* c = s->mesh->ctx;
+        const int rc = mimsem_elem_blocks_apply(c, 1, 1, 0, s->blocks1, 0, s->escale1, 0, r, 0, z, 0, 1.0);
+        return rc ? rc : mimsem_op_apply(c, MIMSEM_OP_WMATINV, 0, 1, 1.0, 0, nullptr, 0, r + s->n1, 0, z + s->n1, 0, 1.0);
+    }
     static int apply_m0h_up(void* user, int, const double* xin, long long, double* y, long long) {
         SWEqn* s = (SWEqn*)user;
         return mimsem_op_apply_up(s->mesh->ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, s->q_tau, 0, s->q_h, 0, s->q_u, 0, xin, 0, y, 0, 1.0);
@@ -214,6 +220,15 @@ private:
         const double a = ROS_ALPHA*dt;
         kspA.setOperatorsSW(a, grav, H_MEAN, fg); kspA.setPCBJacobi();
         can_fix = false;
+        // the coupled [u|h] element blocks exist for orders 1..4 (mimsem_sw_blocks_apply: one wavefront per element); above that the
+        // preconditioner is block diagonal -- the element blocks of ksp1 on the velocity rows, the exact element-wise inverse of M2 (WmatInv)
+        // on the depth rows -- as a PCSHELL, and the solves stay with the KSP objects
+        try { kspA.pcBlocks(&blocksA); }
+        catch (const std::runtime_error&) {
+            ksp1.pcBlocks(&blocks1, &escale1);
+            kspA.setPCShell(&SWEqn::pc_block_diagonal, this);
+            return;
+        }
         if (!fixed_length) return;
         double lo, hi_, im;
         kspA.ritz(40, &lo, &hi_, &im);

@@ -47,8 +47,8 @@ def test_ksp_call_sites_match_dense_solves(tmp_path, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("q_exact,nits,dt,topo,pn", [(False, 2, 360.0, False, 3), (True, 4, 600.0, False, 3), (False, 3, 300.0, True, 3),
-                                                       (False, 2, 360.0, False, 2), (False, 2, 360.0, False, 4)],
-                         ids=["galewsky_style", "williamson2_style", "with_topography", "order_2", "order_4"])
+                                                       (False, 2, 360.0, False, 2), (False, 2, 360.0, False, 4), (False, 2, 360.0, False, 5)],
+                         ids=["galewsky_style", "williamson2_style", "with_topography", "order_2", "order_4", "order_5"])
 def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo, pn):
     """SWEqn::solve (src/SWEqn_Picard.cpp:727-791) orchestrated in C++ (mimsem_amd/host/mimsem_sweqn.hpp: KSP objects, fixed-length
     Chebyshev solves, the same as one hipGraph per Picard iteration) on the cubed sphere of tests/test_gpu_sweqn.py, against the numpy
