@@ -437,8 +437,8 @@ class SWEqn:
 
     def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
         """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
-        if self.graphs and self.cheb and self.graph_iter and bot is None and self.eng.mesh.n <= 4 and self.coupled_pc and self.fused_sweeps:
-            out = self._solve_graphed(un, hn, dt, nits, q_exact, verbose)
+        if self.graphs and self.cheb and self.graph_iter and self.eng.mesh.n <= 4 and self.coupled_pc and self.fused_sweeps:
+            out = self._solve_graphed(un, hn, dt, nits, q_exact, verbose, bot)
             if out is not None:
                 return out
         ui, hi = un, hn                                                    # (read only: the iterate lives in x)
@@ -510,21 +510,24 @@ class SWEqn:
         self.history = hist
         return uj, hj
 
-    def _solve_graphed(self, un, hn, dt, nits, q_exact, verbose):
+    def _solve_graphed(self, un, hn, dt, nits, q_exact, verbose, bot=None):
         """SWEqn::solve with one hipGraph replay per Picard iteration (_PicardGraph); None when the graphed path is not available or one of
         its fixed-length solves missed its tolerance (the caller then runs the step on the adaptive path from the same start state)"""
         pg = self._pg
-        if pg is None or pg.key != (dt, bool(q_exact), tuple(un.shape)):
+        key = (dt, bool(q_exact), tuple(un.shape), bot is not None)
+        if pg is None or pg.key != key:
             if pg is not None and pg.key[0] == dt and pg.broken:
                 return None
             try:
-                pg = self._pg = _PicardGraph(self, dt, bool(q_exact), un, hn)
+                pg = self._pg = _PicardGraph(self, dt, bool(q_exact), un, hn, has_bot=bot is not None)
             except _NoGraph:
-                self._pg = _PicardGraph.__new__(_PicardGraph); self._pg.key = (dt, bool(q_exact), tuple(un.shape)); self._pg.broken = True
+                self._pg = _PicardGraph.__new__(_PicardGraph); self._pg.key = key; self._pg.broken = True
                 return None
         if pg.broken:
             return None
         pg.ui.copy_(un); pg.hi.copy_(hn)
+        if bot is not None:
+            pg.bot.copy_(bot)                        # (a recording names buffers, not values: the topography the caller passes is copied in)
         pg.x[:, :self.n1].copy_(un); pg.x[:, self.n1:].copy_(hn)
         it, hist = 0, []
         while True:
@@ -641,10 +644,11 @@ class _PicardGraph:
     (also diagnoses q of the start-of-step state; uj = ui) and the later ones."""
     NSLOT = 16
 
-    def __init__(self, S, dt, q_exact, un, hn):
+    def __init__(self, S, dt, q_exact, un, hn, has_bot=False):
         from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds
         self.S, self.dt, self.q_exact = S, dt, q_exact
-        self.key = (dt, q_exact, tuple(un.shape))
+        self.key = (dt, q_exact, tuple(un.shape), has_bot)
+        self.bot = torch.zeros_like(hn) if has_bot else None          # bottom topography (SWEqn::solve's `bot`): a fixed buffer of the recording
         self.broken, self.fails = False, 0
         eng = S.eng
         dev = eng.device
@@ -772,7 +776,7 @@ class _PicardGraph:
         elif first and not self.q_exact:
             self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
         qj = None if self.q_exact else (self.qi if first else (self.qj if self.fork else None))
-        f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, None, qi=None if self.q_exact else self.qi,
+        f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, self.bot, qi=None if self.q_exact else self.qi,
                                 qj=qj, it=0 if first else 1, before_q=join)
         ch = self.chA
         torch.neg(f, out=ch.b)
