@@ -302,6 +302,17 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nle
 int mimsem_sw_operator_precond_chebyshev(mimsem_ctx* ctx, int nlev, double a, double grav, double H, const double* f0, long long f0_stride,
                                          const double* blocks, double ca, double cb, double* x, long long x_stride,
                                          double* r, long long r_stride, double* d, long long d_stride);
+/* The same step in TWO launches (round 5): the 1-form part of a step's update -- the gather pass above -- rides in the element pass of the NEXT
+ * step.  A chain of calls:  step2(pending = 0, ...) ; step2(pending = 1, pca, pcb = the previous call's ca, cb, ...) ; ... ; flush(last ca, cb).
+ * Packed [u | h] rows as above.  The 2-form rows are finished by every call in rh, dh (always the same arrays).  The 1-form rows of r and d are
+ * READ from (r_in, d_in) and, when an update is pending, WRITTEN to (r_out, d_out): two pairs of arrays the caller alternates (the other
+ * elements of an edge slot read the old values in the same launch); without a pending update nothing is written to them and d_in supplies
+ * the direction.  mimsem_sw_chebyshev_flush applies the update the chain still owes at its end, in place on the pair that holds the current
+ * 1-form rows.  Same arithmetic, same order, same bits as mimsem_sw_operator_precond_chebyshev; orders 1..4. */
+int mimsem_sw_chebyshev_step2(mimsem_ctx* ctx, int nlev, double a, double grav, double H, const double* f0, long long f0_stride, const double* blocks,
+                              int pending, double pca, double pcb, double ca, double cb, double* x, long long x_stride,
+                              const double* r_in, const double* d_in, double* r_out, double* d_out, double* rh, double* dh, long long v_stride);
+int mimsem_sw_chebyshev_flush(mimsem_ctx* ctx, int nlev, double ca, double cb, double* x, long long x_stride, double* r, double* d, long long v_stride);
 int mimsem_sw_operator_precond_apply(mimsem_ctx* ctx, int nlev, double a, double grav, double H,
                                      const double* f0, long long f0_stride, const double* blocks,
                                      const double* x, long long x_stride, double* z, long long z_stride);

@@ -70,6 +70,9 @@ _SIGS = {
                                                c_dp, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_precond_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, C.c_double, C.c_double,
                                              c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_sw_chebyshev_step2": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ll]),
+    "mimsem_sw_chebyshev_flush": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_dp, c_ll]),
     "mimsem_sw_operator_precond_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_precond_orthogonalize": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, c_ll, C.c_double, c_dp]),
     "mimsem_krylov_reorthonormalize": (C.c_int, [C.c_void_p, C.c_int, c_ll, c_dp, c_ll, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),

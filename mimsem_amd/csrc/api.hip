@@ -1467,6 +1467,24 @@ int mimsem_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, doub
     return launch_sw_operator_precond_chebyshev(c, nlev, a, grav, H, f0, f0s, blocks, ca, cb, x, xs, r, rs, d, ds);
 }
 
+int mimsem_sw_chebyshev_step2(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s, const double* blocks,
+                              int pending, double pca, double pcb, double ca, double cb, double* x, long long xs,
+                              const double* r_in, const double* d_in, double* r_out, double* d_out, double* rh, double* dh, long long vs) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!f0 || !blocks || !x || !r_in || !d_in || !rh || !dh) return MIMSEM_ERR_ARG;
+    if (pending && (!r_out || !d_out || r_out == r_in || d_out == d_in || r_out == d_in || d_out == r_in)) return MIMSEM_ERR_ARG;   // (the other elements of a slot read the old values in the same launch)
+    const long long n = (long long)c->n1 + c->n2;
+    if (nlev > 1 && (xs < n || vs < n)) return MIMSEM_ERR_ARG;
+    return launch_sw_chebyshev_step2(c, nlev, a, grav, H, f0, f0s, blocks, pending, pca, pcb, ca, cb, x, xs, r_in, d_in, r_out, d_out, rh, dh, vs);
+}
+int mimsem_sw_chebyshev_flush(mimsem_ctx* c, int nlev, double ca, double cb, double* x, long long xs, double* r, double* d, long long vs) {
+    if (!c || nlev < 0) return MIMSEM_ERR_ARG;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!x || !r || !d || x == r || x == d || r == d) return MIMSEM_ERR_ARG;
+    return launch_sw_chebyshev_flush(c, nlev, ca, cb, x, xs, r, d, vs);
+}
+
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
     if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null

@@ -225,6 +225,10 @@ int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H,
 int launch_sw_blocks_apply(mimsem_ctx* c, int nlev, const double* B, const double* x, long long xs, double* y, long long ys);
 int launch_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                                          const double* B, double ca, double cb, double* x, long long xs, double* r, long long rs, double* d, long long ds);
+int launch_sw_chebyshev_step2(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s, const double* B,
+                              int pending, double pca, double pcb, double ca, double cb, double* x, long long xs,
+                              const double* r_in, const double* d_in, double* r_out, double* d_out, double* rh, double* dh, long long vs);
+int launch_sw_chebyshev_flush(mimsem_ctx* c, int nlev, double ca, double cb, double* x, long long xs, double* r, double* d, long long vs);
 int launch_sw_operator_precond(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                                const double* B, const double* x, long long xs, double* z, long long zs,
                                const double** unassembled = nullptr /* nlev == 1: skip the 1-form gather of z, return the element-local results */);

@@ -1031,13 +1031,23 @@ __global__ __launch_bounds__(256) void k_interp_quad(int form, int global, int n
 // The reference forms A with MatMatMult / MatGetRow / MatSetValues and applies it inside KSPSolve.  Every term is element-local
 // up to the 1-form gather (M2, E21 and E12 M2 never leave the element), so ONE element pass evaluates all four blocks: the
 // Krylov iteration that dominates the time step issues 2 launches for A instead of 14.  Work item = (level row, element).
-template <int N>
+// PEND (round 5, mimsem_sw_chebyshev_step2): the 1-form part of the input is not read but FORMED -- the vector update of the previous Chebyshev
+// step (the gather epilogue's  x += d;  r -= P A d;  d = ca d + cb r,  k_gather_epilogue mode 4) is applied here, slot by slot, from the
+// element-local P A d of the previous block pass (`ze`, summed through the gather plan in the gather's order: the same bits).  Every element of
+// a slot computes the new d for itself; the slot's first contributor stores x, r and d -- r and d into the OTHER pair of buffers, because the
+// other elements of the slot read the old values in this same launch.
+struct SwPending {
+    const int* plan; const double* ze; long long zes; double ca, cb;
+    double* x; long long xs; const double* r_in; const double* d_in; double* r_out; double* d_out; long long vs;
+};
+template <int N, bool PEND = false>
 __global__ __launch_bounds__(256) void k_sw_operator(int nEl, int nlev, double a, double ag, double aH,
         const int* __restrict__ i0, const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2,
         const double* __restrict__ J, const double* __restrict__ det, const double* __restrict__ tI,
         const double* __restrict__ E, const double* __restrict__ w,
         const double* __restrict__ f0, long long f0s, const double* __restrict__ u, long long us,
-        const double* __restrict__ h, long long hs, double* __restrict__ ye, long long yes, double* __restrict__ yh, long long yhs) {
+        const double* __restrict__ h, long long hs, double* __restrict__ ye, long long yes, double* __restrict__ yh, long long yhs,
+        SwPending pd = SwPending{}) {
     using D = Dims<N>;
     constexpr int LPE = D::LPE, EPB = D::EPB;
     __shared__ double sE[D::mp1*N];
@@ -1052,8 +1062,28 @@ __global__ __launch_bounds__(256) void k_sw_operator(int nEl, int nlev, double a
     const bool qact = act && q < D::mp12;
     int hslot = -1;
     if (act) {
-        const double* uv = u + (size_t)lev*us;
-        if (q < D::n1e) { s_u[el][q] = uv[i1x[e*D::n1e + q]]; s_u[el][D::n1e + q] = uv[i1y[e*D::n1e + q]]; }
+        if (PEND) {
+            if (q < D::n1e) {
+                const double* src = pd.ze + (size_t)lev*pd.zes;
+#pragma unroll
+                for (int which = 0; which < 2; which++) {
+                    const int slot = which ? i1y[e*D::n1e + q] : i1x[e*D::n1e + q];
+                    const int mine = e*2*D::n1e + which*D::n1e + q;
+                    const int p0 = pd.plan[(size_t)slot*2], p1 = pd.plan[(size_t)slot*2 + 1];
+                    double acc = 0.0;
+                    if (p0 >= 0) acc += src[p0];
+                    if (p1 >= 0) acc += src[p1];
+                    const size_t vo = (size_t)lev*pd.vs + slot;
+                    const double dv = pd.d_in[vo], rv = pd.r_in[vo] - acc;
+                    const double dn = fma(pd.ca, dv, pd.cb*rv);
+                    if (p0 == mine) { pd.x[(size_t)lev*pd.xs + slot] += dv; pd.r_out[vo] = rv; pd.d_out[vo] = dn; }
+                    s_u[el][which*D::n1e + q] = dn;
+                }
+            }
+        } else {
+            const double* uv = u + (size_t)lev*us;
+            if (q < D::n1e) { s_u[el][q] = uv[i1x[e*D::n1e + q]]; s_u[el][D::n1e + q] = uv[i1y[e*D::n1e + q]]; }
+        }
         if (q < D::n2e) { hslot = i2 ? i2[e*D::n2e + q] : e*D::n2e + q; s_h[el][q] = h[(size_t)lev*hs + hslot]; }
     }
     __syncthreads();                 // sE for every wave; the element's own staging needs only the wave-level order
@@ -1769,6 +1799,19 @@ static int sw_operator_n(mimsem_ctx* c, int nlev, double a, double ag, double aH
     return MIMSEM_OK;
 }
 
+template <int N>
+static int sw_operator_pending_n(mimsem_ctx* c, int nlev, double a, double ag, double aH, const double* f0, long long f0s,
+                                 const double* h, long long hs, double* ye, long long yes, double* yh, long long yhs, const SwPending& pd) {
+    using D = Dims<N>;
+    const long long total = (long long)c->nEl*nlev;
+    const unsigned grid = (unsigned)((total + D::EPB - 1)/D::EPB);
+    hipLaunchKernelGGL((k_sw_operator<N, true>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, a, ag, aH,
+                       c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_J, c->d_det, c->d_tI, c->d_E, c->d_w,
+                       f0, f0s, (const double*)nullptr, 0LL, h, hs, ye, yes, yh, yhs, pd);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+
 int launch_sw_operator(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,
                        const double* x, long long xs, double* y, long long ys) {
     const ElemSizes& es = c->es;
@@ -1873,6 +1916,46 @@ int launch_sw_operator_precond_chebyshev(mimsem_ctx* c, int nlev, double a, doub
     if (rc) return rc;
     GatherEpilogue g{4, nullptr, 0, nullptr, 0, nullptr, 0};
     g.alpha = ca; g.beta = cb; g.p = d; g.ps = ds; g.cr = r; g.crs = rs;
+    return launch_gather_epilogue(c, 1, nlev, ye1, per, g, x, xs);
+}
+
+// The same step in TWO launches (round 5, late): the gather epilogue of a step rides in the element pass of the NEXT one (k_sw_operator<N, true>).
+// pending != 0: the update of the previous step (coefficients pca, pcb) is still owed -- this call's element pass applies it, reading the
+// 1-form parts of r and d from (r_in, d_in) and writing them to (r_out, d_out); then the block pass finishes THIS step for the 2-form rows (which
+// live in rh, dh: always the same arrays) and leaves the 1-form part of P A d element-local for the next call or for launch_sw_chebyshev_flush.
+int launch_sw_chebyshev_step2(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s, const double* B,
+                              int pending, double pca, double pcb, double ca, double cb, double* x, long long xs,
+                              const double* r_in, const double* d_in, double* r_out, double* d_out, double* rh, double* dh, long long vs) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    if (es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
+    const long long per = (long long)c->nEl*2*es.n1e, nrow = (long long)c->n1 + c->n2;
+    int rc = c->ensure_ye(2*per*nlev + nrow*nlev);
+    if (rc) return rc;
+    double* ye0 = c->d_ye; double* ye1 = c->d_ye + per*nlev; double* yt = c->d_ye + 2*per*nlev;
+    const double ag = a*grav, aH = a*H;
+    const long long n1 = c->n1;
+    SwPending pd{c->d_g1, ye1, per, pca, pcb, x, xs, r_in, d_in, r_out, d_out, vs};
+    switch (es.n) {
+#define MIMSEM_SWC2(N) case N: rc = pending ? sw_operator_pending_n<N>(c, nlev, a, ag, aH, f0, f0s, dh + n1, vs, ye0, per, yt + n1, nrow, pd) \
+                                            : sw_operator_n<N>(c, nlev, a, ag, aH, f0, f0s, d_in, vs, dh + n1, vs, ye0, per, yt + n1, nrow); \
+                       if (!rc) rc = sw_blocks_n<N>(c, nlev, B, yt, nrow, ye1, per, x, xs, ye0, per, ca, cb, rh, vs, dh, vs); break;
+    MIMSEM_SWC2(1) MIMSEM_SWC2(2) MIMSEM_SWC2(3) MIMSEM_SWC2(4)
+#undef MIMSEM_SWC2
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+// the update a chain of launch_sw_chebyshev_step2 calls still owes at its end: the gather epilogue alone, in place on (r, d)
+int launch_sw_chebyshev_flush(mimsem_ctx* c, int nlev, double ca, double cb, double* x, long long xs, double* r, double* d, long long vs) {
+    const ElemSizes& es = c->es;
+    if ((long long)c->nEl*nlev == 0) return MIMSEM_OK;
+    if (es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
+    const long long per = (long long)c->nEl*2*es.n1e;
+    if (!c->d_ye) return MIMSEM_ERR_STATE;
+    double* ye1 = c->d_ye + per*nlev;
+    GatherEpilogue g{4, nullptr, 0, nullptr, 0, nullptr, 0};
+    g.alpha = ca; g.beta = cb; g.p = d; g.ps = vs; g.cr = r; g.crs = vs;
     return launch_gather_epilogue(c, 1, nlev, ye1, per, g, x, xs);
 }
 

@@ -13,6 +13,7 @@
 #pragma once
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 #include "mimsem_shim.hpp"
 
@@ -52,6 +53,8 @@ public:
     double rtol = 1.0e-14;               // tolerance of every nested solve (relative, preconditioned residual)
     bool fixed_length = true;            // Chebyshev solves of fixed length (false: the KSP objects, as the reference)
     bool use_graph = true;               // ... recorded as one hipGraph per Picard iteration kind
+    bool two_launch_steps = false;       // the [u|h] Chebyshev step in two launches (mimsem_sw_chebyshev_step2) instead of three: correct, and no
+                                         // faster -- 445.6 against 450.8-453.0 steps/s (profiles/r05_sw_cpp_ab.txt): the element pass grows by what the epilogue cost
     std::vector<double> history;         // |dx| / |x| of the iterations of the last solve()
     int fallbacks = 0;                   // Picard iterations the fixed mode handed to the krylov mode
     int steps_A = 0, steps_M1 = 0, steps_q = 0;
@@ -60,11 +63,12 @@ public:
     // fg: the Coriolis 0-form (SWEqn::coriolis, src/SWEqn_Picard.cpp:95-140), device, n0 entries; it must outlive the object
     SWEqn(Mesh* m, const double* fg_dev) : mesh(m), fg(fg_dev), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
+        if (const char* e = std::getenv("MIMSEM_SW_STEP2")) two_launch_steps = std::atoi(e) != 0;      // (A/B: scripts/ab_sw_cpp.sh)
         try {
             for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um}) *p = mesh->device_alloc(n1);
             for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
             for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj, &p0}) *p = mesh->device_alloc(n0);
-            for (double** p : {&xsave, &res, &bA, &rA, &dA}) *p = mesh->device_alloc((size_t)N);
+            for (double** p : {&xsave, &res, &bA, &rA, &dA, &rB, &dB}) *p = mesh->device_alloc((size_t)N);
             // the two vectors of a check (last residual | its reference) sit side by side: ONE two-row dot per check instead of two
             // (the second row starts at an even offset: 16-byte aligned like every other vector here)
             pair1 = mesh->device_alloc(2*even(n1)); upd1 = pair1; t1 = pair1 + even(n1);
@@ -145,7 +149,7 @@ public:
 private:
     void release() {
         for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj,
-                           &p0, &xsave, &res, &bA, &rA, &dA, &chk, &pair1, &pair0, &pairx}) { if (*p) mimsem_free(*p); *p = nullptr; }
+                           &p0, &xsave, &res, &bA, &rA, &dA, &rB, &dB, &chk, &pair1, &pair0, &pairx}) { if (*p) mimsem_free(*p); *p = nullptr; }
         t1 = upd1 = t0 = upd0 = x = dx = nullptr;
     }
     static constexpr int NSLOT = 16;
@@ -163,7 +167,7 @@ private:
     double *m0 = nullptr, *m0fg = nullptr, *m0h = nullptr, *dinv = nullptr, *ones0 = nullptr, *rhs0 = nullptr, *t0 = nullptr, *qi = nullptr, *qj = nullptr,
            *p0 = nullptr, *upd0 = nullptr;
     double *x = nullptr, *xsave = nullptr, *res = nullptr, *bA = nullptr, *rA = nullptr, *dA = nullptr, *dx = nullptr, *chk = nullptr;
-    double *pair1 = nullptr, *pair0 = nullptr, *pairx = nullptr;
+    double *pair1 = nullptr, *pair0 = nullptr, *pairx = nullptr, *rB = nullptr, *dB = nullptr;
     const double *blocksA = nullptr, *blocks1 = nullptr, *escale1 = nullptr;
     std::vector<std::pair<double, double>> coefM, qcoef; double thetaA = 1.0, deltaA = 1.0;
     bool inline_fixed = false, can_fix = false;
@@ -297,6 +301,19 @@ private:
             zero(N, dx);
             combine(N, 1.0/thetaA, rA, 0, nullptr, 0.0, nullptr, dA);
             double rho = 1.0/sigma1;
+            if (two_launch_steps) {
+                // the 1-form part of a step's update rides in the element pass of the next step: r and d alternate between two pairs of arrays
+                double *rin = rA, *din = dA, *rout = rB, *dout = dB, pca = 0.0, pcb = 0.0;
+                for (int k = 0; k < steps_A; k++) {
+                    const double rho_new = 1.0/(2.0*sigma1 - rho), ca = rho_new*rho, cb = 2.0*rho_new/deltaA;
+                    check(mimsem_sw_chebyshev_step2(c, 1, a, grav, H_MEAN, fg, 0, blocksA, k > 0, pca, pcb, ca, cb, dx, 0, rin, din, rout, dout, rA, dA, 0),
+                          "mimsem_sw_chebyshev_step2");
+                    if (k > 0) { std::swap(rin, rout); std::swap(din, dout); }
+                    pca = ca; pcb = cb; rho = rho_new;
+                }
+                check(mimsem_sw_chebyshev_flush(c, 1, pca, pcb, dx, 0, rin, din, 0), "mimsem_sw_chebyshev_flush");
+                if (rin != rA) copy(n1, rin, rA);                     // (the norm below is taken over the packed residual)
+            } else
             for (int k = 0; k < steps_A; k++) {
                 const double rho_new = 1.0/(2.0*sigma1 - rho);
                 check(mimsem_sw_operator_precond_chebyshev(c, 1, a, grav, H_MEAN, fg, 0, blocksA, rho_new*rho, 2.0*rho_new/deltaA, dx, 0, rA, 0, dA, 0),

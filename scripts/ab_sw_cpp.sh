@@ -1,10 +1,13 @@
 #!/bin/bash
-# C++-hosted shallow-water step (mimsem_amd/host/sw_call) on the config-3 sphere: the legacy default stream against a stream of the context's own
+# C++-hosted shallow-water step (mimsem_amd/host/sw_call) on the config-3 sphere: A/B of host-side switches
+#   MIMSEM_SW_DEFAULT_STREAM=1   the context on the legacy default stream (graph recorded on a blocking stream) against a stream of its own
+#   MIMSEM_SW_STEP2=1            the [u|h] Chebyshev step in two launches (the gather epilogue in the next element pass) against three
 set -e
 cd "$(dirname "$0")/.."
 python scripts/exp/write_sw_case3.py gpurun_out/sw_case3.bin 200
 for i in 1 2; do
-echo "default stream:"; MIMSEM_SW_DEFAULT_STREAM=1 ./mimsem_amd/host/sw_call gpurun_out/sw_case3.bin 5
-echo "own stream:"; ./mimsem_amd/host/sw_call gpurun_out/sw_case3.bin 5
+for v in "DEFAULT=1" "MIMSEM_SW_STEP2=1" "MIMSEM_SW_DEFAULT_STREAM=1"; do
+echo "$v:"; env $v ./mimsem_amd/host/sw_call gpurun_out/sw_case3.bin 5 | cut -c1-215
+done
 done
 rm -f gpurun_out/sw_case3.bin
