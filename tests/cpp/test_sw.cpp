@@ -22,7 +22,7 @@ static double rel_l2(const std::vector<double>& a, const std::vector<double>& b)
 int main(int argc, char** argv) {
     if (argc < 3) { std::fprintf(stderr, "usage: test_sw in.bin out.bin\n"); return 2; }
     int fails = 0;
-    std::vector<double> out[3][2];
+    std::vector<double> out[4][2];
     int n1 = 0, n2 = 0;
     try {
         const SWCase cs = read_sw_case(argv[1]);
@@ -32,9 +32,9 @@ int main(int argc, char** argv) {
         n1 = cs.n1; n2 = cs.n2;
         Mesh mesh(d);
         double* dfg = mesh.to_device(fg.data(), n0);
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 4; mode++) {              // 0: KSP objects; 1: fixed-length solves, eager; 2: recorded; 3: recorded, the [u|h] step in two launches
             src::SWEqn sw(&mesh, dfg);
-            sw.fixed_length = mode > 0; sw.use_graph = mode == 2;
+            sw.fixed_length = mode > 0; sw.use_graph = mode >= 2; sw.two_launch_steps = mode == 3;
             double *un = mesh.to_device(u0.data(), n1), *hn = mesh.to_device(h0.data(), n2);
             double* bot = cs.bot.empty() ? nullptr : mesh.to_device(cs.bot.data(), n2);          // bottom topography (src/SWEqn_Picard.cpp:727 `bot`)
             for (int s = 0; s < nsteps; s++) {
@@ -54,14 +54,16 @@ int main(int argc, char** argv) {
         }
         mimsem_free(dfg);
     } catch (const std::exception& e) { std::printf("FAIL: %s\n", e.what()); return 1; }
-    for (int mode = 1; mode < 3; mode++) {
+    for (int mode = 1; mode < 4; mode++) {
         const double eu = rel_l2(out[mode][0], out[0][0]), eh = rel_l2(out[mode][1], out[0][1]);
         std::printf("mode %d vs KSP mode: u %.3e  h %.3e\n", mode, eu, eh);
         if (!(eu < 1e-11 && eh < 1e-11)) fails++;
     }
+    // the two-launch step does the three-launch step's arithmetic in the same order: the same bits
+    if (out[3][0] != out[2][0] || out[3][1] != out[2][1]) { std::printf("FAIL: two-launch and three-launch steps differ\n"); fails++; }
     FILE* g = std::fopen(argv[2], "wb");
     if (!g) { std::perror(argv[2]); return 2; }
-    for (int mode = 0; mode < 3; mode++) { std::fwrite(out[mode][0].data(), 8, n1, g); std::fwrite(out[mode][1].data(), 8, n2, g); }
+    for (int mode = 0; mode < 4; mode++) { std::fwrite(out[mode][0].data(), 8, n1, g); std::fwrite(out[mode][1].data(), 8, n2, g); }
     std::fclose(g);
     std::printf(fails ? "FAILED (%d)\n" : "ALL OK\n", fails);
     return fails ? 1 : 0;

@@ -85,8 +85,8 @@ def test_sw_step_driven_from_cpp(tmp_path, oracle, q_exact, nits, dt, topo, pn):
     for _ in range(nsteps):
         ur, hr = O.solve(ur, hr, dt, nits=nits, q_exact=q_exact, bot=bot)
     ur, hr = O.solve(ur, hr, 0.5 * dt, nits=nits, q_exact=q_exact, bot=bot)       # (the C++ test ends with a step at half the time step)
-    res = np.fromfile(fout, dtype=np.float64).reshape(3, dm.n1 + dm.n2)
-    for mode in range(3):
+    res = np.fromfile(fout, dtype=np.float64).reshape(4, dm.n1 + dm.n2)
+    for mode in range(4):
         assert rel_l2(res[mode, :dm.n1], ur) < 1e-9 and rel_l2(res[mode, dm.n1:], hr) < 1e-9, mode
 
 
