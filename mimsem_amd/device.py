@@ -762,6 +762,10 @@ class Engine:
         check(self.L.mimsem_krylov_rowdot(self.ctx, A.shape[0], A.shape[1], _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out)), "rowdot")
         return out
 
+    def rowdot_local(self, A, B, out=None, space=None):
+        """the rank's part of rowdot (one rank: all of it); DistEngine weights by ownership and leaves the all-reduce to the caller"""
+        return self.rowdot(A, B, out=out)
+
     def cg_update(self, num, den, p, Ap, x, r):
         """x += (num/den) p ; r -= (num/den) Ap  row-wise, in place"""
         check(self.L.mimsem_krylov_cg_update(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(p), p.stride(0),

@@ -88,7 +88,7 @@ class DistEngine:
         (mimsem_op_apply_part + mimsem_halo_begin/_end), and every other completion (complete(), incidence, blocks) goes through the
         C ABI's plans too; transport: "dist" (host callback over the process group), an RcclComm / ncclComm_t, or "auto" = an RcclComm
         of its own when the process group runs on RCCL, else "dist"."""
-        self.eng, self.world, self.rank = eng, world, rank
+        self.eng, self.world, self.rank, self.sphere = eng, world, rank, sphere
         dm = eng.mesh
         if plans is None:
             plans = build_plans(sphere, world, rank, dm.gid0, dm.gid1)
@@ -264,6 +264,73 @@ class DistEngine:
         w = self._weight(A.shape[1])
         r = self.eng.rowdot(A * w, B, out=out)
         return self.allreduce(r)
+
+    def rowdot_local(self, A, B, out=None, space=None):
+        """this rank's ownership-weighted part of rowdot, NOT reduced: the fixed-length solves log their check norms with it and the caller
+        all-reduces the whole log once (SWEqn: once per Picard iteration)"""
+        w = self._spaces[space] if space is not None else self._weight(A.shape[1])
+        return self.eng.rowdot(A * w, B, out=out)
+
+    def weights(self, space):
+        return self._spaces[space]
+
+    def randn_global(self, space, seed, cpu_generator=False):
+        """this rank's entries of the standard-normal vector a single context over the whole mesh draws for `space` (0, 1, 2 or "uh") from
+        `seed` -- set-up helper of the spectral estimates: all ranks, and the one-context run, then build the same Krylov space"""
+        cs, dm = self.sphere, self.eng.mesh
+        ng = {0: cs.nDofs0G, 1: cs.nDofs1G, 2: cs.nDofs2G}
+        gid = {0: dm.gid0, 1: dm.gid1, 2: dm.gid2}
+        forms = (1, 2) if space == "uh" else (space,)
+        n = sum(ng[f] for f in forms)
+        dev = self.eng.device
+        if cpu_generator:
+            g = torch.Generator(device="cpu"); g.manual_seed(seed)
+            v = torch.randn((1, n), generator=g, dtype=torch.float64).to(dev)[0]
+        else:
+            g = torch.Generator(device=dev); g.manual_seed(seed)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+        idx, off = [], 0
+        for f in forms:
+            idx.append(torch.as_tensor(gid[f], device=dev).long() + off); off += ng[f]
+        return v[torch.cat(idx)].reshape(1, -1)
+
+    # ---- the fused solver steps of Engine with the halo inside (same signatures): what a fixed-length Chebyshev iteration needs per step is the
+    #      operator's and the preconditioner's 1-form (0-form) results completed -- exchanges, no inner product, no all-reduce -------------------
+    def sw_operator_precond_chebyshev(self, a, grav, H, f0, blocks, ca, cb, x, r, d):
+        """x += d; r -= P A d; d = ca d + cb r on the packed [u|h] rows: element pass + gather, EXCHANGE (edges), block pass + gather, EXCHANGE,
+        one update launch -- 5 launches and 2 symmetric edge exchanges per step (one context: 3 launches, mimsem_sw_operator_precond_chebyshev)"""
+        n1 = self.eng.sizes[1]
+        y = self.eng.sw_operator(a, grav, H, f0, d)
+        self.complete(1, y[:, :n1])
+        z = self.eng.sw_blocks_apply(blocks, y)
+        self.complete(1, z[:, :n1])
+        self.eng.chebyshev_update(ca, cb, z, x, r, d)
+
+    def block_chebyshev_sweep(self, op, blocks, x, b, p, alpha, beta, f=None, elem_scale=None, lev0=0, scale=1.0, flags=0, upd=None):
+        """z = P (b - Op x); p = z + beta p; x += alpha p with both element-local sums completed over the halo (the operator pass split into
+        boundary / interior groups around its exchange where the plan allows); blocks column-major per element as for Engine's sweep"""
+        y = self.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags)
+        torch.sub(b, y, out=y)
+        z = self.blocks_apply(1, blocks, y, transpose=True, elem_scale=elem_scale)       # (column-major storage = the transposed read)
+        self.eng.combine(z, 1.0, None, None, beta, p, out=p)
+        x.add_(p, alpha=alpha)
+        if upd is not None:
+            upd.copy_(z)
+        return x
+
+    def chebyshev_sweep(self, op, x, b, dinv, p, alpha, beta, f=None, u=None, tau=0.0, lev0=0, scale=1.0, flags=0, upd=None):
+        """z = dinv (b - Op x); p = z + beta p; x += alpha p; Op's result completed over the halo (nodes: REVERSE/ADD + FORWARD/INSERT)"""
+        if u is not None:
+            y = self.apply_up(op, x, f, u, lev0=lev0, scale=scale, tau=tau, flags=flags)
+        else:
+            y = self.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags)
+        torch.sub(b, y, out=y)
+        y.mul_(dinv)
+        self.eng.combine(y, 1.0, None, None, beta, p, out=p)
+        x.add_(p, alpha=alpha)
+        if upd is not None:
+            upd.copy_(y)
+        return x
 
     def mdot(self, V, w, k=None, out=None):
         h = self.eng.mdot(V, (w * self._weight(w.numel())).contiguous(), k=k, out=out)

@@ -636,18 +636,32 @@ class GraphedRichardson:
         return None
 
 
-def arnoldi_ritz(body, n, m, device, seed=1):
-    """Ritz values of B = P A from m Arnoldi steps on a random start vector (set-up time: host algebra on the small Hessenberg)"""
+def arnoldi_ritz(body, n, m, device, seed=1, eng=None, space=None):
+    """Ritz values of B = P A from m Arnoldi steps on a random start vector (set-up time: host algebra on the small Hessenberg).
+    eng + space (sharded meshes, DistEngine): the start vector is the rank's part of the GLOBAL random vector a single context would draw
+    (same seed, same generator -> the same Krylov space), inner products are ownership-weighted and all-reduced -- every rank arrives at
+    the same Hessenberg matrix, hence at the same spectral interval and the same fixed step counts."""
     import numpy as np
-    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    dist = eng is not None and hasattr(eng, "halo")
+    if dist:
+        v = eng.randn_global(space, seed).reshape(-1)
+        wgt = eng.weights(space)
+        dots = lambda Vj, w: eng.allreduce((Vj * wgt) @ w)
+        nrm = lambda w: float(torch.sqrt(eng.allreduce(((w * wgt) @ w).reshape(1)))[0])
+        assert v.numel() == n
+    else:
+        gen = torch.Generator(device=device); gen.manual_seed(seed)
+        v = torch.randn(n, dtype=torch.float64, device=device, generator=gen)
+        dots = lambda Vj, w: Vj @ w
+        nrm = lambda w: float(torch.linalg.vector_norm(w))
     V = torch.zeros(m + 1, n, dtype=torch.float64, device=device); H = np.zeros((m + 1, m))
-    v = torch.randn(n, dtype=torch.float64, device=device, generator=gen); V[0] = v / torch.linalg.vector_norm(v)
+    V[0] = v / nrm(v)
     k = m
     for j in range(m):
         w = body(V[j:j + 1].contiguous()).reshape(-1)
         for _ in range(2):
-            hh = V[:j + 1] @ w; w = w - hh @ V[:j + 1]; H[:j + 1, j] += hh.cpu().numpy()
-        H[j + 1, j] = float(torch.linalg.vector_norm(w))
+            hh = dots(V[:j + 1], w); w = w - hh @ V[:j + 1]; H[:j + 1, j] += hh.cpu().numpy()
+        H[j + 1, j] = nrm(w)
         if H[j + 1, j] < 1e-14 * abs(H[0, 0]):
             k = j + 1
             break
@@ -683,11 +697,13 @@ class GraphedChebyshev:
     host round trip -- against eight launches and a synchronisation per Arnoldi step of the GMRES it replaces.  solve() returns None when
     the recurrence residual misses the tolerance (the caller falls back to its Krylov solver from the iterate reached)."""
 
-    def __init__(self, eng, shape, body, precond, lmin, lmax, rtol=1e-14, margin=(0.9, 1.05), dtype=torch.float64, step=None):
+    def __init__(self, eng, shape, body, precond, lmin, lmax, rtol=1e-14, margin=(0.9, 1.05), dtype=torch.float64, step=None, space="uh"):
         """step(ca, cb, x, r, d) (optional): the whole step x += d; r -= B d; d = ca d + cb r as ONE fused engine call (the shallow-water
-        operator has one: mimsem_sw_operator_precond_chebyshev, three launches) instead of body(d) + the update kernel (four)"""
+        operator has one: mimsem_sw_operator_precond_chebyshev, three launches) instead of body(d) + the update kernel (four).
+        space: the vector space of the two check norms (a DistEngine weights them by ownership; they stay LOCAL partial sums -- _run() holds no
+        all-reduce, the caller reduces its whole check vector once)"""
         import math
-        self.eng, self.body, self.precond, self.step = eng, body, precond, step
+        self.eng, self.body, self.precond, self.step, self.space = eng, body, precond, step, space
         self.lmin, self.lmax = margin[0] * lmin, margin[1] * lmax
         self.theta, self.delta = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
         kap = self.lmax / self.lmin
@@ -710,7 +726,7 @@ class GraphedChebyshev:
         self.r.copy_(c)
         self.x.zero_()
         torch.mul(c, 1.0 / self.theta, out=self.d)
-        self.eng.rowdot(c.reshape(1, -1), c.reshape(1, -1), out=self.nrm[1:2])
+        self.eng.rowdot_local(c.reshape(1, -1), c.reshape(1, -1), out=self.nrm[1:2], space=self.space)
         for _ in range(self.steps):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
             if self.step is not None:
@@ -719,15 +735,20 @@ class GraphedChebyshev:
                 Bd = self.body(self.d)
                 self.eng.chebyshev_update(rho_new * rho, 2.0 * rho_new / self.delta, Bd, self.x, self.r, self.d)     # x += d; r -= B d; d = rho' rho d + (2 rho'/delta) r
             rho = rho_new
-        self.eng.rowdot(self.r.reshape(1, -1), self.r.reshape(1, -1), out=self.nrm[0:1])
+        self.eng.rowdot_local(self.r.reshape(1, -1), self.r.reshape(1, -1), out=self.nrm[0:1], space=self.space)
 
     def solve(self, b):
-        if self.graph is None or self.graph_steps != self.steps:
+        if hasattr(self.eng, "halo"):                      # sharded: the same launches eagerly (the exchanges are not recorded), ONE all-reduce of the two norms
             self.b.copy_(b)
-            self.graph, _ = self.eng.capture(self._run)
-            self.graph_steps = self.steps
-        self.b.copy_(b)
-        self.graph.replay()
+            self._run()
+            self.eng.allreduce(self.nrm)
+        else:
+            if self.graph is None or self.graph_steps != self.steps:
+                self.b.copy_(b)
+                self.graph, _ = self.eng.capture(self._run)
+                self.graph_steps = self.steps
+            self.b.copy_(b)
+            self.graph.replay()
         r2, c2 = self.nrm.tolist()
         if c2 == 0.0:
             return self.x.clone(), self.steps, 0.0
@@ -740,13 +761,14 @@ class GraphedChebyshev:
         return self.x.clone(), self.steps, rel
 
 
-def lanczos_bounds(apply_A, precond, b, its=25):
+def lanczos_bounds(apply_A, precond, b, its=25, dot=None):
     """Extreme eigenvalues of P A (A SPD, P SPD) for every row system of b, from the Lanczos tridiagonal that `its` steps of
     preconditioned CG generate (T_kk = 1/a_k + b_{k-1}/a_{k-1}, T_{k,k+1} = sqrt(b_k)/a_k): Ritz values converge to the ends of
     the spectrum first.  Returns (lmin, lmax) over all rows.  Setup-time helper (host synchronisation per step)."""
     import numpy as np
     x = torch.zeros_like(b); r = b.clone(); z = precond(r); p = z.clone()
-    dot = lambda u, v: torch.linalg.vecdot(u, v, dim=1)
+    if dot is None:                                          # (sharded meshes pass the ownership-weighted, all-reduced row dot)
+        dot = lambda u, v: torch.linalg.vecdot(u, v, dim=1)
     rz = dot(r, z)
     al, be = [], []
     for _ in range(its):
@@ -781,10 +803,10 @@ class ChebyshevMass:
     no inner products, no host synchronisation, 3 launches per step against 10 per PCG iteration, and the whole solve can sit
     inside a captured hipGraph.  The norm of the last preconditioned residual is available for a check (`last`)."""
 
-    def __init__(self, eng, sweep, lmin, lmax, rtol=1e-14):
+    def __init__(self, eng, sweep, lmin, lmax, rtol=1e-14, margin=(0.90, 1.05)):
         """sweep(x, b, p, alpha, beta, upd): one fused step (closure over op, blocks, elem_scale, lev0, scale, flags)"""
         self.eng, self.sweep = eng, sweep
-        self.lmin, self.lmax = 0.90 * lmin, 1.05 * lmax
+        self.lmin, self.lmax = margin[0] * lmin, margin[1] * lmax
         kappa = self.lmax / self.lmin
         sg = (math.sqrt(kappa) - 1.0) / (math.sqrt(kappa) + 1.0)
         self.set_steps(max(2, int(math.ceil(math.log(2.0 / rtol) / math.log(1.0 / sg)))))

@@ -38,7 +38,16 @@ class SWEqn:
         self.coriolis()
         self.A_dt = None
         self.its = {}
-        self.graphs = use_graphs and not hasattr(eng, "halo")       # the hipGraph Arnoldi step is single-rank (no collectives inside)
+        self.dist = hasattr(eng, "halo")                             # a DistEngine: this rank's patches + the halo plans
+        self.graphs = use_graphs and not self.dist                  # hipGraph recording is single-rank (the exchanges are not recorded)
+        # ... but the FIXED-LENGTH solves are exactly what a sharded run wants (round 6): a Chebyshev step needs its operator and
+        # preconditioner results completed over the halo and NOTHING else -- no inner product, hence no all-reduce inside any solve; the check
+        # norms of a whole Picard iteration are ownership-weighted partial sums reduced ONCE (_PicardGraph.replay)
+        self.fixed = use_graphs
+        self.recalibrations = 0             # times the spectral regions were estimated again after a missed check (self-healing)
+        self.fixed_iterations = 0           # Picard iterations taken in the fixed-length mode / on the adaptive (Krylov) path
+        self.adaptive_iterations = 0
+        self._misses = 0
         self._gA = None
         self._pcA = None
         self._gq = None
@@ -437,7 +446,7 @@ class SWEqn:
 
     def solve(self, un, hn, dt, nits=99, q_exact=False, bot=None, verbose=False, restart=60):
         """:727-791: Picard iterations x += A^-1 (-f(x)) until |dx|/|x| < 1e-14 or nits"""
-        if self.graphs and self.cheb and self.graph_iter and self.eng.mesh.n <= 4 and self.coupled_pc and self.fused_sweeps:
+        if self.fixed and self.cheb and self.graph_iter and self.eng.mesh.n <= 4 and self.coupled_pc and self.fused_sweeps:
             out = self._solve_graphed(un, hn, dt, nits, q_exact, verbose, bot)
             if out is not None:
                 return out
@@ -508,23 +517,41 @@ class SWEqn:
                 break
         self.step += 1
         self.history = hist
+        self.adaptive_iterations += len(hist)
         return uj, hj
 
+    MAX_MISSES = 3
+
     def _solve_graphed(self, un, hn, dt, nits, q_exact, verbose, bot=None):
-        """SWEqn::solve with one hipGraph replay per Picard iteration (_PicardGraph); None when the graphed path is not available or one of
-        its fixed-length solves missed its tolerance (the caller then runs the step on the adaptive path from the same start state)"""
-        pg = self._pg
+        """SWEqn::solve with one hipGraph replay per Picard iteration (_PicardGraph; sharded: the same launches eagerly with the halo exchanges in
+        between and one all-reduce of the check norms).  SELF-HEALING (round 6): the spectral regions the fixed step counts rest on were
+        estimated on the state of some earlier step (the upwinded q system follows the flow); when a check misses, they are estimated again
+        from the CURRENT start-of-step state, the iteration is recorded again and the step retried once; only the step whose retry fails too
+        runs on the adaptive path (None is returned), and only after MAX_MISSES such steps in a row does the object stay adaptive."""
         key = (dt, bool(q_exact), tuple(un.shape), bot is not None)
-        if pg is None or pg.key != key:
-            if pg is not None and pg.key[0] == dt and pg.broken:
+        for attempt in (0, 1):
+            pg = self._pg
+            if pg is None or pg.key != key:
+                try:
+                    pg = self._pg = _PicardGraph(self, dt, bool(q_exact), un, hn, has_bot=bot is not None, widen=1.0 + 0.5 * min(self._misses + attempt, 4))
+                except _NoGraph:
+                    self._pg = _PicardGraph.__new__(_PicardGraph); self._pg.key = key; self._pg.broken = True
+                    return None
+            if pg.broken:
                 return None
-            try:
-                pg = self._pg = _PicardGraph(self, dt, bool(q_exact), un, hn, has_bot=bot is not None)
-            except _NoGraph:
-                self._pg = _PicardGraph.__new__(_PicardGraph); self._pg.key = key; self._pg.broken = True
-                return None
-        if pg.broken:
-            return None
+            out = self._run_fixed(pg, un, hn, nits, verbose, bot)
+            if out is not None:
+                self._misses = 0
+                return out
+            if attempt == 0:
+                self.recalibrations += 1
+                self._pg = None                      # (estimated again from (un, hn) at the top of the loop)
+        self._misses += 1
+        if self._misses >= self.MAX_MISSES:
+            pg.broken = True
+        return None
+
+    def _run_fixed(self, pg, un, hn, nits, verbose, bot):
         pg.ui.copy_(un); pg.hi.copy_(hn)
         if bot is not None:
             pg.bot.copy_(bot)                        # (a recording names buffers, not values: the topography the caller passes is copied in)
@@ -535,18 +562,18 @@ class SWEqn:
             ok, norm = pg.verify(vals, first=(it == 0))
             if not ok:
                 pg.fails += 1
-                if pg.fails >= 2:
-                    pg.broken = True
+                self.last_miss = pg.last_miss
                 return None
             hist.append(norm)
             if verbose:
-                print("iteration: %d\t|dx|/|x|: %.6e  (graphed)" % (it, norm))
+                print("iteration: %d\t|dx|/|x|: %.6e  (fixed length)" % (it, norm))
             it += 1
             if not (norm > 1.0e-14 and it < nits):
                 break
         self.its.update(pg.its)
         self.step += 1
         self.history = hist
+        self.fixed_iterations += len(hist)
         return pg.x[:, :self.n1].clone(), pg.x[:, self.n1:].clone()
 
     # ---- conservation diagnostics (int0 :1202-1238, int2 :1240-1274, intE :1276-1323, writeConservation :1325-1359) ------------
@@ -643,10 +670,14 @@ class _PicardGraph:
     vector ONCE, checks every solve against its tolerance and takes |dx| / |x| for the Picard loop.  Two graphs: the first iteration of a step
     (also diagnoses q of the start-of-step state; uj = ui) and the later ones."""
     NSLOT = 16
+    SPACE = {"M1": 1, "q": 0, "A": "uh", "picard": "uh"}          # the vector space of each check (a DistEngine weights the norms by ownership)
 
-    def __init__(self, S, dt, q_exact, un, hn, has_bot=False):
+    def __init__(self, S, dt, q_exact, un, hn, has_bot=False, widen=1.0):
+        """widen >= 1: the safety margins around the estimated spectral regions, times widen (a re-estimate after a missed check asks for more)"""
         from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds
         self.S, self.dt, self.q_exact = S, dt, q_exact
+        self.dist = S.dist                   # sharded: eager launches with the exchanges in between, local check norms, one all-reduce (replay)
+        self.last_miss = None
         self.key = (dt, q_exact, tuple(un.shape), has_bot)
         self.bot = torch.zeros_like(hn) if has_bot else None          # bottom topography (SWEqn::solve's `bot`): a fixed buffer of the recording
         self.broken, self.fails = False, 0
@@ -660,21 +691,33 @@ class _PicardGraph:
         self.graphs = {}
         self.its = {}
         # ---- [u|h]: real interval of P A
+        if S._pcA is None or S._pcA[0] != dt:
+            S._pcA = (dt, S._coupled_element_blocks(dt))
         body1 = S._krylov_body1(dt)
-        ev = arnoldi_ritz(body1, n1 + n2, 40, dev)
+        ev = arnoldi_ritz(body1, n1 + n2, 40, dev, eng=eng, space="uh")
         lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
         if not (lmin > 0.02 and imax <= 0.15 * (lmax - lmin)):
             raise _NoGraph()
+        self.regions = {"A": (lmin, lmax, imax)}
         blocks = S._pcA[1]
+        # (a DistEngine has the same call: element pass, exchange, block pass, exchange, update)
         step = lambda ca, cb, x, r, d: eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, S.grav, H_MEAN, S.fg, blocks, ca, cb, x, r, d)
-        self.chA = GraphedChebyshev(eng, (un.shape[0], n1 + n2), body1, lambda r: S.precond_A(r, dt), lmin, lmax, rtol=S.rtol, step=step)
+        self.chA = GraphedChebyshev(eng, (un.shape[0], n1 + n2), body1, lambda r: S.precond_A(r, dt), lmin, lmax, rtol=S.rtol, step=step,
+                                    margin=(1.0 - 0.1 * min(widen, 4.0), 1.0 + 0.05 * widen), space="uh")
         self.its["A"] = self.chA.steps
         # ---- M1: real interval of P M1
         cm = S.m1_pre.transpose(1, 2).contiguous()
-        g = torch.Generator(device="cpu"); g.manual_seed(4321)
-        rb = torch.randn(un.shape, generator=g, dtype=torch.float64).to(dev)
-        l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
-        self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol)
+        if self.dist:
+            rb = eng.randn_global(1, 4321, cpu_generator=True).expand(un.shape[0], -1).contiguous()
+            w1 = eng.weights(1)
+            l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25, dot=lambda a, b: eng.allreduce(torch.linalg.vecdot(a * w1, b, dim=1)))
+        else:
+            g = torch.Generator(device="cpu"); g.manual_seed(4321)
+            rb = torch.randn(un.shape, generator=g, dtype=torch.float64).to(dev)
+            l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
+        self.regions["M1"] = (l1, l2)
+        self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol,
+                                 margin=(1.0 - 0.1 * min(widen, 4.0), 1.0 + 0.05 * widen))
         self.its["F"] = self.chM.steps
         # the two vectors of a check (last preconditioned residual | P b) sit side by side: ONE two-row dot per check instead of two
         self.pairM = torch.zeros(2, un.shape[1], dtype=torch.float64, device=dev) if un.shape[0] == 1 else None
@@ -685,10 +728,11 @@ class _PicardGraph:
         if not q_exact:
             m0h = eng.pvec(0, 1, 1.0, h2=hn)
             tau = 1.0 / (1.0 / (UP_TAU * dt))
-            evq = arnoldi_ritz(lambda v: eng.apply_up("PHMAT_UP", v, hn, un, fac=UP_TAU, dt=dt) / m0h, n0, 40, dev)
+            evq = arnoldi_ritz(lambda v: eng.apply_up("PHMAT_UP", v, hn, un, fac=UP_TAU, dt=dt) / m0h, n0, 40, dev, eng=eng, space=0)
             d0 = 0.5 * float(evq.real.max() + evq.real.min())
-            a_re = 0.5 * float(evq.real.max() - evq.real.min()) * 1.5 + 0.01
-            a_im = float(abs(evq.imag).max()) * 1.2 + 0.01
+            a_re = 0.5 * float(evq.real.max() - evq.real.min()) * 1.5 * widen + 0.01
+            a_im = float(abs(evq.imag).max()) * 1.2 * widen + 0.01
+            self.regions["q"] = (d0, a_re, a_im)
             rate = chebyshev_ellipse_rate(d0, a_re, a_im)
             if not (d0 > 0.2 and rate < 0.6):
                 raise _NoGraph()
@@ -702,7 +746,7 @@ class _PicardGraph:
         self.slot = 0
         self.names = {}
         # MIMSEM_SW_FORK=1: the q solve as a parallel branch of the recorded iteration (second stream + second context of the same mesh)
-        self.fork = (not q_exact) and os.environ.get("MIMSEM_SW_FORK", "0") == "1"
+        self.fork = (not q_exact) and not self.dist and os.environ.get("MIMSEM_SW_FORK", "0") == "1"
         if self.fork:
             from .device import Engine
             self.eng_q = Engine(eng.mesh, device=eng.device.index or 0)
@@ -715,14 +759,15 @@ class _PicardGraph:
         assert k < self.NSLOT
         self.names[k] = name
         eng = self.S.eng
-        eng.rowdot(res.reshape(1, -1), res.reshape(1, -1), out=self.chk[2 * k:2 * k + 1])
-        eng.rowdot(ref.reshape(1, -1), ref.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2])
+        sp = self.SPACE[name]
+        eng.rowdot_local(res.reshape(1, -1), res.reshape(1, -1), out=self.chk[2 * k:2 * k + 1], space=sp)
+        eng.rowdot_local(ref.reshape(1, -1), ref.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2], space=sp)
 
     def _log_pair(self, name, pair):
         k = self.slot; self.slot += 1
         assert k < self.NSLOT
         self.names[k] = name
-        self.S.eng.rowdot(pair, pair, out=self.chk[2 * k:2 * k + 2])
+        self.S.eng.rowdot_local(pair, pair, out=self.chk[2 * k:2 * k + 2], space=self.SPACE[name])
 
     def m1(self, b):
         x = self.chM.solve(b, want_residual=True)
@@ -787,12 +832,23 @@ class _PicardGraph:
         self.x.add_(ch.x)
         k = self.slot; self.slot += 1
         self.names[k] = "picard"
-        S.eng.rowdot(ch.x.reshape(1, -1), ch.x.reshape(1, -1), out=self.chk[2 * k:2 * k + 1])
-        S.eng.rowdot(self.x.reshape(1, -1), self.x.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2])
+        S.eng.rowdot_local(ch.x.reshape(1, -1), ch.x.reshape(1, -1), out=self.chk[2 * k:2 * k + 1], space="uh")
+        S.eng.rowdot_local(self.x.reshape(1, -1), self.x.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2], space="uh")
         self.nslots = self.slot
 
     def replay(self, first):
         S = self.S
+        if self.dist:
+            # the same sequence of launches, eagerly, with the halo exchanges where the element-local sums need completing; every check norm is a
+            # local (ownership-weighted) partial sum: ONE all-reduce of 2 x nslots doubles per Picard iteration, none inside any solve
+            S._inline = self
+            try:
+                self._body(first)
+            finally:
+                S._inline = None
+            self.graphs[first] = (None, dict(self.names), self.nslots)
+            S.eng.allreduce(self.chk)
+            return self.chk.tolist()
         if first not in self.graphs:
             keep = self.x.clone()
             S._inline = self
@@ -820,6 +876,7 @@ class _PicardGraph:
             rel = (res2 / ref2) ** 0.5 if ref2 > 0.0 else 0.0
             if not (rel <= tol):
                 ok = False
+                self.last_miss = (names[k], rel, tol)
         return ok, norm
 
 
