@@ -585,7 +585,7 @@ def sw_extras(local_rank, torch):
     from mimsem_amd.sweqn import SWEqn, galewsky, williamson2
     from mimsem_amd.topo import Topo
     res = {}
-    for name, ne, dt, nits, q_exact, nsteps in (("config2_w2_16x16x6", 16, 600.0, 99, True, 3), ("config3_galewsky_24x24x6", 24, 360.0, 2, False, 5)):
+    for name, ne, dt, nits, q_exact, nsteps in (("config2_w2_16x16x6", 16, 600.0, 99, True, 10), ("config3_galewsky_24x24x6", 24, 360.0, 2, False, 240)):
         cs = CubedSphere(PN, ne, 6); coords = sphere_coords(PN, ne)
         topos = [Topo(cs, p, 1) for p in range(6)]
         geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
@@ -616,7 +616,8 @@ def sw_extras(local_rank, torch):
         if is_w2:
             wq = 2.0 * 38.61068276698372 / 6371220.0 * torch.sin(S.lat)
             errs = {"vorticity": S.err0(S.curl(u), wq), "velocity": S.err1(u, uq), "depth": S.err2(h, hq)}
-        res[name] = {"steps_per_s": nsteps / el, "ms_per_step": 1e3 * el / nsteps, "dt": dt, "picard_iterations_per_step": picard / nsteps,
+        res[name] = {"steps_per_s": nsteps / el, "ms_per_step": 1e3 * el / nsteps, "steps_timed": nsteps, "dt": dt, "picard_iterations_per_step": picard / nsteps,
+                     "fixed_length_iterations": S.fixed_iterations, "adaptive_iterations": S.adaptive_iterations, "recalibrations": S.recalibrations,
                      "relative_drift_over_timed_steps": {k: (c1[k] - c0[k]) / abs(c0[k]) for k in ("mass", "energy", "enstrophy")},
                      "williamson2_error_norms_L1_L2_Linf": errs, "days": (nsteps + 3) * dt / 86400.0,
                      "krylov_iterations_last": dict(S.its), "elements": dm.nEl, "dofs": dm.n1 + dm.n2}
@@ -900,10 +901,11 @@ def compact_record(out, extras_file=None):
             "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall")),
             "cpp_host_per_level_call_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_us_per_call")),
             "cpp_host_per_level_call_in_graph_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_in_a_graph_us_per_call"))}
-    for k in ("weak_scaled", "column_sharded", "horiz_sharded"):
+    for k in ("weak_scaled", "column_sharded", "horiz_sharded", "sw_sharded"):
         v = out.get(k)
         if isinstance(v, dict):
-            summ[k] = {kk: _r(v[kk]) for kk in ("value", "ms_per_step", "schur_column_solves_per_s", "ms_per_evaluation", "error") if kk in v}
+            summ[k] = {kk: _r(v[kk]) for kk in ("value", "ms_per_step", "schur_column_solves_per_s", "ms_per_evaluation", "steps_per_s", "fixed_length_iterations",
+                                                "adaptive_iterations", "error") if kk in v}
     rec["summary"] = {k: v for k, v in summ.items() if v is not None}
     errs = [k for k, v in out.items() if isinstance(v, dict) and "error" in v]
     if errs:
@@ -1417,11 +1419,14 @@ def main():
                     "ms_per_evaluation": 1e3 * tt.item(), "evaluations_per_s": 1.0 / tt.item(), "elements_per_rank": dm.nEl}
         if not a.no_horiz_sharded:
             extra("horiz_sharded", horiz_sharded)
-    if a.sw and world > 1:
-        # the SW step on the ranks' shards (config 3: 24x24x6 sphere over N GPUs, halo over xGMI); latency-bound at this size
+    if world > 1 and not a.no_sw:
+        # the SW step on the ranks' shards (config 3 as the reference driver runs it: the Galewsky jet on the 24x24x6 sphere, dt = 360 s, 2 Picard
+        # iterations, upwinded q) in the FIXED-LENGTH mode over the halo (round 6): Chebyshev solves with the exchanges inside, no all-reduce in any
+        # solve, one all-reduce of the check norms per Picard iteration.  93 312 unknowns over N GPUs: latency-bound by construction (~145
+        # kB-sized exchanges per Picard iteration) -- the number says what xGMI point-to-point latency costs, not what the kernels do
         def sw_sharded():
             from mimsem_amd.distributed import DistEngine
-            from mimsem_amd.sweqn import SWEqn, williamson2
+            from mimsem_amd.sweqn import SWEqn, galewsky
             t1s = [Topo(cs, p, 1) for p in pids]
             g1s = [Geom(t, cs, coords, 1, signed_det=True) for t in t1s]
             for g in g1s:
@@ -1431,16 +1436,29 @@ def main():
             xqs = np.zeros((int(max(g.loc0.max() for g in g1s)) + 1, 3))
             for g in g1s:
                 xqs[g.loc0] = coords[g.loc0]
-            S = SWEqn(DistEngine(engs, cs, world, rank), xqs[dms.gidq])
-            uq, hq = williamson2(torch.as_tensor(xqs[dms.gidq], device=engs.device), alpha=0.0)
+            # the same transport as the headline's exchange: the C ABI's plans on the rank's RCCL communicator (host-staged callback in the rehearsal)
+            des = DistEngine(engs, cs, world, rank, overlap=True, transport=deng.rccl if deng.transport == "rccl" else "dist")
+            S = SWEqn(des, xqs[dms.gidq])
+            uq, hq = galewsky(torch.as_tensor(xqs[dms.gidq], device=engs.device))
             us, hs_ = S.init1(uq), S.init2(hq)
-            us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
-            fence(); t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(2):
                 us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
-            fence(); els = (time.perf_counter() - t1) / 3
-            return {"workload": "SWEqn::solve, Galewsky-style (2 Picard iterations), 24x24x6 sphere sharded over the ranks",
-                    "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "krylov_iterations_last": dict(S.its)}
+            nst = 5 if rehearsal else 20
+            f0, a0 = S.fixed_iterations, S.adaptive_iterations
+            fence(); t1 = time.perf_counter()
+            for _ in range(nst):
+                us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
+            fence(); els = (time.perf_counter() - t1) / nst
+            tt = torch.tensor([els], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            els = tt.item()
+            st = dict(S.its)
+            ex_iter = 2 * st.get("A", 0) + 2 * st.get("F", 0) + 2 * st.get("q", 0)
+            return {"workload": "SWEqn::solve, config 3 (Galewsky jet, dt = 360 s, 2 Picard iterations, upwinded q), 24x24x6 sphere sharded over the ranks, "
+                                "fixed-length Chebyshev solves over the halo (transport %s)" % getattr(des, "transport", "dist"),
+                    "steps_per_s": 1.0 / els, "ms_per_step": 1e3 * els, "steps_timed": nst, "chebyshev_steps": st,
+                    "fixed_length_iterations": S.fixed_iterations - f0, "adaptive_iterations": S.adaptive_iterations - a0, "recalibrations": S.recalibrations,
+                    "all_reduces_per_picard_iteration": 1, "exchanges_in_solves_per_picard_iteration_approx": ex_iter}
         extra("sw_sharded", sw_sharded)
     if rank == 0 and world == 1 and not a.no_pmc and "roofline" in out:
         # roofline.traffic: HBM-side bytes per launch of the dominant kernel from PMC counters collected in THIS run (child rocprofv3

@@ -396,6 +396,85 @@ def test_galewsky_quarter_day_conserves():
     assert bool(torch.isfinite(un).all()) and 70.0 < float(un[..., 0].max()) < 90.0 and float(un[..., 1].abs().max()) < 10.0
 
 
+def test_galewsky_six_days_stay_in_the_fixed_length_mode():
+    """config 3 over a third of the reference driver's run (src/Galewsky.cpp:83-152 integrates 4 800 steps = 20 days; the jet rolls up after
+    day 4): 1 440 steps = 6 days, ~4 s.  The fixed-length mode (Chebyshev solves of known length, one graph replay per Picard iteration) must
+    carry >= 99 % of the Picard iterations -- a missed check re-estimates the spectral regions and retries, it does not drop the run onto the
+    adaptive path for good --, mass to 1e-12, energy / potential enstrophy drifts of the size the reference's writeConservation prints, the
+    instability developed (meridional wind of tens of m/s where the balanced jet has none), nothing blown up."""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.sweqn import SWEqn, galewsky
+    from mimsem_amd.topo import Topo
+    cs = CubedSphere(PN, NE, 6); coords = sphere_coords(PN, NE)
+    topos = [Topo(cs, p, 1) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+    for g in geoms:
+        g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+    dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+    eng = Engine(dm)
+    xq = np.zeros((dm.nq, 3))
+    for g in geoms:
+        xq[g.loc0] = coords[g.loc0]
+    S = SWEqn(eng, xq[dm.gidq])
+    uq, hq = galewsky(torch.as_tensor(xq[dm.gidq], device=eng.device))
+    u, h = S.init1(uq), S.init2(hq)
+    c0 = S.conservation(u, h)
+    nsteps = 1440
+    for _ in range(nsteps):
+        u, h = S.solve(u, h, 360.0, nits=2, q_exact=False)
+    c1 = S.conservation(u, h)
+    total = S.fixed_iterations + S.adaptive_iterations
+    print("Galewsky day 6: fixed-length %d of %d Picard iterations, %d re-estimates; drifts mass %.1e energy %.1e enstrophy %.1e" %
+          (S.fixed_iterations, total, S.recalibrations, *[(c1[k] - c0[k]) / abs(c0[k]) for k in ("mass", "energy", "enstrophy")]))
+    assert total == 2 * nsteps and S.fixed_iterations >= 0.99 * total, (S.fixed_iterations, S.adaptive_iterations, S.recalibrations)
+    assert not S._pg.broken
+    assert abs(c1["mass"] - c0["mass"]) < 1e-12 * abs(c0["mass"])
+    assert abs(c1["energy"] - c0["energy"]) < 2e-6 * abs(c0["energy"])
+    assert abs(c1["enstrophy"] - c0["enstrophy"]) < 6e-2 * abs(c0["enstrophy"])
+    un = eng.interp_quad(1, u)[0]
+    assert bool(torch.isfinite(un).all()) and bool(torch.isfinite(h).all())
+    assert 70.0 < float(un[..., 0].max()) < 110.0 and 20.0 < float(un[..., 1].abs().max()) < 90.0          # rolled up, not blown up
+
+
+def test_fixed_length_mode_heals_itself_after_a_missed_check():
+    """a spectral region that no longer holds (here: sabotaged -- the q ellipse shrunk so that its Chebyshev iteration is far too short) makes a
+    check miss; the step must come back CORRECT through one re-estimate + retry in the fixed-length mode, not through the adaptive path, and the
+    object must stay in the fixed-length mode afterwards"""
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.sweqn import SWEqn, galewsky
+    from mimsem_amd.topo import Topo
+    ne = 8
+    cs = CubedSphere(PN, ne, 6); coords = sphere_coords(PN, ne)
+    topos = [Topo(cs, p, 1) for p in range(6)]
+    geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+    for g in geoms:
+        g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+    dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+    eng = Engine(dm)
+    xq = np.zeros((dm.nq, 3))
+    for g in geoms:
+        xq[g.loc0] = coords[g.loc0]
+    uq, hq = galewsky(torch.as_tensor(xq[dm.gidq], device=eng.device))
+    S = SWEqn(eng, xq[dm.gidq])
+    u0, h0 = S.init1(uq), S.init2(hq)
+    u1, h1 = S.solve(u0, h0, 360.0, nits=2, q_exact=False)                 # healthy step: the reference result
+    assert S.fixed_iterations == 2 and S.recalibrations == 0
+    pg = S._pg
+    pg.qcoef = pg.qcoef[:3]; pg.graphs.clear()                             # sabotage: 3 Chebyshev steps where ~20 are needed
+    u2, h2 = S.solve(u0, h0, 360.0, nits=2, q_exact=False)
+    assert S.recalibrations == 1 and S.adaptive_iterations == 0 and S.fixed_iterations == 4, (S.recalibrations, S.adaptive_iterations, S.fixed_iterations)
+    assert S.last_miss[0] == "q"
+    assert rel_l2(u2.cpu().numpy(), u1.cpu().numpy()) < 1e-12 and rel_l2(h2.cpu().numpy(), h1.cpu().numpy()) < 1e-13
+    u3, h3 = S.solve(u2, h2, 360.0, nits=2, q_exact=False)
+    assert S.recalibrations == 1 and S.fixed_iterations == 6 and not S._pg.broken
+
+
 def test_config5_periodic_box_p4_full_size():
     """config 5 grid: p=4, 32x32 elements, 64 levels, doubly periodic box (1024 columns of 16x16 blocks): area known answer,
     symmetry, batched-level equality, and the residual of the column Schur solve"""
