@@ -404,6 +404,11 @@ int mimsem_column_solve_status(mimsem_ctx* ctx, int* n_unconverged, int* column_
  * concurrently, any number of them.  Orders 1..4, up to 1 024 unknowns per column (nk n2e); beyond that columns are left as they are.
  * on == 2: EVERY column goes through the pivoted LU (validation mode: the reference's algorithm for all columns, at its price). */
 int mimsem_column_set_pivot_fallback(mimsem_ctx* ctx, int on);
+/* Test infrastructure of the fallback's work distribution (replaces nothing in the reference): the NEXT column solve of this context treats
+ * the n listed columns (host array, 0 <= column < nEl) as flagged by its block sweep -- status 1, counted -- whatever their refinement said,
+ * so that a test can put more columns in front of the fallback's wavefronts than rough data ever flags (tests/test_gpu_fullsize.py).
+ * One-shot: the list is consumed by that solve.  n == 0 clears a pending list.                                                        */
+int mimsem_column_flag_for_test(mimsem_ctx* ctx, const int* columns, int n);
 /* the assembled block-tridiagonal L_pi itself: out [nEl][nk][3][n2e][n2e] (sub, diag, super)       */
 int mimsem_column_helmholtz_blocks(mimsem_ctx* ctx, double dt,
         const double* theta, const double* rho, const double* eta, const double* pi, double* out);

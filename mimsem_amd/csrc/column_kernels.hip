@@ -2665,6 +2665,19 @@ int mimsem_selftest_rows_half(mimsem_ctx* c, int ntask, const double* A, const d
     return MIMSEM_OK;
 }
 
+int mimsem_column_flag_for_test(mimsem_ctx* c, const int* columns, int n) {
+    if (!c || n < 0 || (n && !columns)) return MIMSEM_ERR_ARG;
+    for (int i = 0; i < n; i++) if (columns[i] < 0 || columns[i] >= c->nEl) return MIMSEM_ERR_ARG;
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (columns[i] == columns[j]) return MIMSEM_ERR_ARG;      // (a column listed twice would be counted twice)
+    MIMSEM_HIP_TRY(hipSetDevice(c->device));
+    if (c->d_forceflag) { MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_forceflag); c->d_forceflag = nullptr; }
+    c->n_forceflag = 0;
+    if (n == 0) return MIMSEM_OK;
+    MIMSEM_HIP_TRY(hipMalloc((void**)&c->d_forceflag, (size_t)n*sizeof(int)));
+    MIMSEM_HIP_TRY(hipMemcpy(c->d_forceflag, columns, (size_t)n*sizeof(int), hipMemcpyHostToDevice));
+    c->n_forceflag = n;
+    return MIMSEM_OK;
+}
 int mimsem_column_set_pivot_fallback(mimsem_ctx* c, int on) {
     if (!c) return MIMSEM_ERR_ARG;
     c->pivot_fallback = on == 2 ? 2 : (on ? 1 : 0);

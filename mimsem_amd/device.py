@@ -696,6 +696,11 @@ class Engine:
         check(self.L.mimsem_column_solve_status(self.ctx, C.byref(n), st.ctypes.data, ratio.ctypes.data), "column_solve_status")
         return n.value, st[:self.nEl], ratio[:self.nEl]
 
+    def flag_columns_for_test(self, columns):
+        """test hook: the next column solve treats these columns as flagged by its block sweep (mimsem_column_flag_for_test)"""
+        cols = np.ascontiguousarray(columns, dtype=np.int32)
+        check(self.L.mimsem_column_flag_for_test(self.ctx, cols.ctypes.data, int(cols.size)), "column_flag_for_test")
+
     def set_pivot_fallback(self, on=True):
         """(on by default) solve_schur_eta / solve_schur_3 re-solve the columns their unpivoted sweep flags by an LU with partial pivoting over
         the band (what the reference's PCLU does for every column); verified re-solves report status 3; 0 switches it off --

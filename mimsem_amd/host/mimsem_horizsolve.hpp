@@ -21,9 +21,14 @@ public:
     // The ksp1 solves as a Chebyshev semi-iteration of FIXED length on the fused block sweep (mimsem_block_chebyshev_sweep): the spectrum of
     // P M1 belongs to the mesh and its layer thicknesses, so its interval is estimated once (mimsem_ksp_ritz on the object PCSetUp built) and
     // the step count for `rtol` follows -- no inner product, no host round trip: a whole right-hand-side evaluation can be recorded in a
-    // Graph.  The first `verify_first` solves compare the last preconditioned residual with |P b| on the host (a miss falls back to the CG
-    // for good); use_fixed_length(false) keeps the CG of the reference's structure.
-    int verify_first = 3; int cheb_steps = 0; bool fixed_length = false;
+    // Graph.  EVERY solve is checked (round 6; the reference monitors every KSPSolve, round 5 checked the first three only and a later, rougher
+    // right-hand side could have lost accuracy unseen): the first sweep's update is P b, the last sweep's the preconditioned residual it saw --
+    // both norms go into a slot of a small device log with ONE two-row dot (recordable in a Graph, no host round trip); verify() reads the
+    // log once -- per right-hand-side evaluation or per time step, the caller's choice, at least every MAXLOG solves -- and on a miss turns
+    // the fixed-length mode off (the CG of the reference's structure from then on; the caller redoes the evaluation).
+    // levels_changed() after mimsem_ctx_set_levels: PCSetUp and the interval again.  use_fixed_length(false) keeps the CG.
+    static constexpr int MAXLOG = 32;
+    int cheb_steps = 0; bool fixed_length = false; int solves_checked = 0, solves_missed = 0; double worst_rel = 0.0;
 
     // fg: the Coriolis 0-form per level (HorizSolve::coriolis :124-161), device [nk][n0]; nDofs0G: the GLOBAL node count (viscosity() :112-120)
     HorizSolve(Mesh* m, const double* fg_dev, long long nDofs0G = 0, bool visc = true) : mesh(m), fg(fg_dev) {
@@ -31,7 +36,11 @@ public:
         const double dx = std::sqrt(4.0*M_PI*RAD_EARTH*RAD_EARTH/(double)(nDofs0G > 0 ? nDofs0G : n0));
         del2 = -std::sqrt(0.072*std::pow(dx, 3.2));
         try {
-            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1, &upd1, &pb1}) *p = mesh->device_alloc((size_t)nk*n1);
+            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1}) *p = mesh->device_alloc((size_t)nk*n1);
+            // the two vectors of a check side by side (the second row at an even offset): one two-row dot per solve
+            pair1 = mesh->device_alloc(2*even((long long)nk*n1)); upd1 = pair1; pb1 = pair1 + even((long long)nk*n1);
+            chk = mesh->device_alloc(2*MAXLOG);
+            check(mimsem_memset(mesh->ctx, chk, 0, 2*MAXLOG*8), "mimsem_memset");
             for (double** p : {&a2, &b2, &c2}) *p = mesh->device_alloc((size_t)nk*n2);
             for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
             scal = mesh->device_alloc(4);
@@ -45,7 +54,7 @@ public:
         } catch (...) { release(); throw; }                  // (a constructor that throws runs no destructor)
     }
     void use_fixed_length(bool on) {
-        fixed_length = false;
+        fixed_length = false; wanted_fixed = on;
         if (!on) return;
         double lo, hi, im;
         check(mimsem_ksp_ritz(ksp1, 25, &lo, &hi, &im), "mimsem_ksp_ritz");
@@ -56,7 +65,35 @@ public:
         double al = 1.0/d;
         coef.emplace_back(al, 0.0);
         for (int k = 1; k < cheb_steps; k++) { const double be = (k == 1 ? 0.5 : 0.25)*c2*al*al; al = 1.0/(d - be/al); coef.emplace_back(al, be); }
-        verified = 0; fixed_length = true;
+        slot = 0; fixed_length = true;
+    }
+    void shorten_for_test(int steps) { if ((int)coef.size() > steps) { coef.resize(steps); cheb_steps = steps; } }      // (tests: a solve that must miss its check)
+    // after mimsem_ctx_set_levels (new layer thicknesses): the element blocks and the per-(level, element) factors of the preconditioner and
+    // the spectral interval belong to the old ones
+    void levels_changed() {
+        check(mimsem_ksp_set_pc_bjacobi(ksp1), "mimsem_ksp_set_pc_bjacobi");
+        const bool was = fixed_length || wanted_fixed;
+        use_fixed_length(was);
+    }
+    // the checks of every fixed-length solve since the last call, in one read: true = all met 30 rtol (the residual the LAST sweep saw: one more
+    // contraction lies between it and the result).  false: fixed_length is off now -- redo the evaluation (it then runs the CG).  Synchronises.
+    bool verify() {
+        if (!fixed_length && slot == 0) return true;
+        double v[2*MAXLOG];
+        mesh->to_host(v, chk, 2*MAXLOG);
+        check(mimsem_memset(mesh->ctx, chk, 0, 2*MAXLOG*8), "mimsem_memset");
+        slot = 0;
+        bool ok = true;
+        for (int k = 0; k < MAXLOG; k++) {
+            const double r2 = v[2*k], ref2 = v[2*k + 1];
+            if (r2 == 0.0 && ref2 == 0.0) continue;                  // (slot not written, or a zero right-hand side)
+            const double rel = ref2 > 0.0 ? std::sqrt(r2/ref2) : 1.0e300;
+            solves_checked++;
+            if (rel == rel && rel > worst_rel) worst_rel = rel;
+            if (!(rel <= 30.0*rtol)) { ok = false; solves_missed++; }
+        }
+        if (!ok) fixed_length = false;                              // the interval was too optimistic for these right-hand sides: the CG from here on
+        return ok;
     }
     ~HorizSolve() { release(); }
     HorizSolve(const HorizSolve&) = delete; HorizSolve& operator=(const HorizSolve&) = delete;
@@ -171,27 +208,23 @@ public:
         if (fixed_length) {
             mimsem_ctx* c = mesh->ctx;
             const long long tot = (long long)nk*n1;
-            const bool verify = verified < verify_first;
             check(mimsem_memset(c, x, 0, tot*8), "mimsem_memset"); check(mimsem_memset(c, p1, 0, tot*8), "mimsem_memset");
             bool unsupported = false;
+            const size_t last = coef.size() - 1;
             for (size_t k = 0; k < coef.size() && !unsupported; k++) {
+                // the update of sweep 0 (x = 0) is P b; the one of the last sweep the preconditioned residual it saw
+                double* upd = k == last ? upd1 : (k == 0 ? pb1 : nullptr);
                 const int rc = mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
-                                                            coef[k].first, coef[k].second, p1, n1, x, n1, verify && k + 1 == coef.size() ? upd1 : nullptr, n1);
+                                                            coef[k].first, coef[k].second, p1, n1, x, n1, upd, n1);
                 if (k == 0 && rc == MIMSEM_ERR_UNSUPPORTED) unsupported = true;         // (an order the fused sweep does not cover: the CG below)
                 else check(rc, "mimsem_block_chebyshev_sweep");
             }
             if (unsupported) fixed_length = false;
             else {
-            last_its = cheb_steps;
-            if (!verify) return;
-            check(mimsem_elem_blocks_apply(c, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, b, n1, pb1, n1, 1.0), "mimsem_elem_blocks_apply");
-            check(mimsem_krylov_rowdot(c, 1, tot, upd1, tot, upd1, tot, scal + 2), "mimsem_krylov_rowdot");
-            check(mimsem_krylov_rowdot(c, 1, tot, pb1, tot, pb1, tot, scal + 3), "mimsem_krylov_rowdot");
-            double v[2];
-            mesh->to_host(v, scal + 2, 2);
-            // (the residual the LAST sweep saw: one more contraction lies between it and the result)
-            if (v[1] == 0.0 || std::sqrt(v[0]/v[1]) <= 30.0*rtol) { verified++; return; }
-            fixed_length = false;                                   // the interval was too optimistic: the CG from here on
+                last_its = cheb_steps;
+                const int k = slot < MAXLOG ? slot++ : MAXLOG - 1;      // (more than MAXLOG solves between two verify() calls: the last slot is reused)
+                check(mimsem_krylov_rowdot(c, 2, tot, pair1, (long long)even(tot), pair1, (long long)even(tot), chk + 2*k), "mimsem_krylov_rowdot");
+                return;
             }
         }
         check(mimsem_ksp_solve(ksp1, b, n1, x, n1), "mimsem_ksp_solve");
@@ -203,12 +236,14 @@ public:
 private:
     void release() {
         mimsem_ksp_destroy(ksp1); ksp1 = nullptr;
-        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &upd1, &pb1}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &pair1, &chk}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        upd1 = pb1 = nullptr;
     }
+    static size_t even(long long n) { return (size_t)((n + 1) & ~1LL); }
     Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
-    const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int verified = 0;
-    double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr;
+    const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int slot = 0; bool wanted_fixed = true;
+    double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr, *pair1 = nullptr, *chk = nullptr;
     double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
            *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;
     void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {

@@ -39,4 +39,29 @@ for name, fn in (("none", None),
         nb, st, ratio = eng.solve_status()
         print(name, "fallback", mode, "unresolved", nb, "status counts", {int(k): int((st == k).sum()) for k in np.unique(st)},
               "flagged among chosen", int(np.isin(np.nonzero(st != 0)[0], chosen).sum()), flush=True)
+# ---- the fields of the naturally flagged columns copied into 200 others (the geometry of the target element differs)
+rng = np.random.default_rng(5)
+lev = lambda nl, lo, hi: rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz
+a = {"theta": lev(NK, 280, 320), "rho": lev(NK, 0.5, 1.2), "eta": lev(NK, 5, 6), "pi": lev(NK, 700, 1000)}
+F0 = [rng.standard_normal((nEl, n * n2)) * 1e8 for n in (NK - 1, NK, NK, NK)]
+eng.set_pivot_fallback(0)
+eng.solve_schur_eta(75.0, *[eng.tensor(a[k]) for k in ("theta", "rho", "eta", "pi")], *[eng.tensor(x) for x in F0])
+nb, st, ratio = eng.solve_status()
+src = np.nonzero(st == 1)[0]
+print("naturally flagged:", src.tolist())
+for scale_geom in (False, True):
+    b = {k: v.copy() for k, v in a.items()}; G0 = [x.copy() for x in F0]
+    for i, e in enumerate(chosen):
+        s_ = src[i % len(src)]
+        fac = (dm.det[e].mean() / dm.det[s_].mean()) if scale_geom else 1.0      # fields are integrals over the element: rescale to the target's area
+        for k in b:
+            b[k][e] = a[k][s_] * fac
+        for x, y in zip(G0, F0):
+            x[e] = y[s_]
+    for mode in (0, 1):
+        eng.set_pivot_fallback(mode)
+        eng.solve_schur_eta(75.0, *[eng.tensor(b[k]) for k in ("theta", "rho", "eta", "pi")], *[eng.tensor(x) for x in G0])
+        nb, st, ratio = eng.solve_status()
+        print("copied fields (area-scaled %s) fallback %d unresolved %d status counts %s flagged among chosen %d" %
+              (scale_geom, mode, nb, {int(k): int((st == k).sum()) for k in np.unique(st)}, int(np.isin(np.nonzero(st != 0)[0], chosen).sum())), flush=True)
 eng.set_pivot_fallback(1)

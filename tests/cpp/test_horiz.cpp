@@ -3,6 +3,7 @@
 // every level in one call.  Results go back to the wrapper, which compares them with the dense restatement oracle/horiz_oracle.py
 // (per-level dense matrices, LU for the KSP solves) -- the same check the Python host gets in tests/test_gpu_next_rows.py.
 //   usage: test_horiz <in.arr> <out.bin> [ksp]
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include "../../mimsem_amd/host/mimsem_horizsolve.hpp"
@@ -36,6 +37,29 @@ int main(int argc, char** argv) {
         hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuB, Fk, Fz, nullptr, nullptr, Fk);
         const double k2iB = hs.k2i();
         hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuC, Fk, Fz, dwdx1, dwdx2, Fk);      // + the horizontal gradient of w (:704-712)
+        // every fixed-length solve above logged its check norms on the device: ONE read for all of them (round 6: not just the first three)
+        const bool fixed = hs.fixed_length;
+        if (!hs.verify()) { std::printf("FAIL: a fixed-length 1-form mass solve missed its check (worst %.2e)\n", hs.worst_rel); return 1; }
+        if (fixed && hs.solves_checked < 15) { std::printf("FAIL: %d solves checked, 15+ expected\n", hs.solves_checked); return 1; }
+        std::printf("checked %d fixed-length solves, worst |P r| / |P b| = %.2e\n", hs.solves_checked, hs.worst_rel);
+        // a sabotaged interval (half the steps) must be caught by the same log and hand the solves to the CG
+        if (fixed) {
+            HorizSolve bad(&mesh, fg);
+            bad.rtol = 1.0e-14;
+            bad.shorten_for_test(4);
+            bad.grad(Pi, fuC);
+            if (bad.verify() || bad.fixed_length || bad.solves_missed != 1) { std::printf("FAIL: a 4-step Chebyshev solve passed its check\n"); return 1; }
+            bad.grad(Pi, fuC);                                         // now the CG
+            if (bad.last_its < 5) { std::printf("FAIL: the CG did not take over\n"); return 1; }
+            hs.grad(Pi, fuA);
+            std::vector<double> ha(s1), hb(s1);
+            mesh.to_host(ha.data(), fuA, s1); mesh.to_host(hb.data(), fuC, s1);
+            double e2 = 0.0, r2 = 0.0;
+            for (size_t i = 0; i < s1; i++) { e2 += (ha[i] - hb[i])*(ha[i] - hb[i]); r2 += ha[i]*ha[i]; }
+            if (!(std::sqrt(e2/r2) < 1.0e-11)) { std::printf("FAIL: CG after the fallback vs fixed-length: %.2e\n", std::sqrt(e2/r2)); return 1; }
+            hs.momentum_rhs_ec(th, dudz, dudz2, velz, velz2, Pi, u1, u2, h1, h2, fuA, nullptr, nullptr, nullptr, nullptr, Fk);   // (fuA again as the wrapper expects it)
+            hs.k2i();
+        }
         FILE* g = std::fopen(argv[2], "wb");
         if (!g) { std::perror(argv[2]); return 2; }
         auto put = [&](const double* p, size_t n) { std::vector<double> h(n); mesh.to_host(h.data(), p, n); std::fwrite(h.data(), 8, n, g); };

@@ -270,6 +270,41 @@ def test_pivot_fallback_never_marks_a_failed_column_solved(full):
         assert torch.equal(a[keep], b[keep])                             # the neighbours of a poisoned column keep their bits
 
 
+def test_pivot_fallback_with_more_flagged_columns_than_wavefronts(full):
+    """round-5 advisor: the fallback dealt the flagged columns to its 64 wavefronts by a running ordinal over LIVE statuses that other
+    wavefronts rewrite during the launch -- with more than 64 flagged columns one could be skipped (left at 1) or solved twice (the counter
+    under-counts).  Ownership is by column index now.  500 columns are put in front of the fallback (mimsem_column_flag_for_test: rough data
+    flags a handful at most): EXACTLY those -- and the naturally flagged ones -- must end as 3 or 4, none at 1, the count exact, everybody
+    else untouched, the solution's bits those of the run without the forced flags (an accepted column keeps its d)."""
+    import torch
+    cs, dm, eng, _ = full
+    n2, nEl = eng.n2e, dm.nEl
+    area = float(dm.det.mean()) * 4.0 / n2; dz = float(dm.thick.mean())
+    rng = np.random.default_rng(5)
+    lev = lambda nl, lo, hi: eng.tensor(rng.uniform(lo, hi, (nEl, nl * n2)) * area * dz)
+    theta, rho, eta, pi = lev(NK, 280, 320), lev(NK, 0.5, 1.2), lev(NK, 5, 6), lev(NK, 700, 1000)
+    F0 = [rng.standard_normal((nEl, n * n2)) * 1e8 for n in (NK - 1, NK, NK, NK)]
+    clean = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[eng.tensor(x) for x in F0])
+    nb0, st0, _ = eng.solve_status()
+    assert nb0 == 0
+    forced = np.unique(np.concatenate([np.arange(3, nEl, 7)[:436], np.arange(64)]))          # 500: every wavefront owns several, incl. one whole 64-chunk
+    assert forced.size == 500
+    for rep in range(3):                                                 # (the race needed skewed wavefronts: a few launches)
+        eng.flag_columns_for_test(forced)
+        out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[eng.tensor(x) for x in F0])
+        nb, st, ratio = eng.solve_status()
+        assert nb == 0, (rep, nb, np.nonzero(st == 1)[0][:10])
+        was = np.zeros(nEl, bool); was[forced] = True
+        assert np.isin(st[was], (3, 4)).all(), np.unique(st[was], return_counts=True)
+        assert (st[~was] == st0[~was]).all()
+        acc = torch.as_tensor(st != 3, device=out[0].device)             # accepted / untouched columns keep their bits
+        for a, b in zip(out, clean):
+            assert torch.equal(a[acc], b[acc])
+    out = eng.solve_schur_eta(75.0, theta, rho, eta, pi, *[eng.tensor(x) for x in F0])         # one-shot: the next solve is the plain one
+    _, st, _ = eng.solve_status()
+    assert (st == st0).all()
+
+
 def test_column_solve_3_satisfies_its_block_pentadiagonal_system(full):
     """solve_schur_column_3 at full size (row-per-lane 18x18 super-block sweep + refinement): L d_rt = F_rt with the
     block-pentadiagonal L the call itself returns ([nEl, nk, 5, n2, n2], block column = row - 2 + b); F_rt is the updated
