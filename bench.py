@@ -893,6 +893,8 @@ def compact_record(out, extras_file=None):
             "box_p4_schur_eta_ms": _r(_g(cb, "schur_eta", "ms_all_columns")), "box_p4_schur3_ms": _r(_g(cb, "schur_3_box", "ms_all_columns")),
             "box_p4_umat_cold_frac": _r(_g(out, "box_p4", "roofline_cold", "frac"), 3),
             "horiz_rhs_ms": _r(_g(out, "horiz_rhs", "ms_per_evaluation_hipgraph")),
+            "horiz_rhs_ms_reusing_grad_theta": _r(_g(out, "horiz_rhs", "ms_per_evaluation_hipgraph_reusing_grad_theta")),
+            "horiz_m1_sweep_hbm_frac": _r(_g(out, "horiz_rhs", "m1_sweep_roofline", "frac"), 3),
             "horiz_rhs_ms_cpp_host": _r(_g(out, "horiz_rhs", "cpp_host", "ms_per_evaluation_recorded")),
             "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
             "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
@@ -1254,10 +1256,49 @@ def main():
         for _ in range(20):
             graph.replay()
         torch.cuda.synchronize(); elg = (time.perf_counter() - t1) / 20
+        # the same evaluation with grad(theta) of advection_rhs_ec handed to momentum_rhs_ec (the reference solves that system twice per stage
+        # for one answer, eul/HorizSolve.cpp:403 and :659): six 1-form mass solves instead of seven
+        def rhs6():
+            dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
+            return hs.momentum_rhs_ec(th, dudz, dudz, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk, dTheta=hs.dTheta)
+        graph6, gout6 = eng.capture(rhs6)
+        graph6.replay(); torch.cuda.synchronize()
+        err6 = float(torch.linalg.vector_norm(gout6 - ref) / torch.linalg.vector_norm(ref))
+        t1 = time.perf_counter()
+        for _ in range(20):
+            graph6.replay()
+        torch.cuda.synchronize(); elg6 = (time.perf_counter() - t1) / 20
         hs.m1.fixed_its = 0
+        checks_ok = hs.verify()                          # every fixed-length M1 solve of the replays logged its check norms: one read
         res = {"workload": "advection_rhs_ec + momentum_rhs_ec (viscosity on), 3456 elements x 30 levels per evaluation",
                "ms_per_evaluation_eager": 1e3 * el, "ms_per_evaluation_hipgraph": 1e3 * elg, "evaluations_per_s": 1.0 / elg,
-               "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err}
+               "m1_cg_iterations_eager": its, "graph_vs_eager_rel_diff": err,
+               "ms_per_evaluation_hipgraph_reusing_grad_theta": 1e3 * elg6, "reusing_grad_theta_rel_diff": err6,
+               "m1_checks": {"all_met": bool(checks_ok), "solves_checked": hs.m1.solves_checked, "solves_missed": hs.m1.solves_missed, "worst": hs.m1.worst_check}}
+        # a roofline statement for the sweeps that are 73 % of this evaluation.  One Chebyshev sweep of the 1-form mass
+        # solve = {element pass, block pass, gather epilogue}; COMPULSORY bytes: x, rhs, p read + x, p written (5 vectors of nk n1 doubles),
+        # thickInv per (unit, point), the preconditioner's per-(level, element) factor, and once per launch the element blocks
+        # (24 x 24 doubles per element) and the metric (32 B per element point).  Time: a whole solve under HIP events / its step count.
+        if hs.m1.chebyshev and hs.m1._cheb is not None:
+            b1 = hs.m1.apply(u1)
+            for _ in range(2):
+                hs.m1.solve(b1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nsolve = 10
+            e0.record()
+            for _ in range(nsolve):
+                hs.m1.solve(b1)
+            e1.record(); torch.cuda.synchronize()
+            steps = hs.m1._cheb.steps
+            us = e0.elapsed_time(e1) * 1e3 / nsolve / steps
+            mp12 = (PN + 1) ** 2
+            nbytes = 5 * NK * dm.n1 * 8 + dm.nEl * NK * mp12 * 8 + dm.nEl * NK * 8 + dm.nEl * (2 * PN * (PN + 1)) ** 2 * 8 + dm.nEl * mp12 * 32
+            res["m1_sweep_roofline"] = {"bound": "hbm", "kernel": "k_elem_apply<3,UMAT> + k_blocks_residual<3,8> + k_gather_epilogue<2> (one Chebyshev sweep, 103 680 units)",
+                                        "avg_sweep_us": us, "steps_per_solve": steps, "bytes_per_sweep": nbytes, "achieved": nbytes / (us * 1e-6) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "compulsory bytes; the three launches exchange two element-local arrays (24 doubles per unit each, written once and "
+                                                "read twice through the gather plan): ~2.0x the compulsory traffic by construction (DESIGN 8)"}
+            hs.verify()
         # the same evaluation with the HOST in C++ (mimsem_amd/host/horiz_call.cpp over mimsem_horizsolve.hpp; the ksp1 solves are the
         # library's batched CG with its convergence test on the host: not recorded as a graph)
         import subprocess

@@ -38,6 +38,11 @@ class HorizSolve:
         """horizontal kinetic-to-internal energy exchange of the last momentum_rhs_ec (:697-701)"""
         return 0.0 if self.k2i_dev is None else float(self.k2i_dev)
 
+    def verify(self):
+        """every fixed-length 1-form mass solve since the last call met its check (MassSolver.verify: one read of a small device log); False:
+        the solver has switched itself to PCG -- redo the evaluation"""
+        return self.m1.verify()
+
     # ---- operators --------------------------------------------------------------------------------------------------
     def _ap(self, op, x, f=None, flags=0, alpha=1.0, out=None):
         return self.eng.apply(op, x, f=f, lev0=0, scale=SCALE, flags=flags, alpha=alpha, out=out)
@@ -89,7 +94,8 @@ class HorizSolve:
         # (sums of operator results are accumulated by the operator kernels themselves: MIMSEM_FLAG_ACCUM + alpha, no elementwise passes)
         dG = self._ap("WMAT", eng.incidence("E21", Gk), flags=VERT, alpha=0.5)
         self._ap("WHMAT", dFk, f=theta, flags=VERT | ACCUM, alpha=0.5, out=dG)
-        self._ap("WTQUMAT", Fk, f=self.grad(theta), flags=ACCUM, out=dG)        # K incl. its 0.5 factor
+        self.dTheta = self.grad(theta)                                           # (kept: momentum_rhs_ec of the same stage needs the same gradient)
+        self._ap("WTQUMAT", Fk, f=self.dTheta, flags=ACCUM, out=dG)             # K incl. its 0.5 factor
         self.Fk, self.Gk = Fk, Gk
         return dF, dG, Fk, Gk
 
@@ -117,12 +123,16 @@ class HorizSolve:
         return eng.combine(rhs, 1.0, "div", eng.pvec(0, self.nk, SCALE, h2=rho), out=rhs)
 
     def momentum_rhs_ec(self, theta, dudz1, dudz2, velz1, velz2, Pi, velx1, velx2, rho1, rho2, Fx=None, Fz=None,
-                        dwdx1=None, dwdx2=None, Fk=None):
-        """:637-786 for every level at once; returns fu [nk, n1]; self.k2i = the kinetic-to-internal exchange (needs Fk)"""
+                        dwdx1=None, dwdx2=None, Fk=None, dTheta=None):
+        """:637-786 for every level at once; returns fu [nk, n1]; self.k2i = the kinetic-to-internal exchange (needs Fk).
+        dTheta (optional, like Fx): grad(theta) when the caller has it already -- advection_rhs_ec of the same stage solved the same system
+        for the same theta (:403 and :659 in the reference, two KSPSolves with one answer); passing self.dTheta saves one of the seven
+        1-form mass solves of a right-hand-side evaluation"""
         eng = self.eng
         Phi = self.diagnose_Phi(velx1, velx2, velz1, velz2)
         dPi = self.grad(Pi)
-        dTheta = self.grad(theta)
+        if dTheta is None:
+            dTheta = self.grad(theta)
         fu = eng.incidence("E12", Phi)
         uh = eng.combine(velx1, 0.5, beta=0.5, c=velx2)
         q = self.diagnose_q(eng.combine(rho1, 0.5, beta=0.5, c=rho2), uh)

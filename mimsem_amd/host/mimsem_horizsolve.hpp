@@ -36,7 +36,7 @@ public:
         const double dx = std::sqrt(4.0*M_PI*RAD_EARTH*RAD_EARTH/(double)(nDofs0G > 0 ? nDofs0G : n0));
         del2 = -std::sqrt(0.072*std::pow(dx, 3.2));
         try {
-            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1}) *p = mesh->device_alloc((size_t)nk*n1);
+            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1, &gt1}) *p = mesh->device_alloc((size_t)nk*n1);
             // the two vectors of a check side by side (the second row at an even offset): one two-row dot per solve
             pair1 = mesh->device_alloc(2*even((long long)nk*n1)); upd1 = pair1; pb1 = pair1 + even((long long)nk*n1);
             chk = mesh->device_alloc(2*MAXLOG);
@@ -134,9 +134,12 @@ public:
         inc(1, Gk, n1, c2, n2);
         ap(MIMSEM_OP_WMAT, MIMSEM_FLAG_VERT, nullptr, 0, c2, n2, dG, n2, 0.5);
         ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, theta, n2, b2, n2, dG, n2, 0.5);
-        grad(theta, c1);
-        ap(MIMSEM_OP_WTQUMAT, MIMSEM_FLAG_ACCUM, c1, n1, Fk, n1, dG, n2, 1.0);                              // K incl. its 0.5 factor
+        grad(theta, gt1);                                                                                   // (kept: last_grad_theta())
+        ap(MIMSEM_OP_WTQUMAT, MIMSEM_FLAG_ACCUM, gt1, n1, Fk, n1, dG, n2, 1.0);                             // K incl. its 0.5 factor
     }
+    // grad(theta) of the last advection_rhs_ec [nk][n1]: momentum_rhs_ec of the same stage solves the same system for the same theta
+    // (:403 and :659 in the reference, two KSPSolves with one answer) -- passed as its dTheta it saves one of the seven mass solves
+    const double* last_grad_theta() const { return gt1; }
     // :419-470
     void diagnose_Phi(const double* u1, const double* u2, const double* velz1, const double* velz2, double* Phi) {
         ap(MIMSEM_OP_WTQUMAT, 0, u1, n1, u1, n1, Phi, n2, 1.0/3.0);
@@ -162,19 +165,19 @@ public:
     void momentum_rhs_ec(const double* theta, const double* dudz1, const double* dudz2, const double* velz1, const double* velz2, const double* Pi,
                          const double* velx1, const double* velx2, const double* rho1, const double* rho2, double* fu,
                          const double* Fx = nullptr, const double* Fz = nullptr, const double* dwdx1 = nullptr, const double* dwdx2 = nullptr,
-                         const double* Fk = nullptr) {
+                         const double* Fk = nullptr, const double* dTheta = nullptr) {
         mimsem_ctx* c = mesh->ctx;
         diagnose_Phi(velx1, velx2, velz1, velz2, a2);
         inc(2, a2, n2, fu, n1);
         grad(Pi, a1);                                                                                         // dPi
-        grad(theta, b1);                                                                                      // dTheta
+        if (!dTheta) { grad(theta, b1); dTheta = b1; }                                                        // dTheta
         comb(n1, 0.5, velx1, 0, nullptr, 0.5, velx2, c1);                                                     // uh
         comb(n2, 0.5, rho1, 0, nullptr, 0.5, rho2, b2);
         diagnose_q(b2, c1, a0);
         if (!Fx) { uvec_hu4(velx1, velx2, rho1, rho2, d1); solve_M1(d1, e1); Fx = e1; }
         ap(MIMSEM_OP_ROTMAT, MIMSEM_FLAG_ACCUM, a0, n0, Fx, n1, fu, n1, 1.0);
         ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, theta, n2, a1, n1, fu, n1, 0.5);            // pressure gradient force
-        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, Pi, n2, b1, n1, fu, n1, -0.5);
+        ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, Pi, n2, dTheta, n1, fu, n1, -0.5);
         ap(MIMSEM_OP_WHMAT, MIMSEM_FLAG_VERT, Pi, n2, theta, n2, a2, n2, 1.0);
         inc(2, a2, n2, d1, n1);                                                                               // dp
         comb(n1, 0.5, d1, 0, nullptr, 1.0, fu, fu);
@@ -236,14 +239,14 @@ public:
 private:
     void release() {
         mimsem_ksp_destroy(ksp1); ksp1 = nullptr;
-        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &pair1, &chk}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &pair1, &chk, &gt1}) { if (*p) mimsem_free(*p); *p = nullptr; }
         upd1 = pb1 = nullptr;
     }
     static size_t even(long long n) { return (size_t)((n + 1) & ~1LL); }
     Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
     const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int slot = 0; bool wanted_fixed = true;
-    double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr, *pair1 = nullptr, *chk = nullptr;
+    double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr, *pair1 = nullptr, *chk = nullptr, *gt1 = nullptr;
     double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
            *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;
     void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {

@@ -228,6 +228,13 @@ class MassSolver:
         self.fixed_its = 0          # > 0: run exactly that many PCG iterations (hipGraph capture)
         self._cheb = None
         self._cheb_checked = False
+        # every fixed-length solve logs {|P r_last|^2, |P b|^2} per level into a slot of this device log (round 6: round 5 verified the first
+        # solve only; a later, rougher right-hand side could lose accuracy unseen): verify() reads it once per evaluation / step
+        self.MAXLOG = 16
+        self._log = None
+        self._slot = 0
+        self.solves_checked = self.solves_missed = 0
+        self.worst_check = 0.0
         # default solver for the block preconditioner on one rank: fixed-length Chebyshev on the fused sweep (no inner products)
         self.chebyshev = (precond != "jacobi" and os.environ.get("MIMSEM_MASS_SOLVER", "chebyshev") == "chebyshev"
                           and not hasattr(eng, "halo") and eng.mesh.n <= 5)
@@ -278,6 +285,46 @@ class MassSolver:
             self._blocks_cm = self.blocks.transpose(1, 2).contiguous()
         return self._cheb
 
+    def _logged_solve(self, ch, b):
+        """the fixed-length solve with its check norms written to the device log (two extra stores in two sweeps + one two-row-block dot:
+        recordable, no host synchronisation)"""
+        nlev, n = b.shape
+        if self._log is None or self._log.shape[1] != 2 * nlev:
+            self._log = torch.zeros(self.MAXLOG, 2 * nlev, dtype=torch.float64, device=b.device)
+            self._pair = torch.zeros(2 * nlev, n, dtype=torch.float64, device=b.device)
+            self._slot = 0
+        ch.upd = self._pair[:nlev]
+        x = ch.solve(b, want_residual=True, pb=self._pair[nlev:])
+        k = min(self._slot, self.MAXLOG - 1); self._slot += 1
+        self.eng.rowdot(self._pair, self._pair, out=self._log[k])
+        return x
+
+    def verify(self, rtol=1e-14):
+        """the checks of every fixed-length solve since the last call in ONE read: True = every level of every solve had its last
+        preconditioned residual below 30 rtol |P b| (one more contraction lies between that residual and the result).  False: the
+        Chebyshev mode is switched off (PCG from here on) and the caller redoes its evaluation.  Synchronises."""
+        if self._log is None or self._slot == 0:
+            return True
+        v = self._log.cpu().numpy()
+        self._log.zero_(); self._slot = 0
+        nlev = v.shape[1] // 2
+        ok = True
+        for row in v:
+            r2, ref2 = row[:nlev], row[nlev:]
+            if not (r2.any() or ref2.any()):
+                continue
+            import numpy as np
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rel = np.where(ref2 > 0.0, np.sqrt(r2 / np.where(ref2 > 0.0, ref2, 1.0)), np.where(r2 > 0.0, np.inf, 0.0))
+            self.solves_checked += 1
+            worst = float(np.nanmax(rel)) if np.isfinite(rel).any() else float("inf")
+            self.worst_check = max(self.worst_check, worst)
+            if not bool((rel <= 30.0 * rtol).all()):
+                ok = False; self.solves_missed += 1
+        if not ok:
+            self.chebyshev = False
+        return ok
+
     def solve(self, b, lev0=0, rtol=1e-14, maxit=300):
         nlev = b.shape[0]
         if self.kind != "jacobi" and self.chebyshev:
@@ -293,7 +340,7 @@ class MassSolver:
                 ch.set_steps(cal["bound_steps"])
                 self._cheb_checked = False
                 self._cheb_cal = None
-            x = ch.solve(b)
+            x = self._logged_solve(ch, b)
             if not self._cheb_checked and not torch.cuda.is_current_stream_capturing():
                 # one-time check of the spectral bounds on a real right-hand side: a step count derived from wrong bounds would
                 # silently under-solve; fall back to PCG for good if the true residual is not at round-off
@@ -324,7 +371,7 @@ class MassSolver:
                     ch.set_steps(need)
                     self.cheb_calibration = {"bound_steps": full, "steps": need, "floor": res, "floor_random": floor_rnd}
                     self._cheb_cal = {"rtol": rtol, "lev0": lev0, "nlev": nlev, "bound_steps": full}
-                    x = ch.solve(b)
+                    x = self._logged_solve(ch, b)
             return x, ch.steps
         if self.kind != "jacobi":
             if not hasattr(self.eng, "halo") and not self.fixed_its and os.environ.get("MIMSEM_PCG", "c") == "c":
@@ -828,11 +875,17 @@ class ChebyshevMass:
             self.coef.append((c1, c2 * c1_prev / c1))
             rho_prev, c1_prev = rho, c1
 
-    def solve(self, b, x0=None, want_residual=False):
-        """returns x; capturable (fixed shapes and step count, no host synchronisation unless want_residual)"""
+    def solve(self, b, x0=None, want_residual=False, pb=None):
+        """returns x; capturable (fixed shapes and step count, no host synchronisation).  want_residual: self.upd receives the preconditioned
+        residual the LAST sweep saw; pb (a tensor like b, zero start only): receives the FIRST sweep's update, which is P b -- the two vectors
+        of a convergence check without an extra preconditioner application"""
         if self.p is None or self.p.shape != b.shape:
-            self.p = torch.zeros_like(b); self.upd = torch.zeros_like(b)
-        x = torch.zeros_like(b) if x0 is None else x0.clone()
+            self.p = torch.zeros_like(b)
+        if self.upd is None or self.upd.shape != b.shape:
+            self.upd = torch.zeros_like(b)
+        x = torch.zeros_like(b) if x0 is None else x0.clone()           # (p needs no reset: the first step has beta = 0)
+        assert pb is None or x0 is None
         for k, (alpha, beta) in enumerate(self.coef):
-            self.sweep(x, b, self.p, alpha, beta, self.upd if (want_residual and k == self.steps - 1) else None)
+            upd = self.upd if (want_residual and k == self.steps - 1) else (pb if k == 0 else None)
+            self.sweep(x, b, self.p, alpha, beta, upd)
         return x

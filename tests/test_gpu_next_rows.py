@@ -348,6 +348,12 @@ def test_horizsolve_right_hand_sides(oracle):
             k2i += k
             assert rel(got[lev], want) < 1e-8, (lev, kwargs)
         assert abs(hs.k2i - k2i) < 1e-8 * abs(k2i)
+    # grad(theta) of advection_rhs_ec handed to momentum_rhs_ec (one mass solve less): the same bits as the call that solves it again
+    again = hs.momentum_rhs_ec(t(th), t(dudz), t(dudz2), t(velz), t(velz2), t(Pi), t(u1), t(u2), t(h1), t(h2), Fx=t(Fk), Fz=t(velz * 0.7), Fk=t(Fk),
+                               dwdx1=t(dwdx), dwdx2=t(dwdx2), dTheta=hs.dTheta).cpu().numpy()
+    assert np.array_equal(again, got)
+    # every fixed-length mass solve above logged its check norms on the device: one read, all met, none skipped
+    assert hs.verify() and hs.m1.solves_missed == 0 and (hs.m1.solves_checked >= 15 or not hs.m1.chebyshev)
 
 
 def test_krylov_batched_cg_kernels(sphere):
