@@ -582,6 +582,11 @@ int  mimsem_ksp_set_initial_guess_nonzero(mimsem_ksp* ksp, int flag);           
 int  mimsem_ksp_solve(mimsem_ksp* ksp, const double* b, long long b_stride, double* x, long long x_stride);
 /* KSPGetIterationNumber / KSPGetResidualNorm / KSPGetConvergedReason of the last solve (rnorm: relative, worst row)                 */
 int  mimsem_ksp_get_info(const mimsem_ksp* ksp, int* iterations, double* rnorm, int* reason);
+/* Eigenvalues of a real upper Hessenberg matrix H [n][n] (host, row-major, entries below the first subdiagonal ignored; n <= 400) -- the
+ * host-side step of a Ritz estimate (what KSPComputeEigenvalues gets from LAPACK's hseqr in PETSc): a host that runs its own Arnoldi
+ * process (a SHARDED mesh, where the inner products are all-reduced by the host: mimsem_amd/host/mimsem_sweqn.hpp) hands the small
+ * matrix here.  wr / wi [n]: real and imaginary parts, unordered.  Pure host arithmetic (csrc/hqr_host.hpp), no GPU call.              */
+int  mimsem_hessenberg_eigenvalues(int n, const double* H, double* wr, double* wi);
 
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */

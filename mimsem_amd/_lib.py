@@ -136,6 +136,7 @@ _SIGS = {
     "mimsem_krylov_gs_control": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_column_solve_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     "mimsem_column_set_pivot_fallback": (C.c_int, [C.c_void_p, C.c_int]),
+    "mimsem_hessenberg_eigenvalues": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_column_flag_for_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mimsem_krylov_chebyshev_update": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_selftest_rows_half": (C.c_int, [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]),

@@ -1077,9 +1077,14 @@ static bool is_up_op(int op) {
 int mimsem_ctx_set_halo_slots(mimsem_ctx* c, int form, const int* slots, int n) {
     if (!c || form != 1 || n < 0 || (n && !slots)) return MIMSEM_ERR_ARG;
     if (c->is_capturing() || c->split.pending) return MIMSEM_ERR_STATE;      // (a pending BOUNDARY part belongs to the plan in force)
-    if (!c->wave1 && c->h_i1x.empty()) return MIMSEM_OK;      // two-pass form: nothing to reorder (the split degenerates, see mimsem_op_apply_part)
+    if (!c->wave1 && c->h_i1x.empty()) {      // two-pass form: nothing to reorder (the split degenerates, see mimsem_op_apply_part); the marks are kept all the same
+        c->h_halo1.assign(c->n1, 0);
+        for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= c->n1) return MIMSEM_ERR_ARG; c->h_halo1[slots[i]] = 1; }
+        return MIMSEM_OK;
+    }
     std::vector<char> marked(std::max(c->n1, 1), 0);
     for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= c->n1) return MIMSEM_ERR_ARG; marked[slots[i]] = 1; }
+    c->h_halo1.assign(marked.begin(), marked.begin() + c->n1);        // (kept: the block preconditioners weight shared edges by their GLOBAL multiplicity, csrc/ksp.hip)
     MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
     const int rc = setup_wave(c, marked.data());
     return rc == MIMSEM_ERR_UNSUPPORTED ? MIMSEM_OK : rc;      // numbering without a wave-level plan: the two-pass form stays, the split degenerates

@@ -397,6 +397,11 @@ static int edge_weights(const mimsem_ctx* c, int stride, std::vector<double>& d)
     std::vector<int> mult(c->n1, 0);
     for (int v : c->h_e1x) { if (v < 0 || v >= c->n1) return MIMSEM_ERR_ARG; mult[v]++; }
     for (int v : c->h_e1y) { if (v < 0 || v >= c->n1) return MIMSEM_ERR_ARG; mult[v]++; }
+    // a SHARD of a larger mesh (round 6): an edge the host marked as taking part in a halo exchange (mimsem_ctx_set_halo_slots) has its second
+    // element on another rank -- an edge borders at most two elements -- so its global multiplicity is the local one + 1.  Without this the
+    // preconditioner of a shard would weight its boundary edges by 1 where the one-context run uses 1/2.
+    if ((long long)c->h_halo1.size() == (long long)c->n1)
+        for (int i = 0; i < c->n1; i++) if (c->h_halo1[i] && mult[i] == 1) mult[i] = 2;
     d.assign((size_t)nEl*stride, 1.0);
     for (int e = 0; e < nEl; e++)
         for (int i = 0; i < nd1; i++) d[(size_t)e*stride + i] = 1.0/mult[i < n1e ? c->h_e1x[(size_t)e*n1e + i] : c->h_e1y[(size_t)e*n1e + i - n1e]];
@@ -579,6 +584,7 @@ int mimsem_ksp_ritz(mimsem_ksp* k, int m, double* re_min, double* re_max, double
         KTRY(mimsem_krylov_orthogonalize(c, j + 1, N, V, N, -1.0, w, h));
         KTRY(mimsem_krylov_reorthonormalize_ex(c, j + 1, N, V, N, w, V + (long long)(j + 1)*N, h, h2, col, m + 1, 0, k->flag));
         MIMSEM_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (*k->flag) return MIMSEM_ERR_STATE;      // (cannot happen in the three-launch form asked for above -- fused = 0 accumulates the norm from the updated vector and never raises the word; checked so that a change of form cannot go unnoticed: advisor, round 5)
         for (int i = 0; i <= j; i++) H[(size_t)i*m + j] = col[i];
         kk = j + 1;
         if (!(col[m + 1] == col[m + 1])) return MIMSEM_ERR_STATE;                  // NaN
@@ -591,6 +597,14 @@ int mimsem_ksp_ritz(mimsem_ksp* k, int m, double* re_min, double* re_max, double
     double lo = wr[0], hi = wr[0], im = 0.0;
     for (int i = 0; i < kk; i++) { lo = std::min(lo, wr[i]); hi = std::max(hi, wr[i]); im = std::max(im, std::fabs(wi[i])); }
     *re_min = lo; *re_max = hi; *im_max = im;
+    return MIMSEM_OK;
+}
+
+int mimsem_hessenberg_eigenvalues(int n, const double* H, double* wr, double* wi) {
+    if (n < 1 || n > 400 || !H || !wr || !wi) return MIMSEM_ERR_ARG;
+    std::vector<double> a(H, H + (size_t)n*n), r, im;
+    if (hessenberg_eigenvalues(a, n, r, im) != 0) return MIMSEM_ERR_STATE;
+    for (int i = 0; i < n; i++) { wr[i] = r[i]; wi[i] = im[i]; }
     return MIMSEM_OK;
 }
 

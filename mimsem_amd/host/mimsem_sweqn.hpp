@@ -9,15 +9,123 @@
 //                 the [u|h] solve, the update, the check norms) is recorded ONCE as a hipGraph (class Graph) and replayed: one submission and
 //                 one read of a few scalars per Picard iteration.  Every solve logs {|last residual|^2, |P b|^2}; a solve that misses its
 //                 tolerance sends THAT Picard iteration through the krylov mode again from the saved state.
+//   SHARDED (round 6)  a rank that holds some patches of the sphere passes a Shard (below): the fixed mode then runs with the halo exchanges
+//                 inside its solves -- a Chebyshev step needs its operator's and its preconditioner's 1-form (0-form) results completed over
+//                 the halo and nothing else: no inner product, hence NO all-reduce inside any solve -- and the check norms of a whole Picard
+//                 iteration, ownership-weighted partial sums, are reduced ONCE (Shard::allreduce: the host's MPI_Allreduce).  The spectral
+//                 regions come from an Arnoldi process of the host's own (Shard::ritz: weighted, all-reduced inner products, once per dt).
+//                 The reference's distributed step: src/SWEqn_Picard.cpp:751-765, gtol_x :131-153, :341-400, ghost updates :422-425.
 // Header-only, C++17, no HIP toolchain needed (everything goes through include/mimsem_hip.h).
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
+#include <random>
 #include <utility>
 #include "mimsem_shim.hpp"
 
 namespace mimsem_host {
+
+// A rank's share of the exchanges and reductions when the mesh is dealt to several ranks: what replaces VecScatter on gtol_0 /
+// gtol_1 (eul/Topo.cpp:145-155) and MPI_Allreduce in the reference's distributed solves.  Slot lists as for VecScatterHalo: per neighbour
+// rank the local slots this rank holds as GHOSTS of DoFs that rank owns, and the local slots this rank OWNS that the neighbour ghosts
+// ("mirrors"), both in the order of the shared global numbering.
+//   edges (1-forms): an edge borders at most two elements, so a shared edge has exactly two sharers: ONE symmetric exchange completes a
+//     vector of element-local partial sums -- each sharer sends its partial sum to the other and both add (a + b = b + a bit for bit);
+//   nodes (0-forms): patch corners have more than two sharers: REVERSE/ADD to the owner, then FORWARD/INSERT back.
+// own0 / own1: 1 for the DoFs this rank owns, 0 for its ghosts -- inner products count every global DoF once.
+class Shard {
+public:
+    using allreduce_fn = int (*)(void* user, double* v, int n);        // in-place sum over the ranks of n host doubles; 0 = ok
+    Shard(Mesh* m, const std::vector<int>& ranks, const std::vector<int>& ghost1, const std::vector<int>& ghost1_off, const std::vector<int>& mirror1,
+          const std::vector<int>& mirror1_off, const std::vector<int>& ghost0, const std::vector<int>& ghost0_off, const std::vector<int>& mirror0,
+          const std::vector<int>& mirror0_off, const std::vector<double>& own0_host, const std::vector<double>& own1_host, allreduce_fn ar, void* ar_user)
+        : mesh(m), nodes(m, 0, ranks, ghost0, ghost0_off, mirror0, mirror0_off), reduce(ar), user(ar_user) {
+        const int nn = (int)ranks.size();
+        std::vector<int> pidx, poff(1, 0);
+        for (int i = 0; i < nn; i++) {                                  // every slot shared with neighbour i, in slot (= global) order on both sides
+            std::vector<int> s(ghost1.begin() + ghost1_off[i], ghost1.begin() + ghost1_off[i + 1]);
+            s.insert(s.end(), mirror1.begin() + mirror1_off[i], mirror1.begin() + mirror1_off[i + 1]);
+            std::sort(s.begin(), s.end());
+            pidx.insert(pidx.end(), s.begin(), s.end()); poff.push_back((int)pidx.size());
+        }
+        check(mimsem_halo_create(m->ctx, nn, ranks.data(), pidx.data(), poff.data(), pidx.data(), poff.data(), m->n1, m->nk_, &pair), "mimsem_halo_create(pair)");
+        std::vector<int> shared(pidx); std::sort(shared.begin(), shared.end()); shared.erase(std::unique(shared.begin(), shared.end()), shared.end());
+        // the shared edges: their element groups go first in the operators' plans, and the block preconditioners weight them by their GLOBAL multiplicity
+        check(mimsem_ctx_set_halo_slots(m->ctx, 1, shared.data(), (int)shared.size()), "mimsem_ctx_set_halo_slots");
+        if ((int)own0_host.size() != m->n0 || (int)own1_host.size() != m->n1) throw std::runtime_error("Shard: ownership weights of the wrong length");
+        own0 = m->to_device(own0_host.data(), own0_host.size());
+        std::vector<double> ox(own1_host); ox.resize((size_t)m->n1 + m->n2, 1.0);          // packed [u | h]: 2-forms are never shared
+        ownx = m->to_device(ox.data(), ox.size()); own1 = ownx;
+    }
+    ~Shard() { mimsem_halo_destroy(pair); if (own0) mimsem_free(own0); if (ownx) mimsem_free(ownx); }
+    Shard(const Shard&) = delete; Shard& operator=(const Shard&) = delete;
+    void use_transport(mimsem_halo_transport_fn fn, void* u) { nodes.use_transport(fn, u); check(mimsem_halo_set_transport(pair, fn, u), "set_transport"); }
+    void use_rccl(void* nccl_comm) { nodes.use_rccl(nccl_comm); check(mimsem_halo_set_rccl(pair, nccl_comm), "set_rccl"); }
+    // complete a vector of element-local partial sums (one level, contiguous)
+    void complete1(double* v) { exchanges++; check(mimsem_halo_begin(pair, MIMSEM_HALO_ADD, 1, v, mesh->n1), "halo_begin"); check(mimsem_halo_end(pair), "halo_end"); }
+    void complete0(double* v) { exchanges += 2; nodes.reverse_add(v, 1, mesh->n0); nodes.forward_insert(v, 1, mesh->n0); }
+    void allreduce(double* v, int n) { allreduces++; if (reduce && reduce(user, v, n) != 0) throw std::runtime_error("Shard: the host's all-reduce failed"); }
+    // <a, b> over the GLOBAL vector: ownership-weighted local part (tmp: n doubles of device scratch, out: one device double), then all-reduced
+    double dot(const double* wgt, long long n, const double* a, const double* b, double* tmp, double* out) {
+        check(mimsem_vec_combine(mesh->ctx, 1, n, 1.0, a, n, 1, wgt, n, 0.0, nullptr, 0, tmp, n), "mimsem_vec_combine");
+        check(mimsem_krylov_rowdot(mesh->ctx, 1, n, tmp, n, b, n, out), "mimsem_krylov_rowdot");
+        double v = 0.0;
+        mesh->to_host(&v, out, 1);
+        allreduce(&v, 1);
+        return v;
+    }
+    // Ritz values of the operator `body(v, w)` (w = B v on COMPLETED vectors of n entries) from m Arnoldi steps: the region of the spectrum a
+    // fixed-length Chebyshev iteration is built on.  Set-up path: host round trips and all-reduces per step, once per dt.
+    // complete(v): makes the shared entries of a start vector agree on all sharers.
+    void ritz(long long n, int m, const double* wgt, const std::function<void(const double*, double*)>& body, const std::function<void(double*)>& complete,
+              double* re_min, double* re_max, double* im_max, unsigned seed = 1) {
+        mimsem_ctx* c = mesh->ctx;
+        double *V = mesh->device_alloc((size_t)(m + 1)*n), *w = mesh->device_alloc(n), *tmp = mesh->device_alloc(n), *h = mesh->device_alloc(m + 4);
+        std::vector<double> H((size_t)(m + 1)*m, 0.0), hh(m + 2), start(n);
+        try {
+            std::mt19937_64 gen(seed); std::normal_distribution<double> nd;
+            for (double& x : start) x = nd(gen);
+            check(mimsem_memcpy_h2d(c, w, start.data(), n*8), "h2d");
+            check(mimsem_vec_combine(c, 1, n, 1.0, w, n, 1, wgt, n, 0.0, nullptr, 0, w, n), "mimsem_vec_combine");       // the owner's value ...
+            complete(w);                                                                                            // ... on every sharer
+            double nrm = std::sqrt(dot(wgt, n, w, w, tmp, h + m + 2));
+            check(mimsem_vec_combine(c, 1, n, 1.0/nrm, w, n, 0, nullptr, 0, 0.0, nullptr, 0, V, n), "mimsem_vec_combine");
+            int kk = m;
+            for (int j = 0; j < m; j++) {
+                body(V + (size_t)j*n, w);
+                for (int pass = 0; pass < 2; pass++) {                  // classical Gram-Schmidt, twice
+                    check(mimsem_vec_combine(c, 1, n, 1.0, w, n, 1, wgt, n, 0.0, nullptr, 0, tmp, n), "mimsem_vec_combine");
+                    check(mimsem_krylov_mdot(c, j + 1, n, V, n, tmp, h), "mimsem_krylov_mdot");
+                    mesh->to_host(hh.data(), h, j + 1);
+                    allreduce(hh.data(), j + 1);
+                    for (int i = 0; i <= j; i++) H[(size_t)i*m + j] += hh[i];
+                    check(mimsem_memcpy_h2d(c, h, hh.data(), (j + 1)*8), "h2d");
+                    check(mimsem_krylov_maxpy(c, j + 1, n, V, n, h, -1.0, w), "mimsem_krylov_maxpy");
+                }
+                nrm = std::sqrt(dot(wgt, n, w, w, tmp, h + m + 2));
+                H[(size_t)(j + 1)*m + j] = nrm;
+                if (!(nrm == nrm)) throw std::runtime_error("Shard::ritz: NaN in the Arnoldi process");
+                if (nrm <= 1.0e-14*std::fabs(H[0])) { kk = j + 1; break; }
+                check(mimsem_vec_combine(c, 1, n, 1.0/nrm, w, n, 0, nullptr, 0, 0.0, nullptr, 0, V + (size_t)(j + 1)*n, n), "mimsem_vec_combine");
+            }
+            std::vector<double> a((size_t)kk*kk), wr(kk), wi(kk);
+            for (int i = 0; i < kk; i++) for (int j = 0; j < kk; j++) a[(size_t)i*kk + j] = H[(size_t)i*m + j];
+            check(mimsem_hessenberg_eigenvalues(kk, a.data(), wr.data(), wi.data()), "mimsem_hessenberg_eigenvalues");
+            double lo = wr[0], hi = wr[0], im = 0.0;
+            for (int i = 0; i < kk; i++) { lo = std::min(lo, wr[i]); hi = std::max(hi, wr[i]); im = std::max(im, std::fabs(wi[i])); }
+            *re_min = lo; *re_max = hi; *im_max = im;
+        } catch (...) { mimsem_free(V); mimsem_free(w); mimsem_free(tmp); mimsem_free(h); throw; }
+        mimsem_free(V); mimsem_free(w); mimsem_free(tmp); mimsem_free(h);
+    }
+    Mesh* mesh; VecScatterHalo nodes; mimsem_halo* pair = nullptr;
+    double *own0 = nullptr, *own1 = nullptr, *ownx = nullptr;
+    long exchanges = 0, allreduces = 0;                                 // counters (tests: no all-reduce inside a solve)
+private:
+    allreduce_fn reduce; void* user;
+};
 
 // coefficient tables of the Chebyshev iterations (they depend on the spectral region and the step number only)
 namespace cheb {
@@ -61,14 +169,17 @@ public:
     double us_submit = 0.0, us_wait = 0.0; long replays = 0;      // host time inside the graph submissions / waiting for the check norms
 
     // fg: the Coriolis 0-form (SWEqn::coriolis, src/SWEqn_Picard.cpp:95-140), device, n0 entries; it must outlive the object
-    SWEqn(Mesh* m, const double* fg_dev) : mesh(m), fg(fg_dev), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
+    // shard (optional): this rank's exchanges and reductions when the sphere is dealt to several ranks -- fixed-length mode only (the KSP objects
+    // of the krylov mode iterate inside the library on one context's operator), eager launches with the exchanges in between (no graph)
+    SWEqn(Mesh* m, const double* fg_dev, Shard* shard = nullptr) : mesh(m), fg(fg_dev), sh(shard), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
+        if (sh) use_graph = false;
         if (const char* e = std::getenv("MIMSEM_SW_STEP2")) two_launch_steps = std::atoi(e) != 0;      // (A/B: scripts/ab_sw_cpp.sh)
         try {
-            for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um}) *p = mesh->device_alloc(n1);
+            for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &y1, &z1}) *p = mesh->device_alloc(n1);
             for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
-            for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj, &p0}) *p = mesh->device_alloc(n0);
-            for (double** p : {&xsave, &res, &bA, &rA, &dA, &rB, &dB}) *p = mesh->device_alloc((size_t)N);
+            for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj, &p0, &y0}) *p = mesh->device_alloc(n0);
+            for (double** p : {&xsave, &res, &bA, &rA, &dA, &rB, &dB, &yA, &zA}) *p = mesh->device_alloc((size_t)N);
             // the two vectors of a check (last residual | its reference) sit side by side: ONE two-row dot per check instead of two
             // (the second row starts at an even offset: 16-byte aligned like every other vector here)
             pair1 = mesh->device_alloc(2*even(n1)); upd1 = pair1; t1 = pair1 + even(n1);
@@ -77,6 +188,7 @@ public:
             chk = mesh->device_alloc(2*NSLOT);
             mimsem_ctx* c = mesh->ctx;
             check(mimsem_pvec(c, 0, 1, 1.0, nullptr, 0, m0, 0), "mimsem_pvec");                                   // M0 is diagonal (collocated 0-forms)
+            done0(m0);
             combine(n0, 1.0, m0, 1, fg, 0.0, nullptr, m0fg);                                                      // M0 f
             combine(n0, 1.0, m0, 2, m0, 0.0, nullptr, ones0);
             // ksp1: the 1-form mass matrix with one exact block per element (src/SWEqn_Picard.cpp:84-92)
@@ -112,6 +224,7 @@ public:
         check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hi_, 0, uj_, 0, hu, 0, 1.0/6.0), "UHMAT");
         check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj_, 0, ui_, 0, hu, 0, 1.0/6.0), "UHMAT");
         check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj_, 0, uj_, 0, hu, 0, 1.0/3.0), "UHMAT");
+        done1(hu);                                           // (sharded: the four local partial sums, ONE exchange)
         solve_M1(hu, F_);
     }
     void diagnose_Phi(const double* ui_, const double* uj_, const double* hi_, const double* hj_, double* Phi_) {     // :289-320
@@ -126,35 +239,55 @@ public:
     void diagnose_q(double dt_, const double* u_, const double* h_, double* q_) {
         mimsem_ctx* c = mesh->ctx;
         check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, u_, 0, t1, 0, 1.0), "UMAT");
-        check(mimsem_incidence_apply(c, 3, 1, t1, 0, rhs0, 0), "E01");
+        done1(t1);
+        check(mimsem_incidence_apply(c, 3, 1, t1, 0, rhs0, 0), "E01");                                         // (every edge counted by the element that owns it)
+        done0(rhs0);
         combine(n0, 1.0, m0fg, 0, nullptr, 1.0, rhs0, rhs0);
         check(mimsem_pvec(c, 0, 1, 1.0, h_, 0, m0h, 0), "mimsem_pvec");                                       // Phmat::assemble(h) is diagonal
+        done0(m0h);
         if (!(dt_ > 1.0e-6)) { combine(n0, 1.0, rhs0, 2, m0h, 0.0, nullptr, q_); return; }
         combine(n0, 1.0, ones0, 2, m0h, 0.0, nullptr, dinv);
         const double tau = 1.0/(1.0/(UP_TAU*dt_));
         if (inline_fixed && !qcoef.empty()) {
             zero(n0, q_); zero(n0, p0);
-            for (size_t k = 0; k < qcoef.size(); k++)
-                check(mimsem_op_chebyshev_sweep(c, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h_, 0, u_, 0, rhs0, 0, dinv, 0, qcoef[k].first, qcoef[k].second,
-                                                p0, 0, q_, 0, k + 1 == qcoef.size() ? upd0 : nullptr, 0), "mimsem_op_chebyshev_sweep");
+            for (size_t k = 0; k < qcoef.size(); k++) {
+                if (!sh) {
+                    check(mimsem_op_chebyshev_sweep(c, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h_, 0, u_, 0, rhs0, 0, dinv, 0, qcoef[k].first, qcoef[k].second,
+                                                    p0, 0, q_, 0, k + 1 == qcoef.size() ? upd0 : nullptr, 0), "mimsem_op_chebyshev_sweep");
+                    continue;
+                }
+                // sharded: the operator pass, its result completed over the halo, then the sweep's algebra  z = dinv (b - Op x); p = z + beta p; x += alpha p
+                check(mimsem_op_apply_up(c, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h_, 0, u_, 0, q_, 0, y0, 0, 1.0), "PHMAT_UP");
+                sh->complete0(y0);
+                combine(n0, -1.0, y0, 0, nullptr, 1.0, rhs0, y0);
+                combine(n0, 1.0, y0, 1, dinv, 0.0, nullptr, y0);
+                combine(n0, 1.0, y0, 0, nullptr, qcoef[k].second, p0, p0);
+                combine(n0, qcoef[k].first, p0, 0, nullptr, 1.0, q_, q_);
+                if (k + 1 == qcoef.size()) copy(n0, y0, upd0);
+            }
             combine(n0, 1.0, rhs0, 1, dinv, 0.0, nullptr, t0);
-            log(K_MASS, upd0, t0, n0);
+            log(K_MASS, upd0, t0, n0, sh ? sh->own0 : nullptr);
             return;
         }
+        if (sh) throw std::runtime_error("SWEqn (sharded): the upwinded potential-vorticity solve exists in the fixed-length mode only");
         q_h = h_; q_u = u_; q_tau = tau;
         ksp0.setOperatorsShell(n0, &SWEqn::apply_m0h_up, this); ksp0.setPCJacobi(dinv);
         ksp0.solve(rhs0, q_);
     }
+    int recalibrations = 0;              // (sharded) times the spectral regions were estimated again after a missed check
 
 private:
     void release() {
         for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj,
-                           &p0, &xsave, &res, &bA, &rA, &dA, &rB, &dB, &chk, &pair1, &pair0, &pairx}) { if (*p) mimsem_free(*p); *p = nullptr; }
+                           &p0, &xsave, &res, &bA, &rA, &dA, &rB, &dB, &chk, &pair1, &pair0, &pairx, &y1, &z1, &y0, &yA, &zA}) { if (*p) mimsem_free(*p); *p = nullptr; }
         t1 = upd1 = t0 = upd0 = x = dx = nullptr;
     }
     static constexpr int NSLOT = 16;
     enum LogKind { K_MASS = 1, K_A = 2, K_PICARD = 3 };
-    Mesh* mesh; const double* fg;
+    Mesh* mesh; const double* fg; Shard* sh = nullptr;
+    double *y1 = nullptr, *z1 = nullptr, *y0 = nullptr, *yA = nullptr, *zA = nullptr; double widen = 1.0;
+    void done1(double* v) { if (sh) sh->complete1(v); }      // element-local partial sums of a 1-form / 0-form result completed over the halo (one rank: nothing to do)
+    void done0(double* v) { if (sh) sh->complete0(v); }
     // (src/Assembly.h's Umat is built from (Topo*, Geom*); this one from the Mesh of a raw descriptor)
     struct MassOp : OperatorBase { explicit MassOp(Mesh* m) : OperatorBase(m, MIMSEM_OP_UMAT) {} void assemble() { up = false; field = nullptr; } };
     KSP ksp1, ksp0, kspA;
@@ -180,10 +313,16 @@ private:
     }
     void copy(long long n, const double* a, double* out) { combine(n, 1.0, a, 0, nullptr, 0.0, nullptr, out); }
     void zero(long long n, double* a) { check(mimsem_memset(mesh->ctx, a, 0, n*(long long)sizeof(double)), "mimsem_memset"); }
-    void log(int kind, const double* r, const double* ref, long long n) {
+    void log(int kind, const double* r, const double* ref, long long n, const double* wgt = nullptr) {
         if (slot >= NSLOT) throw std::runtime_error("SWEqn: check-norm slots exhausted");
         kinds[slot] = kind;
-        if (ref == r + even(n)) check(mimsem_krylov_rowdot(mesh->ctx, 2, n, r, (long long)even(n), r, (long long)even(n), chk + 2*slot), "mimsem_krylov_rowdot");     // (side by side: both norms in one call)
+        if (wgt) {           // sharded: this rank's ownership-weighted part of both norms; the whole log is all-reduced once per Picard iteration
+            double* tmp = n == n0 ? y0 : (n == n1 ? y1 : yA);
+            combine(n, 1.0, r, 1, wgt, 0.0, nullptr, tmp);
+            check(mimsem_krylov_rowdot(mesh->ctx, 1, n, tmp, n, r, n, chk + 2*slot), "mimsem_krylov_rowdot");
+            combine(n, 1.0, ref, 1, wgt, 0.0, nullptr, tmp);
+            check(mimsem_krylov_rowdot(mesh->ctx, 1, n, tmp, n, ref, n, chk + 2*slot + 1), "mimsem_krylov_rowdot");
+        } else if (ref == r + even(n)) check(mimsem_krylov_rowdot(mesh->ctx, 2, n, r, (long long)even(n), r, (long long)even(n), chk + 2*slot), "mimsem_krylov_rowdot");     // (side by side: both norms in one call)
         else {
             check(mimsem_krylov_rowdot(mesh->ctx, 1, n, r, n, r, n, chk + 2*slot), "mimsem_krylov_rowdot");
             check(mimsem_krylov_rowdot(mesh->ctx, 1, n, ref, n, ref, n, chk + 2*slot + 1), "mimsem_krylov_rowdot");
@@ -206,13 +345,28 @@ private:
         mimsem_ctx* c = mesh->ctx;
         if (inline_fixed) {
             zero(n1, out); zero(n1, p1);
-            for (size_t k = 0; k < coefM.size(); k++)
-                check(mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, blocks1, escale1, 0, b, 0, coefM[k].first, coefM[k].second,
-                                                   p1, 0, out, 0, k + 1 == coefM.size() ? upd1 : nullptr, 0), "mimsem_block_chebyshev_sweep");
+            for (size_t k = 0; k < coefM.size(); k++) {
+                if (!sh) {
+                    check(mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, blocks1, escale1, 0, b, 0, coefM[k].first, coefM[k].second,
+                                                       p1, 0, out, 0, k + 1 == coefM.size() ? upd1 : nullptr, 0), "mimsem_block_chebyshev_sweep");
+                    continue;
+                }
+                // sharded: z = P (b - M1 x) with both element-local sums completed over the halo; p = z + beta p; x += alpha p
+                check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, out, 0, y1, 0, 1.0), "UMAT");
+                sh->complete1(y1);
+                combine(n1, -1.0, y1, 0, nullptr, 1.0, b, y1);
+                check(mimsem_elem_blocks_apply(c, 1, 1, 0, blocks1, 0, escale1, 0, y1, 0, z1, 0, 1.0), "mimsem_elem_blocks_apply");
+                sh->complete1(z1);
+                combine(n1, 1.0, z1, 0, nullptr, coefM[k].second, p1, p1);
+                combine(n1, coefM[k].first, p1, 0, nullptr, 1.0, out, out);
+                if (k + 1 == coefM.size()) copy(n1, z1, upd1);
+            }
             check(mimsem_elem_blocks_apply(c, 1, 1, 0, blocks1, 0, escale1, 0, b, 0, t1, 0, 1.0), "mimsem_elem_blocks_apply");
-            log(K_MASS, upd1, t1, n1);
+            done1(t1);
+            log(K_MASS, upd1, t1, n1, sh ? sh->own1 : nullptr);
             return;
         }
+        if (sh) throw std::runtime_error("SWEqn (sharded): the 1-form mass solve exists in the fixed-length mode only");
         ksp1.solve(b, out);
     }
 
@@ -235,32 +389,56 @@ private:
         }
         if (!fixed_length) return;
         double lo, hi_, im;
-        kspA.ritz(40, &lo, &hi_, &im);
+        // (sharded: the host's own Arnoldi process on the COMPLETED operator -- the library's Ritz estimate sees one context's elements only)
+        const double mlo = 1.0 - 0.1*std::min(widen, 4.0), mhi = 1.0 + 0.05*widen;       // safety margins; a re-estimate after a missed check widens them
+        if (sh) sh->ritz(N, 40, sh->ownx, [&](const double* v, double* w) { apply_PA(a, v, w); }, [&](double* v) { sh->complete1(v); }, &lo, &hi_, &im);
+        else kspA.ritz(40, &lo, &hi_, &im);
         if (!(lo > 0.02 && im <= 0.15*(hi_ - lo))) return;
         kspA.pcBlocks(&blocksA);
-        const double lminA = 0.9*lo, lmaxA = 1.05*hi_;
+        const double lminA = mlo*lo, lmaxA = mhi*hi_;
         thetaA = 0.5*(lmaxA + lminA); deltaA = 0.5*(lmaxA - lminA);
         steps_A = std::max(2, (int)std::ceil(std::log(0.5*rtol)/std::log(cheb::interval_rate(lminA, lmaxA))) + 1);
-        ksp1.ritz(25, &lo, &hi_, &im);
-        if (!(lo > 0.02)) return;
         ksp1.pcBlocks(&blocks1, &escale1);
-        const double l1 = 0.90*lo, l2 = 1.05*hi_;
+        if (sh) sh->ritz(n1, 25, sh->own1, [&](const double* v, double* w) {
+                             check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, v, 0, y1, 0, 1.0), "UMAT"); sh->complete1(y1);
+                             check(mimsem_elem_blocks_apply(mesh->ctx, 1, 1, 0, blocks1, 0, escale1, 0, y1, 0, w, 0, 1.0), "mimsem_elem_blocks_apply"); sh->complete1(w); },
+                         [&](double* v) { sh->complete1(v); }, &lo, &hi_, &im, 4321);
+        else ksp1.ritz(25, &lo, &hi_, &im);
+        if (!(lo > 0.02)) return;
+        const double l1 = mlo*lo, l2 = mhi*hi_;
         steps_M1 = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/cheb::interval_rate(l1, l2))));
         coefM = cheb::ellipse(0.5*(l1 + l2), 0.25*(l2 - l1)*(l2 - l1), steps_M1);
         qcoef.clear(); steps_q = 0;
         if (!q_exact) {
             // the upwinded lumped 0-form mass under its diagonal: 1 +- i sigma (the upwinding is a skew perturbation of the identity)
             check(mimsem_pvec(mesh->ctx, 0, 1, 1.0, hn, 0, m0h, 0), "mimsem_pvec");
+            done0(m0h);
             combine(n0, 1.0, ones0, 2, m0h, 0.0, nullptr, dinv);
             q_h = hn; q_u = un; q_tau = 1.0/(1.0/(UP_TAU*dt));
-            ksp0.setOperatorsShell(n0, &SWEqn::apply_m0h_up, this); ksp0.setPCJacobi(dinv);
-            ksp0.ritz(40, &lo, &hi_, &im);
-            const double d0 = 0.5*(hi_ + lo), a_re = 0.5*(hi_ - lo)*1.5 + 0.01, a_im = im*1.2 + 0.01, rate = cheb::ellipse_rate(d0, a_re, a_im);
+            if (sh) sh->ritz(n0, 40, sh->own0, [&](const double* v, double* w) {
+                                 check(mimsem_op_apply_up(mesh->ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, q_tau, 0, q_h, 0, q_u, 0, v, 0, w, 0, 1.0), "PHMAT_UP"); sh->complete0(w);
+                                 combine(n0, 1.0, w, 1, dinv, 0.0, nullptr, w); },
+                             [&](double* v) { sh->complete0(v); }, &lo, &hi_, &im);
+            else {
+                ksp0.setOperatorsShell(n0, &SWEqn::apply_m0h_up, this); ksp0.setPCJacobi(dinv);
+                ksp0.ritz(40, &lo, &hi_, &im);
+            }
+            const double d0 = 0.5*(hi_ + lo), a_re = 0.5*(hi_ - lo)*1.5*widen + 0.01, a_im = im*1.2*widen + 0.01, rate = cheb::ellipse_rate(d0, a_re, a_im);
             if (!(d0 > 0.2 && rate < 0.6)) return;
             steps_q = std::max(2, (int)std::ceil(std::log(0.5*rtol)/std::log(rate)) + 1);
             qcoef = cheb::ellipse(d0, a_re*a_re - a_im*a_im, steps_q);
         }
         can_fix = true;
+    }
+
+    // sharded: w = P A v on packed [u|h] rows with both element-local sums completed over the halo (element pass + gather, EXCHANGE, block pass +
+    // gather, EXCHANGE: what one context does in three launches without ever assembling A v)
+    void apply_PA(double a, const double* v, double* w) {
+        mimsem_ctx* c = mesh->ctx;
+        check(mimsem_sw_operator_apply(c, 1, a, grav, H_MEAN, fg, 0, v, 0, yA, 0), "mimsem_sw_operator_apply");
+        sh->complete1(yA);
+        check(mimsem_sw_blocks_apply(c, 1, blocksA, yA, 0, w, 0), "mimsem_sw_blocks_apply");
+        sh->complete1(w);
     }
 
     // assemble_residual (:402-607) + KSPSolve(kspA, -f, dx) + x += dx (:751-757) on the member arrays
@@ -289,6 +467,7 @@ private:
         combine(n1, 1.0, uj, 0, nullptr, -1.0, ui, t1);
         check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, t1, 0, res, 0, 1.0), "UMAT");
         combine(n1, dt, fu, 0, nullptr, 1.0, res, res);
+        done1(res);                                          // (sharded: E12 Phi, the rotational terms and M1 (uj - ui) were all LOCAL partial sums: one exchange for the lot)
         check(mimsem_incidence_apply(c, 1, 1, F, 0, t2, 0), "E21");
         combine(n2, 1.0, hj, 0, nullptr, -1.0, hi, t2b);
         combine(n2, dt, t2, 0, nullptr, 1.0, t2b, t2b);
@@ -297,11 +476,21 @@ private:
         if (inline_fixed) {
             const double a = ROS_ALPHA*dt, sigma1 = thetaA/deltaA;
             check(mimsem_sw_blocks_apply(c, 1, blocksA, bA, 0, rA, 0), "mimsem_sw_blocks_apply");
-            check(mimsem_krylov_rowdot(c, 1, N, rA, N, rA, N, chk + 2*slot + 1), "mimsem_krylov_rowdot");
+            done1(rA);
+            if (sh) { combine(N, 1.0, rA, 1, sh->ownx, 0.0, nullptr, zA); check(mimsem_krylov_rowdot(c, 1, N, zA, N, rA, N, chk + 2*slot + 1), "mimsem_krylov_rowdot"); }
+            else check(mimsem_krylov_rowdot(c, 1, N, rA, N, rA, N, chk + 2*slot + 1), "mimsem_krylov_rowdot");
             zero(N, dx);
             combine(N, 1.0/thetaA, rA, 0, nullptr, 0.0, nullptr, dA);
             double rho = 1.0/sigma1;
-            if (two_launch_steps) {
+            if (sh) {
+                // sharded: a step = P A d with its two exchanges, then ONE update launch  x += d; r -= P A d; d = ca d + cb r  -- no inner product
+                for (int k = 0; k < steps_A; k++) {
+                    const double rho_new = 1.0/(2.0*sigma1 - rho);
+                    apply_PA(a, dA, zA);
+                    check(mimsem_krylov_chebyshev_update(c, 1, N, rho_new*rho, 2.0*rho_new/deltaA, zA, N, dx, N, rA, N, dA, N), "mimsem_krylov_chebyshev_update");
+                    rho = rho_new;
+                }
+            } else if (two_launch_steps) {
                 // the 1-form part of a step's update rides in the element pass of the next step: r and d alternate between two pairs of arrays
                 double *rin = rA, *din = dA, *rout = rB, *dout = dB, pca = 0.0, pcb = 0.0;
                 for (int k = 0; k < steps_A; k++) {
@@ -320,13 +509,15 @@ private:
                       "mimsem_sw_operator_precond_chebyshev");
                 rho = rho_new;
             }
-            check(mimsem_krylov_rowdot(c, 1, N, rA, N, rA, N, chk + 2*slot), "mimsem_krylov_rowdot");
+            if (sh) { combine(N, 1.0, rA, 1, sh->ownx, 0.0, nullptr, zA); check(mimsem_krylov_rowdot(c, 1, N, zA, N, rA, N, chk + 2*slot), "mimsem_krylov_rowdot"); }
+            else check(mimsem_krylov_rowdot(c, 1, N, rA, N, rA, N, chk + 2*slot), "mimsem_krylov_rowdot");
             kinds[slot++] = K_A;
         } else {
+            if (sh) throw std::runtime_error("SWEqn (sharded): the [u|h] solve exists in the fixed-length mode only");
             kspA.solve(bA, dx);
         }
         combine(N, 1.0, dx, 0, nullptr, 1.0, x, x);
-        log(K_PICARD, dx, x, N);
+        log(K_PICARD, dx, x, N, sh ? sh->ownx : nullptr);
     }
 
     // one Picard iteration; returns |dx| / |x|
@@ -347,6 +538,7 @@ private:
             }
             inline_fixed = false;
             mesh->to_host(v, chk, 2*NSLOT);
+            if (sh) sh->allreduce(v, 2*nslots_of[g]);          // the ONE all-reduce of a Picard iteration: every check norm was a rank-local, ownership-weighted sum
             if (replay) {
                 const auto t2 = std::chrono::steady_clock::now();
                 us_submit += std::chrono::duration<double, std::micro>(t1 - t0).count(); us_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
@@ -371,9 +563,22 @@ private:
                 return norm;
             }
             fallbacks++;
-            if (++misses >= 3) can_fix = false;                // three iterations in a row: the spectral regions no longer hold -- the KSP objects from here on
             copy(N, xsave, x);
+            if (sh) {
+                // sharded: no Krylov mode to hand the iteration to.  The regions were estimated on an earlier state: estimate them again from the
+                // start-of-step state with wider margins and take the iteration again (every rank takes this branch: the norms were all-reduced)
+                if (++misses >= 3) throw std::runtime_error("SWEqn (sharded): three Picard iterations in a row missed their checks after re-estimating the spectral regions");
+                recalibrations++;
+                widen += 0.5;
+                const int keep = misses;
+                setup(dt, qx, bt, ui, hi);
+                misses = keep;
+                if (!can_fix) throw std::runtime_error("SWEqn (sharded): the spectral regions do not admit the fixed-length solves");
+                return iteration(first);
+            }
+            if (++misses >= 3) can_fix = false;                // three iterations in a row: the spectral regions no longer hold -- the KSP objects from here on
         }
+        if (sh) throw std::runtime_error("SWEqn (sharded): the spectral regions do not admit the fixed-length solves (no Krylov mode on a shard)");
         body(first);
         mesh->to_host(v, chk, 2*NSLOT);
         const int k = slot - 1;                                // the Picard norms are the last slot logged

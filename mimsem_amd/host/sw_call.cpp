@@ -3,16 +3,31 @@
 // per Picard iteration) and with the KSP objects (the reference's structure).  Built by __graft_entry__.build(), run as a child of bench.py.
 //   usage: sw_call <case.bin> [warm-up steps]      prints one JSON object
 #include <chrono>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
+#include <execinfo.h>
+#include <unistd.h>
 #include "mimsem_sweqn.hpp"
 #include "sw_io.hpp"
 
 using namespace mimsem_host;
 using clk = std::chrono::steady_clock;
 
+// MIMSEM_BACKTRACE=1: the frames of a fatal signal on stderr (module + offset), so that a crash under a profiler can be attributed to the tool's
+// library or to this one from ONE run (round 5 left a SIGSEGV of this program under rocprofv3 --kernel-trace unexplained: scripts/prof_sw_cpp.sh)
+static void on_fatal(int sig) {
+    void* fr[64];
+    const int n = backtrace(fr, 64);
+    const char msg[] = "sw_call: fatal signal, frames of the faulting thread:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(fr, n, 2);
+    signal(sig, SIG_DFL); raise(sig);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: sw_call case.bin [warm-up steps]\n"); return 2; }
+    if (const char* e = std::getenv("MIMSEM_BACKTRACE")) if (std::atoi(e)) { signal(SIGSEGV, on_fatal); signal(SIGBUS, on_fatal); signal(SIGABRT, on_fatal); }
     const int warm = argc > 2 ? std::atoi(argv[2]) : 3;
     try {
         const SWCase cs = read_sw_case(argv[1]);

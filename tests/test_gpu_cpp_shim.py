@@ -8,9 +8,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp, name="test_shim"):
+def _build(tmp, name="test_shim", extra=()):
     exe = os.path.join(tmp, name)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", *extra, os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L" + os.path.join(ROOT, "mimsem_amd"), "-lmimsem_hip", "-L" + os.path.join(ROOT, "oracle"), "-loracle",
                            "-Wl,-rpath," + os.path.join(ROOT, "mimsem_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
                            "-Wl,-rpath,/opt/rocm/lib"])
@@ -27,6 +27,7 @@ def test_shim_compiles_and_links(tmp_path, oracle):
     assert os.path.exists(_build(str(tmp_path), "test_sw"))
     assert os.path.exists(_build(str(tmp_path), "test_horiz"))
     assert os.path.exists(_build(str(tmp_path), "test_vert"))
+    assert os.path.exists(_build(str(tmp_path), "test_sw_sharded", ["-pthread"]))
 
 
 @pytest.mark.gpu
@@ -224,3 +225,80 @@ def test_vertical_newton_loop_driven_from_cpp(tmp_path, oracle, patch):
         for hd, ho in zip(hist, want[4]):
             for j, k in enumerate(("exner", "w", "rho", "eta")):
                 assert abs(hd[j] - ho[k]) <= 1e-5 * ho[k] + 1e-15, (k, hd[j], ho[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sw_step_driven_from_cpp(tmp_path, oracle, world):
+    """N3 on several ranks from C++ (round 6): src::SWEqn over a Shard (mimsem_sweqn.hpp) -- the fixed-length Chebyshev solves with the halo
+    exchanges inside, ONE all-reduce of the check norms per Picard iteration, the spectral regions from the host's own all-reduced Arnoldi
+    process -- with the ranks as threads of one process on the one GPU (tests/cpp/test_sw_sharded.cpp).  Three Galewsky-style steps against the
+    one-context run of the Python host: state to 1e-10, the executable itself asserts the all-reduce count and that no check missed."""
+    import numpy as np
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.partition import build_plans, patches_of_rank
+    from mimsem_amd.sweqn import SWEqn, williamson2
+    from mimsem_amd.topo import Topo
+    from mimsem_amd.workloads import mesh_arrays, write_arrays
+    pn, ne, npatch, nsteps = 3, 4, 6, 3
+    cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+
+    def build(pids):
+        topos = [Topo(cs, p, 1) for p in pids]
+        geoms = [Geom(t, cs, coords, 1, signed_det=True) for t in topos]
+        for g in geoms:
+            g.set_levels(np.stack([np.zeros(g.n0), np.ones(g.n0)]))
+        dm = DeviceMesh(topos, geoms, nk=1, numbering="global")
+        xq = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
+        for g in geoms:
+            xq[g.loc0] = coords[g.loc0]
+        return dm, xq[dm.gidq]
+    dm1, xq1 = build(list(range(npatch)))
+    eng1 = Engine(dm1)
+    S1 = SWEqn(eng1, xq1)
+    uq, hq = williamson2(torch.as_tensor(xq1, device=eng1.device), alpha=0.0)
+    lam = torch.atan2(torch.as_tensor(xq1[:, 1]), torch.as_tensor(xq1[:, 0])).to(eng1.device)
+    uq = uq + torch.stack([3.0 * torch.sin(2 * lam), 2.0 * torch.cos(lam)], dim=1)            # perturbed: every term active
+    u0, h0 = S1.init1(uq), S1.init2(hq)
+    u, h = u0, h0
+    for _ in range(nsteps):
+        u, h = S1.solve(u, h, 360.0, nits=2, q_exact=False)
+    assert S1.fixed_iterations == 2 * nsteps
+    fg = S1.fg[0].cpu().numpy(); ug0 = u0[0].cpu().numpy(); hg0 = h0[0].cpu().numpy()
+    want_u, want_h = u[0].cpu().numpy(), h[0].cpu().numpy()
+    dms = []
+    for rank in range(world):
+        dm, _ = build(patches_of_rank(npatch, world, rank))
+        p0, p1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)
+        ranks = p1.neighbours()
+        assert ranks == p0.neighbours() and len(ranks) == world - 1
+        empty = np.zeros(0, np.int32)
+
+        def lists(by_rank):
+            off = np.zeros(len(ranks) + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(by_rank.get(r, empty)) for r in ranks])
+            return np.concatenate([by_rank.get(r, empty) for r in ranks]).astype(np.int32), off
+        arr = mesh_arrays(dm)
+        g1, g1o = lists(p1.ghost_slots); m1, m1o = lists(p1.mirror_slots); g0, g0o = lists(p0.ghost_slots); m0, m0o = lists(p0.mirror_slots)
+        arr.update(ranks=np.asarray(ranks, np.int32), ghost1=g1, ghost1_off=g1o, mirror1=m1, mirror1_off=m1o, ghost0=g0, ghost0_off=g0o, mirror0=m0,
+                   mirror0_off=m0o, own0=p0.owned.astype(np.float64), own1=p1.owned.astype(np.float64), fg=fg[dm.gid0], u=ug0[dm.gid1], h=hg0[dm.gid2],
+                   params=np.array([360.0, 2.0, 0.0]))
+        write_arrays(str(tmp_path / ("rank%d.arr" % rank)), arr)
+        dms.append(dm)
+    out = subprocess.run([_build(str(tmp_path), "test_sw_sharded", ["-pthread"]), str(world), str(tmp_path / "rank"), str(tmp_path / "out"), str(nsteps)],
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "DONE" in out.stdout
+    got_u = np.full(cs.nDofs1G, np.nan); got_h = np.full(cs.nDofs2G, np.nan)
+    for rank, dm in enumerate(dms):
+        res = np.fromfile(str(tmp_path / ("out%d.bin" % rank)), dtype=np.float64)
+        ul, hl = res[:dm.n1], res[dm.n1:]
+        # every copy of a shared DoF agrees with the one-context value (ghosts included)
+        assert np.linalg.norm(ul - want_u[dm.gid1]) <= 1e-10 * np.linalg.norm(want_u[dm.gid1]), rank
+        got_u[dm.gid1] = ul; got_h[dm.gid2] = hl
+    eu = np.linalg.norm(got_u - want_u) / np.linalg.norm(want_u); eh = np.linalg.norm(got_h - want_h) / np.linalg.norm(want_h)
+    print("C++ sharded SW step, world %d: |u - u_1ctx| = %.2e  |h - h_1ctx| = %.2e" % (world, eu, eh))
+    assert eu < 1e-10 and eh < 1e-11 and np.linalg.norm(want_u - ug0) > 0

@@ -128,3 +128,51 @@ def test_workspace_growth_inside_a_capture_is_refused():
     # the context is still usable afterwards
     d = eng.solve_schur_eta(75.0, *cols, *F)
     assert all(bool(torch.isfinite(v).all()) for v in d)
+
+
+def test_c_abi_graph_replays_hold_no_growing_state():
+    """what does the library do PER REPLAY of a graph recorded through mimsem_graph_*?  By reading (csrc/api.hip): one
+    hipGraphLaunch on the recording's stream, nothing created, nothing retired; the host's read of the check norms goes through one pinned
+    4 KB buffer allocated once.  This test holds it to that: 1 000 replays of a recorded operator sequence with the C++ hosts' read-back
+    pattern (mimsem_memcpy_d2h of a few scalars after every replay) -- workspace bytes, open handles and resident memory stay where they were,
+    and the result of the last replay equals the first."""
+    import ctypes as C
+    import os
+    import psutil
+    import torch
+    from mimsem_amd._lib import check
+    dm, eng = _engine()
+    L = eng.L
+    rng = np.random.default_rng(3)
+    x = eng.tensor(rng.standard_normal((4, dm.n1))); y = eng.zeros(4, dm.n1); z = eng.zeros(4, dm.n2)
+    nrm = eng.zeros(4)
+
+    def seq():
+        eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)
+        eng.apply("WTQUMAT", y, f=x, lev0=0, scale=SCALE, out=z)
+        eng.rowdot(y, y, out=nrm)
+    seq(); eng.sync()                                       # (workspaces reach their size outside the recording)
+    check(L.mimsem_ctx_use_own_stream(eng.ctx), "use_own_stream")
+    seq(); eng.sync()
+    g = C.c_void_p()
+    check(L.mimsem_graph_begin(eng.ctx), "graph_begin")
+    seq()
+    check(L.mimsem_graph_end(eng.ctx, C.byref(g)), "graph_end")
+    host = (C.c_double * 4)()
+    first = None
+    proc = psutil.Process()
+    ws0 = L.mimsem_ctx_workspace_bytes(eng.ctx)
+    for k in range(1100):
+        check(L.mimsem_graph_launch(g), "graph_launch")
+        check(L.mimsem_memcpy_d2h(eng.ctx, host, nrm.data_ptr(), 32), "d2h")
+        if k == 0:
+            first = list(host)
+        if k == 99:                                         # (the first replays settle the runtime's own pools)
+            rss0, fd0 = proc.memory_info().rss, len(os.listdir("/proc/self/fd"))
+    rss1, fd1 = proc.memory_info().rss, len(os.listdir("/proc/self/fd"))
+    assert list(host) == first and all(v > 0 for v in first)
+    assert L.mimsem_ctx_workspace_bytes(eng.ctx) == ws0
+    assert fd1 == fd0, (fd0, fd1)
+    assert rss1 - rss0 < 8 << 20, (rss0, rss1)
+    L.mimsem_graph_destroy(g)
+    eng.use_stream(torch.cuda.current_stream(eng.device))
