@@ -639,6 +639,20 @@ int  mimsem_halo_set_rccl(mimsem_halo* plan, void* nccl_comm);        /* ncclCom
 int  mimsem_halo_use_rccl_library(void* dl_handle);
 int  mimsem_halo_set_transport(mimsem_halo* plan, mimsem_halo_transport_fn fn, void* user);
 int  mimsem_halo_set_loopback(mimsem_halo* plan);
+/* ONE-SIDED transport (round 6; replaces the same VecScatterBegin/End, eul/Assembly.cpp:2194-2195, eul/Euler_2.cpp:1455-1456): the plan's
+ * receive buffer is exported with hipIpcGetMemHandle and opened by the neighbour ranks; mimsem_halo_begin then packs every message STRAIGHT
+ * INTO the neighbour's receive buffer (xGMI between the GPUs of a node) and publishes a per-exchange sequence number into its arrival flags,
+ * mimsem_halo_end waits for the flags of all neighbours in a one-wavefront kernel and unpacks -- kernels only, no library call and no
+ * communication stream on the critical path, recordable in a hipGraph (mimsem_graph_begin/_end) with the solver around it.  Set-up, once
+ * per plan: every rank calls _peer_export, the host exchanges the blobs (MPI_Allgather of MIMSEM_HALO_PEER_BLOB bytes per rank and plan),
+ * then every rank calls _set_peer with its neighbours' blobs in the plan's neighbour order.  Ranks of one node, one process per rank
+ * (a rank may list itself: its own buffer).  The wait is bounded (~2 s): _peer_status reports an exchange that gave up.
+ * Status: verified between processes on ONE GPU, bit-equal to the callback transport; not yet A/B-ed against RCCL between GPUs --
+ * RCCL stays the default transport of the hosts.                                                                                       */
+#define MIMSEM_HALO_PEER_BLOB 1024
+int  mimsem_halo_peer_export(mimsem_halo* plan, int my_rank, void* blob /* MIMSEM_HALO_PEER_BLOB bytes, host */);
+int  mimsem_halo_set_peer(mimsem_halo* plan, int my_rank, const void* neighbour_blobs /* nneigh x MIMSEM_HALO_PEER_BLOB bytes, host */);
+int  mimsem_halo_peer_status(mimsem_halo* plan, unsigned long long* timed_out_seq);
 int  mimsem_halo_begin(mimsem_halo* plan, int mode, int nlev, double* v, long long v_stride);
 int  mimsem_halo_end(mimsem_halo* plan);
 
@@ -671,8 +685,10 @@ int  mimsem_ksp_ritz(mimsem_ksp* ksp, int m, double* re_min, double* re_max, dou
  * capture (a context on the default stream gets a stream of its own for the duration), every call of this library made on the context
  * until mimsem_graph_end is recorded instead of executed -- calls that synchronise, copy to pageable host memory or would have to grow a
  * workspace return MIMSEM_ERR_STATE (run the sequence once un-captured first) -- and mimsem_graph_launch replays the whole sequence with
- * one submission, in stream order with the context's other work.  Pointers are baked in: the replay reads and writes the same
- * arrays (VecGetArray of the same Vecs).  Replaces: nothing in the reference (PETSc has no such facility); it is what "capture
+ * one submission, in stream order with the context's other work: on the context's CURRENT stream (a later mimsem_ctx_set_stream /
+ * _use_own_stream moves the replays with it; only a recording made on the capture stream lent to a default-stream context stays there).
+ * A recording belongs to its context: after mimsem_ctx_destroy its launch returns MIMSEM_ERR_STATE (destroy it all the same).
+ * Pointers are baked in: the replay reads and writes the same arrays (VecGetArray of the same Vecs).  Replaces: nothing in the reference (PETSc has no such facility); it is what "capture
  * launch-bound inner loops in hipGraphs" means for a host behind this C ABI.
  * Errors: MIMSEM_ERR_STATE (begin while capturing, end without begin, a capture invalidated by an illegal call), MIMSEM_ERR_HIP. */
 typedef struct mimsem_graph mimsem_graph;

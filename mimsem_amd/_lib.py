@@ -136,6 +136,9 @@ _SIGS = {
     "mimsem_krylov_gs_control": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_column_solve_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     "mimsem_column_set_pivot_fallback": (C.c_int, [C.c_void_p, C.c_int]),
+    "mimsem_halo_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mimsem_halo_set_peer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mimsem_halo_peer_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mimsem_hessenberg_eigenvalues": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_column_flag_for_test": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mimsem_krylov_chebyshev_update": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
@@ -154,6 +157,7 @@ _SIGS = {
 }
 
 # signature of the host transport of mimsem_halo_set_transport (include/mimsem_hip.h: mimsem_halo_transport_fn)
+HALO_PEER_BLOB = 1024        # MIMSEM_HALO_PEER_BLOB
 HALO_TRANSPORT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p, C.POINTER(C.c_longlong), C.c_int,
                              C.POINTER(C.c_int), C.c_void_p)
 

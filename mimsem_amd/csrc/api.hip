@@ -832,6 +832,8 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") ? atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
     if (d->nEl > 0) { c->h_e1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_e1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
                       c->h_e0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e); }
+    c->memset_node = getenv("MIMSEM_MEMSET_NODE") && atoi(getenv("MIMSEM_MEMSET_NODE")) != 0;      // (read once: mimsem_memset is a hot call of the recorded solves)
+    c->blu_stop = getenv("MIMSEM_BLU_STOP") ? atoi(getenv("MIMSEM_BLU_STOP")) : 0;
     c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 1;      // on by default since round 5 (mimsem_column_set_pivot_fallback)
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
         c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
@@ -857,9 +859,12 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     return MIMSEM_OK;
 }
 
+struct mimsem_graph;
+static void orphan_graphs(mimsem_ctx* c);
 void mimsem_ctx_destroy(mimsem_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    orphan_graphs(c);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
                     c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
@@ -889,7 +894,11 @@ int mimsem_ctx_use_own_stream(mimsem_ctx* c) {
     return MIMSEM_OK;
 }
 // ---- hipGraph capture for hosts without a HIP toolchain (include/mimsem_hip.h) -----------------------------------------------------
-struct mimsem_graph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t stream = nullptr; int nodes = 0; };
+// A recording belongs to the context it was made on (advisor, round 5): it replays on the context's CURRENT stream -- so that "in stream order
+// with the context's other work" stays true after mimsem_ctx_set_stream / _use_own_stream -- except that a recording made on the capture
+// stream a default-stream context was lent keeps that stream (the legacy default stream cannot launch graphs in order with it either way);
+// mimsem_ctx_destroy orphans the recordings still alive: their launch returns MIMSEM_ERR_STATE instead of using a destroyed stream.
+struct mimsem_graph { hipGraph_t g = nullptr; hipGraphExec_t x = nullptr; hipStream_t stream = nullptr; int nodes = 0; mimsem_ctx* c = nullptr; bool lent = false; };
 int mimsem_graph_begin(mimsem_ctx* c) {
     if (!c) return MIMSEM_ERR_ARG;
     if (c->cap_active || c->is_capturing()) return MIMSEM_ERR_STATE;
@@ -918,22 +927,26 @@ int mimsem_graph_end(mimsem_ctx* c, mimsem_graph** out) {
     if (c->cap_swapped) { c->stream = c->cap_saved; c->cap_swapped = false; }
     if (he != hipSuccess || !g) { (void)hipGetLastError(); return he == hipSuccess ? MIMSEM_ERR_STATE : mimsem::hip_fail(he, "hipStreamEndCapture"); }
     mimsem_graph* gr = new mimsem_graph();
-    gr->g = g; gr->stream = used;
+    gr->g = g; gr->stream = used; gr->c = c; gr->lent = used != c->stream;
     size_t nn = 0;
     if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) gr->nodes = (int)nn;
     const hipError_t hi = hipGraphInstantiate(&gr->x, g, nullptr, nullptr, 0);
     if (hi != hipSuccess) { (void)hipGraphDestroy(g); delete gr; return mimsem::hip_fail(hi, "hipGraphInstantiate"); }
+    c->graphs.push_back(gr);
     *out = gr;
     return MIMSEM_OK;
 }
 int mimsem_graph_launch(mimsem_graph* g) {
     if (!g || !g->x) return MIMSEM_ERR_ARG;
-    MIMSEM_HIP_TRY(hipGraphLaunch(g->x, g->stream));
+    if (!g->c) return MIMSEM_ERR_STATE;                                  // its context is gone
+    MIMSEM_HIP_TRY(hipGraphLaunch(g->x, (g->lent || g->c->stream == nullptr) ? g->stream : g->c->stream));
     return MIMSEM_OK;
 }
 int mimsem_graph_num_nodes(const mimsem_graph* g) { return g ? g->nodes : MIMSEM_ERR_ARG; }
+static void orphan_graphs(mimsem_ctx* c) { for (void* p : c->graphs) ((mimsem_graph*)p)->c = nullptr; c->graphs.clear(); }
 void mimsem_graph_destroy(mimsem_graph* g) {
     if (!g) return;
+    if (g->c) { auto& v = g->c->graphs; v.erase(std::remove(v.begin(), v.end(), (void*)g), v.end()); }
     if (g->x) (void)hipGraphExecDestroy(g->x);
     if (g->g) (void)hipGraphDestroy(g->g);
     delete g;
@@ -1045,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_fill64(long long n, unsigned long long 
 int mimsem_memset(mimsem_ctx* c, void* dev, int byte, long long bytes) {
     if (!c || !dev || bytes < 0) return MIMSEM_ERR_ARG;
     if (bytes == 0) return MIMSEM_OK;
-    if (bytes % 8 == 0 && ((uintptr_t)dev & 7u) == 0 && !(getenv("MIMSEM_MEMSET_NODE") && atoi(getenv("MIMSEM_MEMSET_NODE")) != 0)) {
+    if (bytes % 8 == 0 && ((uintptr_t)dev & 7u) == 0 && !c->memset_node) {
         const unsigned long long v = 0x0101010101010101ull*(unsigned long long)(unsigned char)byte;
         const long long n = bytes/8;
         hipLaunchKernelGGL(k_fill64, dim3((unsigned)((n + 255)/256)), dim3(256), 0, c->stream, n, v, (unsigned long long*)dev);

@@ -118,6 +118,8 @@ struct mimsem_ctx {
     double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
     int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
+    std::vector<void*> graphs;  // the recordings (mimsem_graph*) made on this context and still alive: orphaned by mimsem_ctx_destroy
+    bool memset_node = false; int blu_stop = 0;      // MIMSEM_MEMSET_NODE / MIMSEM_BLU_STOP, read once at creation
     std::vector<char> h_halo1;  // [n1] 1 = the 1-form slot takes part in a halo exchange (mimsem_ctx_set_halo_slots): its second element lives on another rank
     int* d_forceflag = nullptr; int n_forceflag = 0;      // mimsem_column_flag_for_test: columns the next solve treats as flagged (one-shot)
     int pivot_fallback = 1;     // mimsem_column_set_pivot_fallback: flagged columns are re-solved by a band LU with partial pivoting (column_pivot.inc)

@@ -7,9 +7,18 @@
 //   end  : the context's stream waits for the transport's event -> unpack (INSERT, or ADD in rank-ordered ranges so that sums
 //          whose targets repeat between neighbours are formed in a fixed order).
 // Transports: RCCL (grouped ncclSend/ncclRecv over xGMI; librccl is dlopen'ed on first use -- the process's already-loaded copy when
-// there is one --, the communicator is the host's), a host callback (GPU-aware MPI, torch.distributed, a test double), or loop-back
-// (a plan whose only neighbour is the rank itself: periodic single-rank layouts and tests).
+// there is one --, the communicator is the host's), a host callback (GPU-aware MPI, torch.distributed, a test double), loop-back
+// (a plan whose only neighbour is the rank itself: periodic single-rank layouts and tests), or -- round 6 -- ONE-SIDED ("peer"):
+//   the receive buffers are exported with hipIpcGetMemHandle and opened by the neighbour ranks when the plan is connected; begin's pack
+//   kernel writes every message STRAIGHT INTO the neighbour's receive buffer (over xGMI between GPUs of a node) and a one-wavefront kernel
+//   behind it publishes the exchange's sequence number into the neighbour's arrival flags (system-scope release); end's unpack is preceded
+//   by a one-wavefront kernel that waits for the flags of all neighbours (system-scope acquire, bounded spin).  No library call on the
+//   critical path, no communication stream, and nothing but kernel nodes -- the exchange can be recorded in a hipGraph with the solver
+//   around it, which a kB-sized message inside a 20 us step needs to have any chance against an RCCL launch.  Receive buffers are double
+//   (exchange parity): a neighbour may already write exchange k + 1 while this rank still unpacks exchange k; it cannot reach k + 2 before
+//   it has seen this rank's message k + 1, which this rank packs after that unpack (stream order).
 #include <dlfcn.h>
+#include <cstring>
 #include <mutex>
 #include <set>
 #include <vector>
@@ -24,7 +33,15 @@ struct mimsem_halo {
     double *d_send = nullptr, *d_recv = nullptr;
     hipStream_t comm = nullptr;
     hipEvent_t ev_packed = nullptr, ev_done = nullptr;
-    int transport = 0;                                       // 0 none, 1 callback, 2 loop-back, 3 RCCL
+    int transport = 0;                                       // 0 none, 1 callback, 2 loop-back, 3 RCCL, 4 one-sided (peer)
+    // ---- one-sided transport: [2][nr*max_nlev] doubles of receive buffer + MIMSEM_HALO_MAX_SEGMENTS arrival flags + 1 error word, ONE allocation (one IPC handle)
+    double* d_peer = nullptr; size_t peer_half = 0;          // doubles per half
+    unsigned long long* d_flags = nullptr;                   // my arrival flags [MAX_SEGMENTS] + error word, inside d_peer
+    void* peer_base[MIMSEM_HALO_MAX_SEGMENTS] = {};          // neighbours' allocations as opened here (hipIpcOpenMemHandle)
+    size_t peer_half_of[MIMSEM_HALO_MAX_SEGMENTS] = {};      // their doubles per half
+    long long peer_off[MIMSEM_HALO_MAX_SEGMENTS] = {};       // where MY message starts in neighbour i's buffer (slots per level)
+    int peer_slot[MIMSEM_HALO_MAX_SEGMENTS] = {};            // which of neighbour i's flags is mine
+    int my_rank = -1;
     mimsem_halo_transport_fn fn = nullptr; void* user = nullptr;
     void* nccl_comm = nullptr;
     // state of the exchange in flight
@@ -63,6 +80,73 @@ Rccl& rccl() {
     return g_rccl;
 }
 constexpr int kNcclFloat64 = 8;                                       // ncclDataType_t: ncclDouble
+
+// ---- one-sided transport: kernels ------------------------------------------------------------------------------------------------------
+struct PeerSegs { int nseg; int off[MIMSEM_HALO_MAX_SEGMENTS + 1]; double* dst[MIMSEM_HALO_MAX_SEGMENTS]; long long half[MIMSEM_HALO_MAX_SEGMENTS]; };
+// The exchange counter lives in DEVICE memory (word SEQ of the flag block) and is advanced by the publish kernel: nothing of an exchange is
+// baked into kernel arguments, so a recorded exchange replays correctly (exchange k of a replay uses parity and sequence number k).
+constexpr int PEER_ERR = MIMSEM_HALO_MAX_SEGMENTS, PEER_SEQ = MIMSEM_HALO_MAX_SEGMENTS + 1, PEER_WORDS = MIMSEM_HALO_MAX_SEGMENTS + 2;
+// pack: entry (level, slot j of segment s) of v goes to neighbour s's receive buffer (the half of this exchange's parity), [level][slot] inside its message
+__global__ __launch_bounds__(256) void k_halo_pack_peer(PeerSegs sg, int nlev, const int* __restrict__ idx, const double* __restrict__ v, long long vs,
+                                                        const unsigned long long* __restrict__ myflags) {
+    const int total = sg.off[sg.nseg];
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= (long long)total*nlev) return;
+    const unsigned long long seq = myflags[PEER_SEQ] + 1;             // (advanced by k_halo_publish, which follows in the stream)
+    const int gi = (int)(t%total), lev = (int)(t/total);
+    int s = 0;
+    while (gi >= sg.off[s + 1]) s++;
+    const int cnt = sg.off[s + 1] - sg.off[s];
+    sg.dst[s][(size_t)(seq & 1)*sg.half[s] + (size_t)lev*cnt + (gi - sg.off[s])] = v[(size_t)lev*vs + idx[gi]];
+}
+struct PeerFlags { int n; unsigned long long* flag[MIMSEM_HALO_MAX_SEGMENTS]; };
+// publish: the pack kernel before this one in the stream has finished (its stores are released at its end); one lane per neighbour stores the
+// exchange's sequence number with a system-scope release, then the counter advances
+__global__ void k_halo_publish(PeerFlags pf, unsigned long long* myflags) {
+    const int i = threadIdx.x;
+    const unsigned long long seq = myflags[PEER_SEQ] + 1;
+    if (i < pf.n) {
+        __threadfence_system();
+        __hip_atomic_store(pf.flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (i == 0) myflags[PEER_SEQ] = seq;
+}
+// wait: one lane per neighbour polls ITS arrival flag (system-scope acquire) until it carries this exchange's number; bounded: after
+// ~2 s the error word is set and the kernel leaves -- every wave reaches an exit whatever the neighbours do
+__global__ void k_halo_wait(unsigned long long* myflags, int n) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long seq = myflags[PEER_SEQ];
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(myflags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(myflags + PEER_ERR, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // (100 MHz constant clock: 2 s)
+    }
+}
+// unpack from the half of the exchange's parity (k_halo_segments with the buffer chosen on the device): mode 1 insert, 2 add
+struct PeerRecv { int nseg; int off[MIMSEM_HALO_MAX_SEGMENTS + 1]; };
+__global__ __launch_bounds__(256) void k_halo_unpack_peer(PeerRecv sg, int s_begin, int s_end, int nlev, int mode, const int* __restrict__ idx,
+                                                          const double* __restrict__ base, long long half, const unsigned long long* __restrict__ myflags,
+                                                          double* __restrict__ v, long long vs) {
+    const int g0 = sg.off[s_begin], total = sg.off[s_end] - g0;
+    const long long t = (long long)blockIdx.x*256 + threadIdx.x;
+    if (t >= (long long)total*nlev) return;
+    const double* buf = base + (size_t)(myflags[PEER_SEQ] & 1)*half;
+    const int gi = g0 + (int)(t%total), lev = (int)(t/total);
+    int s = s_begin;
+    while (gi >= sg.off[s + 1]) s++;
+    const int cnt = sg.off[s + 1] - sg.off[s];
+    const double b = buf[(size_t)sg.off[s]*nlev + (size_t)lev*cnt + (gi - sg.off[s])];
+    double* o = v + (size_t)lev*vs + idx[gi];
+    if (mode == 1) *o = b; else *o += b;
+}
+struct PeerBlob {                                                      // what a rank tells its neighbours about a plan (fits MIMSEM_HALO_PEER_BLOB)
+    unsigned magic; int rank, nneigh, max_nlev; long long half;        // doubles per half of the receive allocation
+    int ranks[MIMSEM_HALO_MAX_SEGMENTS]; int recv_off[MIMSEM_HALO_MAX_SEGMENTS + 1];
+    hipIpcMemHandle_t mem;
+};
+static_assert(sizeof(PeerBlob) <= MIMSEM_HALO_PEER_BLOB, "PeerBlob must fit the blob the header promises");
 }  // namespace
 
 extern "C" {
@@ -118,7 +202,8 @@ void mimsem_halo_destroy(mimsem_halo* h) {
     if (h->comm) { (void)hipStreamSynchronize(h->comm); (void)hipStreamDestroy(h->comm); }
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
-    void* ptrs[] = {h->d_send_idx, h->d_recv_idx, h->d_send, h->d_recv};
+    for (int i = 0; i < MIMSEM_HALO_MAX_SEGMENTS; i++) if (h->peer_base[i]) (void)hipIpcCloseMemHandle(h->peer_base[i]);
+    void* ptrs[] = {h->d_send_idx, h->d_recv_idx, h->d_send, h->d_recv, h->d_peer};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -151,11 +236,80 @@ int mimsem_halo_set_rccl(mimsem_halo* h, void* nccl_comm) {
     return MIMSEM_OK;
 }
 
+// ---- one-sided transport: set-up -------------------------------------------------------------------------------------------------------
+int mimsem_halo_peer_export(mimsem_halo* h, int my_rank, void* blob) {
+    if (!h || !blob || my_rank < 0 || h->in_flight) return MIMSEM_ERR_ARG;
+    mimsem_ctx* c = h->c;
+    MIMSEM_HIP_TRY(hipSetDevice(c->device));
+    if (!h->d_peer) {
+        const size_t nr = (size_t)std::max(h->nneigh ? h->recv_off[h->nneigh] : 0, 1);
+        h->peer_half = (nr*h->max_nlev + 1) & ~(size_t)1;
+        const size_t bytes = 2*h->peer_half*sizeof(double) + PEER_WORDS*sizeof(unsigned long long);
+        MIMSEM_HIP_TRY(hipMalloc((void**)&h->d_peer, bytes));
+        MIMSEM_HIP_TRY(hipMemset(h->d_peer, 0, bytes));
+        h->d_flags = (unsigned long long*)(h->d_peer + 2*h->peer_half);
+    }
+    PeerBlob b{};
+    b.magic = 0x4d48504bu; b.rank = my_rank; b.nneigh = h->nneigh; b.max_nlev = h->max_nlev; b.half = (long long)h->peer_half;
+    for (int i = 0; i < h->nneigh; i++) b.ranks[i] = h->ranks[i];
+    for (int i = 0; i <= h->nneigh; i++) b.recv_off[i] = h->recv_off[i];
+    MIMSEM_HIP_TRY(hipIpcGetMemHandle(&b.mem, h->d_peer));
+    std::memset(blob, 0, MIMSEM_HALO_PEER_BLOB);
+    std::memcpy(blob, &b, sizeof b);
+    h->my_rank = my_rank;
+    return MIMSEM_OK;
+}
+int mimsem_halo_set_peer(mimsem_halo* h, int my_rank, const void* neighbour_blobs) {
+    if (!h || h->in_flight || my_rank < 0 || (h->nneigh && !neighbour_blobs)) return MIMSEM_ERR_ARG;
+    if (!h->d_peer || h->my_rank != my_rank) return MIMSEM_ERR_STATE;      // export first (the neighbours need this rank's handle too)
+    mimsem_ctx* c = h->c;
+    MIMSEM_HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < h->nneigh; i++) {
+        PeerBlob b;
+        std::memcpy(&b, (const char*)neighbour_blobs + (size_t)i*MIMSEM_HALO_PEER_BLOB, sizeof b);
+        if (b.magic != 0x4d48504bu || b.rank != h->ranks[i] || b.nneigh < 0 || b.nneigh > MIMSEM_HALO_MAX_SEGMENTS || b.max_nlev != h->max_nlev) return MIMSEM_ERR_ARG;
+        int j = -1;
+        for (int k = 0; k < b.nneigh; k++) if (b.ranks[k] == my_rank) j = k;
+        if (j < 0) return MIMSEM_ERR_ARG;                                // the neighbour does not list this rank
+        if (b.recv_off[j + 1] - b.recv_off[j] != h->send_off[i + 1] - h->send_off[i]) return MIMSEM_ERR_ARG;      // what it expects is not what this rank sends
+        if (h->peer_base[i]) { (void)hipIpcCloseMemHandle(h->peer_base[i]); h->peer_base[i] = nullptr; }
+        if (b.rank == my_rank) h->peer_base[i] = nullptr;                // (a rank listed as its own neighbour: its own buffer, no handle to open)
+        else MIMSEM_HIP_TRY(hipIpcOpenMemHandle(&h->peer_base[i], b.mem, hipIpcMemLazyEnablePeerAccess));
+        h->peer_half_of[i] = (size_t)b.half; h->peer_off[i] = b.recv_off[j]; h->peer_slot[i] = j;
+    }
+    h->transport = 4;
+    return MIMSEM_OK;
+}
+
 int mimsem_halo_begin(mimsem_halo* h, int mode, int nlev, double* v, long long vs) {
     if (!h || !v || nlev < 1 || nlev > h->max_nlev || (mode != MIMSEM_HALO_INSERT && mode != MIMSEM_HALO_ADD)) return MIMSEM_ERR_ARG;
     if (h->in_flight || h->transport == 0) return MIMSEM_ERR_STATE;
     mimsem_ctx* c = h->c;
     int rc;
+    if (h->transport == 4) {
+        // one-sided: pack straight into the neighbours' receive buffers (the half of this exchange's parity), then publish the sequence number
+        if (h->nneigh && h->send_off[h->nneigh]) {
+            PeerSegs sg; sg.nseg = h->nneigh;
+            for (int i = 0; i <= h->nneigh; i++) sg.off[i] = h->send_off[i];
+            for (int i = 0; i < h->nneigh; i++) {
+                double* base = h->peer_base[i] ? (double*)h->peer_base[i] : h->d_peer;
+                sg.dst[i] = base + (size_t)h->peer_off[i]*nlev; sg.half[i] = (long long)h->peer_half_of[i];
+            }
+            const long long total = (long long)h->send_off[h->nneigh]*nlev;
+            hipLaunchKernelGGL(k_halo_pack_peer, dim3((unsigned)((total + 255)/256)), dim3(256), 0, c->stream, sg, nlev, h->d_send_idx, v, vs, h->d_flags);
+        }
+        if (h->nneigh) {
+            PeerFlags pf; pf.n = h->nneigh;
+            for (int i = 0; i < h->nneigh; i++) {
+                unsigned long long* fl = (unsigned long long*)((h->peer_base[i] ? (double*)h->peer_base[i] : h->d_peer) + 2*h->peer_half_of[i]);
+                pf.flag[i] = fl + h->peer_slot[i];
+            }
+            hipLaunchKernelGGL(k_halo_publish, dim3(1), dim3(64), 0, c->stream, pf, h->d_flags);
+        }
+        MIMSEM_HIP_TRY(hipGetLastError());
+        h->in_flight = true; h->mode = mode; h->nlev = nlev; h->v = v; h->vs = vs;
+        return MIMSEM_OK;
+    }
     if (h->nneigh && h->send_off[h->nneigh]) {
         rc = launch_halo_segments(c, h->d_send_idx, h->nneigh, h->send_off.data(), 0, h->nneigh, nlev, 0, h->d_send, v, vs);
         if (rc) return rc;
@@ -193,6 +347,23 @@ int mimsem_halo_end(mimsem_halo* h) {
     if (!h->in_flight) return MIMSEM_ERR_STATE;
     mimsem_ctx* c = h->c;
     h->in_flight = false;
+    if (h->transport == 4) {
+        if (!h->nneigh) return MIMSEM_OK;
+        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, c->stream, h->d_flags, h->nneigh);
+        if (h->recv_off[h->nneigh]) {
+            PeerRecv sg; sg.nseg = h->nneigh;
+            for (int i = 0; i <= h->nneigh; i++) sg.off[i] = h->recv_off[i];
+            auto unpack = [&](int b, int e, int md) {
+                const long long total = (long long)(h->recv_off[e] - h->recv_off[b])*h->nlev;
+                if (total > 0) hipLaunchKernelGGL(k_halo_unpack_peer, dim3((unsigned)((total + 255)/256)), dim3(256), 0, c->stream, sg, b, e, h->nlev, md,
+                                                  h->d_recv_idx, h->d_peer, (long long)h->peer_half, h->d_flags, h->v, h->vs);
+            };
+            if (h->mode == MIMSEM_HALO_INSERT) unpack(0, h->nneigh, 1);
+            else for (auto& r : h->add_ranges) unpack(r.first, r.second, 2);      // fixed order => reproducible sums
+        }
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     MIMSEM_HIP_TRY(hipStreamWaitEvent(c->stream, h->ev_done, 0));
     if (!h->nneigh || !h->recv_off[h->nneigh]) return MIMSEM_OK;
     if (h->mode == MIMSEM_HALO_INSERT)
@@ -201,6 +372,18 @@ int mimsem_halo_end(mimsem_halo* h) {
         int rc = launch_halo_segments(c, h->d_recv_idx, h->nneigh, h->recv_off.data(), r.first, r.second, h->nlev, 2, h->d_recv, h->v, h->vs);
         if (rc) return rc;
     }
+    return MIMSEM_OK;
+}
+
+
+// the error word of the one-sided transport: non-zero = the sequence number of an exchange whose wait gave up after ~2 s (a neighbour that
+// never published); synchronises the context's stream
+int mimsem_halo_peer_status(mimsem_halo* h, unsigned long long* timed_out_seq) {
+    if (!h || !timed_out_seq) return MIMSEM_ERR_ARG;
+    *timed_out_seq = 0;
+    if (h->transport != 4 || !h->d_flags) return MIMSEM_OK;
+    MIMSEM_HIP_TRY(hipStreamSynchronize(h->c->stream));
+    MIMSEM_HIP_TRY(hipMemcpy(timed_out_seq, h->d_flags + PEER_ERR, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MIMSEM_OK;
 }
 

@@ -289,7 +289,10 @@ class CHalo:
       "dist"      a host callback over torch.distributed, staged through host memory (how a host with a plain MPI would do it;
                   the test rehearsal of several ranks on one GPU over gloo uses it),
       "loopback"  every neighbour is the rank itself (single-rank tests),
-      an int      an ncclComm_t of the caller: grouped ncclSend/ncclRecv on the plan's communication stream (xGMI).
+      an int      an ncclComm_t of the caller: grouped ncclSend/ncclRecv on the plan's communication stream (xGMI),
+      "peer"      ONE-SIDED (round 6): the receive buffers are exported through hipIpc and opened by the neighbour ranks; the pack kernel
+                  writes straight into the neighbour's buffer and publishes a sequence flag, the unpack waits for the flags -- kernels only
+                  (mimsem_halo_peer_export / _set_peer; the handles travel once, over the process group, at construction).
     begin()/end() are split so that interior work can be enqueued in between."""
 
     def __init__(self, plan, engine, max_nlev, transport="dist"):
@@ -320,7 +323,20 @@ class CHalo:
             check(self.L.mimsem_halo_create(engine.ctx, len(ranks), self.ranks.ctypes.data, si.ctypes.data, so.ctypes.data,
                                             ri.ctypes.data, ro.ctypes.data, nslots, max_nlev, C.byref(h)), "halo_create")
             self.handles[name] = h
-        if transport == "loopback":
+        if transport == "peer":
+            from ._lib import HALO_PEER_BLOB
+            me = dist.get_rank()
+            mine = {}
+            for name, h in self.handles.items():
+                blob = C.create_string_buffer(HALO_PEER_BLOB)
+                check(self.L.mimsem_halo_peer_export(h, me, blob), "halo_peer_export")
+                mine[name] = bytes(blob.raw)
+            everyone = [None] * dist.get_world_size()
+            dist.all_gather_object(everyone, mine)                     # (the one collective of this transport: the handles, once)
+            for name, h in self.handles.items():
+                blobs = b"".join(everyone[int(r)][name] for r in ranks)
+                check(self.L.mimsem_halo_set_peer(h, me, blobs if blobs else None), "halo_set_peer")
+        elif transport == "loopback":
             for h in self.handles.values():
                 check(self.L.mimsem_halo_set_loopback(h), "halo_set_loopback")
         elif transport == "dist":
@@ -372,6 +388,17 @@ class CHalo:
     def sum_all(self, v):
         """1-forms: every sharer sends its partial sums to the other and adds what it receives (a + b = b + a bitwise)"""
         self.end(self.begin("pair", v, True))
+
+    def peer_timeouts(self):
+        """one-sided transport: sequence numbers of exchanges whose wait gave up (a neighbour that never published), per plan; {} = none"""
+        C = self.C
+        out = {}
+        for name, h in self.handles.items():
+            v = C.c_ulonglong(0)
+            self._check(self.L.mimsem_halo_peer_status(h, C.byref(v)), "halo_peer_status")
+            if v.value:
+                out[name] = v.value
+        return out
 
     def close(self):
         for h in self.handles.values():

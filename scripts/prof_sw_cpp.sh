@@ -3,7 +3,7 @@
 # kernels against the wall time of a step -> what part of a graph node's ~5 us is the kernel and what part the hand-over between nodes
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-python scripts/exp/write_sw_case3.py gpurun_out/sw_case3.bin 20    # (rocprofv3 crashes inside hipGraphLaunch on longer runs of these graphs: 200 steps die, 20 live)
+python scripts/exp/write_sw_case3.py gpurun_out/sw_case3.bin 20    # (20 steps: on the 200-step case rocprofv3 --kernel-trace dies with a SIGSEGV inside librocprofiler-sdk.so's HSA packet interception, below hipGraphLaunch -- the tool, not this library: the backtraced run is profiles/r06_rocprof_graph_sigsegv.txt, scripts/exp/rocprof_graph_200.sh)
 ./mimsem_amd/host/sw_call gpurun_out/sw_case3.bin 3 | cut -c1-260
 rm -rf gpurun_out/prof_swcpp
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_swcpp -o p --output-format csv -- ./mimsem_amd/host/sw_call gpurun_out/sw_case3.bin 3 > gpurun_out/prof_swcpp.log 2>&1

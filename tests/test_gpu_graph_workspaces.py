@@ -176,3 +176,29 @@ def test_c_abi_graph_replays_hold_no_growing_state():
     assert rss1 - rss0 < 8 << 20, (rss0, rss1)
     L.mimsem_graph_destroy(g)
     eng.use_stream(torch.cuda.current_stream(eng.device))
+
+
+def test_a_recording_outlives_its_context_safely():
+    """advisor, round 5: a mimsem_graph kept the stream it was recorded on and replayed there for ever -- after mimsem_ctx_destroy that was a
+    destroyed stream.  A recording now belongs to its context: destroyed context => launch returns MIMSEM_ERR_STATE; and a later
+    mimsem_ctx_use_own_stream moves the replays with the context (same result)."""
+    import ctypes as C
+    from mimsem_amd._lib import check
+    dm, eng = _engine()
+    L = eng.L
+    rng = np.random.default_rng(4)
+    x = eng.tensor(rng.standard_normal((4, dm.n1))); y = eng.zeros(4, dm.n1)
+    seq = lambda: eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y)
+    check(L.mimsem_ctx_use_own_stream(eng.ctx), "use_own_stream")
+    seq(); eng.sync()
+    want = y.clone()
+    g = C.c_void_p()
+    check(L.mimsem_graph_begin(eng.ctx), "graph_begin"); seq(); check(L.mimsem_graph_end(eng.ctx, C.byref(g)), "graph_end")
+    y.zero_(); eng.sync()
+    check(L.mimsem_graph_launch(g), "graph_launch"); eng.sync()
+    import torch
+    assert torch.equal(y, want)
+    L.mimsem_ctx_destroy(eng.ctx); eng.ctx = C.c_void_p()
+    rc = L.mimsem_graph_launch(g)
+    assert rc != 0, "a recording whose context is gone must refuse to launch"
+    L.mimsem_graph_destroy(g)

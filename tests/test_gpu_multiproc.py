@@ -54,6 +54,37 @@ def _worker(rank, world, port, q):
             ch = CHalo(plans[form], eng, max_nlev=nk, transport="dist")
             ch.reverse_add(y2); ch.forward_insert(y2)
             ok = ok and bool(torch.equal(y2, y))
+            # ... and through the ONE-SIDED transport (round 6: receive buffers exported through hipIpc, the pack kernel writes straight into the
+            # neighbour's buffer and publishes a sequence flag, the unpack waits for the flags: kernels only) -- bit for bit, over several
+            # exchanges in a row (both parities of the double receive buffer), the symmetric "pair" exchange included, and RECORDED in a graph
+            cp = CHalo(plans[form], eng, max_nlev=nk, transport="peer")
+            y4 = eng.apply(op, eng.tensor(xglob[:, gid]), lev0=0, scale=SCALE, flags=1 if form == 1 else 0)
+            cp.reverse_add(y4); cp.forward_insert(y4)
+            same = bool(torch.equal(y4, y))
+            for rep in range(3):
+                a = eng.apply(op, eng.tensor(xglob[:, gid] * (rep + 2.0)), lev0=0, scale=SCALE, flags=1 if form == 1 else 0); b = a.clone()
+                if form == 1:
+                    ch.sum_all(a); cp.sum_all(b)
+                else:
+                    ch.reverse_add(a); ch.forward_insert(a); cp.reverse_add(b); cp.forward_insert(b)
+                same = same and bool(torch.equal(a, b))
+            if form == 1:
+                src = eng.apply(op, eng.tensor(xglob[:, gid] * 7.0), lev0=0, scale=SCALE, flags=1); want_g = src.clone(); ch.sum_all(want_g)
+                buf = torch.zeros_like(src)
+
+                def recorded():
+                    buf.copy_(src)
+                    cp.sum_all(buf)
+                graph, _ = eng.capture(recorded)
+                for _ in range(3):                                     # every replay is a new exchange: sequence number and parity live on the device
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    same = same and bool(torch.equal(buf, want_g))
+            same = same and cp.peer_timeouts() == {}
+            if not same:
+                print("rank", rank, "one-sided transport differs from the callback transport (form %d)" % form, cp.peer_timeouts(), flush=True)
+            ok = ok and same
+            cp.close()
             ch.close()
             if form == 1:
                 # DistEngine with the interior / boundary split: boundary groups, exchange in flight, interior groups, unpack
