@@ -1,0 +1,15 @@
+"""Run-time switches.  The product reads a short list of documented user switches (MIMSEM_LIB, MIMSEM_VERBOSE,
+MIMSEM_COLUMN_PIVOT_FALLBACK, MIMSEM_REFINE, MIMSEM_WAVE, MIMSEM_SCHUR_FUSED, MIMSEM_PATCH_MAP, MIMSEM_MASS_SOLVER, MIMSEM_CHEB_CALIBRATE,
+MIMSEM_SW_CHEB, MIMSEM_SW_GRAPH_ITER, MIMSEM_NEWTON_FUSED, MIMSEM_PCG).  Everything else -- the switches of variants that were built,
+measured and declined, whose records live under profiles/ -- is a CLOSED EXPERIMENT: read only when MIMSEM_EXPERIMENTS=1 is set
+(scripts/ab_*.sh and the parity tests of those variants set it), in this package and in the library (csrc/ctx.hpp::exp_env) alike."""
+import os
+
+
+def experiments_on():
+    return os.environ.get("MIMSEM_EXPERIMENTS", "0") not in ("", "0")
+
+
+def experiment(name, default):
+    """the value of a closed experiment's switch: the environment's when MIMSEM_EXPERIMENTS=1, else the default (the measured best)"""
+    return os.environ.get(name, default) if experiments_on() else default

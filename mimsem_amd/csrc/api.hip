@@ -588,14 +588,14 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     const ElemSizes& es = c->es;
     WavePlan P;
     const int lpe = es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64));
-    const bool singles = getenv("MIMSEM_WAVE_SINGLES") && atoi(getenv("MIMSEM_WAVE_SINGLES")) != 0;
+    const bool singles = exp_env("MIMSEM_WAVE_SINGLES") && atoi(exp_env("MIMSEM_WAVE_SINGLES")) != 0;
     // MIMSEM_WAVE_FIN=1: the experimental in-kernel finishing phase (side layout of the partial sums, no mixed pairs); default: round 2's
     // dense layout with mixed pairs + the perimeter pass (measured faster: DESIGN 4.6)
-    const bool want_fin = getenv("MIMSEM_WAVE_FIN") && atoi(getenv("MIMSEM_WAVE_FIN")) != 0;
-    const bool mixed = !want_fin && !(getenv("MIMSEM_WAVE_MIXED") && atoi(getenv("MIMSEM_WAVE_MIXED")) == 0);
+    const bool want_fin = exp_env("MIMSEM_WAVE_FIN") && atoi(exp_env("MIMSEM_WAVE_FIN")) != 0;
+    const bool mixed = !want_fin && !(exp_env("MIMSEM_WAVE_MIXED") && atoi(exp_env("MIMSEM_WAVE_MIXED")) == 0);
     // round 5: TILE mode -- four wave-groups per workgroup, the partial sums of the slots they share meet in LDS behind ONE barrier per work
     // item instead of travelling through the workspace to the perimeter pass (MIMSEM_WAVE_TILE=0 | 1; orders 3 and 4, no halo split)
-    const bool want_tile = (es.n == 3 || es.n == 4) && !marked && getenv("MIMSEM_WAVE_TILE") && atoi(getenv("MIMSEM_WAVE_TILE")) != 0;
+    const bool want_tile = (es.n == 3 || es.n == 4) && !marked && exp_env("MIMSEM_WAVE_TILE") && atoi(exp_env("MIMSEM_WAVE_TILE")) != 0;
     int rc = build_wave_plan(es.n, c->n1, c->nEl, es.n1e, es.n0e, 64/lpe, c->h_i1x.data(), c->h_i1y.data(), c->h_i0.data(), singles, mixed, marked, P, want_tile);
     if (rc && want_tile) {                                             // a numbering the tiles do not fit: the plain plan
         P = WavePlan();
@@ -648,13 +648,13 @@ static int setup_wave(mimsem_ctx* c, const char* marked) {
     }
     c->w_ndirect = P.ndirect; c->w_ngroups = P.ngroups; c->w_nsing = P.nsing; c->w_nps = P.nps; c->w_npart = P.npart;
     c->w_npwritten = P.npwritten; c->w_nsides = P.nsides;
-    if (const char* kind = getenv("MIMSEM_WPART_MEM")) c->w_partmem = !strcmp(kind, "plain") ? 2 : (!strcmp(kind, "finegrained") ? 1 : 0);
+    if (const char* kind = exp_env("MIMSEM_WPART_MEM")) c->w_partmem = !strcmp(kind, "plain") ? 2 : (!strcmp(kind, "finegrained") ? 1 : 0);
     c->w_fin = P.fin_ok && want_fin;
     c->w_nbgroups = P.nbgroups; c->w_nbrec = P.nbrec; c->w_split = marked != nullptr; c->wave1 = true;
-    if (const char* ev = getenv("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
-    if (const char* ev = getenv("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
-    if (const char* ev = getenv("MIMSEM_WAVE_CPP")) c->wave_cpp = atoi(ev);
-    if (const char* ev = getenv("MIMSEM_WAVE2")) c->wave2_mode = atoi(ev);
+    if (const char* ev = exp_env("MIMSEM_WAVE_ORDER")) c->wave_order = atoi(ev);
+    if (const char* ev = exp_env("MIMSEM_WAVE_LCH")) c->wave_lch = atoi(ev);
+    if (const char* ev = exp_env("MIMSEM_WAVE_CPP")) c->wave_cpp = atoi(ev);
+    if (const char* ev = exp_env("MIMSEM_WAVE2")) c->wave2_mode = atoi(ev);
     if (getenv("MIMSEM_VERBOSE"))
         fprintf(stderr, "[mimsem] wave plan: %d groups of %d elements (%d on the halo boundary), %d perimeter slots (%d partials in %d sides) of %d; "
                         "in-kernel finishing %s; tiles %d (%d inner slots finished in LDS, widest LDS row %d doubles)\n", P.ngroups, 64/lpe, P.nbgroups, P.nps,
@@ -720,8 +720,8 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
 
     mimsem_ctx* c = new mimsem_ctx();
     c->device = device;
-    if (const char* ev = getenv("MIMSEM_LCH")) c->lch_override = atoi(ev);
-    if (const char* ev = getenv("MIMSEM_NOSWZ")) c->swz = atoi(ev) ? 0 : 1;
+    if (const char* ev = exp_env("MIMSEM_LCH")) c->lch_override = atoi(ev);
+    if (const char* ev = exp_env("MIMSEM_NOSWZ")) c->swz = atoi(ev) ? 0 : 1;
     c->es = ElemSizes(d->elOrd);
     c->nEl = d->nEl; c->nk = d->nk; c->n0 = d->n0; c->n1 = d->n1; c->n2 = d->n2;
     const ElemSizes& es = c->es;
@@ -800,11 +800,11 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         c->nsh0 = (int)sh.size();
         // measured SLOWER on MI355X (pass 1 14.9 -> 17.4 us: the single-contributor stores are scattered, the ye stores coalesce;
         // pass 2 over the shared-slot list 7.4 -> 8.2 us), profiles/r01_direct_interior_ab.txt: opt-in only
-        c->direct = getenv("MIMSEM_DIRECT") != nullptr;
+        c->direct = exp_env("MIMSEM_DIRECT") != nullptr;
     }
     // Fused single-barrier scatter-add (group-local sums in LDS + perimeter pass): measured SLOWER than the two-pass
     // form on MI355X in round 1 (profiles/r01_fused_scatter_ab.txt), so it is opt-in (MIMSEM_FUSE=1) for further tuning.
-    if (getenv("MIMSEM_FUSE")) {
+    if (exp_env("MIMSEM_FUSE")) {
         FusedPlan P;
         const int epb = 256/(es.mp12 <= 4 ? 4 : (es.mp12 <= 16 ? 16 : (es.mp12 <= 32 ? 32 : 64)));
         rc = build_fused_plan(d->n1, d->nEl, es.n1e, epb, d->inds1x, d->inds1y, P);
@@ -829,11 +829,11 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     // block pass of the Chebyshev / Richardson sweeps on the matrix cores: the default at p = 4 (40 x 40 blocks: 32.1 us against 32.8 us for
     // the register-row form on the config-5 grid, profiles/r03_mfma_p4_ab.txt), off at p <= 3 (24 x 24: 25.3 against 23.8 us);
     // MIMSEM_BLOCKS_MFMA=0 | 1 overrides
-    c->blocks_mfma = getenv("MIMSEM_BLOCKS_MFMA") ? atoi(getenv("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
+    c->blocks_mfma = exp_env("MIMSEM_BLOCKS_MFMA") ? atoi(exp_env("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
     if (d->nEl > 0) { c->h_e1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_e1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
                       c->h_e0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e); }
-    c->memset_node = getenv("MIMSEM_MEMSET_NODE") && atoi(getenv("MIMSEM_MEMSET_NODE")) != 0;      // (read once: mimsem_memset is a hot call of the recorded solves)
-    c->blu_stop = getenv("MIMSEM_BLU_STOP") ? atoi(getenv("MIMSEM_BLU_STOP")) : 0;
+    c->memset_node = exp_env("MIMSEM_MEMSET_NODE") && atoi(exp_env("MIMSEM_MEMSET_NODE")) != 0;      // (read once: mimsem_memset is a hot call of the recorded solves)
+    c->blu_stop = exp_env("MIMSEM_BLU_STOP") ? atoi(exp_env("MIMSEM_BLU_STOP")) : 0;
     c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 1;      // on by default since round 5 (mimsem_column_set_pivot_fallback)
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
         c->h_i1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_i1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
@@ -992,7 +992,7 @@ int mimsem_ctx_set_levels(mimsem_ctx* c, const double* thick, const double* thic
         // the ABI takes it gathered per element: 16 values per element at p = 3 of which 9 are distinct per element on average.  Only when
         // every element holds the same bits at a shared node (and quadrature points are the nodes: mp12 == n0e)
         if (c->d_tIn) { (void)hipFree(c->d_tIn); c->d_tIn = nullptr; }
-        if (getenv("MIMSEM_WAVE_TNODE") && atoi(getenv("MIMSEM_WAVE_TNODE")) == 1 && c->es.mp12 == c->es.n0e && !c->h_i0.empty() && c->n0 > 0) {
+        if (exp_env("MIMSEM_WAVE_TNODE") && atoi(exp_env("MIMSEM_WAVE_TNODE")) == 1 && c->es.mp12 == c->es.n0e && !c->h_i0.empty() && c->n0 > 0) {
             const size_t n0 = (size_t)c->n0;
             std::vector<double> nod((size_t)c->nk*n0, 1.0), tn(2*np*n0*2, 1.0);
             std::vector<unsigned char> seen(n0);
@@ -1244,7 +1244,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
         // parts of a split apply: their partial sums wait for the other part, and the perimeter pass finishes them)
         const bool fin = c->w_fin && !splits && !a.wtfin && (nlev + a.lch*a.wcpp - 1)/(a.lch*a.wcpp) <= std::max(c->nk, 1);
         a.wfin = fin ? c->d_wfin : nullptr; a.wsslot = c->d_wsslot; a.wcnt = c->d_wcnt;
-        a.wfence = (fin && c->w_partmem == 2 && getenv("MIMSEM_WAVE_FIN_FENCE") && atoi(getenv("MIMSEM_WAVE_FIN_FENCE")) != 0) ? 1 : 0;
+        a.wfence = (fin && c->w_partmem == 2 && exp_env("MIMSEM_WAVE_FIN_FENCE") && atoi(exp_env("MIMSEM_WAVE_FIN_FENCE")) != 0) ? 1 : 0;
         if (splits) {
             // the pending BOUNDARY part and its INTERIOR part must match; nothing else can consume or overwrite the partial sums
             if (part == MIMSEM_PART_BOUNDARY) {
@@ -1261,7 +1261,7 @@ static int op_apply_core(mimsem_ctx* c, int op, int geom_lev0, int nlev, double 
 #ifdef MIMSEM_STAMPS      // diagnostic build: per-phase s_memtime stamps of every work item of this launch, summarised on stderr
         static long long* d_st = nullptr; static size_t st_items = 0;
         const size_t items = (size_t)c->w_ngroups*((nlev + a.lch - 1)/a.lch);
-        if (getenv("MIMSEM_WAVE_STAMPS")) {
+        if (exp_env("MIMSEM_WAVE_STAMPS")) {
             if (items > st_items) { if (d_st) (void)hipFree(d_st); (void)hipMalloc((void**)&d_st, items*16*8); st_items = items; }
             (void)hipMemsetAsync(d_st, 0, items*16*8, c->stream);
             a.wstamps = d_st;

@@ -566,11 +566,11 @@ int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double
     switch (n) {                     // register-resident one-lane-per-row kernel for the block sizes of p <= 4
     case 1:  return launch_inverse_reg<1>(c, nblocks, blocks, err);
     case 4:  return launch_inverse_reg<4>(c, nblocks, blocks, err);
-    case 9:  return getenv("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks, err) : launch_inverse_reg<9>(c, nblocks, blocks, err);
+    case 9:  return exp_env("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks, err) : launch_inverse_reg<9>(c, nblocks, blocks, err);
     case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks, err);
     default: break;                  // 25, 36, 49: thread-per-matrix in LDS below
     }
-    if (n > 16 && n <= 64 && !(getenv("MIMSEM_INV_THREAD") && atoi(getenv("MIMSEM_INV_THREAD")) != 0)) {      // one wavefront per block (round 5)
+    if (n > 16 && n <= 64 && !(exp_env("MIMSEM_INV_THREAD") && atoi(exp_env("MIMSEM_INV_THREAD")) != 0)) {      // one wavefront per block (round 5)
         const size_t lds = (size_t)n*(n | 1)*sizeof(double) + (size_t)3*n*sizeof(int);
         hipLaunchKernelGGL(k_block_inverse_wave, dim3((unsigned)nblocks), dim3(64), lds, c->stream, nblocks, n, blocks, err);
         MIMSEM_HIP_TRY(hipGetLastError());
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_colop_apply_mf(CG g, int colop, unsigne
 int launch_colop_apply_mf(mimsem_ctx* c, int colop, unsigned flags, int transpose, const double* f1, const double* f2,
                           const double* x, double* y) {
     if (colop_is_inverse(colop) || colop == MIMSEM_V_EOS_BLOCK || colop == MIMSEM_V_EOS_BLOCK_INV ||
-        colop == MIMSEM_V_LINEAR_RHO2_UP || colop == MIMSEM_V_LINCON2_UP || getenv("MIMSEM_COLOP_BLOCKS"))
+        colop == MIMSEM_V_LINEAR_RHO2_UP || colop == MIMSEM_V_LINCON2_UP || exp_env("MIMSEM_COLOP_BLOCKS"))
         return MIMSEM_ERR_UNSUPPORTED;
     int nr, nw, nx, ny;
     colop_shape(colop, c->nk, &nr, &nw, &nx, &ny);
@@ -1437,8 +1437,8 @@ __global__ __launch_bounds__(64) void k_block_thomas_resolve(int nEl, int nk, co
 
 int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, double* Gws, double* yws, double* Dinv = nullptr) {
     const int n2 = c->es.n2e, nn = n2*n2;
-    const bool rows = !getenv("MIMSEM_THOMAS_WAVE");          // row-per-lane kernel (4 columns per wavefront); the wave-per-column one stays selectable
-    if (rows && !getenv("MIMSEM_THOMAS_WG") && (n2 == 4 || n2 == 9 || n2 == 16)) {
+    const bool rows = !exp_env("MIMSEM_THOMAS_WAVE");          // row-per-lane kernel (4 columns per wavefront); the wave-per-column one stays selectable
+    if (rows && !exp_env("MIMSEM_THOMAS_WG") && (n2 == 4 || n2 == 9 || n2 == 16)) {
         const unsigned grid = (unsigned)((c->nEl + 3)/4);
         switch (n2) {
 #define MIMSEM_TRW(N) case N: hipLaunchKernelGGL((k_block_thomas_rows<N>), dim3(grid), dim3(64), 0, c->stream, c->nEl, c->nk, L, f, d, Gws, yws, Dinv); \
@@ -1447,7 +1447,7 @@ int block_thomas(mimsem_ctx* c, const double* L, const double* f, double* d, dou
 #undef MIMSEM_TRW
         }
     }
-    if (!getenv("MIMSEM_THOMAS_WG")) {
+    if (!exp_env("MIMSEM_THOMAS_WG")) {
         switch (n2) {
 #define MIMSEM_TW(N) case N: hipLaunchKernelGGL((k_block_thomas_wave<N>), dim3(c->nEl), dim3(64), 0, c->stream, c->nk, L, f, d, Gws, yws, Dinv); \
                      MIMSEM_HIP_TRY(hipGetLastError()); return MIMSEM_OK;
@@ -1485,10 +1485,10 @@ int block_thomas_refined(mimsem_ctx* c, const double* L, const double* f, double
                          double* Dinv /* [nEl][nk][nn] scratch or null */) {
     int rc;
     const int n2 = c->es.n2e, nk = c->nk, nEl = c->nEl;
-    const bool wave = !getenv("MIMSEM_THOMAS_WG") && (n2 == 1 || n2 == 4 || n2 == 9 || n2 == 16);
+    const bool wave = !exp_env("MIMSEM_THOMAS_WG") && (n2 == 1 || n2 == 4 || n2 == 9 || n2 == 16);
     const bool keep = Dinv && wave && (size_t)(64/n2)*nk*n2*sizeof(double) <= 48*1024;
     if ((rc = block_thomas(c, L, f, d, Gws, yws, keep ? Dinv : nullptr))) return rc;
-    if (getenv("MIMSEM_NO_REFINE")) return MIMSEM_OK;
+    if (exp_env("MIMSEM_NO_REFINE")) return MIMSEM_OK;
     if ((rc = block_tridiag_residual(c, nk, n2, L, f, d, r))) return rc;
     if (keep) {                      // substitution only, with the factors of the first sweep
         const int cpw = 64/n2;
@@ -2447,7 +2447,7 @@ int schur_assemble(mimsem_ctx* c, double dt, const double* theta, const double* 
     if ((rc = grad(eta, S.geta))) return rc;
     if ((rc = colop_blocks_into(c, MIMSEM_V_CONLIN_W, 0, S.geta, nullptr, C2.p, cq, tmpM))) return rc;
     // EOS blocks                                                     (:736, :739)
-    if (c->es.n == 3 && !getenv("MIMSEM_EOS_WIDE")) {
+    if (c->es.n == 3 && !exp_env("MIMSEM_EOS_WIDE")) {
         // p = 3: thread-per-block register kernel for N = B B(f)^-1 B (93 us per call vs 210 us for coef + inverse + 2 products + copy);
         // the same treatment of the interface factors (A^-1, X, G_pi) needs two blocks live per thread, spills, and measured no gain
         const CG g = make_cg(c);
@@ -2471,7 +2471,7 @@ int mimsem_column_diag_theta_blend(mimsem_ctx* c, const double* rho, const doubl
 
 int mimsem_column_diag_theta(mimsem_ctx* c, int which, const double* rho, const double* rt, double* theta) {
     if (!c || !rho || !rt || !theta || which < 0 || which > 1) return MIMSEM_ERR_ARG;
-    if (diag_theta_fused_supported(c) && !getenv("MIMSEM_DIAG_THETA_WIDE"))      // orders 1..3: one launch on the DPP row algebra (column_newton.inc)
+    if (diag_theta_fused_supported(c) && !exp_env("MIMSEM_DIAG_THETA_WIDE"))      // orders 1..3: one launch on the DPP row algebra (column_newton.inc)
         return which == 0 ? mimsem_column_diag_theta_blend(c, rho, rt, nullptr, nullptr, theta, nullptr, 1.0, 0.0)
                           : mimsem_column_diag_theta_blend(c, rho, rt, theta, nullptr, nullptr, nullptr, 1.0, 0.0);
     const int nk = c->nk, n2 = c->es.n2e, nn = n2*n2, nEl = c->nEl;

@@ -5,6 +5,15 @@
 #include <vector>
 #include "../../include/mimsem_hip.h"
 #include "basis_host.hpp"
+#include <cstdlib>
+
+// CLOSED EXPERIMENTS: the switches of the variants that were built, measured and declined (their records are under profiles/) are
+// read only when MIMSEM_EXPERIMENTS=1 is set in the environment -- scripts/ab_*.sh and the parity tests of those variants set it; a process
+// without it has the documented user switches (pivot fallback, refinement steps, operator form, column-solve path, verbosity) and nothing else.
+inline const char* exp_env(const char* name) {
+    static const bool on = std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS")) != 0;
+    return on ? std::getenv(name) : nullptr;
+}
 
 namespace mimsem {
 extern thread_local std::string g_last_hip_error;

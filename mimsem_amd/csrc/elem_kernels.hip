@@ -1456,7 +1456,7 @@ int launch_blocks_apply(mimsem_ctx* c, int form, int nlev, int transposed, const
     const long long total = (long long)c->nEl*nlev;
     if (total == 0) return MIMSEM_OK;
     if (escale && bstride_lev != 0) return MIMSEM_ERR_ARG;
-    if (bstride_lev == 0 && nd <= 64 && !getenv("MIMSEM_BLOCKS_LDS")) {
+    if (bstride_lev == 0 && nd <= 64 && !exp_env("MIMSEM_BLOCKS_LDS")) {
         // register-resident rows, wave-level synchronisation
         const int* ia = form == 1 ? c->d_i1x : (form == 0 ? c->d_i0 : c->d_i2);
         const int* ib = form == 1 ? c->d_i1y : nullptr;
@@ -1637,7 +1637,7 @@ int launch_gather_sum(mimsem_ctx* c, int form, int nlev, const double* ye, long 
     const int* slots = shared_only ? (form == 1 ? c->d_sh1 : c->d_sh0) : nullptr;
     const int nslots = shared_only ? (form == 1 ? c->nsh1 : c->nsh0) : (form == 1 ? c->n1 : c->n0);
     if (nslots == 0 || nlev == 0) return MIMSEM_OK;
-    static const int lc = getenv("MIMSEM_GS_LC") ? std::max(1, atoi(getenv("MIMSEM_GS_LC"))) : GS_LC;
+    static const int lc = exp_env("MIMSEM_GS_LC") ? std::max(1, atoi(exp_env("MIMSEM_GS_LC"))) : GS_LC;
     const dim3 grid((unsigned)((nslots + 255)/256), (unsigned)((nlev + lc - 1)/lc));
     hipEvent_t s0 = c->ev_k2[0], s1 = c->ev_k2[1];
 #define MIMSEM_GS(K, PLAN) \

@@ -471,7 +471,7 @@ int mimsem_krylov_cgs2(mimsem_ctx* c, int k, long long n, const double* V, long 
 int mimsem_krylov_reorthonormalize(mimsem_ctx* c, int k, long long n, const double* V, long long ldv, double* w, double* v,
                                    const double* h1, double* h2, double* col, int norm_slot) {
     if (!c) return MIMSEM_ERR_ARG;
-    if (c->gs_fused < 0) c->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
+    if (c->gs_fused < 0) c->gs_fused = !(exp_env("MIMSEM_GS_FUSED_NORM") && atoi(exp_env("MIMSEM_GS_FUSED_NORM")) == 0);
     return mimsem_krylov_reorthonormalize_ex(c, k, n, V, ldv, w, v, h1, h2, col, norm_slot, c->gs_fused, c->gs_flag);
 }
 

@@ -326,8 +326,8 @@ int mimsem_ksp_create(mimsem_ctx* ctx, int type, mimsem_ksp** out) {
     if (!ctx || !out || (type != MIMSEM_KSP_CG && type != MIMSEM_KSP_GMRES)) return MIMSEM_ERR_ARG;
     mimsem_ksp* k = new mimsem_ksp();
     k->c = ctx; k->type = type;
-    k->gs_fused = !(getenv("MIMSEM_GS_FUSED_NORM") && atoi(getenv("MIMSEM_GS_FUSED_NORM")) == 0);
-    k->cgs2 = getenv("MIMSEM_GS_CGS2") && atoi(getenv("MIMSEM_GS_CGS2")) == 1;
+    k->gs_fused = !(exp_env("MIMSEM_GS_FUSED_NORM") && atoi(exp_env("MIMSEM_GS_FUSED_NORM")) == 0);
+    k->cgs2 = exp_env("MIMSEM_GS_CGS2") && atoi(exp_env("MIMSEM_GS_CGS2")) == 1;
     *out = k;
     return MIMSEM_OK;
 }

@@ -174,7 +174,8 @@ public:
     SWEqn(Mesh* m, const double* fg_dev, Shard* shard = nullptr) : mesh(m), fg(fg_dev), sh(shard), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
         if (sh) use_graph = false;
-        if (const char* e = std::getenv("MIMSEM_SW_STEP2")) two_launch_steps = std::atoi(e) != 0;      // (A/B: scripts/ab_sw_cpp.sh)
+        if (std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS")))        // (closed experiment; A/B: scripts/ab_sw_cpp.sh)
+            if (const char* e = std::getenv("MIMSEM_SW_STEP2")) two_launch_steps = std::atoi(e) != 0;
         try {
             for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &y1, &z1}) *p = mesh->device_alloc(n1);
             for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);

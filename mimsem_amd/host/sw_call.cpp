@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
         const SWCase cs = read_sw_case(argv[1]);
         const mimsem_mesh_desc d = cs.desc();
         Mesh mesh(d);
-        if (const char* e = std::getenv("MIMSEM_SW_DEFAULT_STREAM")) if (std::atoi(e)) mesh.use_default_stream();      // (A/B: scripts/ab_sw_cpp.sh)
+        if (std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS")))        // (closed experiment; A/B: scripts/ab_sw_cpp.sh)
+            if (const char* e = std::getenv("MIMSEM_SW_DEFAULT_STREAM")) if (std::atoi(e)) mesh.use_default_stream();
         double* fg = mesh.to_device(cs.fg.data(), cs.fg.size());
         std::printf("{");
         for (int mode = 0; mode < 2; mode++) {

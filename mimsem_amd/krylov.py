@@ -10,6 +10,8 @@ import os
 
 import torch
 
+from ._switches import experiment
+
 from .device import no_gc
 
 
@@ -488,17 +490,17 @@ class GraphedGMRES:
         self.col_host = torch.zeros(restart, restart + 2, dtype=dtype).pin_memory()     # row j: Hessenberg column of step j
         self.graphs = [None] * restart
         self.pool = None
-        self.lookahead = int(os.environ.get("MIMSEM_GMRES_LOOKAHEAD", "8"))
+        self.lookahead = int(experiment("MIMSEM_GMRES_LOOKAHEAD", "8"))
         # the two-launch re-orthonormalisation takes its norm from w.w - h2.h2; the kernel raises this (pinned) word should that
         # ever cancel, and the cycle is then repeated on the three-launch form
         # (round 4: this object's OWN word and form, handed to every call -- rounds 2-3 registered the word with the context, where a
         # second GraphedGMRES on the same engine overwrote it)
         self.gs_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.gs_fused = os.environ.get("MIMSEM_GS_FUSED_NORM", "1") != "0"
+        self.gs_fused = experiment("MIMSEM_GS_FUSED_NORM", "1") != "0"
         # mimsem_krylov_cgs2 (round 4: the whole CGS2 step in three launches) is OPT-IN: measured SLOWER than the four launches it replaces
         # (config 3: 175 against 204 steps/s, config 2: 13.5 against 15.4) -- its middle kernel serialises k block reductions and the last
         # one then reduces n/512 partials per row instead of 32; kept with its parity test as the record (profiles/r04_sw_cgs2_ab.txt)
-        self.cgs2 = os.environ.get("MIMSEM_GS_CGS2", "0") == "1" and not hasattr(eng, "halo")      # (a DistEngine reduces its dots over the ranks)
+        self.cgs2 = experiment("MIMSEM_GS_CGS2", "0") == "1" and not hasattr(eng, "halo")      # (a DistEngine reduces its dots over the ranks)
 
     def _step(self, j):
         eng, V, k = self.eng, self.V, j + 1

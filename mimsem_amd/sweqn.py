@@ -10,6 +10,8 @@ import os
 import numpy as np
 import torch
 
+from ._switches import experiment
+
 from .geom import gll_weights
 from .krylov import GraphedGMRES, GraphedRichardson, gmres, pcg_engine
 
@@ -55,9 +57,9 @@ class SWEqn:
         self._rM1 = None
         self._guess = {}
         self._m0fg = None
-        self.chunk = int(os.environ.get("MIMSEM_SW_CHUNK", "10"))
-        self.fused_sweeps = os.environ.get("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
-        self.warm_start = os.environ.get("MIMSEM_SW_WARM_START", "1") == "1"
+        self.chunk = int(experiment("MIMSEM_SW_CHUNK", "10"))
+        self.fused_sweeps = experiment("MIMSEM_SW_FUSED_SWEEPS", "1") == "1"
+        self.warm_start = experiment("MIMSEM_SW_WARM_START", "1") == "1"
         # Initial guesses of the nested solves from the counterpart solves of the previous steps (round 5 experiment, OFF): every solve of a
         # step has a counterpart a step ago -- the same diagnostic, the same Picard iteration.  MIMSEM_SW_EXTRAPOLATE=2 starts from the linear
         # extrapolation 2 x(n-1) - x(n-2) of the last two counterparts, 1 from the last one, 0 (default) from what round 4 did (the last
@@ -65,7 +67,7 @@ class SWEqn:
         # of successive steps are NOT close -- |P (b - A x0)| / |P b| = 0.5 ... 1.8 for the extrapolated guess of the [u|h] solve on the
         # Galewsky run (dt = 360 s resolves the grid-scale gravity waves with 2.5 steps per period: the increments oscillate) -- GMRES needs
         # its 25-26 iterations either way and the step is 0-6 % slower.  Kept as the record of the experiment.
-        self.extrapolate = int(os.environ.get("MIMSEM_SW_EXTRAPOLATE", "0"))
+        self.extrapolate = int(experiment("MIMSEM_SW_EXTRAPOLATE", "0"))
         # Polynomial preconditioning of the [u|h] solve (round 5): d Richardson steps on the coupled element blocks as ONE application of the
         # preconditioner, P_d = sum_{i<d} (I - P A)^i P -- an Arnoldi step then costs d operator passes but ONE orthogonalisation (4 launches +
         # a host synchronisation, ~28 of the ~43 us of a step), and GMRES needs ~1/d of the iterations where I - P A contracts.
@@ -73,7 +75,7 @@ class SWEqn:
         # 26 -> 16 / 13 / 11 for d = 2 / 3 / 4, config 3 211.9 -> 222.7 / 222.1 / 220.3 steps/s, config 2 16.1 -> 16.1 / 16.4 / 16.1; error norms
         # and conservation drifts unchanged to 12 digits.  The iterations fall more slowly than 1/d (I - P A is not a strong contraction on the
         # gravity-wave part of the spectrum), so the operator passes grow 26 -> 32 / 39 / 44 while the orthogonalisations shrink: d = 2 it is.
-        self.poly = max(1, int(os.environ.get("MIMSEM_SW_POLY", "2")))
+        self.poly = max(1, int(experiment("MIMSEM_SW_POLY", "2")))
         # Round 5: the [u|h] solve WITHOUT a Krylov method.  Under the coupled element blocks the spectrum of P A is a real interval to within
         # a few per cent (Ritz values on the config-3 sphere, dt = 360 s: Re in [0.347, 1.184], |Im| <= 0.047; scripts/exp/sw_spectrum.py), so
         # a Chebyshev semi-iteration with a FIXED step count applies (krylov.GraphedChebyshev): ~30 steps of {P A d: 3 launches, one fused
@@ -90,8 +92,8 @@ class SWEqn:
         self._inline = None                 # the _PicardGraph that is recording / warming up: nested solves run inline and log their check norms
         self._pg = None
         self._hist = {}
-        self.richardson = os.environ.get("MIMSEM_SW_RICHARDSON", "1") == "1"
-        self.coupled_pc = os.environ.get("MIMSEM_SW_PC", "coupled") == "coupled"
+        self.richardson = experiment("MIMSEM_SW_RICHARDSON", "1") == "1"
+        self.coupled_pc = experiment("MIMSEM_SW_PC", "coupled") == "coupled"
 
     # ---- operator applies (src flavour: scale 1, flags 0) ---------------------------------------------------
     def _guess_for(self, key, shape):
@@ -149,7 +151,7 @@ class SWEqn:
         if self._inline is not None:
             return self._inline.m1(b)
         if self.graphs and self.cheb and self.eng.mesh.n <= 5 and self.fused_sweeps and not hasattr(self.eng, "halo") and \
-                os.environ.get("MIMSEM_SW_CHEB_M1", "1") == "1":
+                experiment("MIMSEM_SW_CHEB_M1", "1") == "1":
             # round 5: a FIXED-length Chebyshev semi-iteration on the fused block sweep (krylov.ChebyshevMass: 3 launches per step, spectrum of
             # P M1 from 25 Lanczos steps once), the whole solve with its two norms in ONE hipGraph replay -- ~15 steps where the Richardson
             # sweeps below take 20 and a host read per chunk of 10
@@ -419,7 +421,7 @@ class SWEqn:
         Gram-Schmidt pass (mimsem_sw_operator_precond_orthogonalize, round 4).  OPT-IN (MIMSEM_SW_FUSED_DOTS=1): one launch less per Arnoldi step and
         SLOWER -- every one of the k row-blocks of the dot pass repeats the gather (192-196 against 205-208 steps/s, profiles/r04_sw_cgs2_ab.txt);
         None otherwise, and where the fused body does not apply"""
-        if not (self.eng.mesh.n <= 4 and self.coupled_pc and not hasattr(self.eng, "halo")) or os.environ.get("MIMSEM_SW_FUSED_DOTS", "0") != "1":
+        if not (self.eng.mesh.n <= 4 and self.coupled_pc and not hasattr(self.eng, "halo")) or experiment("MIMSEM_SW_FUSED_DOTS", "0") != "1":
             return None
         if self.poly > 1:
             return None                                               # (the fused form is the plain preconditioner's)
@@ -471,7 +473,7 @@ class SWEqn:
                         lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
                         ok = lmin > 0.02 and imax <= 0.15 * (lmax - lmin)          # a real, positive interval (else: the GMRES)
                         step = None
-                        if os.environ.get("MIMSEM_SW_CHEB_FUSED", "1") == "1" and not hasattr(self.eng, "halo"):
+                        if experiment("MIMSEM_SW_CHEB_FUSED", "1") == "1" and not hasattr(self.eng, "halo"):
                             blocks = self._pcA[1]                                   # (set by _krylov_body1: the coupled element blocks of this dt)
                             step = lambda ca, cb, x, r, d: self.eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, self.grav, H_MEAN, self.fg, blocks, ca, cb, x, r, d)
                         self._cA = (dt, GraphedChebyshev(self.eng, tuple(f.shape), body1, lambda r: self.precond_A(r, dt), lmin, lmax, rtol=self.rtol, step=step)
@@ -676,7 +678,10 @@ class _PicardGraph:
         """widen >= 1: the safety margins around the estimated spectral regions, times widen (a re-estimate after a missed check asks for more)"""
         from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds
         self.S, self.dt, self.q_exact = S, dt, q_exact
-        self.dist = S.dist                   # sharded: eager launches with the exchanges in between, local check norms, one all-reduce (replay)
+        self.dist = S.dist                   # sharded: local (ownership-weighted) check norms, one all-reduce per Picard iteration (replay)
+        # ... recorded as a hipGraph all the same when the exchanges are kernels only (the one-sided transport of csrc/halo.hip: pack into the
+        # neighbour's buffer, sequence flags, a device-side exchange counter); with a library or host transport the same launches run eagerly
+        self.record = (not S.dist) or getattr(S.eng, "transport", None) == "peer"
         self.last_miss = None
         self.key = (dt, q_exact, tuple(un.shape), has_bot)
         self.bot = torch.zeros_like(hn) if has_bot else None          # bottom topography (SWEqn::solve's `bot`): a fixed buffer of the recording
@@ -746,7 +751,7 @@ class _PicardGraph:
         self.slot = 0
         self.names = {}
         # MIMSEM_SW_FORK=1: the q solve as a parallel branch of the recorded iteration (second stream + second context of the same mesh)
-        self.fork = (not q_exact) and not self.dist and os.environ.get("MIMSEM_SW_FORK", "0") == "1"
+        self.fork = (not q_exact) and not self.dist and experiment("MIMSEM_SW_FORK", "0") == "1"
         if self.fork:
             from .device import Engine
             self.eng_q = Engine(eng.mesh, device=eng.device.index or 0)
@@ -838,7 +843,7 @@ class _PicardGraph:
 
     def replay(self, first):
         S = self.S
-        if self.dist:
+        if self.dist and not self.record:
             # the same sequence of launches, eagerly, with the halo exchanges where the element-local sums need completing; every check norm is a
             # local (ownership-weighted) partial sum: ONE all-reduce of 2 x nslots doubles per Picard iteration, none inside any solve
             S._inline = self
@@ -859,6 +864,8 @@ class _PicardGraph:
             self.x.copy_(keep)
         g, _, _ = self.graphs[first]
         g.replay()
+        if self.dist:
+            S.eng.allreduce(self.chk)
         return self.chk.tolist()
 
     def verify(self, vals, first):

@@ -4,6 +4,7 @@
   * HIP-event time of the operator's kernels, both forms.
 usage: python scripts/ab_fin.py [R=8] [rounds=60]"""
 import os
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import sys
 import time
 

@@ -1,6 +1,7 @@
 """small launches (the reference's single-level assemble + MatMult granularity): Umat apply wall time per call, default two-launch form
 against the in-kernel finishing phase (MIMSEM_WAVE_FIN=1) -- where the second LAUNCH, not the bytes, is the cost"""
 import os, sys, time
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

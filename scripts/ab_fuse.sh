@@ -1,3 +1,4 @@
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 python -m pytest tests -m gpu -q -x > gpurun_out/t16.log 2>&1; tail -3 gpurun_out/t16.log
 for v in 1 0; do
   echo "FUSE=$v"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of a library variant (build_ab/libmimsem_hip_$1.so, scripts/build_variant.sh) against the default: bench.py hot and cold, twice each
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 out=gpurun_out/ab_lib_$1.log; : > $out
 run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column --no-families --no-sweep 2>>gpurun_out/ab_lib.err | python -c "
 import json,sys

@@ -2,6 +2,7 @@
 # MFMA A/B on the p = 4 element block product: kernel time and the matrix-core counters of the block pass of a
 # Chebyshev sweep on the config-5 grid, register-row form against k_blocks_residual_mfma.  Counters in their own passes (--pmc with
 # --kernel-trace only).  Output: gpurun_out/mfma_p4.txt (copied to profiles/r03_mfma_p4_ab.txt).
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/mfma_p4; mkdir -p $O; out=$R/gpurun_out/mfma_p4.txt; : > $out
 for m in 0 1; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: levels per thread of k_wave_perim (rebuilt in the box's ephemeral copy of the repo)
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 cd $GRAFT_REPO_ROOT
 run() { echo "== $*"; python bench.py --no-cpu --no-pmc --no-sw --no-column 2>/dev/null | python -c "
 import json,sys

@@ -1,5 +1,6 @@
 #!/bin/bash
 # levels per task of k_s3_sweep<4> on config 5's columns, one box (round 4): MIMSEM_SWEEP_CHUNK = 16 | 22 | 32 | 64, kernel averages
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_s3chunk; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for round in 1 2; do
 for c in 16 22 32 64; do

@@ -2,6 +2,7 @@
 # C++-hosted shallow-water step (mimsem_amd/host/sw_call) on the config-3 sphere: A/B of host-side switches
 #   MIMSEM_SW_DEFAULT_STREAM=1   the context on the legacy default stream (graph recorded on a blocking stream) against a stream of its own
 #   MIMSEM_SW_STEP2=1            the [u|h] Chebyshev step in two launches (the gather epilogue in the next element pass) against three
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 set -e
 cd "$(dirname "$0")/.."
 python scripts/exp/write_sw_case3.py gpurun_out/sw_case3.bin 200

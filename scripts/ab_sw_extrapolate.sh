@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the initial guesses of the SW step's nested solves (mimsem_amd/sweqn.py, MIMSEM_SW_EXTRAPOLATE = 0: round 4, 1: the counterpart
 # solve of the last step, 2: linear extrapolation of the last two) -> steps/s, Krylov counts, error norms, drifts on configs 2 and 3
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; cd $R
 for e in 0 1 2; do
   MIMSEM_SW_EXTRAPOLATE=$e python3 bench.py --no-families --no-column --no-sweep --cold 0 --no-pmc --no-cpu > /dev/null 2> /dev/null

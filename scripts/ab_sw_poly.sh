@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the polynomial preconditioner of the [u|h] solve (mimsem_amd/sweqn.py, MIMSEM_SW_POLY = d Richardson steps on the coupled element
 # blocks per application) -> steps/s, Krylov counts, error norms, drifts on configs 2 and 3
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; cd $R
 for e in 1 2 3 4; do
   MIMSEM_SW_POLY=$e python3 bench.py --no-families --no-column --no-sweep --cold 0 --no-pmc --no-cpu > /dev/null 2> /dev/null

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The Helmholtz solve inside solve_schur_column_eta (3 456 columns x 30 levels): one-sided sweep (MIMSEM_THOMAS2=0) against the two-sided
 # sweep at one wavefront per SIMD (MIMSEM_THOMAS_WPS=1, round 3) and at two (default, round 5); wall clock per solve and rocprofv3 kernel averages of the three kernels of the solve.
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 out=gpurun_out/ab_thomas.log; : > $out
 cd /tmp && export TMPDIR=/tmp
 for v in "MIMSEM_THOMAS2=0" "MIMSEM_THOMAS_WPS=1" "DEFAULT=1"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; cd $R
 run() {
   env "$@" python3 bench.py --steps 200 --warmup 20 --no-families --no-column --no-sweep --no-sw --no-cpu --no-pmc > /dev/null 2> /dev/null

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on one box (round 4): thickInv of k_apply_wave from the [element][point] pair table (default) or from the NODAL pair table
 # (MIMSEM_WAVE_TNODE=1): kernel averages of the headline step, cache-resident (103 680 units) and HBM-resident (8 spheres)
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_tnode; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for round in 1 2; do
 for v in 0 1; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B: thickInv of a level pair in one 16-byte load (default) against one 8-byte load per level (build_ab/libmimsem_hip_notpair.so, built
 # with -DMIMSEM_NO_TPAIR); bench.py hot and cold, both variants twice in ONE run (boxes of the pool differ by ~10 %).
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 out=gpurun_out/ab_tpair.log; : > $out
 run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_tpair.err | python -c "
 import json,sys

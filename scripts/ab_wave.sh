@@ -2,6 +2,7 @@
 # A/B of the wave-level fused 1-form kernel (k_apply_wave + k_wave_perim) against the two-pass form (MIMSEM_WAVE=0) and of its knobs:
 # MIMSEM_WAVE_CPP = chunks of 8 levels per wavefront (default: balanced parts leaving >= 1536 wavefronts), MIMSEM_WAVE_ORDER, MIMSEM_WAVE_LCH.
 # bench.py hot (103 680 units) and cold (829 440 units); all variants in ONE run (boxes of the pool differ by ~10 %).
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 out=gpurun_out/ab_wave.log; : > $out
 run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_wave.err | python -c "
 import json,sys

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: wavefronts per workgroup of k_apply_wave (rebuilt in the box's ephemeral copy) and kernel arguments in device memory
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 cd $GRAFT_REPO_ROOT
 run() { echo "== $*"; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>/dev/null | python -c "
 import json,sys

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build another variant of the library next to the default one: scripts/build_variant.sh NAME "-DFLAG ..." -> build_ab/libmimsem_hip_NAME.so
 # (select it with MIMSEM_LIB=$PWD/build_ab/libmimsem_hip_NAME.so; build_ab/ is git-ignored and travels to the GPU box)
+export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 set -e
 name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)

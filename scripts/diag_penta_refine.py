@@ -2,6 +2,7 @@
 """how the refinement of the block-pentadiagonal solve converges: |last correction| / |solution| per column after 1..4 allowed steps,
 on the rough random columns of bench.py's `column` extra (config 4 grid) and on the hydrostatic columns of config 5"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench

@@ -2,6 +2,7 @@
 """true residual |F - L d| / |F| of solve_schur_column_3's pentadiagonal system per column: fused path vs round 2's chain + super-block sweep,
 on bench.py's random column workload and on a hydrostatic config-4 state"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench

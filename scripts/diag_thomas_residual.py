@@ -3,6 +3,7 @@
 seeds and refinement counts, next to what LAPACK's pivoted LU (numpy.linalg.solve) leaves on the SAME worst column -- the floor set
 by the conditioning (eps |L| |d| / |f|), not by the solver"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from mimsem_amd.device import DeviceMesh, Engine

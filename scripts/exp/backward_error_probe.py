@@ -3,6 +3,7 @@
 the bench's 3 456 rough random columns, WITHOUT refinement and after 1 / 2 steps: how many columns leave the unpivoted block elimination at
 round-off level already (LAPACK's xGERFS would not refine them) -- the question behind skipping the refinement's second solve per column"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from mimsem_amd.device import DeviceMesh, Engine

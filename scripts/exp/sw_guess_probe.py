@@ -1,6 +1,7 @@
 """how good are the extrapolated initial guesses of the SW step's solves?  prints, per step and Picard iteration, the GMRES iteration count of
 the [u|h] solve and the relative size of the initial residual (MIMSEM_SW_EXTRAPOLATE = 0 | 1 | 2)"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from mimsem_amd.device import DeviceMesh, Engine

@@ -1,6 +1,7 @@
 """Ritz values of P A (the coupled element-block preconditioner times the [u|h] operator of the SW Picard step) from an Arnoldi process:
 where does the spectrum lie (real interval -> Chebyshev; vertical segment around 1 -> gravity-wave pairs)?"""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 os.environ["MIMSEM_SW_POLY"] = "1"

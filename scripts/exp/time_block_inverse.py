@@ -1,6 +1,7 @@
 """mimsem_block_inverse on the 3 456 coupled [u|h] blocks (33 x 33) of the config-3 SW preconditioner and on the 24 x 24 M1 blocks:
 one wavefront per block (round 5) against the thread-per-block kernel (MIMSEM_INV_THREAD=1)"""
 import os, sys, time
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from mimsem_amd.device import DeviceMesh, Engine

@@ -5,6 +5,7 @@ block times the gathered residuals of every level -- the block pass of the Cheby
 v_mfma_f64_16x16x4 over 16 levels).  Run under rocprofv3 by scripts/ab_mfma_p4.sh (kernel time, SQ_INSTS_VALU_MFMA_MOPS_F64,
 SQ_VALU_MFMA_BUSY_CYCLES)."""
 import os, sys, time
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

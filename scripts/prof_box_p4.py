@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The config-5 element step alone (Umat apply, p = 4, 32 x 32 periodic box x 64 levels, 65 536 units) for rocprofv3 passes."""
 import os, sys
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

@@ -2,6 +2,7 @@
 """The bench.py step (Umat apply over the config-4 sphere x 30 levels) alone, hot (103 680 units) and cold (8 spheres), for rocprofv3
 passes: scripts/prof_umat_pmc.sh.  MIMSEM_WAVE=0 selects the two-pass form."""
 import os
+os.environ.setdefault("MIMSEM_EXPERIMENTS", "1")      # (closed-experiment switches are read only under this master switch: DESIGN 9.1)
 import sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

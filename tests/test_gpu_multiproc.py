@@ -225,7 +225,10 @@ def _sw_worker(rank, world, port, q):
                 xq[g.loc0] = coords[g.loc0]
             return dm, Engine(dm), xq[dm.gidq]
         dm, eng, xq = build(patches_of_rank(npatch, world, rank))
-        deng = DistEngine(eng, cs, world, rank)
+        # world 2: the C ABI's plans on the ONE-SIDED transport -- exchanges that are kernels only, so the whole Picard iteration is RECORDED as a
+        # hipGraph on every rank (exchanges inside); world 3: the host-staged exchanger, the same launches eagerly
+        peer = world == 2
+        deng = DistEngine(eng, cs, world, rank, overlap=True, transport="peer") if peer else DistEngine(eng, cs, world, rank)
         S = SWEqn(deng, xq)
         uq, hq = williamson2(torch.as_tensor(xq, device=eng.device), alpha=0.0)
         lam = torch.atan2(torch.as_tensor(xq[:, 1]), torch.as_tensor(xq[:, 0])).to(eng.device)
@@ -250,6 +253,8 @@ def _sw_worker(rank, world, port, q):
         u2, h2 = S.solve(u1, h1, 360.0, nits=2, q_exact=False)
         tdist.all_reduce = real_all_reduce
         fixed = fixed and S.fixed_iterations == 4 and S.adaptive_iterations == 0 and calls["n"] == 2
+        if peer:
+            fixed = fixed and S._pg.record and all(g is not None for g, _, _ in S._pg.graphs.values()) and deng.chalo.peer_timeouts() == {}
         if not fixed:
             print("rank", rank, "fixed-length mode not engaged:", S.fixed_iterations, S.adaptive_iterations, S.recalibrations, calls, getattr(S, "last_miss", None), flush=True)
         ug = deng.gather_owned(1, u1, dm.gid1, cs.nDofs1G).cpu().numpy()
