@@ -238,8 +238,9 @@ class MassSolver:
         self.solves_checked = self.solves_missed = 0
         self.worst_check = 0.0
         # default solver for the block preconditioner on one rank: fixed-length Chebyshev on the fused sweep (no inner products)
-        self.chebyshev = (precond != "jacobi" and os.environ.get("MIMSEM_MASS_SOLVER", "chebyshev") == "chebyshev"
-                          and not hasattr(eng, "halo") and eng.mesh.n <= 5)
+        # (round 6: also over a halo -- a DistEngine has the sweep with its two exchanges inside, no inner product: no all-reduce in the solve)
+        self.dist = hasattr(eng, "halo")
+        self.chebyshev = (precond != "jacobi" and os.environ.get("MIMSEM_MASS_SOLVER", "chebyshev") == "chebyshev" and eng.mesh.n <= 5)
         if precond == "jacobi":
             diag = eng.zeros(eng.nk, dm.n1)
             for k in range(eng.nk):
@@ -280,9 +281,16 @@ class MassSolver:
         """the fixed-length Chebyshev solver on the fused block sweep (single rank, 2 n1e <= 64 rows); spectral bounds over all levels"""
         if self._cheb is None:
             eng = self.eng
-            g = torch.Generator(device="cpu"); g.manual_seed(1234)
-            b = torch.randn(eng.nk, eng.sizes[1], generator=g, dtype=torch.float64).to(eng.device)
-            lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25)
+            if self.dist:
+                # the rank's rows of the global random right-hand side (every level its own draw), ownership-weighted all-reduced inner products
+                b = torch.cat([eng.randn_global(1, 1234 + k, cpu_generator=True) for k in range(eng.nk)], dim=0).contiguous()
+                w1 = eng.weights(1)
+                lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25,
+                                            dot=lambda u, v: eng.allreduce(torch.linalg.vecdot(u * w1, v, dim=1)))
+            else:
+                g = torch.Generator(device="cpu"); g.manual_seed(1234)
+                b = torch.randn(eng.nk, eng.sizes[1], generator=g, dtype=torch.float64).to(eng.device)
+                lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25)
             self._cheb = ChebyshevMass(eng, None, lmin, lmax, rtol=1e-15)
             self._blocks_cm = self.blocks.transpose(1, 2).contiguous()
         return self._cheb
@@ -298,7 +306,7 @@ class MassSolver:
         ch.upd = self._pair[:nlev]
         x = ch.solve(b, want_residual=True, pb=self._pair[nlev:])
         k = min(self._slot, self.MAXLOG - 1); self._slot += 1
-        self.eng.rowdot(self._pair, self._pair, out=self._log[k])
+        self.eng.rowdot_local(self._pair, self._pair, out=self._log[k], space=1)       # (sharded: this rank's ownership-weighted part; verify() reduces the log once)
         return x
 
     def verify(self, rtol=1e-14):
@@ -307,6 +315,8 @@ class MassSolver:
         Chebyshev mode is switched off (PCG from here on) and the caller redoes its evaluation.  Synchronises."""
         if self._log is None or self._slot == 0:
             return True
+        if self.dist:
+            self.eng.allreduce(self._log)                       # ONE all-reduce for every solve since the last call
         v = self._log.cpu().numpy()
         self._log.zero_(); self._slot = 0
         nlev = v.shape[1] // 2
@@ -343,6 +353,8 @@ class MassSolver:
                 self._cheb_checked = False
                 self._cheb_cal = None
             x = self._logged_solve(ch, b)
+            if self.dist:
+                return x, ch.steps           # (sharded: the bound-based count stands -- the one-time calibration below measures true residuals on the host; every solve is checked by verify())
             if not self._cheb_checked and not torch.cuda.is_current_stream_capturing():
                 # one-time check of the spectral bounds on a real right-hand side: a step count derived from wrong bounds would
                 # silently under-solve; fall back to PCG for good if the true residual is not at round-off
