@@ -1490,6 +1490,12 @@ def main():
                 us, hs_ = S.init1(uq), S.init2(hq)
                 for _ in range(2):
                     us, hs_ = S.solve(us, hs_, 360.0, nits=2, q_exact=False)
+                    if transport == "peer":
+                        # (a neighbour that never publishes costs a bounded 2 s wait PER exchange: leave at the first sign of one, on every rank)
+                        bad = torch.tensor([1.0 if (des.chalo.peer_timeouts() or des.chalo0.peer_timeouts()) else 0.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                        if bad.item() > 0:
+                            raise RuntimeError("one-sided transport: an exchange timed out during the warm-up steps")
                 f0, a0 = S.fixed_iterations, S.adaptive_iterations
                 fence(); t1 = time.perf_counter()
                 for _ in range(nst):

@@ -10,9 +10,9 @@
 // there is one --, the communicator is the host's), a host callback (GPU-aware MPI, torch.distributed, a test double), loop-back
 // (a plan whose only neighbour is the rank itself: periodic single-rank layouts and tests), or -- round 6 -- ONE-SIDED ("peer"):
 //   the receive buffers are exported with hipIpcGetMemHandle and opened by the neighbour ranks when the plan is connected; begin's pack
-//   kernel writes every message STRAIGHT INTO the neighbour's receive buffer (over xGMI between GPUs of a node) and a one-wavefront kernel
-//   behind it publishes the exchange's sequence number into the neighbour's arrival flags (system-scope release); end's unpack is preceded
-//   by a one-wavefront kernel that waits for the flags of all neighbours (system-scope acquire, bounded spin).  No library call on the
+//   kernel writes every message STRAIGHT INTO the neighbour's receive buffer (over xGMI between GPUs of a node) and its last block
+//   publishes the exchange's sequence number into the neighbour's arrival flags (system-scope release); end's unpack kernel first waits for
+//   the flags of all neighbours (system-scope acquire, bounded spin).  TWO kernels per exchange, no library call on the
 //   critical path, no communication stream, and nothing but kernel nodes -- the exchange can be recorded in a hipGraph with the solver
 //   around it, which a kB-sized message inside a 20 us step needs to have any chance against an RCCL launch.  Receive buffers are double
 //   (exchange parity): a neighbour may already write exchange k + 1 while this rank still unpacks exchange k; it cannot reach k + 2 before
@@ -85,59 +85,62 @@ constexpr int kNcclFloat64 = 8;                                       // ncclDat
 struct PeerSegs { int nseg; int off[MIMSEM_HALO_MAX_SEGMENTS + 1]; double* dst[MIMSEM_HALO_MAX_SEGMENTS]; long long half[MIMSEM_HALO_MAX_SEGMENTS]; };
 // The exchange counter lives in DEVICE memory (word SEQ of the flag block) and is advanced by the publish kernel: nothing of an exchange is
 // baked into kernel arguments, so a recorded exchange replays correctly (exchange k of a replay uses parity and sequence number k).
-constexpr int PEER_ERR = MIMSEM_HALO_MAX_SEGMENTS, PEER_SEQ = MIMSEM_HALO_MAX_SEGMENTS + 1, PEER_WORDS = MIMSEM_HALO_MAX_SEGMENTS + 2;
-// pack: entry (level, slot j of segment s) of v goes to neighbour s's receive buffer (the half of this exchange's parity), [level][slot] inside its message
-__global__ __launch_bounds__(256) void k_halo_pack_peer(PeerSegs sg, int nlev, const int* __restrict__ idx, const double* __restrict__ v, long long vs,
-                                                        const unsigned long long* __restrict__ myflags) {
+constexpr int PEER_ERR = MIMSEM_HALO_MAX_SEGMENTS, PEER_SEQ = MIMSEM_HALO_MAX_SEGMENTS + 1, PEER_CNT = MIMSEM_HALO_MAX_SEGMENTS + 2, PEER_WORDS = MIMSEM_HALO_MAX_SEGMENTS + 3;
+struct PeerFlags { int n; unsigned long long* flag[MIMSEM_HALO_MAX_SEGMENTS]; };
+// begin = ONE kernel: entry (level, slot j of segment s) of v goes to neighbour s's receive buffer (the half of this exchange's parity, [level][slot]
+// inside its message); the block that finishes LAST (a device-scope counter behind a system-scope fence: every block's stores are visible before
+// the counter says so) publishes the exchange's sequence number into every neighbour's arrival flags with a system-scope release and advances
+// the counter of exchanges.  total == 0 (nothing to send, neighbours all the same): one block that only publishes.
+__global__ __launch_bounds__(256) void k_halo_pack_peer(PeerSegs sg, PeerFlags pf, int nlev, const int* __restrict__ idx, const double* __restrict__ v, long long vs,
+                                                        unsigned long long* myflags) {
     const int total = sg.off[sg.nseg];
     const long long t = (long long)blockIdx.x*256 + threadIdx.x;
-    if (t >= (long long)total*nlev) return;
-    const unsigned long long seq = myflags[PEER_SEQ] + 1;             // (advanced by k_halo_publish, which follows in the stream)
-    const int gi = (int)(t%total), lev = (int)(t/total);
-    int s = 0;
-    while (gi >= sg.off[s + 1]) s++;
-    const int cnt = sg.off[s + 1] - sg.off[s];
-    sg.dst[s][(size_t)(seq & 1)*sg.half[s] + (size_t)lev*cnt + (gi - sg.off[s])] = v[(size_t)lev*vs + idx[gi]];
-}
-struct PeerFlags { int n; unsigned long long* flag[MIMSEM_HALO_MAX_SEGMENTS]; };
-// publish: the pack kernel before this one in the stream has finished (its stores are released at its end); one lane per neighbour stores the
-// exchange's sequence number with a system-scope release, then the counter advances
-__global__ void k_halo_publish(PeerFlags pf, unsigned long long* myflags) {
-    const int i = threadIdx.x;
-    const unsigned long long seq = myflags[PEER_SEQ] + 1;
-    if (i < pf.n) {
+    const unsigned long long seq = myflags[PEER_SEQ] + 1;             // (advanced by the last block below, after every block has read it)
+    if (t < (long long)total*nlev) {
+        const int gi = (int)(t%total), lev = (int)(t/total);
+        int s = 0;
+        while (gi >= sg.off[s + 1]) s++;
+        const int cnt = sg.off[s + 1] - sg.off[s];
+        sg.dst[s][(size_t)(seq & 1)*sg.half[s] + (size_t)lev*cnt + (gi - sg.off[s])] = v[(size_t)lev*vs + idx[gi]];
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = atomicAdd((unsigned long long*)(myflags + PEER_CNT), 1ULL) == (unsigned long long)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if ((int)threadIdx.x < pf.n) {
         __threadfence_system();
-        __hip_atomic_store(pf.flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pf.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    if (i == 0) myflags[PEER_SEQ] = seq;
+    if (threadIdx.x == 0) { myflags[PEER_CNT] = 0; myflags[PEER_SEQ] = seq; }
 }
-// wait: one lane per neighbour polls ITS arrival flag (system-scope acquire) until it carries this exchange's number; bounded: after
-// ~2 s the error word is set and the kernel leaves -- every wave reaches an exit whatever the neighbours do
-__global__ void k_halo_wait(unsigned long long* myflags, int n) {
-    const int i = threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long seq = myflags[PEER_SEQ];
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(myflags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(myflags + PEER_ERR, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // (100 MHz constant clock: 2 s)
-    }
-}
-// unpack from the half of the exchange's parity (k_halo_segments with the buffer chosen on the device): mode 1 insert, 2 add
+// end = the unpack kernel itself waits: the first lanes of every block poll the arrival flags of ALL neighbours (system-scope acquire, s_sleep
+// between, bounded: after ~2 s the error word is set and the block goes on -- every wave reaches an exit whatever the neighbours do), then the
+// block unpacks from the half of the exchange's parity (k_halo_segments with the buffer chosen on the device): mode 1 insert, 2 add
 struct PeerRecv { int nseg; int off[MIMSEM_HALO_MAX_SEGMENTS + 1]; };
 __global__ __launch_bounds__(256) void k_halo_unpack_peer(PeerRecv sg, int s_begin, int s_end, int nlev, int mode, const int* __restrict__ idx,
-                                                          const double* __restrict__ base, long long half, const unsigned long long* __restrict__ myflags,
+                                                          const double* __restrict__ base, long long half, unsigned long long* myflags,
                                                           double* __restrict__ v, long long vs) {
+    const unsigned long long seq = myflags[PEER_SEQ];
+    if ((int)threadIdx.x < sg.nseg) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(myflags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000LL) { __hip_atomic_store(myflags + PEER_ERR, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // (100 MHz constant clock: 2 s)
+        }
+    }
+    __syncthreads();
     const int g0 = sg.off[s_begin], total = sg.off[s_end] - g0;
     const long long t = (long long)blockIdx.x*256 + threadIdx.x;
     if (t >= (long long)total*nlev) return;
-    const double* buf = base + (size_t)(myflags[PEER_SEQ] & 1)*half;
+    const double* buf = base + (size_t)(seq & 1)*half;
     const int gi = g0 + (int)(t%total), lev = (int)(t/total);
     int s = s_begin;
     while (gi >= sg.off[s + 1]) s++;
     const int cnt = sg.off[s + 1] - sg.off[s];
-    const double b = buf[(size_t)sg.off[s]*nlev + (size_t)lev*cnt + (gi - sg.off[s])];
+    const double b = __builtin_nontemporal_load(buf + (size_t)sg.off[s]*nlev + (size_t)lev*cnt + (gi - sg.off[s]));
     double* o = v + (size_t)lev*vs + idx[gi];
     if (mode == 1) *o = b; else *o += b;
 }
@@ -288,23 +291,17 @@ int mimsem_halo_begin(mimsem_halo* h, int mode, int nlev, double* v, long long v
     int rc;
     if (h->transport == 4) {
         // one-sided: pack straight into the neighbours' receive buffers (the half of this exchange's parity), then publish the sequence number
-        if (h->nneigh && h->send_off[h->nneigh]) {
+        if (h->nneigh) {
             PeerSegs sg; sg.nseg = h->nneigh;
+            PeerFlags pf; pf.n = h->nneigh;
             for (int i = 0; i <= h->nneigh; i++) sg.off[i] = h->send_off[i];
             for (int i = 0; i < h->nneigh; i++) {
                 double* base = h->peer_base[i] ? (double*)h->peer_base[i] : h->d_peer;
                 sg.dst[i] = base + (size_t)h->peer_off[i]*nlev; sg.half[i] = (long long)h->peer_half_of[i];
+                pf.flag[i] = (unsigned long long*)(base + 2*h->peer_half_of[i]) + h->peer_slot[i];
             }
             const long long total = (long long)h->send_off[h->nneigh]*nlev;
-            hipLaunchKernelGGL(k_halo_pack_peer, dim3((unsigned)((total + 255)/256)), dim3(256), 0, c->stream, sg, nlev, h->d_send_idx, v, vs, h->d_flags);
-        }
-        if (h->nneigh) {
-            PeerFlags pf; pf.n = h->nneigh;
-            for (int i = 0; i < h->nneigh; i++) {
-                unsigned long long* fl = (unsigned long long*)((h->peer_base[i] ? (double*)h->peer_base[i] : h->d_peer) + 2*h->peer_half_of[i]);
-                pf.flag[i] = fl + h->peer_slot[i];
-            }
-            hipLaunchKernelGGL(k_halo_publish, dim3(1), dim3(64), 0, c->stream, pf, h->d_flags);
+            hipLaunchKernelGGL(k_halo_pack_peer, dim3((unsigned)std::max<long long>(1, (total + 255)/256)), dim3(256), 0, c->stream, sg, pf, nlev, h->d_send_idx, v, vs, h->d_flags);
         }
         MIMSEM_HIP_TRY(hipGetLastError());
         h->in_flight = true; h->mode = mode; h->nlev = nlev; h->v = v; h->vs = vs;
@@ -349,7 +346,6 @@ int mimsem_halo_end(mimsem_halo* h) {
     h->in_flight = false;
     if (h->transport == 4) {
         if (!h->nneigh) return MIMSEM_OK;
-        hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, c->stream, h->d_flags, h->nneigh);
         if (h->recv_off[h->nneigh]) {
             PeerRecv sg; sg.nseg = h->nneigh;
             for (int i = 0; i <= h->nneigh; i++) sg.off[i] = h->recv_off[i];
