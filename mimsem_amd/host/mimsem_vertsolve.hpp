@@ -22,6 +22,11 @@ public:
     // the horizontal transport tendencies the loop adds (:1799, :1822-1826): forcing(rho_i, rho_j, theta_l2_h, add_rho, add_rt) fills the two
     // output arrays ([nEl][nk*n2e]); empty = no horizontal wind
     std::function<void(const double*, const double*, const double*, double*, double*)> horiz_forcing;
+    // Several ranks (round 6): the columns of an element live on ONE rank, so the solve needs no exchange at all -- what crosses
+    // ranks is the reference's MPI_Allreduce(MAX) of the four update norms per iteration (eul/VertSolve.cpp:1915-1918: every rank must stop at
+    // the same iteration) and the sum of k2i_z.  A host with more than one rank sets the two callbacks (in place, n host doubles; MPI_Allreduce
+    // with MPI_MAX / MPI_SUM on MPI_COMM_WORLD); unset = one rank.
+    std::function<void(double*, int)> allreduce_max, allreduce_sum;
 
     VertSolveEta(Mesh* m, double dt_) : mesh(m), dt(dt_) {
         nEl = m->nEl_; n2 = m->n2e; nk = m->nk_;
@@ -73,6 +78,7 @@ public:
             check(mimsem_column_diag_theta_blend(c, rho_j, rt_j, theta_h, theta_i, theta_l2_h, theta_l2_i, 0.5, 0.5), "diag_theta_blend");  // :1896-1912
             double mx[4];
             mesh->to_host(mx, sums + 4*(size_t)nEl, 4);
+            if (allreduce_max) allreduce_max(mx, 4);                                                                                    // :1915-1918
             history.push_back({mx[0], mx[1], mx[2], mx[3]});
             if (mx[0] < tol && mx[2] < tol) break;
         }
@@ -81,6 +87,7 @@ public:
             double s = 0.0;
             check(mimsem_krylov_rowdot(c, 1, (long long)ni, k2i, (long long)ni, onesi(), 0, sums), "krylov_rowdot");
             mesh->to_host(&s, sums, 1);
+            if (allreduce_sum) allreduce_sum(&s, 1);
             k2i_z = s/1.0e8;
         }
         copy(velz, velz_j, ni); copy(rho, rho_j, nl); copy(rt, rt_j, nl); copy(exner, exner_j, nl);

@@ -3,6 +3,8 @@
 // state the pytest wrapper wrote: (1) three iterations without forcing, (2) two iterations with the Held-Suarez temperature forcing and the
 // u dw/dx term.  States and max-norm histories go back to the wrapper, which compares them with oracle/vert_oracle.py.
 //   usage: test_vert <in.arr> <out.bin>
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 #include "../../mimsem_amd/host/mimsem_vertsolve.hpp"
@@ -34,6 +36,26 @@ int main(int argc, char** argv) {
             for (double* p : {velz, rho, rt, exner}) mimsem_free(p);
         }
         std::fclose(g);
+        // the reductions of a multi-rank host (round 6: MPI_Allreduce(MAX) of the four norms per iteration, eul/VertSolve.cpp:1915-1918, and the sum of
+        // k2i_z): the callbacks are called once per iteration / once per solve, and what they return decides the stopping test -- a second "rank"
+        // whose norms are still large keeps this one iterating
+        {
+            int nmax = 0, nsum = 0;
+            vs.allreduce_max = [&](double* v, int n) { nmax++; for (int i = 0; i < n; i++) v[i] = std::max(v[i], 1.0e-3); };       // (the other rank has not converged)
+            vs.allreduce_sum = [&](double* v, int n) { nsum++; for (int i = 0; i < n; i++) v[i] *= 2.0; };                          // (... and holds as much k2i_z)
+            double *velz = dev("velz"), *rho = dev("rho"), *rt = dev("rt"), *exner = dev("exner");
+            VertSolveEta one(&mesh, dt);
+            double *v1 = dev("velz"), *r1 = dev("rho"), *t1 = dev("rt"), *e1 = dev("exner");
+            const int its1 = one.solve_schur_eta(v1, r1, t1, e1, zv, 4, 1.0e-6);            // alone: stops as soon as its own norms are below 1e-6
+            const int its = vs.solve_schur_eta(velz, rho, rt, exner, zv, 4, 1.0e-6);        // with the unconverged neighbour: all 4 iterations
+            if (its1 > 4 || its != 4 || nmax != 4 || nsum != 1 || !(vs.history.back().exner >= 1.0e-3) || std::fabs(vs.k2i_z - 2.0*[&] { VertSolveEta w(&mesh, dt);
+                    double *a2 = dev("velz"), *b2 = dev("rho"), *c2 = dev("rt"), *d2 = dev("exner"); w.solve_schur_eta(a2, b2, c2, d2, zv, 4, 0.0); const double k = w.k2i_z;
+                    for (double* p : {a2, b2, c2, d2}) mimsem_free(p); return k; }()) > 1.0e-9*std::fabs(vs.k2i_z)) {
+                std::printf("FAIL: multi-rank reductions: its alone %d, with neighbour %d, max calls %d, sum calls %d\n", its1, its, nmax, nsum); return 1;
+            }
+            std::printf("multi-rank reductions: alone %d iterations, with an unconverged neighbour %d; %d MAX reductions, %d SUM\n", its1, its, nmax, nsum);
+            for (double* p : {velz, rho, rt, exner, v1, r1, t1, e1}) mimsem_free(p);
+        }
         for (double* p : {zv, lat, udwdx}) mimsem_free(p);
     } catch (const std::exception& e) { std::printf("FAIL: %s\n", e.what()); return 1; }
     std::printf("DONE\n");
