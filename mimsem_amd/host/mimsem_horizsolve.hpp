@@ -6,10 +6,14 @@
 // PCBJACOBI, the thickness of a level as a per-(level, element) factor).
 // Field layout: horizontal, one row per level -- 1-forms [nk][n1], 2-forms [nk][n2], 0-forms [nk][n0]; interface quantities (velz, dudz,
 // dwdx, Fz) [nk-1][.].  Header-only, C++17, no HIP toolchain needed.
+// SHARDED (round 6): with a Shard (mimsem_shard.hpp) every 0/1-form result is completed over the halo -- one exchange per operator result,
+// accumulations (MIMSEM_FLAG_ACCUM) through a completed temporary --, the ksp1 solves are the fixed-length Chebyshev iteration with both
+// element-local sums of a sweep completed (no inner product: no all-reduce inside a solve), their spectral interval comes from Shard::ritz,
+// the check log is ownership-weighted and all-reduced ONCE by verify(), and k2i() is an all-reduced weighted sum.
 #pragma once
 #include <cmath>
 #include <utility>
-#include "mimsem_shim.hpp"
+#include "mimsem_shard.hpp"
 
 namespace mimsem_host {
 
@@ -31,12 +35,20 @@ public:
     int cheb_steps = 0; bool fixed_length = false; int solves_checked = 0, solves_missed = 0; double worst_rel = 0.0;
 
     // fg: the Coriolis 0-form per level (HorizSolve::coriolis :124-161), device [nk][n0]; nDofs0G: the GLOBAL node count (viscosity() :112-120)
-    HorizSolve(Mesh* m, const double* fg_dev, long long nDofs0G = 0, bool visc = true) : mesh(m), fg(fg_dev) {
+    // shard (optional): this rank's part of the exchanges and reductions; nDofs0G must then be the GLOBAL node count
+    HorizSolve(Mesh* m, const double* fg_dev, long long nDofs0G = 0, bool visc = true, Shard* shard = nullptr) : mesh(m), fg(fg_dev), sh(shard) {
         nk = m->nk_; n0 = m->n0; n1 = m->n1; n2 = m->n2; do_visc = visc;
+        if (sh && nDofs0G <= 0) throw std::runtime_error("HorizSolve (sharded): the global node count is needed for the viscosity");
         const double dx = std::sqrt(4.0*M_PI*RAD_EARTH*RAD_EARTH/(double)(nDofs0G > 0 ? nDofs0G : n0));
         del2 = -std::sqrt(0.072*std::pow(dx, 3.2));
         try {
-            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1, &gt1}) *p = mesh->device_alloc((size_t)nk*n1);
+            for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &p1, &gt1, &w1, &y1, &z1}) *p = mesh->device_alloc((size_t)nk*n1);
+            if (sh) {                                         // ownership weights of all levels side by side (the rows of a batched inner product)
+                std::vector<double> o1(n1), on((size_t)nk*n1);
+                mesh->to_host(o1.data(), sh->own1, n1);
+                for (int k = 0; k < nk; k++) std::copy(o1.begin(), o1.end(), on.begin() + (size_t)k*n1);
+                own1n = mesh->to_device(on.data(), on.size());
+            }
             // the two vectors of a check side by side (the second row at an even offset): one two-row dot per solve
             pair1 = mesh->device_alloc(2*even((long long)nk*n1)); upd1 = pair1; pb1 = pair1 + even((long long)nk*n1);
             chk = mesh->device_alloc(2*MAXLOG);
@@ -45,6 +57,7 @@ public:
             for (double** p : {&m0, &a0, &b0}) *p = mesh->device_alloc((size_t)nk*n0);
             scal = mesh->device_alloc(4);
             check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, nullptr, 0, m0, n0), "mimsem_pvec");                   // M0 is diagonal (collocated 0-forms)
+            if (sh) sh->complete0(m0, nk);
             // ksp1 (:77-96): the 1-form mass of every level, one element block each
             check(mimsem_ksp_create(mesh->ctx, MIMSEM_KSP_CG, &ksp1), "mimsem_ksp_create");
             check(mimsem_ksp_set_operator(ksp1, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0), "mimsem_ksp_set_operator");
@@ -57,8 +70,18 @@ public:
         fixed_length = false; wanted_fixed = on;
         if (!on) return;
         double lo, hi, im;
-        check(mimsem_ksp_ritz(ksp1, 25, &lo, &hi, &im), "mimsem_ksp_ritz");
-        if (!(lo > 0.02) || mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) return;
+        if (sh) {
+            // (the blocks first: the sharded interval is that of the COMPLETED operator, from the host's own Arnoldi process)
+            if (mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) throw std::runtime_error("HorizSolve (sharded): no element blocks for this order");
+            sh->ritz((long long)nk*n1, 25, own1n, [&](const double* v, double* w) {
+                         check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, v, n1, y1, n1, 1.0), "UMAT"); sh->complete1(y1, nk);
+                         check(mimsem_elem_blocks_apply(mesh->ctx, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, y1, n1, w, n1, 1.0), "mimsem_elem_blocks_apply"); sh->complete1(w, nk); },
+                     [&](double* v) { sh->complete1(v, nk); }, &lo, &hi, &im, 1234);
+        } else check(mimsem_ksp_ritz(ksp1, 25, &lo, &hi, &im), "mimsem_ksp_ritz");
+        if (!(lo > 0.02) || mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) {
+            if (sh) throw std::runtime_error("HorizSolve (sharded): the spectral interval does not admit the fixed-length solves (no CG on a shard)");
+            return;
+        }
         const double l1 = 0.90*lo, l2 = 1.05*hi, sg = (std::sqrt(l2/l1) - 1.0)/(std::sqrt(l2/l1) + 1.0), d = 0.5*(l1 + l2), c2 = 0.25*(l2 - l1)*(l2 - l1);
         cheb_steps = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/sg)));
         coef.clear();
@@ -81,6 +104,7 @@ public:
         if (!fixed_length && slot == 0) return true;
         double v[2*MAXLOG];
         mesh->to_host(v, chk, 2*MAXLOG);
+        if (sh) sh->allreduce(v, 2*MAXLOG);                          // ONE all-reduce for every solve since the last call
         check(mimsem_memset(mesh->ctx, chk, 0, 2*MAXLOG*8), "mimsem_memset");
         slot = 0;
         bool ok = true;
@@ -92,6 +116,7 @@ public:
             if (rel == rel && rel > worst_rel) worst_rel = rel;
             if (!(rel <= 30.0*rtol)) { ok = false; solves_missed++; }
         }
+        if (!ok && sh) throw std::runtime_error("HorizSolve (sharded): a fixed-length mass solve missed its check (no CG on a shard)");
         if (!ok) fixed_length = false;                              // the interval was too optimistic for these right-hand sides: the CG from here on
         return ok;
     }
@@ -158,6 +183,7 @@ public:
         inc(3, g1, n1, q, n0);
         comb(n0, 1.0, m0, 1, fg, 1.0, q, q);
         check(mimsem_pvec(mesh->ctx, 0, nk, SCALE, rho, n2, b0, n0), "mimsem_pvec");
+        if (sh) sh->complete0(b0, nk);
         comb(n0, 1.0, q, 2, b0, 0.0, nullptr, q);
     }
     // :637-786 for every level at once: fu [nk][n1].  Optional: Fx (the mass flux, else diagnosed), Fz (vertical mass flux on the interfaces,
@@ -182,14 +208,15 @@ public:
         inc(2, a2, n2, d1, n1);                                                                               // dp
         comb(n1, 0.5, d1, 0, nullptr, 1.0, fu, fu);
         have_k2i = Fk != nullptr;
-        if (Fk) check(mimsem_krylov_rowdot(c, 1, (long long)nk*n1, Fk, (long long)nk*n1, d1, (long long)nk*n1, scal), "mimsem_krylov_rowdot");
+        if (Fk && sh) { combr(nk, n1, 1.0, Fk, 1, own1n, 0.0, nullptr, w1); check(mimsem_krylov_rowdot(c, 1, (long long)nk*n1, w1, (long long)nk*n1, d1, (long long)nk*n1, scal), "mimsem_krylov_rowdot"); }
+        else if (Fk) check(mimsem_krylov_rowdot(c, 1, (long long)nk*n1, Fk, (long long)nk*n1, d1, (long long)nk*n1, scal), "mimsem_krylov_rowdot");
         // second vorticity term: interface i feeds levels i and i+1 (:704-746)
         if (nk > 1) {
             combr(nk - 1, n1, 0.5, dudz1, 0, nullptr, 0.5, dudz2, a1);                                        // dz
             if (dwdx1) { combr(nk - 1, n1, -0.5, dwdx1, 0, nullptr, 1.0, a1, a1); combr(nk - 1, n1, -0.5, dwdx2, 0, nullptr, 1.0, a1, a1); }
             const double* v = Fz;
             if (!v) { combr(nk - 1, n2, 0.5, velz1, 0, nullptr, 0.5, velz2, a2); v = a2; }
-            check(mimsem_op_apply(c, MIMSEM_OP_UTQWMAT, 0, nk - 1, SCALE, 0, a1, n1, v, n2, b1, n1, 1.0), "UTQWMAT");     // UtQWmat::assemble(u1, scale): no thickness
+            apn(nk - 1, MIMSEM_OP_UTQWMAT, 0, a1, n1, v, n2, b1, n1, 1.0);                                      // UtQWmat::assemble(u1, scale): no thickness
             combr(nk - 1, n1, 0.5, b1, 0, nullptr, 1.0, fu + n1, fu + n1);
             combr(nk - 1, n1, 0.5, b1, 0, nullptr, 1.0, fu, fu);
         }
@@ -204,6 +231,7 @@ public:
         if (!have_k2i) return 0.0;
         double v = 0.0;
         mesh->to_host(&v, scal, 1);
+        if (sh) sh->allreduce(&v, 1);
         return v/SCALE;
     }
     // KSPSolve(ksp1, b, x) for all levels
@@ -217,6 +245,18 @@ public:
             for (size_t k = 0; k < coef.size() && !unsupported; k++) {
                 // the update of sweep 0 (x = 0) is P b; the one of the last sweep the preconditioned residual it saw
                 double* upd = k == last ? upd1 : (k == 0 ? pb1 : nullptr);
+                if (sh) {
+                    // sharded: z = P (b - M1 x) with both element-local sums completed over the halo; p = z + beta p; x += alpha p -- no inner product
+                    check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, x, n1, y1, n1, 1.0), "UMAT");
+                    sh->complete1(y1, nk);
+                    comb(n1, -1.0, y1, 0, nullptr, 1.0, b, y1);
+                    check(mimsem_elem_blocks_apply(c, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, y1, n1, z1, n1, 1.0), "mimsem_elem_blocks_apply");
+                    sh->complete1(z1, nk);
+                    comb(n1, 1.0, z1, 0, nullptr, coef[k].second, p1, p1);
+                    comb(n1, coef[k].first, p1, 0, nullptr, 1.0, x, x);
+                    if (upd) comb(n1, 1.0, z1, 0, nullptr, 0.0, nullptr, upd);
+                    continue;
+                }
                 const int rc = mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
                                                             coef[k].first, coef[k].second, p1, n1, x, n1, upd, n1);
                 if (k == 0 && rc == MIMSEM_ERR_UNSUPPORTED) unsupported = true;         // (an order the fused sweep does not cover: the CG below)
@@ -226,10 +266,16 @@ public:
             else {
                 last_its = cheb_steps;
                 const int k = slot < MAXLOG ? slot++ : MAXLOG - 1;      // (more than MAXLOG solves between two verify() calls: the last slot is reused)
-                check(mimsem_krylov_rowdot(c, 2, tot, pair1, (long long)even(tot), pair1, (long long)even(tot), chk + 2*k), "mimsem_krylov_rowdot");
+                if (sh) {                                              // this rank's ownership-weighted part of both norms
+                    comb(n1, 1.0, upd1, 1, own1n, 0.0, nullptr, w1);
+                    check(mimsem_krylov_rowdot(c, 1, tot, w1, tot, upd1, tot, chk + 2*k), "mimsem_krylov_rowdot");
+                    comb(n1, 1.0, pb1, 1, own1n, 0.0, nullptr, w1);
+                    check(mimsem_krylov_rowdot(c, 1, tot, w1, tot, pb1, tot, chk + 2*k + 1), "mimsem_krylov_rowdot");
+                } else check(mimsem_krylov_rowdot(c, 2, tot, pair1, (long long)even(tot), pair1, (long long)even(tot), chk + 2*k), "mimsem_krylov_rowdot");
                 return;
             }
         }
+        if (sh) throw std::runtime_error("HorizSolve (sharded): the 1-form mass solve exists in the fixed-length mode only");
         check(mimsem_ksp_solve(ksp1, b, n1, x, n1), "mimsem_ksp_solve");
         double rn; int reason;
         check(mimsem_ksp_get_info(ksp1, &last_its, &rn, &reason), "mimsem_ksp_get_info");
@@ -239,26 +285,55 @@ public:
 private:
     void release() {
         mimsem_ksp_destroy(ksp1); ksp1 = nullptr;
-        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &pair1, &chk, &gt1}) { if (*p) mimsem_free(*p); *p = nullptr; }
+        for (double** p : {&a1, &b1, &c1, &d1, &e1, &g1, &a2, &b2, &c2, &m0, &a0, &b0, &scal, &p1, &pair1, &chk, &gt1, &w1, &y1, &z1, &own1n}) { if (*p) mimsem_free(*p); *p = nullptr; }
         upd1 = pb1 = nullptr;
     }
     static size_t even(long long n) { return (size_t)((n + 1) & ~1LL); }
-    Mesh* mesh; const double* fg; mimsem_ksp* ksp1 = nullptr;
+    Mesh* mesh; const double* fg; Shard* sh = nullptr; mimsem_ksp* ksp1 = nullptr;
+    double *w1 = nullptr, *y1 = nullptr, *z1 = nullptr, *own1n = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
     const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int slot = 0; bool wanted_fixed = true;
     double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr, *pair1 = nullptr, *chk = nullptr, *gt1 = nullptr;
     double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
            *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;
-    void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {
-        check(mimsem_op_apply(mesh->ctx, op, 0, nk, SCALE, flags, f, fs, x, xs, y, ys, alpha), "mimsem_op_apply");
+    static bool to_1form(int op) { return op == MIMSEM_OP_UMAT || op == MIMSEM_OP_UHMAT || op == MIMSEM_OP_ROTMAT || op == MIMSEM_OP_UTQWMAT || op == MIMSEM_OP_UTMAT || op == MIMSEM_OP_UTMAT_H; }
+    // one operator over `rows` levels; sharded + 1-form result: the element-local sums are completed over the halo before anybody reads them -- an
+    // accumulation (MIMSEM_FLAG_ACCUM) goes through a completed temporary (y holds complete values: partial sums must not be mixed into it)
+    void apn(int rows, int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) {
+        if (sh && to_1form(op)) {
+            if (flags & MIMSEM_FLAG_ACCUM) {
+                check(mimsem_op_apply(mesh->ctx, op, 0, rows, SCALE, flags & ~(unsigned)MIMSEM_FLAG_ACCUM, f, fs, x, xs, w1, n1, alpha), "mimsem_op_apply");
+                sh->complete1(w1, rows);
+                combr(rows, n1, 1.0, w1, 0, nullptr, 1.0, y, y);
+            } else {
+                check(mimsem_op_apply(mesh->ctx, op, 0, rows, SCALE, flags, f, fs, x, xs, y, ys, alpha), "mimsem_op_apply");
+                sh->complete1(y, rows);
+            }
+            return;
+        }
+        check(mimsem_op_apply(mesh->ctx, op, 0, rows, SCALE, flags, f, fs, x, xs, y, ys, alpha), "mimsem_op_apply");
     }
-    void inc(int which, const double* x, long long xs, double* y, long long ys) { check(mimsem_incidence_apply(mesh->ctx, which, nk, x, xs, y, ys), "mimsem_incidence_apply"); }
+    void ap(int op, unsigned flags, const double* f, long long fs, const double* x, long long xs, double* y, long long ys, double alpha) { apn(nk, op, flags, f, fs, x, xs, y, ys, alpha); }
+    void inc(int which, const double* x, long long xs, double* y, long long ys) {
+        check(mimsem_incidence_apply(mesh->ctx, which, nk, x, xs, y, ys), "mimsem_incidence_apply");
+        if (sh && (which == 0 || which == 2)) sh->complete1(y, nk);       // E10, E12: every edge computed by the element that owns it
+        if (sh && which == 3) sh->complete0(y, nk);                        // E01
+    }
     void combr(int rows, long long n, double a, const double* A, int op, const double* B, double b, const double* C, double* out) {
         check(mimsem_vec_combine(mesh->ctx, rows, n, a, A, n, op, B, n, b, C, n, out, n), "mimsem_vec_combine");
     }
     void comb(long long n, double a, const double* A, int op, const double* B, double b, const double* C, double* out) { combr(nk, n, a, A, op, B, b, C, out); }
     // the four m1->assemble_hu(level, SCALE, u, h, false, fac) calls (:300-305, :675-682)
     void uvec_hu4(const double* ua, const double* ub, const double* ha, const double* hb, double* hu) {
+        if (sh) {                                             // the four LOCAL partial sums first, ONE exchange for their sum
+            mimsem_ctx* c = mesh->ctx;
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, ha, n2, ua, n1, hu, n1, 1.0/3.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, hb, n2, ua, n1, hu, n1, 1.0/6.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, ha, n2, ub, n1, hu, n1, 1.0/6.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, hb, n2, ub, n1, hu, n1, 1.0/3.0), "UHMAT");
+            sh->complete1(hu, nk);
+            return;
+        }
         ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT, ha, n2, ua, n1, hu, n1, 1.0/3.0);
         ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, hb, n2, ua, n1, hu, n1, 1.0/6.0);
         ap(MIMSEM_OP_UHMAT, MIMSEM_FLAG_VERT | MIMSEM_FLAG_ACCUM, ha, n2, ub, n1, hu, n1, 1.0/6.0);

@@ -28,6 +28,7 @@ def test_shim_compiles_and_links(tmp_path, oracle):
     assert os.path.exists(_build(str(tmp_path), "test_horiz"))
     assert os.path.exists(_build(str(tmp_path), "test_vert"))
     assert os.path.exists(_build(str(tmp_path), "test_sw_sharded", ["-pthread"]))
+    assert os.path.exists(_build(str(tmp_path), "test_horiz_sharded", ["-pthread"]))
 
 
 @pytest.mark.gpu
@@ -302,3 +303,85 @@ def test_sharded_sw_step_driven_from_cpp(tmp_path, oracle, world):
     eu = np.linalg.norm(got_u - want_u) / np.linalg.norm(want_u); eh = np.linalg.norm(got_h - want_h) / np.linalg.norm(want_h)
     print("C++ sharded SW step, world %d: |u - u_1ctx| = %.2e  |h - h_1ctx| = %.2e" % (world, eu, eh))
     assert eu < 1e-10 and eh < 1e-11 and np.linalg.norm(want_u - ug0) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_horizsolve_driven_from_cpp(tmp_path, oracle, world):
+    """N2 on several ranks from C++ (round 6): mimsem_host::HorizSolve over a Shard -- every 0/1-form result completed over the halo, the ksp1
+    solves fixed-length Chebyshev iterations with the exchanges inside (the executable asserts: NO all-reduce inside the evaluation, every solve
+    checked) -- ranks as threads of one process (tests/cpp/test_horiz_sharded.cpp).  advection_rhs_ec + momentum_rhs_ec (viscosity on) against
+    the one-context evaluation of the Python host."""
+    import numpy as np
+    import torch
+    from mimsem_amd.device import DeviceMesh, Engine
+    from mimsem_amd.geom import Geom
+    from mimsem_amd.horizsolve import HorizSolve
+    from mimsem_amd.mesh import CubedSphere, sphere_coords
+    from mimsem_amd.partition import build_plans, patches_of_rank
+    from mimsem_amd.topo import Topo
+    from mimsem_amd.workloads import mesh_arrays, write_arrays, z_levels
+    pn, ne, npatch, nk = 3, 4, 6, 3
+    cs = CubedSphere(pn, ne, npatch); coords = sphere_coords(pn, ne)
+
+    def build(pids):
+        topos = [Topo(cs, p, nk) for p in pids]
+        geoms = [Geom(t, cs, coords, nk) for t in topos]
+        for g in geoms:
+            g.set_levels(z_levels(nk, g.n0))
+        dm = DeviceMesh(topos, geoms, nk=nk, numbering="global")
+        xq = np.zeros((int(max(g.loc0.max() for g in geoms)) + 1, 3))
+        for g in geoms:
+            xq[g.loc0] = coords[g.loc0]
+        return dm, xq[dm.gidq]
+    dm1, xq1 = build(list(range(npatch)))
+    eng1 = Engine(dm1)
+    hs1 = HorizSolve(eng1, quad_coords=xq1)
+    r = np.random.default_rng(31)
+    N0, N1, N2 = cs.nDofs0G, cs.nDofs1G, cs.nDofs2G
+    area = float(dm1.det.mean()) * 4.0 / (pn * pn); dz = float(dm1.thick.mean()); ln = area ** 0.5
+    G = dict(u1=r.standard_normal((nk, N1)) * 20.0 * ln * dz, h1=r.uniform(0.8, 1.2, (nk, N2)) * area * dz, theta=r.uniform(290, 310, (nk, N2)) * area * dz,
+             Pi=r.uniform(900, 1000, (nk, N2)) * area * dz, velz=r.standard_normal((nk - 1, N2)) * area, dudz=r.standard_normal((nk - 1, N1)) * 1e-3 * ln)
+    G["u2"] = G["u1"] * 1.03; G["h2"] = G["h1"] * 1.01
+    t = lambda k: eng1.tensor(G[k])
+    dF, dG, Fk, Gk = hs1.advection_rhs_ec(t("u1"), t("u2"), t("h1"), t("h2"), t("theta"))
+    fu = hs1.momentum_rhs_ec(t("theta"), t("dudz"), t("dudz"), t("velz"), t("velz"), t("Pi"), t("u1"), t("u2"), t("h1"), t("h2"), Fx=Fk, Fk=Fk, dTheta=hs1.dTheta)
+    want_fu, want_dG, want_k2i = fu.cpu().numpy(), dG.cpu().numpy(), hs1.k2i
+    fg = hs1.fg.cpu().numpy()
+    fg = fg if fg.shape[0] == nk else np.broadcast_to(fg, (nk, N0))
+    dms = []
+    for rank in range(world):
+        dm, _ = build(patches_of_rank(npatch, world, rank))
+        p0, p1 = build_plans(cs, world, rank, dm.gid0, dm.gid1)
+        ranks = p1.neighbours()
+        assert ranks == p0.neighbours() and len(ranks) == world - 1
+        empty = np.zeros(0, np.int32)
+
+        def lists(by_rank):
+            off = np.zeros(len(ranks) + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(by_rank.get(q, empty)) for q in ranks])
+            return np.concatenate([by_rank.get(q, empty) for q in ranks]).astype(np.int32), off
+        arr = mesh_arrays(dm)
+        g1, g1o = lists(p1.ghost_slots); m1, m1o = lists(p1.mirror_slots); g0, g0o = lists(p0.ghost_slots); m0, m0o = lists(p0.mirror_slots)
+        arr.update(ranks=np.asarray(ranks, np.int32), ghost1=g1, ghost1_off=g1o, mirror1=m1, mirror1_off=m1o, ghost0=g0, ghost0_off=g0o, mirror0=m0,
+                   mirror0_off=m0o, own0=p0.owned.astype(np.float64), own1=p1.owned.astype(np.float64), fg=np.ascontiguousarray(fg[:, dm.gid0]),
+                   params=np.array([float(N0)]))
+        for k, gid in (("u1", dm.gid1), ("u2", dm.gid1), ("dudz", dm.gid1), ("h1", dm.gid2), ("h2", dm.gid2), ("theta", dm.gid2), ("Pi", dm.gid2), ("velz", dm.gid2)):
+            arr[k] = np.ascontiguousarray(G[k][:, gid])
+        write_arrays(str(tmp_path / ("rank%d.arr" % rank)), arr)
+        dms.append(dm)
+    out = subprocess.run([_build(str(tmp_path), "test_horiz_sharded", ["-pthread"]), str(world), str(tmp_path / "rank"), str(tmp_path / "out")],
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "DONE" in out.stdout
+    got_fu = np.full((nk, N1), np.nan); got_dG = np.full((nk, N2), np.nan)
+    for rank, dm in enumerate(dms):
+        res = np.fromfile(str(tmp_path / ("out%d.bin" % rank)), dtype=np.float64)
+        s1, s2 = nk * dm.n1, nk * dm.n2
+        fl, gl, k2i = res[:s1].reshape(nk, dm.n1), res[s1:s1 + s2].reshape(nk, dm.n2), res[s1 + s2]
+        assert np.linalg.norm(fl - want_fu[:, dm.gid1]) <= 1e-9 * np.linalg.norm(want_fu[:, dm.gid1]), rank          # ghosts included
+        assert abs(k2i - want_k2i) <= 1e-9 * abs(want_k2i), (rank, k2i, want_k2i)
+        got_fu[:, dm.gid1] = fl; got_dG[:, dm.gid2] = gl
+    e1 = np.linalg.norm(got_fu - want_fu) / np.linalg.norm(want_fu); e2 = np.linalg.norm(got_dG - want_dG) / np.linalg.norm(want_dG)
+    print("C++ sharded HorizSolve, world %d: |fu - fu_1ctx| = %.2e  |dG - dG_1ctx| = %.2e" % (world, e1, e2))
+    assert e1 < 1e-9 and e2 < 1e-9
