@@ -1,7 +1,6 @@
 #!/bin/bash
 # Round-end evidence: the default bench line, the same command under rocprofv3 --kernel-trace --stats, and the two PMC passes.
 # Outputs under gpurun_out/final/ (copied into profiles/ afterwards).
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp

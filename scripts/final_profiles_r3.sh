@@ -2,7 +2,6 @@
 # Round-3 evidence in one call on one box: the default bench line, the same command under rocprofv3 --kernel-trace --stats, SEPARATE kernel
 # summaries of the hot (103 680 units) and the cold (829 440 units) launch, the two PMC traffic passes, the column / Newton / HorizSolve /
 # SW kernel summaries and the SQ counters of the column solves.  Outputs under gpurun_out/final3/ (copied into profiles/r03_* afterwards).
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final3; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp

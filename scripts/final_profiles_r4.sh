@@ -3,7 +3,6 @@
 # command under rocprofv3 --kernel-trace --stats, hot / cold launches of the headline step separately, the column / schur_3 / box-p4 /
 # Newton / HorizSolve / SW kernel summaries and the SQ + traffic counters of the column solves.  Outputs under gpurun_out/final4/
 # (copied into profiles/r04_* afterwards).
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final4; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp

@@ -1,6 +1,5 @@
 #!/bin/bash
 # SQ / TA counters of the p = 4 element step (scripts/prof_box_p4.py), counters in their own passes
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/pmc_box; rm -rf $O; mkdir -p $O
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"

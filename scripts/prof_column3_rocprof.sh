@@ -1,5 +1,4 @@
 #!/bin/bash
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_col3 -o r01 -- python3 $R/scripts/prof_column3.py > $R/gpurun_out/prof_col3.log 2>&1
 grep -v amdgpu.ids $R/gpurun_out/prof_col3.log | tail -1

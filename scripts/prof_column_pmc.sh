@@ -2,7 +2,6 @@
 # PMC passes (rocprofv3 --pmc with --kernel-trace only; counters in their own runs) over the column Schur sweep, scripts/prof_column.py:
 # the fused DPP kernels of round 2 (default) and the round-1 row-per-lane kernels (MIMSEM_SCHUR_FUSED=rows) side by side.
 # Output: gpurun_out/pmc_col/{sweep,rows}_{a,b}/ and a per-kernel summary on stdout (copied to profiles/r02_column_pmc.txt).
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/pmc_col; mkdir -p $O
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"

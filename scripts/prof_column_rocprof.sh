@@ -1,6 +1,5 @@
 #!/bin/bash
 # kernel-level profile of the column Schur sweep (scripts/prof_column.py) -> gpurun_out/prof_col/
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_col -o r01 -- python3 $R/scripts/prof_column.py > $R/gpurun_out/prof_col.log 2>&1
 grep -v amdgpu.ids $R/gpurun_out/prof_col.log | tail -1

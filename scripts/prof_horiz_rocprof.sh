@@ -1,6 +1,5 @@
 #!/bin/bash
 # kernel-level profile of one HorizSolve advection_rhs_ec + momentum_rhs_ec evaluation (scripts/prof_horiz.py) -> gpurun_out/prof_h/
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_h -o r02 -- python3 $R/scripts/prof_horiz.py > $R/gpurun_out/prof_h.log 2>&1
 grep -v amdgpu.ids $R/gpurun_out/prof_h.log | tail -1

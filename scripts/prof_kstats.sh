@@ -1,6 +1,5 @@
 #!/bin/bash
 # usage: prof_kstats.sh <tag> <script.py> [env assignments are inherited]: rocprofv3 --kernel-trace --stats summary of one workload script
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 TAG=$1; SCRIPT=$2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o r -- python3 $R/$SCRIPT > $R/gpurun_out/prof_$TAG.log 2>&1

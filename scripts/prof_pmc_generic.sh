@@ -1,7 +1,6 @@
 #!/bin/bash
 # usage: prof_pmc_generic.sh <tag> <script.py> <kernel-name-substrings, comma separated>
 # SQ counter passes (rocprofv3 --pmc with --kernel-trace only, each set in its own run) over one workload script; per-kernel summary on stdout.
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 TAG=$1; SCRIPT=$2; KEYS=$3
 O=$R/gpurun_out/pmc_$TAG; mkdir -p $O

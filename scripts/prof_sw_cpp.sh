@@ -1,7 +1,6 @@
 #!/bin/bash
 # kernel trace of the C++-hosted shallow-water step (mimsem_amd/host/sw_call, config-3 sphere, recorded Picard iterations): busy time of the
 # kernels against the wall time of a step -> what part of a graph node's ~5 us is the kernel and what part the hand-over between nodes
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 python scripts/exp/write_sw_case3.py gpurun_out/sw_case3.bin 20    # (20 steps: on the 200-step case rocprofv3 --kernel-trace dies with a SIGSEGV inside librocprofiler-sdk.so's HSA packet interception, below hipGraphLaunch -- the tool, not this library: the backtraced run is profiles/r06_rocprof_graph_sigsegv.txt, scripts/exp/rocprof_graph_200.sh)

@@ -1,6 +1,5 @@
 #!/bin/bash
 # kernel-level profile of the config-3 shallow-water step (scripts/prof_sw.py) -> gpurun_out/prof_sw/
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sw -o r01 -- python3 $R/scripts/prof_sw.py > $R/gpurun_out/prof_sw.log 2>&1
 grep -v amdgpu.ids $R/gpurun_out/prof_sw.log | tail -2

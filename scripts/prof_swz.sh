@@ -1,4 +1,3 @@
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 for v in 0 1; do
   MIMSEM_NOSWZ=$v rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_swz$v -o r01 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu --no-sw --no-column > $R/gpurun_out/prof_swz$v.json 2> /dev/null

@@ -1,7 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over scripts/prof_umat.py (the bench.py step alone): kernel stats, SQ counters and HBM traffic of the wave-level
 # fused kernel (default) and of the two-pass form (MIMSEM_WAVE=0).  Counters in their own runs, --kernel-trace only.
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/pmc_umat; mkdir -p $O
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"

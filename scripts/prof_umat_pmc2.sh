@@ -1,7 +1,6 @@
 #!/bin/bash
 # second set of rocprofv3 --pmc passes over scripts/prof_umat.py: memory pipeline (TA / TCP / TCC), instruction fetch, dispatcher.
 # One block type per pass where possible; counters only with --kernel-trace.  MODES="wave twopass"
-export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/pmc_umat2; mkdir -p $O
 declare -A P
