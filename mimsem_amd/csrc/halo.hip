@@ -18,6 +18,8 @@
 //   (exchange parity): a neighbour may already write exchange k + 1 while this rank still unpacks exchange k; it cannot reach k + 2 before
 //   it has seen this rank's message k + 1, which this rank packs after that unpack (stream order).
 #include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -248,7 +250,18 @@ int mimsem_halo_peer_export(mimsem_halo* h, int my_rank, void* blob) {
         const size_t nr = (size_t)std::max(h->nneigh ? h->recv_off[h->nneigh] : 0, 1);
         h->peer_half = (nr*h->max_nlev + 1) & ~(size_t)1;
         const size_t bytes = 2*h->peer_half*sizeof(double) + PEER_WORDS*sizeof(unsigned long long);
-        MIMSEM_HIP_TRY(hipMalloc((void**)&h->d_peer, bytes));
+        // UNCACHED device memory (MTYPE UC: not held in this GPU's L2): what a neighbour GPU writes over xGMI -- the message and the arrival flag --
+        // must be seen by loads of a kernel that is already running here; an ordinary (coarse-grained) allocation is coherent with other agents at
+        // kernel boundaries only, and a poll or a re-read of a buffer half could be served from a stale L2 line for ever.  (Two processes on ONE
+        // GPU share its L2 and would not notice the difference: the property matters between GPUs.)  Ordinary memory is the fallback if the
+        // runtime refuses the flag.
+        bool uncached = true;
+        if (hipExtMallocWithFlags((void**)&h->d_peer, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            uncached = false;
+            MIMSEM_HIP_TRY(hipMalloc((void**)&h->d_peer, bytes));
+        }
+        if (getenv("MIMSEM_VERBOSE")) fprintf(stderr, "[mimsem] halo plan %p: one-sided receive buffer %zu bytes, %s device memory\n", (void*)h, bytes, uncached ? "UNCACHED" : "ordinary (hipExtMallocWithFlags refused)");
         MIMSEM_HIP_TRY(hipMemset(h->d_peer, 0, bytes));
         h->d_flags = (unsigned long long*)(h->d_peer + 2*h->peer_half);
     }
