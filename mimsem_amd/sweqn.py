@@ -306,24 +306,28 @@ class SWEqn:
         Phi = self.diagnose_Phi(ui, uj, hi, hj)
         if bot is not None:
             Phi = Phi + self.grav * self.M2(bot)
-        fu = self.E("E12", Phi)
+        # (sharded: E12 Phi, the rotational terms and M1 (uj - ui) are all LOCAL partial sums of 1-form results until the packed residual is
+        #  complete -- they are added on the rank's own engine and completed over the halo ONCE, as the C++ host does; one rank: loc is eng)
+        loc = getattr(self.eng, "eng", self.eng)
+        fu = loc.incidence("E12", Phi)
         if q_exact:
             um, hm = torch.add(ui, uj).mul_(0.5), torch.add(hi, hj).mul_(0.5)
             q = self.diagnose_q(0.0, um, hm, key="qm%d" % it)
-            self.eng.apply("ROTMAT", F, f=q, flags=2, out=fu)                                    # fu += R(q) F
+            loc.apply("ROTMAT", F, f=q, flags=2, out=fu)                                          # fu += R(q) F
         else:
             if before_q is not None:
                 before_q()                     # (qi / qj were diagnosed on a parallel branch of the recorded graph: join it here)
             qi = self.diagnose_q(dt, ui, hi, key="qi") if qi is None else qi
             qj = self.diagnose_q(dt, uj, hj, key="qj%d" % it) if qj is None else qj
-            self.eng.apply_up("ROTMAT_UP", F, qi, ui, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)      # fu += 1/2 R_up(qi, ui) F
-            self.eng.apply_up("ROTMAT_UP", F, qj, uj, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)
+            loc.apply_up("ROTMAT_UP", F, qi, ui, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)            # fu += 1/2 R_up(qi, ui) F
+            loc.apply_up("ROTMAT_UP", F, qj, uj, fac=UP_TAU, dt=dt, alpha=0.5, flags=2, out=fu)
         # the mass terms are linear: M1 (uj - ui) and M2 (hj - hi + dt E21 F) -- two applies instead of five; both halves of the packed
         # residual are written in place (no concatenation)
         res = torch.empty(ui.shape[0], self.n1 + self.n2, dtype=ui.dtype, device=ui.device)
         ru, rh = res[:, :self.n1], res[:, self.n1:]
-        self.eng.apply("UMAT", uj - ui, out=ru)
+        loc.apply("UMAT", uj - ui, out=ru)
         ru.add_(fu, alpha=dt)
+        self.eng.complete(1, ru)
         self.eng.apply("WMAT", torch.add(hj - hi, self.E("E21", F), alpha=dt), out=rh)
         return res
 
