@@ -105,6 +105,9 @@ enum mimsem_op {
 
 /* ---- context ------------------------------------------------------------------------------- */
 int  mimsem_abi_version(void);
+/* 1 when the library was built with -DMIMSEM_WITH_EXPERIMENTS (the closed experiments' kernel variants and their MIMSEM_* switches are compiled
+ * in: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS"), 0 for the default build.  Test / A-B infrastructure; replaces nothing. */
+int  mimsem_build_has_experiments(void);
 const char* mimsem_strerror(int code);
 const char* mimsem_last_hip_error(void);
 int  mimsem_device_count(void);

@@ -26,6 +26,7 @@ class MimsemError(RuntimeError):
 
 _SIGS = {
     "mimsem_abi_version": (C.c_int, []),
+    "mimsem_build_has_experiments": (C.c_int, []),
     "mimsem_strerror": (C.c_char_p, [C.c_int]),
     "mimsem_last_hip_error": (C.c_char_p, []),
     "mimsem_device_count": (C.c_int, []),

@@ -690,6 +690,7 @@ int mimsem_ctx_profile_read(mimsem_ctx* c, double* ms1, double* ms2, long long* 
 }
 
 int mimsem_abi_version(void) { return MIMSEM_ABI_VERSION; }
+int mimsem_build_has_experiments(void) { return kExperiments ? 1 : 0; }
 
 const char* mimsem_strerror(int code) {
     switch (code) {

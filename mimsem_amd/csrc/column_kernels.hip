@@ -566,7 +566,11 @@ int mimsem_block_inverse_inplace(mimsem_ctx* c, long long nblocks, int n, double
     switch (n) {                     // register-resident one-lane-per-row kernel for the block sizes of p <= 4
     case 1:  return launch_inverse_reg<1>(c, nblocks, blocks, err);
     case 4:  return launch_inverse_reg<4>(c, nblocks, blocks, err);
+#ifdef MIMSEM_WITH_EXPERIMENTS
     case 9:  return exp_env("MIMSEM_INV_ROWS") ? launch_inverse_rows<9, 16>(c, nblocks, blocks, err) : launch_inverse_reg<9>(c, nblocks, blocks, err);
+#else
+    case 9:  return launch_inverse_reg<9>(c, nblocks, blocks, err);
+#endif
     case 16: return launch_inverse_rows<16, 16>(c, nblocks, blocks, err);
     default: break;                  // 25, 36, 49: thread-per-matrix in LDS below
     }
@@ -1488,7 +1492,7 @@ int block_thomas_refined(mimsem_ctx* c, const double* L, const double* f, double
     const bool wave = !exp_env("MIMSEM_THOMAS_WG") && (n2 == 1 || n2 == 4 || n2 == 9 || n2 == 16);
     const bool keep = Dinv && wave && (size_t)(64/n2)*nk*n2*sizeof(double) <= 48*1024;
     if ((rc = block_thomas(c, L, f, d, Gws, yws, keep ? Dinv : nullptr))) return rc;
-    if (exp_env("MIMSEM_NO_REFINE")) return MIMSEM_OK;
+    if (getenv("MIMSEM_NO_REFINE")) return MIMSEM_OK;
     if ((rc = block_tridiag_residual(c, nk, n2, L, f, d, r))) return rc;
     if (keep) {                      // substitution only, with the factors of the first sweep
         const int cpw = 64/n2;

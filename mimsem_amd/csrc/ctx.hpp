@@ -7,13 +7,23 @@
 #include "basis_host.hpp"
 #include <cstdlib>
 
-// CLOSED EXPERIMENTS: the switches of the variants that were built, measured and declined (their records are under profiles/) are
-// read only when MIMSEM_EXPERIMENTS=1 is set in the environment -- scripts/ab_*.sh and the parity tests of those variants set it; a process
-// without it has the documented user switches (pivot fallback, refinement steps, operator form, column-solve path, verbosity) and nothing else.
+// CLOSED EXPERIMENTS: the variants that were built, measured and declined (their records are under profiles/).
+//   default build           their switches do not exist (exp_env is a compile-time null) and the kernel families only they launch are not
+//                           compiled in (kExperiments: the fused-scatter element kernels, the tile mode of k_apply_wave, the 16-lane order-4
+//                           walk of solve_schur_column_3, the residency variants of k_thomas_dpp2, the row-parallel 9 x 9 inverse);
+//   -DMIMSEM_WITH_EXPERIMENTS  (scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS" -> build_ab/libmimsem_hip_exp.so, MIMSEM_LIB=...)
+//                           everything is compiled in and the switches are read when MIMSEM_EXPERIMENTS=1 is set in the environment -- what
+//                           scripts/ab_*.sh and the variants' parity tests run against.
+#ifdef MIMSEM_WITH_EXPERIMENTS
+constexpr bool kExperiments = true;
 inline const char* exp_env(const char* name) {
     static const bool on = std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS")) != 0;
     return on ? std::getenv(name) : nullptr;
 }
+#else
+constexpr bool kExperiments = false;
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 namespace mimsem {
 extern thread_local std::string g_last_hip_error;

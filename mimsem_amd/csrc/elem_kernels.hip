@@ -1384,7 +1384,7 @@ int dispatch_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
         if (c->ev_k1[0]) hipExtLaunchKernelGGL((k_elem_apply<N, OPV, FU>), dim3(GRID), dim3(256), 0, c->stream, c->ev_k1[0], c->ev_k1[1], 0, a); \
         else hipLaunchKernelGGL((k_elem_apply<N, OPV, FU>), dim3(GRID), dim3(256), 0, c->stream, a)
 #define MIMSEM_CASE(OPV) case OPV: \
-        if constexpr (OpTraits<OPV>::out == S1) { if (a.fperm) { MIMSEM_LAUNCH(OPV, true, fgrid); break; } } \
+        if constexpr (kExperiments && OpTraits<OPV>::out == S1) { if (a.fperm) { MIMSEM_LAUNCH(OPV, true, fgrid); break; } } \
         MIMSEM_LAUNCH(OPV, false, grid); \
         break;
     switch (op) {
@@ -1560,7 +1560,7 @@ static int dispatch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a) {
     if (items >= (1LL << 31)) return MIMSEM_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)((items + WNW - 1)/WNW);
     if (grid == 0) return MIMSEM_OK;
-    constexpr bool TILEABLE = (N == 3 || N == 4) && WNW == 4;
+    constexpr bool TILEABLE = kExperiments && (N == 3 || N == 4) && WNW == 4;      // (tile mode: a closed experiment)
     const bool tile = a.wtfin != nullptr;
     if (tile && (!TILEABLE || a.wgroups%4 != 0 || a.wg0 != 0 || a.lch*a.wcpp > MIMSEM_WTLEV)) return MIMSEM_ERR_STATE;
 #define MIMSEM_WL1(OPV, LCT, ACC, TL) \

@@ -3,6 +3,7 @@
 # Chebyshev sweep on the config-5 grid, register-row form against k_blocks_residual_mfma.  Counters in their own passes (--pmc with
 # --kernel-trace only).  Output: gpurun_out/mfma_p4.txt (copied to profiles/r03_mfma_p4_ab.txt).
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd /tmp
 O=$R/gpurun_out/mfma_p4; mkdir -p $O; out=$R/gpurun_out/mfma_p4.txt; : > $out
 for m in 0 1; do

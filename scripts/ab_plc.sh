@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on the GPU box: levels per thread of k_wave_perim (rebuilt in the box's ephemeral copy of the repo)
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 cd $GRAFT_REPO_ROOT
 run() { echo "== $*"; python bench.py --no-cpu --no-pmc --no-sw --no-column 2>/dev/null | python -c "
 import json,sys

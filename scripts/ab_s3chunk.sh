@@ -1,6 +1,7 @@
 #!/bin/bash
 # levels per task of k_s3_sweep<4> on config 5's columns, one box (round 4): MIMSEM_SWEEP_CHUNK = 16 | 22 | 32 | 64, kernel averages
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_s3chunk; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for round in 1 2; do
 for c in 16 22 32 64; do

@@ -2,6 +2,7 @@
 # A/B of the Chebyshev semi-iteration for the [u|h] solve of the SW Picard step (mimsem_amd/sweqn.py, MIMSEM_SW_CHEB = 1) against the GMRES
 # (0: polynomially preconditioned, round 5) -> steps/s, iteration counts, error norms, drifts on configs 2 and 3
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; cd $R
 for e in 0 1 0 1; do
   MIMSEM_SW_CHEB=$e python3 bench.py --no-families --no-column --no-sweep --cold 0 --no-pmc --no-cpu > /dev/null 2> /dev/null

@@ -2,6 +2,7 @@
 # A/B of the whole-Picard-iteration hipGraph (mimsem_amd/sweqn.py _PicardGraph, MIMSEM_SW_GRAPH_ITER = 1) against the nested solves in their own
 # graphs with Python in between (0) -> steps/s, iteration counts, error norms, drifts on configs 2 and 3
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; cd $R
 for e in 0 1 0 1; do
   MIMSEM_SW_GRAPH_ITER=$e python3 bench.py --no-families --no-column --no-sweep --cold 0 --no-pmc --no-cpu > /dev/null 2> /dev/null

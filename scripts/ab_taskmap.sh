@@ -2,6 +2,7 @@
 # A/B of the task mapping of the chunked column walks on one box (round 4): build_ab/libmimsem_hip_oldmap.so (-DMIMSEM_TASKMAP_OLD: (column,
 # chunk) pairs in task order) against the in-tree library (four columns of one chunk per wavefront).  Kernel totals (ns over the script's calls).
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_taskmap; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for round in 1 2; do
 for v in default oldmap; do

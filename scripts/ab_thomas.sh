@@ -2,6 +2,7 @@
 # The Helmholtz solve inside solve_schur_column_eta (3 456 columns x 30 levels): one-sided sweep (MIMSEM_THOMAS2=0) against the two-sided
 # sweep at one wavefront per SIMD (MIMSEM_THOMAS_WPS=1, round 3) and at two (default, round 5); wall clock per solve and rocprofv3 kernel averages of the three kernels of the solve.
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 out=gpurun_out/ab_thomas.log; : > $out
 cd /tmp && export TMPDIR=/tmp
 for v in "MIMSEM_THOMAS2=0" "MIMSEM_THOMAS_WPS=1" "DEFAULT=1"; do

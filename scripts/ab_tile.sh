@@ -3,6 +3,7 @@
 # work item) against the default two-launch form: headline step (cache resident) and the 8-sphere HBM-resident workload, kernel times from the
 # context's HIP events, PMC traffic from the bench's child rocprofv3 passes
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; cd $R
 for t in 0 1 0 1; do
   MIMSEM_WAVE_TILE=$t MIMSEM_VERBOSE=1 python3 bench.py --steps 200 --warmup 20 --no-families --no-column --no-sweep --no-sw --no-cpu > /tmp/ab_tile_$t.json 2> /tmp/ab_tile_$t.err

@@ -2,6 +2,7 @@
 # A/B on one box (round 4): thickInv of k_apply_wave from the [element][point] pair table (default) or from the NODAL pair table
 # (MIMSEM_WAVE_TNODE=1): kernel averages of the headline step, cache-resident (103 680 units) and HBM-resident (8 spheres)
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab_tnode; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 for round in 1 2; do
 for v in 0 1; do

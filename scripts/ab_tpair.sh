@@ -2,6 +2,7 @@
 # A/B: thickInv of a level pair in one 16-byte load (default) against one 8-byte load per level (build_ab/libmimsem_hip_notpair.so, built
 # with -DMIMSEM_NO_TPAIR); bench.py hot and cold, both variants twice in ONE run (boxes of the pool differ by ~10 %).
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 out=gpurun_out/ab_tpair.log; : > $out
 run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_tpair.err | python -c "
 import json,sys

@@ -3,6 +3,7 @@
 # MIMSEM_WAVE_CPP = chunks of 8 levels per wavefront (default: balanced parts leaving >= 1536 wavefronts), MIMSEM_WAVE_ORDER, MIMSEM_WAVE_LCH.
 # bench.py hot (103 680 units) and cold (829 440 units); all variants in ONE run (boxes of the pool differ by ~10 %).
 export MIMSEM_EXPERIMENTS=1      # (the switches below belong to closed experiments: DESIGN 9.1)
+EXP_LIB="$(cd "$(dirname "$0")/.." && pwd)/build_ab/libmimsem_hip_exp.so"; [ -z "$MIMSEM_LIB" ] && [ -f "$EXP_LIB" ] && export MIMSEM_LIB="$EXP_LIB"      # (the variants are compiled in only with -DMIMSEM_WITH_EXPERIMENTS: scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS")
 out=gpurun_out/ab_wave.log; : > $out
 run() { echo "== $*" >> $out; env "$@" python bench.py --no-cpu --no-pmc --no-sw --no-column 2>>gpurun_out/ab_wave.err | python -c "
 import json,sys

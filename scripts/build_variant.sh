@@ -7,7 +7,7 @@ name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
 d=$root/build_ab/obj_$name; mkdir -p $d
 for f in api elem_kernels column_kernels krylov_kernels halo ksp; do
-  if [ "$f" = api ] || [ "$f" = elem_kernels ] || [ ! -f $d/$f.o ]; then
+  if [ ! -f $d/$f.o ] || [ -n "$(find $root/mimsem_amd/csrc $root/include -newer $d/$f.o \( -name '*.hip' -o -name '*.inc' -o -name '*.hpp' -o -name '*.h' \) | head -1)" ]; then      # (any source newer than the object: rebuild it)
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable $flags -c $root/mimsem_amd/csrc/$f.hip -o $d/$f.o &
   fi
 done
