@@ -53,6 +53,64 @@ def test_loopback_reverse_add_and_forward_insert(eng):
     h.close()
 
 
+def test_one_sided_transport_with_the_rank_as_its_own_neighbour(eng):
+    """the one-sided transport (round 6: the pack kernel writes into the neighbour's receive buffer and publishes a sequence flag, the unpack
+    waits for it) in ONE process: a plan whose only neighbour is the rank itself needs no hipIpc handle (its own buffer), so export / connect /
+    begin / end run here -- the same results as the loop-back transport over many exchanges (both halves of the double buffer), work in
+    between begin and end, a recorded exchange replayed, no time-outs.  Between processes: tests/test_gpu_multiproc.py."""
+    import ctypes as C
+    import torch
+    from mimsem_amd._lib import HALO_PEER_BLOB, check
+    from mimsem_amd.partition import CHalo
+    e, P = eng
+    n = P.n1
+    rng = np.random.default_rng(4)
+    ghost = rng.choice(n, 40, replace=False).astype(np.int32)
+    mirror = rng.choice(np.setdiff1d(np.arange(n), ghost), 40, replace=False).astype(np.int32)
+    ref = CHalo(_plan(n, ghost, mirror), e, max_nlev=4, transport="loopback")
+    h = CHalo(_plan(n, ghost, mirror), e, max_nlev=4, transport="loopback")
+    for name, hd in h.handles.items():                                 # connect every plan of h to itself through the one-sided set-up calls
+        blob = C.create_string_buffer(HALO_PEER_BLOB)
+        check(e.L.mimsem_halo_peer_export(hd, 0, blob), "halo_peer_export")
+        check(e.L.mimsem_halo_set_peer(hd, 0, blob.raw), "halo_set_peer")
+    for rep, nlev in enumerate((4, 1, 3, 2, 4)):
+        v0 = rng.standard_normal((nlev, n))
+        a, b = e.tensor(v0), e.tensor(v0)
+        ref.reverse_add(a); h.reverse_add(b)
+        assert torch.equal(a, b), rep
+        ref.forward_insert(a); h.forward_insert(b)
+        assert torch.equal(a, b), rep
+    v0 = rng.standard_normal((4, n)); v = e.tensor(v0)
+    tok = h.begin("reverse", v, True)
+    y = e.apply("UMAT", e.tensor(rng.standard_normal((4, n))), lev0=0, scale=1.0e8, flags=1)
+    h.end(tok)
+    want = v0.copy(); want[:, mirror] += v0[:, ghost]
+    assert np.array_equal(v.cpu().numpy(), want) and torch.isfinite(y).all()
+    # recorded: the exchange counter and the buffer parity live in device memory, so every replay is a new, correct exchange
+    src = e.tensor(rng.standard_normal((4, n))); buf = torch.zeros_like(src)
+    want = src.cpu().numpy().copy(); want[:, mirror] += want[:, ghost]
+
+    def recorded():
+        buf.copy_(src)
+        h.reverse_add(buf)
+    g, _ = e.capture(recorded)
+    for _ in range(5):
+        buf.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), want)
+    assert h.peer_timeouts() == {}
+    # errors: connecting before exporting, or with a blob that is not one
+    h2 = CHalo(_plan(n, ghost, mirror), e, max_nlev=4, transport="loopback")
+    hd = h2.handles["reverse"]
+    assert e.L.mimsem_halo_set_peer(hd, 0, bytes(HALO_PEER_BLOB)) != 0
+    blob = C.create_string_buffer(HALO_PEER_BLOB)
+    check(e.L.mimsem_halo_peer_export(hd, 0, blob), "halo_peer_export")
+    assert e.L.mimsem_halo_set_peer(hd, 0, bytes(HALO_PEER_BLOB)) != 0          # (no magic)
+    assert e.L.mimsem_halo_set_peer(hd, 1, blob.raw) != 0                        # (exported as rank 0)
+    for x in (ref, h, h2):
+        x.close()
+
+
 def test_ordered_add_with_repeated_targets(eng):
     """two neighbours' messages land on the same slots (cube-corner nodes): added in neighbour order, range by range"""
     import ctypes as C
