@@ -903,7 +903,7 @@ def compact_record(out, extras_file=None):
             "reference_local_1_level_call_us": _r(_g(out, "reference_local_layout", "rows", "reference_local", "1_level_per_call", "us_per_call_wall")),
             "cpp_host_per_level_call_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_us_per_call")),
             "cpp_host_per_level_call_in_graph_us": _r(_g(out, "reference_local_layout", "rows", "cpp_host", "per_level_calls_in_a_graph_us_per_call"))}
-    for k in ("weak_scaled", "column_sharded", "horiz_sharded", "sw_sharded"):
+    for k in ("weak_scaled", "umat_one_sided", "column_sharded", "horiz_sharded", "sw_sharded"):
         v = out.get(k)
         if isinstance(v, dict):
             summ[k] = {kk: _r(v[kk]) for kk in ("value", "ms_per_step", "schur_column_solves_per_s", "ms_per_evaluation", "steps_per_s", "fixed_length_iterations",
@@ -1421,6 +1421,36 @@ def main():
                     "unit": "element operator-applies/s", "ms_per_step": 1e3 * tt.item() / nst, "halo_bytes_sent_per_rank_per_step": halo_bytes,
                     "transport": deng.transport}
         extra("weak_scaled", weak_scaled)
+
+        # the HEADLINE step over the one-sided transport (hipIpc-opened receive buffers, two kernels per exchange, no library call): never run
+        # between GPUs before this -- reported beside the headline (never as it), and only if every rank's result equals the headline
+        # transport's bit for bit and no wait timed out
+        def umat_one_sided():
+            eng2 = Engine(dm, device=local_rank)
+            d2 = DistEngine(eng2, cs, world, rank, overlap=True, transport="peer", plans=plans)
+            y2 = eng2.zeros(NK, dm.n1)
+            step()                                                   # (y: the headline transport's result for this x)
+            for _ in range(3):
+                d2.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y2)
+            torch.cuda.synchronize()
+            okl = 1.0 if (torch.equal(y2, y) and not d2.chalo.peer_timeouts()) else 0.0
+            flag = torch.tensor([okl], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() != 1.0:
+                return {"error": "result differs from the headline transport's or an exchange timed out (this rank: equal %s, time-outs %s)" % (bool(torch.equal(y2, y)), d2.chalo.peer_timeouts())}
+            fence(); t1 = time.perf_counter()
+            for _ in range(a.steps):
+                d2.apply("UMAT", x, lev0=0, scale=SCALE, flags=1, out=y2)
+            fence(); el = time.perf_counter() - t1
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bad = bool(d2.chalo.peer_timeouts())
+            d2.close()
+            if bad:
+                return {"error": "an exchange timed out during the timed steps"}
+            return {"workload": "the headline step (boundary groups | exchange | interior groups) with the exchange on the one-sided transport", "value": cs.ne * cs.ne * 6 * NK * a.steps / tt.item(),
+                    "ms_per_step": 1e3 * tt.item() / a.steps, "equal_to_headline_transport": True, "headline_ms_per_step": 1e3 * dt / a.steps}
+        extra("umat_one_sided", umat_one_sided)
     if world > 1 and not a.no_column:
         # the column half of the hot path sharded: all nk levels of an element live on one GPU, so the Schur solves and the Newton loop
         # need no halo at all -- only the MPI_Allreduce(MAX) of the four norms per iteration.  Aggregate = all columns / slowest rank.
