@@ -592,6 +592,19 @@ int  mimsem_ksp_get_info(const mimsem_ksp* ksp, int* iterations, double* rnorm, 
 int  mimsem_hessenberg_eigenvalues(int n, const double* H, double* wr, double* wi);
 
 
+/* Two INDEPENDENT fixed-length Chebyshev solves of one shallow-water Picard iteration in shared launches (round 6): the 1-form mass system of
+ * diagnose_F (src/SWEqn_Picard.cpp:253-284: nA sweeps of {element pass, block pass, gather epilogue}) and the upwinded lumped 0-form mass system
+ * of diagnose_q (:322-341: nB sweeps of {element pass, gather epilogue}) read nothing of each other; at the ~3 500 elements of the src/ drivers
+ * every launch is a ~5 us dispatch floor, and launch k of both chains goes out as ONE grid (csrc/elem_kernels.hip: k_sw_pair -- the bodies of
+ * the very kernels the two sweep entry points below use: the same bits).  Equivalent to nA calls of mimsem_block_chebyshev_sweep(ctx,
+ * MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1], p1, 0, x1, 0, last ? upd1 : NULL, 0) and nB calls of
+ * mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0, b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0,
+ * last ? upd0 : NULL, 0).  coefA / coefB: HOST arrays of (alpha, beta) pairs; single level, scale 1, no flags (the src/ flavour); orders 2..4
+ * (MIMSEM_ERR_UNSUPPORTED otherwise: call the two sweeps).  upd1 / upd0 may be NULL.                                                     */
+int mimsem_sw_dual_chebyshev(mimsem_ctx* ctx, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1,
+                             int nB, const double* coefB, double tau, const double* h, const double* u, const double* b0, const double* dinv,
+                             double* p0, double* x0, double* upd0);
+
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer
  * (torch.distributed / ncclSend-ncclRecv) on the buffers these calls fill.

@@ -1504,6 +1504,60 @@ int mimsem_sw_chebyshev_flush(mimsem_ctx* c, int nlev, double ca, double cb, dou
     return launch_sw_chebyshev_flush(c, nlev, ca, cb, x, xs, r, d, vs);
 }
 
+// the element-pass arguments of a single-level sweep on the src/ flavour (scale 1, no thickness), as op_apply_core fills them for its epilogue path
+static void sweep_elem_args(mimsem_ctx* c, ElemArgs& a, const double* f, const double* f2, double param, const double* x, double* out, long long os) {
+    a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr; a.wfence = 0;
+    a.nEl = c->nEl; a.nlev = 1; a.lev0 = 0; a.total = c->nEl;
+    a.flags = 0; a.scale = 1.0; a.alpha = 1.0;
+    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.tps = (long long)c->nEl*c->es.mp12*2; a.tnode = 0; a.E = c->d_E; a.w = c->d_w;
+    a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2; a.iq = c->d_iq;
+    a.f = f; a.fs = 0; a.x = x; a.xs = 0;
+    a.f2 = f2; a.f2s = 0; a.param = param; a.xn = c->d_xn;
+    a.lch = level_chunk(c, 1); a.swz = 0;
+    a.fperm = nullptr; a.accum = 0; a.d0 = a.d1x = a.d1y = nullptr; a.y = nullptr; a.ys = 0;
+    a.out = out; a.os = os;
+}
+
+// Two independent fixed-length Chebyshev solves of a shallow-water Picard iteration in SHARED launches (round 6; csrc/elem_kernels.hip:
+// k_sw_pair): exactly the sequence
+//     for k < nA: mimsem_block_chebyshev_sweep(ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1], p1, 0, x1, 0, k == nA-1 ? upd1 : NULL, 0)
+//     for k < nB: mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0, b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0, k == nB-1 ? upd0 : NULL, 0)
+// -- the same kernels' bodies, the same bits -- with launch k of the first chain (3 per sweep) and launch k of the second (2 per sweep) in one grid.
+int mimsem_sw_dual_chebyshev(mimsem_ctx* c, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1,
+                             int nB, const double* coefB, double tau, const double* h, const double* u, const double* b0, const double* dinv,
+                             double* p0, double* x0, double* upd0) {
+    if (!c || nA < 1 || nB < 1 || !coefA || !coefB || !blocks1 || !b1 || !p1 || !x1 || !h || !u || !b0 || !dinv || !p0 || !x0) return MIMSEM_ERR_ARG;
+    if (c->nEl == 0) return MIMSEM_OK;
+    const ElemSizes& es = c->es;
+    if (es.n < 2 || es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
+    const long long per1 = (long long)c->nEl*2*es.n1e, per0 = (long long)c->nEl*es.n0e;
+    int rc = c->ensure_ye(2*per1 + per0);
+    if (rc) return rc;
+    double *yeA = c->d_ye, *zeA = c->d_ye + per1, *yeQ = c->d_ye + 2*per1;
+    ElemArgs ea, eq;
+    sweep_elem_args(c, ea, nullptr, nullptr, 0.0, x1, yeA, per1);
+    sweep_elem_args(c, eq, h, u, tau, x0, yeQ, per0);
+    PairBlocks ba{c->nEl, 1, c->d_i1x, c->d_i1y, c->d_g1, blocks1, yeA, per1, b1, zeA, per1};
+    PairGather ga{zeA, per1, c->d_g1, c->n1, GatherEpilogue{3, b1, 0, nullptr, 0, nullptr, 0}, x1};
+    PairGather gq{yeQ, per0, c->d_g0, c->n0, GatherEpilogue{5, b0, 0, dinv, 0, nullptr, 0}, x0};
+    ga.g.p = p1; ga.g.ps = 0; gq.g.p = p0; gq.g.ps = 0;
+    c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+    const int LA = 3*nA, LB = 2*nB, L = std::max(LA, LB);
+    for (int k = 0; k < L; k++) {
+        const int PA = k < LA ? k%3 : -1, PB = k < LB ? k%2 : -1;
+        if (PA == 2) { const int st = k/3; ga.g.alpha = coefA[2*st]; ga.g.beta = coefA[2*st + 1]; ga.g.upd = st == nA - 1 ? upd1 : nullptr; ga.g.us = 0; }
+        if (PB == 1) { const int st = k/2; gq.g.alpha = coefB[2*st]; gq.g.beta = coefB[2*st + 1]; gq.g.upd = st == nB - 1 ? upd0 : nullptr; gq.g.us = 0; }
+        if (PA >= 0 && PB >= 0) rc = launch_sw_pair(c, PA, PB, ea, ba, ga, eq, gq);
+        else if (PA == 0) rc = launch_elem_apply(c, MIMSEM_OP_UMAT, ea);                                  // (the longer chain's tail: its own kernels)
+        else if (PA == 1) rc = launch_blocks_residual(c, 1, blocks1, yeA, per1, b1, 0, zeA, per1, nullptr, 0);
+        else if (PA == 2) rc = launch_gather_epilogue(c, 1, 1, zeA, per1, ga.g, x1, 0);
+        else if (PB == 0) rc = launch_elem_apply(c, MIMSEM_OP_PHMAT_UP, eq);
+        else rc = launch_gather_epilogue(c, 0, 1, yeQ, per0, gq.g, x0, 0);
+        if (rc) return rc;
+    }
+    return MIMSEM_OK;
+}
+
 int mimsem_halo_pack(mimsem_ctx* c, const int* idx, int count, int nlev, const double* v, long long vs, double* buf) {
     if (!c || count < 0 || nlev < 0) return MIMSEM_ERR_ARG;
     if (count == 0 || nlev == 0) return MIMSEM_OK;        // empty message: pointers of empty arrays may be null

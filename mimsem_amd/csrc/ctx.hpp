@@ -221,6 +221,12 @@ struct GatherEpilogue {
     // d lives in p (in/out), r in cr
     double* cr = nullptr; long long crs = 0;
 };
+// two independent Chebyshev sweeps in the same launches (elem_kernels.hip: k_sw_pair): the block pass and the gather epilogue of one level
+struct PairBlocks { int nEl, lch; const int *i1x, *i1y, *plan; const double *B, *ye; long long yes; const double* b; double* ze; long long zes; };
+struct PairGather { const double* ye; long long yes; const int* plan; int nslots; GatherEpilogue g; double* x; };
+// phase PA of the 1-form mass sweep (0 element pass, 1 block pass, 2 gather epilogue) and phase PB of the upwinded 0-form sweep (0 element
+// pass, 1 gather epilogue) in ONE launch; orders 2..4
+int launch_sw_pair(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const PairBlocks& ba, const PairGather& ga, const ElemArgs& eq, const PairGather& gq);
 int launch_gather_epilogue(mimsem_ctx* c, int form, int nlev, const double* ye, long long ye_stride, const GatherEpilogue& g,
                            double* x, long long xs);
 int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const double* ye, long long yes,

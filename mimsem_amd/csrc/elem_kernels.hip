@@ -283,8 +283,11 @@ __device__ __forceinline__ void interp_point(const double* dofs, const double* s
 // Work item = (element, chunk of `lch` consecutive levels).  Level-invariant data (metric, quadrature weight,
 // gather slots) is loaded ONCE into registers; the level loop prefetches the next level's DoFs and thickness
 // while the current level is interpolated / scaled / projected.
+// (round 6: the bodies of the three kernels of a Chebyshev sweep -- element pass, block pass, gather epilogue -- are __device__ functions of the
+//  block index so that k_sw_pair below can run two of them, belonging to two INDEPENDENT sweeps, in one launch; the kernels themselves are
+//  thin wrappers that pass their own block index and grid size)
 template <int N, int OP, bool FUSED>
-__global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
+__device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigned bid, const unsigned gdim) {
     using D = Dims<N>;
     using T = OpTraits<OP>;
     // the test-upwind operators keep per-point basis tables in LDS: at p = 7 two elements per workgroup (128 threads) fit in 64 KB
@@ -307,12 +310,12 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
     bool act; int e, lbeg, lend, grp = 0;
     if constexpr (FUSED) {
         // one workgroup = one element group x one level chunk; every lane runs the same number of levels
-        grp = blockIdx.x%a.ngroups;
+        grp = bid%a.ngroups;
         const int pe = a.fperm[grp*EPB + el];
         act = pe >= 0; e = act ? pe : 0;
-        lbeg = (blockIdx.x/a.ngroups)*a.lch; lend = min(a.nlev, lbeg + a.lch);
+        lbeg = (bid/a.ngroups)*a.lch; lend = min(a.nlev, lbeg + a.lch);
     } else {
-        const long long item = (long long)xcd_swizzle(blockIdx.x, gridDim.x, a.swz)*EPB + el;   // item = chunk*nEl + e
+        const long long item = (long long)xcd_swizzle(bid, gdim, a.swz)*EPB + el;   // item = chunk*nEl + e
         act = item < (long long)a.nEl*nchunk;
         e = act ? (int)(item%a.nEl) : 0;
         lbeg = act ? (int)(item/a.nEl)*a.lch : 0;
@@ -558,6 +561,8 @@ __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) {
         }
     }
 }
+template <int N, int OP, bool FUSED>
+__global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) { body_elem_apply<N, OP, FUSED>(a, blockIdx.x, gridDim.x); }
 
 // pass 2: y[slot] = (+=) sum of its element-local contributions, fixed order.  One thread per slot and
 // chunk of LC levels: the plan entry is read once per chunk, level reads/writes are coalesced across slots.
@@ -590,15 +595,15 @@ __global__ __launch_bounds__(256) void k_gather_sum(const double* __restrict__ y
 // preconditioner) or x[s] += acc (acc already is the preconditioned update); the update itself is stored on request (its
 // norm is the preconditioned residual the solver monitors).  Same plan, same summation order as k_gather_sum.
 template <int K>
-__global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restrict__ ye, long long ye_stride,
-                                                         const int* __restrict__ plan, int nslots, int nlev, GatherEpilogue g,
-                                                         double* __restrict__ x, long long xs) {
-    const int s = blockIdx.x*256 + threadIdx.x;
+__device__ __forceinline__ void body_gather_epilogue(const double* __restrict__ ye, long long ye_stride,
+                                                     const int* __restrict__ plan, int nslots, int nlev, const GatherEpilogue& g,
+                                                     double* __restrict__ x, long long xs, const unsigned bid, const unsigned bidy) {
+    const int s = bid*256 + threadIdx.x;
     if (s >= nslots) return;
     int j[K];
 #pragma unroll
     for (int k = 0; k < K; k++) j[k] = plan[(size_t)s*K + k];
-    const int l0 = blockIdx.y*GS_LC, l1 = min(nlev, l0 + GS_LC);      // level chunks across blockIdx.y, as k_gather_sum
+    const int l0 = bidy*GS_LC, l1 = min(nlev, l0 + GS_LC);      // level chunks across the grid's second dimension, as k_gather_sum
     for (int lev = l0; lev < l1; lev++) {
         const double* src = ye + (size_t)lev*ye_stride;
         double acc = 0.0;
@@ -620,14 +625,20 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
         if (g.upd) g.upd[(size_t)lev*g.us + s] = d;
     }
 }
+template <int K>
+__global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restrict__ ye, long long ye_stride,
+                                                         const int* __restrict__ plan, int nslots, int nlev, GatherEpilogue g,
+                                                         double* __restrict__ x, long long xs) {
+    body_gather_epilogue<K>(ye, ye_stride, plan, nslots, nlev, g, x, xs, blockIdx.x, blockIdx.y);
+}
 
 // block-preconditioned Richardson, middle pass: r_e = (b - gather(ye)) restricted to the element (gathered on the fly through
 // the 1-form plan), z_e = B_e r_e with B_e stored column-major ([c][r]); z_e goes to the second element-local buffer.
 template <int N, int LC>
-__global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
+__device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
-        const double* __restrict__ escale, long long ess) {
+        const double* __restrict__ escale, long long ess, const unsigned bid) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int 
     const int tid = threadIdx.x, el = tid/LPE, r = tid%LPE;
     // work item = (element, chunk of lch levels): this lane's block row stays in registers over the chunk (k_blocks_apply_reg)
     const int nchunk = (nlev + lch - 1)/lch;
-    const long long item = (long long)blockIdx.x*EPB + el;
+    const long long item = (long long)bid*EPB + el;
     const bool eact = item < (long long)nEl*nchunk;
     const int e = eact ? (int)(item%nEl) : 0;
     const int l0 = eact ? (int)(item/nEl)*lch : 0, l1 = eact ? min(nlev, l0 + lch) : 0;
@@ -686,6 +697,33 @@ __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int 
         for (int c = 0; c < ND; c++) s += brow[c]*sx[c];
         s *= es[l];
         if (act && lev < l1) ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
+    }
+}
+template <int N, int LC>
+__global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
+        const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
+        const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
+        const double* __restrict__ escale, long long ess) {
+    body_blocks_residual<N, LC>(nEl, nlev, lch, i1x, i1y, plan, B, ye, yes, b, bs, ze, zes, escale, ess, blockIdx.x);
+}
+
+// ---- two independent Chebyshev sweeps in the SAME launches (round 6) ---------------------------------------------------------------------
+// A Picard iteration of the shallow-water step solves the 1-form mass system (diagnose_F: 15 sweeps of {element pass, block pass, gather
+// epilogue}) and the upwinded lumped 0-form mass system (diagnose_q: 20 sweeps of {element pass, gather epilogue}); neither reads what the other
+// writes, and at 3 456 elements every one of those 85 launches is a ~5 us dispatch floor.  k_sw_pair runs launch k of BOTH chains
+// in one grid -- blocks [0, nA) execute phase PA of the mass sweep, blocks [nA, nA + nB) phase PB of the q sweep, the very bodies of the three
+// kernels above (same arithmetic, same bits) -- so the two solves cost max(45, 40) launches instead of 45 + 40.  (Two streams inside the
+// recorded graph were tried in round 5, MIMSEM_SW_FORK: slower -- a cross-stream edge costs more than the nodes it overlaps.)
+template <int N, int PA, int PB, int K0>           // PA: 0 element pass (Umat), 1 block pass, 2 gather epilogue, 3 nothing;  PB: 0 element pass (Phmat_up), 1 gather epilogue, 3 nothing
+__global__ __launch_bounds__(256) void k_sw_pair(ElemArgs ea, PairBlocks ba, PairGather ga, ElemArgs eq, PairGather gq, unsigned nA) {
+    if (blockIdx.x < nA) {
+        if constexpr (PA == 0) body_elem_apply<N, MIMSEM_OP_UMAT, false>(ea, blockIdx.x, nA);
+        else if constexpr (PA == 1) body_blocks_residual<N, 1>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x);
+        else if constexpr (PA == 2) body_gather_epilogue<2>(ga.ye, ga.yes, ga.plan, ga.nslots, 1, ga.g, ga.x, 0, blockIdx.x, 0);
+    } else {
+        const unsigned bid = blockIdx.x - nA, nB = gridDim.x - nA;
+        if constexpr (PB == 0) body_elem_apply<N, MIMSEM_OP_PHMAT_UP, false>(eq, bid, nB);
+        else if constexpr (PB == 1) body_gather_epilogue<K0>(gq.ye, gq.yes, gq.plan, gq.nslots, 1, gq.g, gq.x, 0, bid, 0);
     }
 }
 
@@ -1957,6 +1995,33 @@ int launch_sw_chebyshev_flush(mimsem_ctx* c, int nlev, double ca, double cb, dou
     GatherEpilogue g{4, nullptr, 0, nullptr, 0, nullptr, 0};
     g.alpha = ca; g.beta = cb; g.p = d; g.ps = vs; g.cr = r; g.crs = vs;
     return launch_gather_epilogue(c, 1, nlev, ye1, per, g, x, xs);
+}
+
+template <int N, int K0>
+static int sw_pair_n(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const PairBlocks& ba, const PairGather& ga, const ElemArgs& eq, const PairGather& gq) {
+    using D = Dims<N>;
+    constexpr int ND = 2*D::n1e, LPEb = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPBb = 256/LPEb;
+    const unsigned nA = PA == 0 ? (unsigned)((c->nEl + D::EPB - 1)/D::EPB) : (PA == 1 ? (unsigned)((c->nEl + EPBb - 1)/EPBb) : (unsigned)((ga.nslots + 255)/256));
+    const unsigned nB = PB == 0 ? (unsigned)((c->nEl + D::EPB - 1)/D::EPB) : (unsigned)((gq.nslots + 255)/256);
+#define MIMSEM_PAIR(A_, B_) hipLaunchKernelGGL((k_sw_pair<N, A_, B_, K0>), dim3(nA + nB), dim3(256), 0, c->stream, ea, ba, ga, eq, gq, nA)
+    switch (PA*2 + PB) {
+    case 0: MIMSEM_PAIR(0, 0); break;   case 1: MIMSEM_PAIR(0, 1); break;
+    case 2: MIMSEM_PAIR(1, 0); break;   case 3: MIMSEM_PAIR(1, 1); break;
+    case 4: MIMSEM_PAIR(2, 0); break;   case 5: MIMSEM_PAIR(2, 1); break;
+    default: return MIMSEM_ERR_ARG;
+    }
+#undef MIMSEM_PAIR
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int launch_sw_pair(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const PairBlocks& ba, const PairGather& ga, const ElemArgs& eq, const PairGather& gq) {
+    if (PA < 0 || PA > 2 || PB < 0 || PB > 1 || (c->G0 != 4 && c->G0 != 8)) return MIMSEM_ERR_ARG;
+    switch (c->es.n*10 + (c->G0 == 4 ? 4 : 8)) {
+    case 24: return sw_pair_n<2, 4>(c, PA, PB, ea, ba, ga, eq, gq);   case 28: return sw_pair_n<2, 8>(c, PA, PB, ea, ba, ga, eq, gq);
+    case 34: return sw_pair_n<3, 4>(c, PA, PB, ea, ba, ga, eq, gq);   case 38: return sw_pair_n<3, 8>(c, PA, PB, ea, ba, ga, eq, gq);
+    case 44: return sw_pair_n<4, 4>(c, PA, PB, ea, ba, ga, eq, gq);   case 48: return sw_pair_n<4, 8>(c, PA, PB, ea, ba, ga, eq, gq);
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_halo_segments(mimsem_ctx* c, const int* idx, int nseg, const int* seg_off, int s_begin, int s_end, int nlev, int mode,

@@ -62,6 +62,7 @@ public:
     double rtol = 1.0e-14;               // tolerance of every nested solve (relative, preconditioned residual)
     bool fixed_length = true;            // Chebyshev solves of fixed length (false: the KSP objects, as the reference)
     bool use_graph = true;               // ... recorded as one hipGraph per Picard iteration kind
+    bool dual_solves = true;             // the mass-flux and the potential-vorticity solve of an iteration in shared launches (mimsem_sw_dual_chebyshev: the same bits, ~40 launches fewer)
     bool two_launch_steps = false;       // the [u|h] Chebyshev step in two launches (mimsem_sw_chebyshev_step2) instead of three: correct, and no
                                          // faster -- 445.6 against 450.8-453.0 steps/s (profiles/r05_sw_cpp_ab.txt): the element pass grows by what the epilogue cost
     std::vector<double> history;         // |dx| / |x| of the iterations of the last solve()
@@ -75,8 +76,10 @@ public:
     SWEqn(Mesh* m, const double* fg_dev, Shard* shard = nullptr) : mesh(m), fg(fg_dev), sh(shard), ksp1(m, KSP::CG), ksp0(m, KSP::GMRES), kspA(m, KSP::GMRES), M1(m), gr{Graph(m), Graph(m)} {
         n0 = m->n0; n1 = m->n1; n2 = m->n2; N = (long long)n1 + n2;
         if (sh) use_graph = false;
-        if (std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS")))        // (closed experiment; A/B: scripts/ab_sw_cpp.sh)
+        if (std::getenv("MIMSEM_EXPERIMENTS") && std::atoi(std::getenv("MIMSEM_EXPERIMENTS"))) {      // (closed experiments; A/B: scripts/ab_sw_cpp.sh)
             if (const char* e = std::getenv("MIMSEM_SW_STEP2")) two_launch_steps = std::atoi(e) != 0;
+            if (const char* e = std::getenv("MIMSEM_SW_DUAL")) dual_solves = std::atoi(e) != 0;
+        }
         try {
             for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &y1, &z1}) *p = mesh->device_alloc(n1);
             for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
@@ -349,8 +352,36 @@ private:
         slot = 0;
         copy(N, x, xsave);
         copy(n1, x, uj); copy(n2, x + n1, hj);
-        if (first && !qx) diagnose_q(dt, ui, hi, qi);
-        diagnose_F(ui, uj, hi, hj, F);
+        // round 6: the mass-flux solve (diagnose_F: steps_M1 sweeps x 3 launches) and the potential-vorticity solve (diagnose_q: steps_q x 2) read
+        // nothing of each other -- mimsem_sw_dual_chebyshev issues launch k of both chains as ONE grid (the same kernels' bodies, the same bits)
+        const bool dual = dual_solves && inline_fixed && !sh && !qx && !qcoef.empty() && !escale1;
+        bool q_done = false;
+        if (dual) {
+            const double* uq = first ? ui : uj; const double* hq = first ? hi : hj; double* qdst = first ? qi : qj;
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, 0, hi, 0, ui, 0, hu, 0, 1.0/3.0), "UHMAT");                       // the right-hand side of diagnose_F
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hi, 0, uj, 0, hu, 0, 1.0/6.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj, 0, ui, 0, hu, 0, 1.0/6.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj, 0, uj, 0, hu, 0, 1.0/3.0), "UHMAT");
+            check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, uq, 0, t1, 0, 1.0), "UMAT");                          // ... and of diagnose_q
+            check(mimsem_incidence_apply(c, 3, 1, t1, 0, rhs0, 0), "E01");
+            combine(n0, 1.0, m0fg, 0, nullptr, 1.0, rhs0, rhs0);
+            check(mimsem_pvec(c, 0, 1, 1.0, hq, 0, m0h, 0), "mimsem_pvec");
+            combine(n0, 1.0, ones0, 2, m0h, 0.0, nullptr, dinv);
+            zero(n1, F); zero(n1, p1); zero(n0, qdst); zero(n0, p0);
+            std::vector<double> ca, cb;
+            for (auto& pr : coefM) { ca.push_back(pr.first); ca.push_back(pr.second); }
+            for (auto& pr : qcoef) { cb.push_back(pr.first); cb.push_back(pr.second); }
+            check(mimsem_sw_dual_chebyshev(c, (int)coefM.size(), ca.data(), blocks1, hu, p1, F, upd1, (int)qcoef.size(), cb.data(), 1.0/(1.0/(UP_TAU*dt)), hq, uq, rhs0, dinv,
+                                           p0, qdst, upd0), "mimsem_sw_dual_chebyshev");
+            check(mimsem_elem_blocks_apply(c, 1, 1, 0, blocks1, 0, escale1, 0, hu, 0, t1, 0, 1.0), "mimsem_elem_blocks_apply");
+            log(K_MASS, upd1, t1, n1);
+            combine(n0, 1.0, rhs0, 1, dinv, 0.0, nullptr, t0);
+            log(K_MASS, upd0, t0, n0);
+            q_done = true;
+        } else {
+            if (first && !qx) diagnose_q(dt, ui, hi, qi);
+            diagnose_F(ui, uj, hi, hj, F);
+        }
         diagnose_Phi(ui, uj, hi, hj, Phi);
         if (bt) check(mimsem_op_apply(c, MIMSEM_OP_WMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, nullptr, 0, bt, 0, Phi, 0, grav), "WMAT");
         check(mimsem_incidence_apply(c, 2, 1, Phi, 0, fu, 0), "E12");
@@ -361,7 +392,7 @@ private:
         } else {
             const double tau = 1.0/(1.0/(UP_TAU*dt));
             const double* qj_ = qi;
-            if (!first) { diagnose_q(dt, uj, hj, qj); qj_ = qj; }
+            if (!first) { if (!q_done) diagnose_q(dt, uj, hj, qj); qj_ = qj; }
             check(mimsem_op_apply_up(c, MIMSEM_OP_ROTMAT_UP, 0, 1, 1.0, tau, MIMSEM_FLAG_ACCUM, qi, 0, ui, 0, F, 0, fu, 0, 0.5), "ROTMAT_UP");
             check(mimsem_op_apply_up(c, MIMSEM_OP_ROTMAT_UP, 0, 1, 1.0, tau, MIMSEM_FLAG_ACCUM, qj_, 0, uj, 0, F, 0, fu, 0, 0.5), "ROTMAT_UP");
         }

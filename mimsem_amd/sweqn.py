@@ -227,15 +227,25 @@ class SWEqn:
         """:236-250: w = M0^-1 E01 M1 u"""
         return self.E("E01", self.M1(u)) / self.m0
 
-    def diagnose_F(self, ui, uj, hi, hj, key="F"):
-        """:253-284: F = M1^-1 (1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj)"""
+    def F_rhs(self, ui, uj, hi, hj):
+        """the right-hand side of diagnose_F: 1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj"""
         loc = getattr(self.eng, "eng", self.eng)                   # local partial sums, one halo reduction
         hu = loc.apply("UHMAT", ui, f=hi, alpha=1.0 / 3.0)
         loc.apply("UHMAT", uj, f=hi, alpha=1.0 / 6.0, flags=2, out=hu)
         loc.apply("UHMAT", ui, f=hj, alpha=1.0 / 6.0, flags=2, out=hu)
         loc.apply("UHMAT", uj, f=hj, alpha=1.0 / 3.0, flags=2, out=hu)
         self.eng.complete(1, hu)
-        return self.solve_M1(hu, key)
+        return hu
+
+    def diagnose_F(self, ui, uj, hi, hj, key="F"):
+        """:253-284: F = M1^-1 (1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj)"""
+        return self.solve_M1(self.F_rhs(ui, uj, hi, hj), key)
+
+    def q_rhs(self, u, h):
+        """the right-hand side and the lumped diagonal of diagnose_q: M0 f + E01 M1 u, Phmat::assemble(h)"""
+        if self._m0fg is None:
+            self._m0fg = self.m0 * self.fg
+        return self._m0fg + self.E("E01", self.M1(u)), self.eng.pvec(0, 1, 1.0, h2=h)
 
     def diagnose_Phi(self, ui, uj, hi, hj):
         """:289-320 (integral form): 1/3 K(ui) ui + 1/3 K(ui) uj + 1/3 K(uj) uj + g/2 M2 (hi + hj)"""
@@ -249,10 +259,7 @@ class SWEqn:
 
     def diagnose_q(self, dt, u, h, key="q"):
         """:322-341: M0h q = M0 f + E01 M1 u ; M0h upwinded (Phmat::assemble_up) when dt > 1e-6"""
-        if self._m0fg is None:
-            self._m0fg = self.m0 * self.fg
-        rhs = self._m0fg + self.E("E01", self.M1(u))
-        m0h = self.eng.pvec(0, 1, 1.0, h2=h)                     # Phmat::assemble(h) is diagonal
+        rhs, m0h = self.q_rhs(u, h)                              # (Phmat::assemble(h) is diagonal)
         if dt > 1.0e-6 and self._inline is not None:
             return self._inline.q(rhs, m0h, h, u, dt)
         if dt > 1.0e-6:
@@ -299,10 +306,12 @@ class SWEqn:
     def pack(self, u, h): return torch.cat([u, h], dim=1)
     def unpack(self, x): return x[:, :self.n1].contiguous(), x[:, self.n1:].contiguous()
 
-    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None, it=0, before_q=None):
+    def assemble_residual(self, ui, hi, uj, hj, dt, q_exact=False, bot=None, qi=None, qj=None, it=0, before_q=None, F=None):
         """:402-607.  qi / qj: potential vorticities already diagnosed from (ui, hi) / (uj, hj) -- the reference re-solves for qi in
-        every Picard iteration although (ui, hi) is the fixed start-of-step state; solve() passes the first result back in."""
-        F = self.diagnose_F(ui, uj, hi, hj, key="F%d" % it)          # (keys: the counterpart of a solve is the same Picard iteration of the last step)
+        every Picard iteration although (ui, hi) is the fixed start-of-step state; solve() passes the first result back in.
+        F: the mass flux when the caller has solved for it already (_PicardGraph: together with q, in shared launches)."""
+        if F is None:
+            F = self.diagnose_F(ui, uj, hi, hj, key="F%d" % it)      # (keys: the counterpart of a solve is the same Picard iteration of the last step)
         Phi = self.diagnose_Phi(ui, uj, hi, hj)
         if bot is not None:
             Phi = Phi + self.grav * self.M2(bot)
@@ -725,6 +734,7 @@ class _PicardGraph:
             rb = torch.randn(un.shape, generator=g, dtype=torch.float64).to(dev)
             l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
         self.regions["M1"] = (l1, l2)
+        self.cm = cm
         self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol,
                                  margin=(1.0 - 0.1 * min(widen, 4.0), 1.0 + 0.05 * widen))
         self.its["F"] = self.chM.steps
@@ -756,6 +766,11 @@ class _PicardGraph:
         self.names = {}
         # MIMSEM_SW_FORK=1: the q solve as a parallel branch of the recorded iteration (second stream + second context of the same mesh)
         self.fork = (not q_exact) and not self.dist and experiment("MIMSEM_SW_FORK", "0") == "1"
+        # round 6: the mass-flux solve (15 sweeps x 3 launches) and the potential-vorticity solve (20 x 2) of an iteration read nothing of each
+        # other: mimsem_sw_dual_chebyshev issues launch k of BOTH chains as one grid -- 45 launches instead of 85 of an iteration's ~210, the same
+        # bits (MIMSEM_SW_DUAL=0 under MIMSEM_EXPERIMENTS=1: the two solves one after the other, as round 5)
+        self.dual = ((not q_exact) and not self.dist and not self.fork and 2 <= eng.mesh.n <= 4 and self.pairM is not None
+                     and getattr(self, "pair0", None) is not None and experiment("MIMSEM_SW_DUAL", "1") == "1")
         if self.fork:
             from .device import Engine
             self.eng_q = Engine(eng.mesh, device=eng.device.index or 0)
@@ -802,6 +817,19 @@ class _PicardGraph:
             self._log("q", self.qupd, rhs * dinv)
         return x
 
+    def solve_F_and_q(self, hu, rhs0, m0h, h, u):
+        """M1 F = hu and M0h_up(h, u) q = rhs0 by their fixed-length Chebyshev iterations in SHARED launches; both checks logged as m1() / q() do"""
+        S, eng = self.S, self.S.eng
+        dinv = torch.reciprocal(m0h)
+        F = torch.zeros_like(hu); q = torch.zeros_like(rhs0)
+        self.qp.zero_()
+        eng.sw_dual_chebyshev(self.chM.coef, self.cm, hu, self.chM.p, F, self.pairM[0:1], self.qcoef, self.qtau, h, u, rhs0, dinv, self.qp, q, self.pair0[0:1])
+        S.precond_M1(hu, out=self.pairM[1:2])
+        self._log_pair("M1", self.pairM)
+        torch.mul(rhs0, dinv, out=self.pair0[1:2])
+        self._log_pair("q", self.pair0)
+        return F, q
+
     def _q_on_a_branch(self, first, uj, hj):
         """the potential vorticity of this iteration (from (ui, hi) in the first, (uj, hj) in the later ones) on a SECOND stream and a second
         context of the same mesh (own workspaces): ~45 of an iteration's ~225 graph nodes that depend on nothing the mass flux F and the
@@ -825,13 +853,25 @@ class _PicardGraph:
         self.slot = 0
         uj, hj = self.x[:, :n1].contiguous(), self.x[:, n1:].contiguous()
         join = None
-        if self.fork and not self.q_exact:
-            join = self._q_on_a_branch(first, uj, hj)
-        elif first and not self.q_exact:
-            self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
-        qj = None if self.q_exact else (self.qi if first else (self.qj if self.fork else None))
+        F = None
+        if self.dual:
+            # both right-hand sides first, then the two solves together: q of (ui, hi) in the first iteration of a step (uj = ui: it is qj too),
+            # of (uj, hj) in the later ones
+            hu = S.F_rhs(self.ui, uj, self.hi, hj)
+            uq_, hq_ = (self.ui, self.hi) if first else (uj, hj)
+            rhs0, m0h = S.q_rhs(uq_, hq_)
+            F, qn = self.solve_F_and_q(hu, rhs0, m0h, hq_, uq_)
+            if first:
+                self.qi.copy_(qn)
+            qj = self.qi if first else qn
+        else:
+            if self.fork and not self.q_exact:
+                join = self._q_on_a_branch(first, uj, hj)
+            elif first and not self.q_exact:
+                self.qi.copy_(S.diagnose_q(self.dt, self.ui, self.hi, key="qi"))
+            qj = None if self.q_exact else (self.qi if first else (self.qj if self.fork else None))
         f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, self.bot, qi=None if self.q_exact else self.qi,
-                                qj=qj, it=0 if first else 1, before_q=join)
+                                qj=qj, it=0 if first else 1, before_q=join, F=F)
         ch = self.chA
         torch.neg(f, out=ch.b)
         ch._run()

@@ -503,3 +503,33 @@ def test_sw_chebyshev_step_and_solve(sw):
     g = GraphedGMRES(eng, n, body, restart=60)
     xg, its, _ = g.solve(lambda v: S.apply_A(v, dt), b, pc, rtol=1e-13, maxit=200)
     assert rel_l2(sols[1].cpu().numpy(), xg.cpu().numpy()) < 1e-11
+
+
+def test_dual_chebyshev_solve_equals_the_two_sweep_sequences(sw):
+    """round 6: mimsem_sw_dual_chebyshev runs the 1-form mass solve and the upwinded lumped 0-form mass solve of a Picard iteration in SHARED
+    launches (launch k of both chains in one grid, the bodies of the very kernels of the two sweep entry points): bit for bit the two sequences
+    of block_chebyshev_sweep / chebyshev_sweep calls, whichever chain is the longer one"""
+    import torch
+    cs, eng, O, S, uq, hq = sw
+    r = np.random.default_rng(17)
+    n0, n1, n2 = eng.sizes[0], eng.sizes[1], eng.sizes[2]
+    cm = S.m1_pre.transpose(1, 2).contiguous()
+    u = _t(eng, O.init1(uq)); h = _t(eng, O.init2(hq))
+    b1 = eng.tensor(r.standard_normal((1, n1))); b0 = eng.tensor(r.standard_normal((1, n0)))
+    dinv = torch.reciprocal(eng.pvec(0, 1, 1.0, h2=h))
+    tau = 1.0 / (1.0 / (0.5 * 360.0))
+    for nA, nB in ((15, 20), (9, 3), (2, 11), (1, 1)):
+        coefA = [(0.9 + 0.01 * k, 0.0 if k == 0 else 0.05 + 0.001 * k) for k in range(nA)]
+        coefB = [(1.0 - 0.005 * k, 0.0 if k == 0 else -0.01 - 0.0005 * k) for k in range(nB)]
+        x1, p1, u1 = eng.zeros(1, n1), eng.zeros(1, n1), eng.zeros(1, n1)
+        x0, p0, u0 = eng.zeros(1, n0), eng.zeros(1, n0), eng.zeros(1, n0)
+        for k, (al, be) in enumerate(coefA):
+            eng.block_chebyshev_sweep("UMAT", cm, x1, b1, p1, al, be, upd=u1 if k == nA - 1 else None)
+        for k, (al, be) in enumerate(coefB):
+            eng.chebyshev_sweep("PHMAT_UP", x0, b0, dinv, p0, al, be, f=h, u=u, tau=tau, upd=u0 if k == nB - 1 else None)
+        y1, q1, v1 = eng.zeros(1, n1), eng.zeros(1, n1), eng.zeros(1, n1)
+        y0, q0, v0 = eng.zeros(1, n0), eng.zeros(1, n0), eng.zeros(1, n0)
+        eng.sw_dual_chebyshev(coefA, cm, b1, q1, y1, v1, coefB, tau, h, u, b0, dinv, q0, y0, v0)
+        for a, b, name in ((x1, y1, "x1"), (p1, q1, "p1"), (u1, v1, "upd1"), (x0, y0, "x0"), (p0, q0, "p0"), (u0, v0, "upd0")):
+            assert torch.equal(a, b), (nA, nB, name, float((a - b).abs().max()))
+        assert float(x1.abs().max()) > 0 and float(x0.abs().max()) > 0
