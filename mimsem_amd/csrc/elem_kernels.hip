@@ -1234,6 +1234,9 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
     }
     wave_lds_sync();
     if (!act) return;
+    // (priced in round 6 and declined: the coupled blocks stored as 4-byte entries -- a preconditioner may be approximate -- take the pass + gather
+    //  from 9.8 to 8.1 us back to back (scripts/exp/probe_f32_blocks.py on a probe build): 5 % of the step at most, for a second copy of the blocks
+    //  and a rounded P in every place that applies it)
     const double* Be = B + (size_t)e*ND*ND + r;
     double s = 0.0;
 #pragma unroll
