@@ -198,7 +198,7 @@ def test_bench_extras_watchdog_keeps_the_headline_line():
     assert "in_flight" in d["extras_watchdog"] and "exit status 3" in d["extras_watchdog"]["note"]
 
 
-def _sw_worker(rank, world, port, q):
+def _sw_worker(rank, world, port, q, peer=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -227,7 +227,7 @@ def _sw_worker(rank, world, port, q):
         dm, eng, xq = build(patches_of_rank(npatch, world, rank))
         # world 2: the C ABI's plans on the ONE-SIDED transport -- exchanges that are kernels only, so the whole Picard iteration is RECORDED as a
         # hipGraph on every rank (exchanges inside); world 3: the host-staged exchanger, the same launches eagerly
-        peer = world == 2
+        peer = (world == 2) if peer is None else peer
         deng = DistEngine(eng, cs, world, rank, overlap=True, transport="peer") if peer else DistEngine(eng, cs, world, rank)
         S = SWEqn(deng, xq)
         uq, hq = williamson2(torch.as_tensor(xq, device=eng.device), alpha=0.0)
@@ -286,15 +286,15 @@ def _sw_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_shallow_water_step_as_processes(world):
+@pytest.mark.parametrize("world,peer", [(2, True), (3, False), (3, True)], ids=["2_one_sided_recorded", "3_host_staged_eager", "3_one_sided_recorded"])
+def test_sharded_shallow_water_step_as_processes(world, peer):
     """N3 on several ranks: SWEqn over a DistEngine takes the same Picard step as the single-context run IN THE FIXED-LENGTH MODE (Chebyshev
     solves with the halo exchanges inside, no all-reduce in any solve, one all-reduce of the check norms per Picard iteration), with the same
     step counts; the adaptive path agrees too"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sw_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sw_worker, args=(r, world, port, q, peer)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
