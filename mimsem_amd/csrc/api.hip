@@ -565,6 +565,10 @@ int mimsem_ctx::ensure_kry(long long doubles) {
     if (d_kry) { retired.push_back(d_kry); d_kry = nullptr; kry_doubles = 0; }
     MIMSEM_HIP_TRY(hipMalloc((void**)&d_kry, (size_t)doubles*sizeof(double)));
     kry_doubles = doubles; bytes += doubles*8;
+    if (!d_rdcnt) {                                                  // arrival counters of the one-launch rowdot: zeroed once, every call leaves them zero
+        MIMSEM_HIP_TRY(hipMalloc((void**)&d_rdcnt, MIMSEM_RD_COUNTERS*sizeof(unsigned)));
+        MIMSEM_HIP_TRY(hipMemsetAsync(d_rdcnt, 0, MIMSEM_RD_COUNTERS*sizeof(unsigned), stream));
+    }
     return MIMSEM_OK;
 }
 int mimsem_ctx::ensure_col(long long doubles) {
@@ -837,6 +841,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     if (d->nEl > 0) { c->h_e1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_e1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
                       c->h_e0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e); }
     c->memset_node = exp_env("MIMSEM_MEMSET_NODE") && atoi(exp_env("MIMSEM_MEMSET_NODE")) != 0;      // (read once: mimsem_memset is a hot call of the recorded solves)
+    c->rd_two = exp_env("MIMSEM_ROWDOT_TWO") && atoi(exp_env("MIMSEM_ROWDOT_TWO")) != 0;
     c->blu_stop = exp_env("MIMSEM_BLU_STOP") ? atoi(exp_env("MIMSEM_BLU_STOP")) : 0;
     c->pivot_fallback = getenv("MIMSEM_COLUMN_PIVOT_FALLBACK") ? std::min(2, std::max(0, atoi(getenv("MIMSEM_COLUMN_PIVOT_FALLBACK")))) : 1;      // on by default since round 5 (mimsem_column_set_pivot_fallback)
     if (!(getenv("MIMSEM_WAVE") && atoi(getenv("MIMSEM_WAVE")) == 0) && !c->fused1 && !c->direct && d->nEl > 0 && es.n <= 4) {
@@ -870,7 +875,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     (void)hipSetDevice(c->device);
     orphan_graphs(c);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_rdcnt, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);

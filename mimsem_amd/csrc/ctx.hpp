@@ -14,6 +14,7 @@
 //   -DMIMSEM_WITH_EXPERIMENTS  (scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS" -> build_ab/libmimsem_hip_exp.so, MIMSEM_LIB=...)
 //                           everything is compiled in and the switches are read when MIMSEM_EXPERIMENTS=1 is set in the environment -- what
 //                           scripts/ab_*.sh and the variants' parity tests run against.
+constexpr int MIMSEM_RD_COUNTERS = 1024;
 #ifdef MIMSEM_WITH_EXPERIMENTS
 constexpr bool kExperiments = true;
 inline const char* exp_env(const char* name) {
@@ -137,7 +138,9 @@ struct mimsem_ctx {
     double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
     int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
+    unsigned* d_rdcnt = nullptr;   // [MIMSEM_RD_COUNTERS] arrival counters of the one-launch rowdot (krylov_kernels.hip: k_rowdot_fused), zero between calls
     std::vector<void*> graphs;  // the recordings (mimsem_graph*) made on this context and still alive: orphaned by mimsem_ctx_destroy
+    bool rd_two = false;           // MIMSEM_ROWDOT_TWO (experiments build): the two-launch rowdot, for the A/B of round 6
     bool memset_node = false; int blu_stop = 0;      // MIMSEM_MEMSET_NODE / MIMSEM_BLU_STOP, read once at creation
     std::vector<char> h_halo1;  // [n1] 1 = the 1-form slot takes part in a halo exchange (mimsem_ctx_set_halo_slots): its second element lives on another rank
     int* d_forceflag = nullptr; int n_forceflag = 0;      // mimsem_column_flag_for_test: columns the next solve treats as flagged (one-shot)

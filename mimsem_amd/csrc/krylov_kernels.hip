@@ -229,6 +229,33 @@ __global__ __launch_bounds__(256) void k_gs_update_dots(int k, int nb, long long
     __syncthreads();
     for (int i = threadIdx.x; i <= k; i += 256) part2[(size_t)i*gridDim.x + blockIdx.x] = (red[i*4] + red[i*4 + 1]) + (red[i*4 + 2] + red[i*4 + 3]);
 }
+// rowdot in ONE launch (round 6): every block leaves its partial sum as k_rowdot_partial does; the block that arrives LAST at the row's counter
+// (device scope, behind a fence) reduces the row's partial sums in the order and with the tree of k_rowdot_final -- the same bits as the two
+// launches -- and clears the counter for the next call.  Worth a launch (~5 us) per inner product where the vectors are short: the check
+// norms of the shallow-water iteration (12 launches -> 6 per Picard iteration), the CG of the library's KSP objects.
+__global__ __launch_bounds__(256) void k_rowdot_fused(long long n, long long chunk, const double* __restrict__ A, long long lda,
+                                                      const double* __restrict__ B, long long ldb, double* part, unsigned* counters, double* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.y, nb = gridDim.x;
+    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
+    const double* a = A + (size_t)row*lda; const double* b = B + (size_t)row*ldb;
+    double s = 0.0;
+    for (long long t = lo + tid; t < hi; t += 256) s += a[t]*b[t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(part + (size_t)row*nb + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_RELEASE);                     // (agent scope: the partial sum is visible before the arrival is counted)
+        last = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1;
+    }
+    __syncthreads();
+    if (!last || wave != 0) return;
+    double v = (lane < nb) ? __hip_atomic_load(part + (size_t)row*nb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) { out[row] = v; __hip_atomic_store(counters + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
 __global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
     const int row = blockIdx.x, lane = threadIdx.x;
     double s = (lane < nb) ? part[(size_t)row*nb + lane] : 0.0;
@@ -317,6 +344,11 @@ int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A,
     const long long chunk = (n + nb - 1)/nb;
     int rc = c->ensure_kry((long long)nb*nrows);
     if (rc) return rc;
+    if (nrows <= MIMSEM_RD_COUNTERS && c->d_rdcnt && !c->rd_two) {                 // one launch: the last block of a row reduces it (same bits as the two below)
+        hipLaunchKernelGGL(k_rowdot_fused, dim3(nb, nrows), dim3(256), 0, c->stream, n, chunk, A, lda, B, ldb, c->d_kry, c->d_rdcnt, out);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     hipLaunchKernelGGL(k_rowdot_partial, dim3(nb, nrows), dim3(256), 0, c->stream, n, chunk, A, lda, B, ldb, c->d_kry);
     hipLaunchKernelGGL(k_rowdot_final, dim3(nrows), dim3(64), 0, c->stream, nb, c->d_kry, out);
     MIMSEM_HIP_TRY(hipGetLastError());
