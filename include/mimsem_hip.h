@@ -294,6 +294,19 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* ctx, int op, int geom_lev0, int nle
                                  const double* b, long long b_stride, double alpha, double beta, double* p, long long p_stride,
                                  double* x, long long x_stride, double* upd, long long upd_stride);
 
+/* A whole FIXED-length Chebyshev solve of  Umat x = b  from x = 0 (what KSPSolve(ksp1, b, x) with a zero initial guess is in
+ * eul/HorizSolve.cpp:224, 246, 305, 326): nsteps steps of mimsem_block_chebyshev_sweep with coef = {alpha_0, beta_0, alpha_1, beta_1, ...},
+ * in ONE call: the first step needs no operator pass (Op 0 = 0) and writes x and its direction vector instead of updating them, so
+ * neither is cleared or kept by the caller.  The same bits as the sequence of sweeps on x = 0.  x: result (need not
+ * be initialised); pb (may be NULL): receives P b, the first step's preconditioned residual; upd (may be NULL): the last step's -- the two
+ * vectors of a convergence check.  op must be MIMSEM_OP_UMAT (flags: MIMSEM_FLAG_VERT or 0; f unused), orders <= 5.  Capturable once the
+ * context's workspaces have the size (a first call outside the capture). */
+int mimsem_block_chebyshev_solve(mimsem_ctx* ctx, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                 const double* f, long long f_stride, const double* blocks,
+                                 const double* elem_scale, long long elem_scale_stride,
+                                 const double* b, long long b_stride, int nsteps, const double* coef,
+                                 double* x, long long x_stride, double* pb, long long pb_stride, double* upd, long long upd_stride);
+
 /* z = P (A x) for the left-preconditioned Krylov iteration on the shallow-water operator: mimsem_sw_operator_apply followed by
  * mimsem_sw_blocks_apply in three launches instead of four -- the block pass reads the operator's element-local results through
  * the gather plan, the assembled A x is never written. */

@@ -69,6 +69,8 @@ _SIGS = {
                                                 c_dp, c_ll, c_dp, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_block_chebyshev_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll, c_dp, c_dp, c_ll,
                                                c_dp, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
+    "mimsem_block_chebyshev_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint, c_dp, c_ll, c_dp, c_dp, c_ll,
+                                               c_dp, c_ll, C.c_int, C.POINTER(C.c_double), c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_operator_precond_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, C.c_double, C.c_double,
                                              c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_chebyshev_step2": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, c_ll, c_dp, C.c_int, C.c_double, C.c_double, C.c_double,

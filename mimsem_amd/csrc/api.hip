@@ -539,6 +539,14 @@ int mimsem_ctx::ensure_ye(long long doubles) {
     ye_doubles = doubles; bytes += doubles*8;
     return MIMSEM_OK;
 }
+int mimsem_ctx::ensure_cheb(long long doubles) {
+    if (doubles <= cheb_doubles) return MIMSEM_OK;
+    if (is_capturing()) return MIMSEM_ERR_STATE;
+    if (d_cheb) { retired.push_back(d_cheb); d_cheb = nullptr; cheb_doubles = 0; }
+    MIMSEM_HIP_TRY(hipMalloc((void**)&d_cheb, (size_t)doubles*sizeof(double)));
+    cheb_doubles = doubles; bytes += doubles*8;
+    return MIMSEM_OK;
+}
 int mimsem_ctx::ensure_wpart(long long doubles) {
     if (doubles <= wpart_doubles) return MIMSEM_OK;
     if (is_capturing()) return MIMSEM_ERR_STATE;
@@ -837,6 +845,7 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
     // block pass of the Chebyshev / Richardson sweeps on the matrix cores: the default at p = 4 (40 x 40 blocks: 32.1 us against 32.8 us for
     // the register-row form on the config-5 grid, profiles/r03_mfma_p4_ab.txt), off at p <= 3 (24 x 24: 25.3 against 23.8 us);
     // MIMSEM_BLOCKS_MFMA=0 | 1 overrides
+    c->cheb_pend = exp_env("MIMSEM_CHEB_PEND") && atoi(exp_env("MIMSEM_CHEB_PEND")) != 0;
     c->blocks_mfma = exp_env("MIMSEM_BLOCKS_MFMA") ? atoi(exp_env("MIMSEM_BLOCKS_MFMA")) != 0 : es.n == 4;
     if (d->nEl > 0) { c->h_e1x.assign(d->inds1x, d->inds1x + (size_t)d->nEl*es.n1e); c->h_e1y.assign(d->inds1y, d->inds1y + (size_t)d->nEl*es.n1e);
                       c->h_e0.assign(d->inds0, d->inds0 + (size_t)d->nEl*es.n0e); }
@@ -875,7 +884,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     (void)hipSetDevice(c->device);
     orphan_graphs(c);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_rdcnt, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_rdcnt, c->d_cheb, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -1471,6 +1480,84 @@ int mimsem_block_chebyshev_sweep(mimsem_ctx* c, int op, int geom_lev0, int nlev,
     GatherEpilogue g{3, b, bs, nullptr, 0, upd, upds};
     g.alpha = alpha; g.beta = beta; g.p = p; g.ps = ps; g.escale = elem_scale; g.ess = es_stride;
     return op_apply_core(c, op, geom_lev0, nlev, scale, flags, f, fs, nullptr, 0, 0.0, x, xs, x, xs, 1.0, &g, blocks);
+}
+
+// A whole fixed-length Chebyshev solve of  Umat x = b  from x = 0 in ONE call (round 6): the first step has no element pass (Op 0 = 0: the block
+// pass takes b as its residual) and writes x and p instead of updating them, so neither needs clearing; steps 1 .. nsteps - 1 are the three
+// launches of mimsem_block_chebyshev_sweep.  The same bits as nsteps calls of that entry on x = 0, p = anything finite (up to the sign of a zero).
+// EXPERIMENT (experiments build, MIMSEM_CHEB_PEND=1): two launches per step -- the gather epilogue of step k folded into the element pass of
+// step k + 1 (body_elem_apply<..., PEND>), x and p alternating between two buffers.  Bit-equal and SLOWER (8.22 against 7.07 ms per HorizSolve
+// evaluation): the folded update turns the epilogue's coalesced slot-order accesses into 96 gathers per unit on 12 of 32 lanes.
+int mimsem_block_chebyshev_solve(mimsem_ctx* c, int op, int geom_lev0, int nlev, double scale, unsigned flags,
+                                 const double* f, long long fs, const double* blocks, const double* elem_scale, long long es_stride,
+                                 const double* b, long long bs, int nsteps, const double* coef,
+                                 double* x, long long xs, double* pb, long long pbs, double* upd, long long upds) {
+    if (!c || nlev < 0 || nsteps < 1 || !coef || (flags & ~MIMSEM_FLAG_VERT)) return MIMSEM_ERR_ARG;
+    if (op != MIMSEM_OP_UMAT) return MIMSEM_ERR_UNSUPPORTED;
+    if (c->es.n > 5) return MIMSEM_ERR_UNSUPPORTED;
+    if (nlev == 0 || c->nEl == 0) return MIMSEM_OK;
+    if (!b || !blocks || !x || x == b || geom_lev0 < 0 || geom_lev0 + nlev > c->nk) return MIMSEM_ERR_ARG;
+    if (nlev > 1 && (xs < c->n1 || bs < c->n1 || (pb && pbs < c->n1) || (upd && upds < c->n1))) return MIMSEM_ERR_ARG;
+    (void)f; (void)fs;
+    const ElemSizes& es = c->es;
+    const long long per = (long long)c->nEl*2*es.n1e, n1 = c->n1;
+    const bool pend = kExperiments && c->cheb_pend && nsteps > 1;
+    int rc;
+    if ((rc = c->ensure_ye(per*nlev*2))) return rc;
+    if ((rc = c->ensure_cheb((pend ? 3 : 1)*n1*nlev))) return rc;
+    double* ye = c->d_ye; double* ze = c->d_ye + per*nlev;
+    ElemArgs a;
+    a.wfin = nullptr; a.wsslot = nullptr; a.wcnt = nullptr; a.wfence = 0;
+    a.nEl = c->nEl; a.nlev = nlev; a.lev0 = geom_lev0; a.total = c->nEl*nlev;
+    a.flags = flags; a.scale = scale; a.alpha = 1.0;
+    a.J = c->d_J; a.det = c->d_det; a.tI = c->d_tI; a.th = c->d_th; a.tIp = c->d_tIp; a.tnp = c->nk/2 + 1; a.tps = (long long)c->nEl*es.mp12*2; a.tnode = 0; a.E = c->d_E; a.w = c->d_w;
+    a.i0 = c->d_i0; a.i1x = c->d_i1x; a.i1y = c->d_i1y; a.i2 = c->d_i2; a.iq = c->d_iq;
+    a.f = nullptr; a.fs = 0; a.f2 = nullptr; a.f2s = 0; a.param = 0.0; a.xn = c->d_xn;
+    a.lch = level_chunk(c, nlev); a.swz = 0;
+    a.fperm = nullptr; a.accum = 0; a.d0 = a.d1x = a.d1y = nullptr; a.y = nullptr; a.ys = 0;
+    a.out = ye; a.os = per;
+    c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
+    // step 0: z_0 = P b
+    if ((rc = launch_blocks_residual(c, nlev, blocks, nullptr, per, b, bs, ze, per, elem_scale, es_stride))) return rc;
+    GatherEpilogue g{3, b, bs, nullptr, 0, nullptr, 0};
+    if (!pend) {
+        double* p = c->d_cheb;
+        g.p = p; g.ps = n1;
+        for (int k = 0; k < nsteps; k++) {
+            if (k > 0) {
+                a.x = x; a.xs = xs;
+                if ((rc = launch_elem_apply(c, MIMSEM_OP_UMAT, a))) return rc;
+                if ((rc = launch_blocks_residual(c, nlev, blocks, ye, per, b, bs, ze, per, elem_scale, es_stride))) return rc;
+            }
+            g.alpha = coef[2*k]; g.beta = coef[2*k + 1]; g.zero = k == 0;
+            // the check vectors: pb = z_0, upd = z_{nsteps-1}; a one-step solve has one z for both
+            g.upd = k == nsteps - 1 && upd ? upd : (k == 0 ? pb : nullptr); g.us = k == nsteps - 1 && upd ? upds : pbs;
+            if ((rc = launch_gather_epilogue(c, 1, nlev, ze, per, g, x, xs))) return rc;
+        }
+        if (nsteps == 1 && upd && pb)
+            for (int l = 0; l < nlev; l++) MIMSEM_HIP_TRY(hipMemcpyAsync(pb + (size_t)l*pbs, upd + (size_t)l*upds, (size_t)n1*sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return MIMSEM_OK;
+    }
+    // after nsteps - 1 alternations the iterate must sit in the caller's x
+    double* X[2]; long long XS[2];
+    const int cx = (nsteps - 1) & 1;
+    X[cx] = x; XS[cx] = xs; X[cx ^ 1] = c->d_cheb; XS[cx ^ 1] = n1;
+    double* P[2] = {c->d_cheb + n1*nlev, c->d_cheb + 2*n1*nlev};
+    int cur = 0;
+    for (int k = 1; k < nsteps; k++) {
+        ElemPending pd;
+        pd.plan = c->d_g1; pd.ze = ze; pd.zes = per; pd.alpha = coef[2*(k - 1)]; pd.beta = coef[2*(k - 1) + 1]; pd.first = k == 1;
+        pd.p_in = P[cur]; pd.p_out = P[cur ^ 1]; pd.ps = n1;
+        pd.x_out = X[cur ^ 1]; pd.xos = XS[cur ^ 1];
+        pd.upd = k == 1 ? pb : nullptr; pd.us = pbs;
+        a.x = X[cur]; a.xs = XS[cur];
+        if ((rc = launch_elem_apply_pending(c, a, pd))) return rc;
+        cur ^= 1;
+        if ((rc = launch_blocks_residual(c, nlev, blocks, ye, per, b, bs, ze, per, elem_scale, es_stride))) return rc;
+    }
+    g.upd = upd; g.us = upds;
+    g.alpha = coef[2*(nsteps - 1)]; g.beta = coef[2*(nsteps - 1) + 1]; g.p = P[cur]; g.ps = n1;
+    return launch_gather_epilogue(c, 1, nlev, ze, per, g, X[cur], XS[cur]);
 }
 
 int mimsem_sw_operator_precond_apply(mimsem_ctx* c, int nlev, double a, double grav, double H, const double* f0, long long f0s,

@@ -14,7 +14,7 @@
 //   -DMIMSEM_WITH_EXPERIMENTS  (scripts/build_variant.sh exp "-DMIMSEM_WITH_EXPERIMENTS" -> build_ab/libmimsem_hip_exp.so, MIMSEM_LIB=...)
 //                           everything is compiled in and the switches are read when MIMSEM_EXPERIMENTS=1 is set in the environment -- what
 //                           scripts/ab_*.sh and the variants' parity tests run against.
-constexpr int MIMSEM_RD_COUNTERS = 1024;
+constexpr int MIMSEM_RD_COUNTERS = 8;
 #ifdef MIMSEM_WITH_EXPERIMENTS
 constexpr bool kExperiments = true;
 inline const char* exp_env(const char* name) {
@@ -66,6 +66,7 @@ struct mimsem_ctx {
     double* d_det = nullptr;    // [nEl][mp12]
     double* d_th = nullptr;     // [nk][nEl][mp12] thickness at the element's own quad points
     double* d_tI = nullptr;     // [nk][nEl][mp12] inverse thickness
+    bool cheb_pend = false;     // MIMSEM_CHEB_PEND=1 (experiments build): mimsem_block_chebyshev_solve in two launches per step
     bool blocks_mfma = false;   // block pass of the Chebyshev / Richardson sweeps on the matrix cores (default at p = 4, MIMSEM_BLOCKS_MFMA=0|1 at context creation overrides; p <= 3: register-row form)
     double* d_tIp = nullptr;    // [2][nk/2 + 1][nEl][mp12][2]: the same in level PAIRS {L, L+1}, first index = parity of L (k_apply_wave: one 16-byte load per two levels)
     double* d_tIn = nullptr;    // [2][nk/2 + 1][n0][2]: the same per NODE (MIMSEM_WAVE_TNODE=1; null unless every element holds the same value at a shared node)
@@ -131,6 +132,8 @@ struct mimsem_ctx {
     // workspace
     double* d_ye = nullptr;     // [nk_ws][nEl][max(2*n1e, n0e)] element-local results
     long long ye_doubles = 0;
+    double* d_cheb = nullptr; long long cheb_doubles = 0;      // mimsem_block_chebyshev_solve: the second iterate and two direction vectors, [3][nlev][n1]
+    int ensure_cheb(long long doubles);
     int *d_d0 = nullptr, *d_d1x = nullptr, *d_d1y = nullptr;   // direct-write slots (single-contributor DoFs), see ElemArgs
     int *d_sh0 = nullptr, *d_sh1 = nullptr; int nsh0 = 0, nsh1 = 0;   // slots with >= 2 contributors: the only ones pass 2 visits
     bool direct = false;
@@ -138,7 +141,7 @@ struct mimsem_ctx {
     double* d_colratio = nullptr;   // [nEl] |last correction| / |solution| of that solve
     int* d_colstat = nullptr;   // [1 + nEl] status of the last block-tridiagonal column solve (mimsem_column_solve_status)
     double* d_col = nullptr;    // column-solver workspace
-    unsigned* d_rdcnt = nullptr;   // [MIMSEM_RD_COUNTERS] arrival counters of the one-launch rowdot (krylov_kernels.hip: k_rowdot_fused), zero between calls
+    unsigned* d_rdcnt = nullptr;   // [MIMSEM_RD_COUNTERS] arrival counters of the one-launch rowdot (krylov_kernels.hip: k_rowdot_fused, calls of up to 8 rows), zero between calls
     std::vector<void*> graphs;  // the recordings (mimsem_graph*) made on this context and still alive: orphaned by mimsem_ctx_destroy
     bool rd_two = false;           // MIMSEM_ROWDOT_TWO (experiments build): the two-launch rowdot, for the A/B of round 6
     bool memset_node = false; int blu_stop = 0;      // MIMSEM_MEMSET_NODE / MIMSEM_BLU_STOP, read once at creation
@@ -211,6 +214,17 @@ struct ElemArgs {
     const int *d0, *d1x, *d1y;       // [nEl][n0e|n1e]: the slot when the element is its only contributor, else -1 (null = off)
 };
 
+// The vector update a Chebyshev step still owes (mimsem_block_chebyshev_solve: the gather epilogue of step k folded into the element pass of
+// step k + 1).  For the slots of its element a lane forms  z = sum of the element-local P r through the plan (the epilogue's order),
+// p = z + beta p_in,  x = x_in + alpha p  and applies the operator to THAT x; the slot's first contributor stores x and p into the OTHER
+// pair of buffers (the other elements of the slot read the old values in this same launch).  first: x_in = 0 and p_in are not read.
+struct ElemPending {
+    const int* plan; const double* ze; long long zes;
+    double alpha, beta; int first;
+    const double* p_in; double* p_out; long long ps;                     // [nlev][n1] rows (x_in is ElemArgs::x, stride ElemArgs::xs)
+    double* x_out; long long xos;
+    double* upd; long long us;                                           // receives z if given
+};
 // pass 2 with an epilogue (the Richardson sweeps): what happens to the gathered sum `acc` of a slot
 struct GatherEpilogue {
     int mode;                        // 1, 5: d = dinv*(b - acc) ; 2, 3: d = acc.   1, 2: x += d.   3, 5: p = d + beta p ; x += alpha p.   upd = d if given
@@ -223,6 +237,7 @@ struct GatherEpilogue {
     // mode 4 (round 5): the vector algebra of a Chebyshev step on B = P A with acc = (B d)[s]:  x += d;  r -= acc;  d = alpha d + beta r.
     // d lives in p (in/out), r in cr
     double* cr = nullptr; long long crs = 0;
+    int zero = 0;                    // mode 3, first step of a solve from x = 0: p = d, x = alpha d -- neither is read (mimsem_block_chebyshev_solve)
 };
 // two independent Chebyshev sweeps in the same launches (elem_kernels.hip: k_sw_pair): the block pass and the gather epilogue of one level
 struct PairBlocks { int nEl, lch; const int *i1x, *i1y, *plan; const double *B, *ye; long long yes; const double* b; double* ze; long long zes; };
@@ -236,6 +251,7 @@ int launch_blocks_residual(mimsem_ctx* c, int nlev, const double* B, const doubl
                            const double* b, long long bs, double* ze, long long zes,
                            const double* escale = nullptr, long long ess = 0);
 int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a);
+int launch_elem_apply_pending(mimsem_ctx* c, const ElemArgs& a, const ElemPending& pd);      // Umat with the owed Chebyshev update (orders <= 5)
 int launch_gather_perim(mimsem_ctx* c, int nlev, const double* yp, long long yps, int accum, double* y, long long ys,
                         const int* pslot = nullptr, const int* ppart = nullptr, int nps = -1);
 int launch_apply_wave(mimsem_ctx* c, int op, const ElemArgs& a);

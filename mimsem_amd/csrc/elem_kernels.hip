@@ -286,8 +286,9 @@ __device__ __forceinline__ void interp_point(const double* dofs, const double* s
 // (round 6: the bodies of the three kernels of a Chebyshev sweep -- element pass, block pass, gather epilogue -- are __device__ functions of the
 //  block index so that k_sw_pair below can run two of them, belonging to two INDEPENDENT sweeps, in one launch; the kernels themselves are
 //  thin wrappers that pass their own block index and grid size)
-template <int N, int OP, bool FUSED>
-__device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigned bid, const unsigned gdim) {
+template <int N, int OP, bool FUSED, bool PEND = false>
+__device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigned bid, const unsigned gdim, const ElemPending* pdp = nullptr) {
+    static_assert(!PEND || (OP == MIMSEM_OP_UMAT && !FUSED), "the owed Chebyshev update rides in the 1-form mass operator's element pass");
     using D = Dims<N>;
     using T = OpTraits<OP>;
     // the test-upwind operators keep per-point basis tables in LDS: at p = 7 two elements per workgroup (128 threads) fit in 64 KB
@@ -344,6 +345,12 @@ __device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigne
     if constexpr (T::cf != SN) dof_slots<N, T::cf>(a, e, q, act, fs0, fs1);
     int us0 = -1, us1 = -1;
     if constexpr (T::cf2 != SN) dof_slots<N, T::cf2>(a, e, q, act, us0, us1);
+    // PEND: the two contributors of this lane's slots (the gather plan's order) and whether this element is the first of them (it stores)
+    int pa0 = -1, pa1 = -1, pb0 = -1, pb1 = -1; bool own0 = false, own1 = false;
+    if constexpr (PEND) {
+        if (xs0 >= 0) { pa0 = pdp->plan[(size_t)xs0*2]; pa1 = pdp->plan[(size_t)xs0*2 + 1]; own0 = pa0 == e*2*D::n1e + q; }
+        if (xs1 >= 0) { pb0 = pdp->plan[(size_t)xs1*2]; pb1 = pdp->plan[(size_t)xs1*2 + 1]; own1 = pb0 == e*2*D::n1e + D::n1e + q; }
+    }
     const size_t lstride = (size_t)a.nEl*D::mp12;
     const size_t gq = (size_t)e*D::mp12 + q;
     // direct path: this lane's output DoFs that no other element touches go straight to y
@@ -359,8 +366,27 @@ __device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigne
     double nx0 = 0.0, nx1 = 0.0, nf0 = 0.0, nf1 = 0.0, ng0 = 0.0, ng1 = 0.0, ntI = 1.0, nth0 = 1.0, nth1 = 1.0;
     auto fetch = [&](int lev) {
         const double* xv = a.x + (size_t)lev*a.xs;
-        if (xs0 >= 0) nx0 = xv[xs0];
-        if constexpr (T::in == S1 || T::in == SQ2) { if (xs1 >= 0) nx1 = xv[xs1]; }
+        if constexpr (PEND) {
+            // x of this step = the owed update of the previous one, formed slot by slot as k_gather_epilogue (mode 3) forms it: the same bits
+            const ElemPending& pd = *pdp;
+            const double* zv = pd.ze + (size_t)lev*pd.zes;
+            const size_t ro = (size_t)lev*pd.ps;
+            auto owed = [&](int slot, int j0, int j1, bool own) {
+                double acc = 0.0;
+                if (j0 >= 0) acc += zv[j0];
+                if (j1 >= 0) acc += zv[j1];
+                double pn, xn;
+                if (pd.first) { pn = acc; xn = pd.alpha*pn; }
+                else { pn = fma(pd.beta, pd.p_in[ro + slot], acc); xn = fma(pd.alpha, pn, xv[slot]); }
+                if (own) { pd.x_out[(size_t)lev*pd.xos + slot] = xn; pd.p_out[ro + slot] = pn; if (pd.upd) pd.upd[(size_t)lev*pd.us + slot] = acc; }
+                return xn;
+            };
+            if (xs0 >= 0) nx0 = owed(xs0, pa0, pa1, own0);
+            if (xs1 >= 0) nx1 = owed(xs1, pb0, pb1, own1);
+        } else {
+            if (xs0 >= 0) nx0 = xv[xs0];
+            if constexpr (T::in == S1 || T::in == SQ2) { if (xs1 >= 0) nx1 = xv[xs1]; }
+        }
         if constexpr (T::cf != SN) {
             const double* fv = a.f + (size_t)lev*a.fs;
             if (fs0 >= 0) nf0 = fv[fs0];
@@ -563,6 +589,8 @@ __device__ __forceinline__ void body_elem_apply(const ElemArgs& a, const unsigne
 }
 template <int N, int OP, bool FUSED>
 __global__ __launch_bounds__(256) void k_elem_apply(ElemArgs a) { body_elem_apply<N, OP, FUSED>(a, blockIdx.x, gridDim.x); }
+template <int N>
+__global__ __launch_bounds__(256) void k_elem_apply_pending(ElemArgs a, ElemPending pd) { body_elem_apply<N, MIMSEM_OP_UMAT, false, true>(a, blockIdx.x, gridDim.x, &pd); }
 
 // pass 2: y[slot] = (+=) sum of its element-local contributions, fixed order.  One thread per slot and
 // chunk of LC levels: the plan entry is read once per chunk, level reads/writes are coalesced across slots.
@@ -618,9 +646,9 @@ __device__ __forceinline__ void body_gather_epilogue(const double* __restrict__ 
             *dp = fma(g.alpha, dv, g.beta*rv);
         } else if (g.mode == 3 || g.mode == 5) {           // Chebyshev semi-iteration: direction p = z + beta p, iterate x += alpha p (5: z = dinv (b - acc))
             double* pp = g.p + (size_t)lev*g.ps + s;
-            const double pn = d + g.beta*(*pp);
+            const double pn = g.zero ? d : fma(g.beta, *pp, d);
             *pp = pn;
-            x[(size_t)lev*xs + s] += g.alpha*pn;
+            x[(size_t)lev*xs + s] = g.zero ? g.alpha*pn : fma(g.alpha, pn, x[(size_t)lev*xs + s]);
         } else x[(size_t)lev*xs + s] += d;
         if (g.upd) g.upd[(size_t)lev*g.us + s] = d;
     }
@@ -678,8 +706,8 @@ __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch,
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const int lev = min(l0 + l, max(nlev - 1, 0));
-        const double* src = ye + (size_t)lev*yes;
-        a0[l] = src[q0]; a1[l] = src[q1];
+        if (ye) { const double* src = ye + (size_t)lev*yes; a0[l] = src[q0]; a1[l] = src[q1]; }      // (null: the operator result is zero -- the first step of a solve from x = 0)
+        else { a0[l] = 0.0; a1[l] = 0.0; }
         bb[l] = b[(size_t)lev*bs + slot];
         es[l] = escale ? escale[(size_t)lev*ess + e] : 1.0;
     }
@@ -1485,6 +1513,28 @@ int launch_elem_apply(mimsem_ctx* c, int op, const ElemArgs& a) {
     case 3: return dispatch_apply<3>(c, op, a); case 4: return dispatch_apply<4>(c, op, a);
     case 5: return dispatch_apply<5>(c, op, a); case 6: return dispatch_apply<6>(c, op, a);
     case 7: return dispatch_apply<7>(c, op, a);
+    default: return MIMSEM_ERR_UNSUPPORTED;
+    }
+}
+
+template <int N>
+static int elem_apply_pending_n(mimsem_ctx* c, const ElemArgs& a, const ElemPending& pd) {
+    using D = Dims<N>;
+    if constexpr (!kExperiments) return MIMSEM_ERR_UNSUPPORTED;          // (a closed experiment: profiles/r06_cheb_whole_ab.txt)
+    else {
+    const long long items = (long long)a.nEl*((a.nlev + a.lch - 1)/a.lch);
+    const unsigned grid = (unsigned)((items + D::EPB - 1)/D::EPB);
+    if (grid == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL((k_elem_apply_pending<N>), dim3(grid), dim3(256), 0, c->stream, a, pd);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+    }
+}
+int launch_elem_apply_pending(mimsem_ctx* c, const ElemArgs& a, const ElemPending& pd) {
+    switch (c->es.n) {
+    case 1: return elem_apply_pending_n<1>(c, a, pd); case 2: return elem_apply_pending_n<2>(c, a, pd);
+    case 3: return elem_apply_pending_n<3>(c, a, pd); case 4: return elem_apply_pending_n<4>(c, a, pd);
+    case 5: return elem_apply_pending_n<5>(c, a, pd);
     default: return MIMSEM_ERR_UNSUPPORTED;
     }
 }

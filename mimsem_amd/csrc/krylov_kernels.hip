@@ -247,8 +247,12 @@ __global__ __launch_bounds__(256) void k_rowdot_fused(long long n, long long chu
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(part + (size_t)row*nb + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __atomic_thread_fence(__ATOMIC_RELEASE);                     // (agent scope: the partial sum is visible before the arrival is counted)
-        last = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1;
+        // The partial sum went out as a write-through store (sc1: coherent at device scope once acknowledged); waiting for that acknowledgement
+        // and then counting the arrival with a RELAXED atomic orders the two without a release fence.  A release here is `buffer_wbl2 sc1` on
+        // gfx950 -- a write-back of the XCD's whole L2, which holds the previous kernel's output: 48 us per call for 60 rows of HorizSolve's
+        // check norms where the two launches took 12.  The reader below uses sc1 loads for the same reason (no acquire / buffer_inv).
+        __builtin_amdgcn_s_waitcnt(0);
+        last = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1;
     }
     __syncthreads();
     if (!last || wave != 0) return;
@@ -344,7 +348,10 @@ int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A,
     const long long chunk = (n + nb - 1)/nb;
     int rc = c->ensure_kry((long long)nb*nrows);
     if (rc) return rc;
-    if (nrows <= MIMSEM_RD_COUNTERS && c->d_rdcnt && !c->rd_two) {                 // one launch: the last block of a row reduces it (same bits as the two below)
+    // one launch where a launch is what the call costs (few rows: the check norms of the shallow-water iteration, the CG of the KSP objects): the
+    // last block of a row reduces it, same bits as the two launches below.  Many rows stay on two launches: their arrivals (rows x 32 atomics
+    // on neighbouring words) serialise -- 17 us against 7.4 + 4.8 for the 60 rows x 62 208 of HorizSolve's check norms
+    if (nrows <= MIMSEM_RD_COUNTERS && c->d_rdcnt && !c->rd_two) {
         hipLaunchKernelGGL(k_rowdot_fused, dim3(nb, nrows), dim3(256), 0, c->stream, n, chunk, A, lda, B, ldb, c->d_kry, c->d_rdcnt, out);
         MIMSEM_HIP_TRY(hipGetLastError());
         return MIMSEM_OK;

@@ -299,6 +299,24 @@ class Engine:
                                                   _ptr(upd), upd.stride(0) if upd is not None else 0), "block_chebyshev_sweep(%s)" % op)
         return x
 
+    def block_chebyshev_solve(self, op, blocks, b, coef, x=None, elem_scale=None, lev0=0, scale=1.0, flags=0, pb=None, upd=None):
+        """the whole fixed-length solve from x = 0 as ONE call: len(coef) steps of block_chebyshev_sweep, the first without its operator pass
+        and without cleared x / p (mimsem_block_chebyshev_solve; the same bits).  coef: [(alpha, beta)]; pb / upd receive the first / last
+        preconditioned residual."""
+        import ctypes
+        nd = 2 * self.n1e
+        assert b.dim() == 2 and b.shape[1] == self.sizes[1] and blocks.shape == (self.nEl, nd, nd)
+        x = torch.empty_like(b) if x is None else x
+        assert x.shape == b.shape and (pb is None or pb.shape == b.shape) and (upd is None or upd.shape == b.shape)
+        assert elem_scale is None or elem_scale.shape == (b.shape[0], self.nEl)
+        flat = (ctypes.c_double * (2 * len(coef)))(*[v for ab in coef for v in ab])
+        check(self.L.mimsem_block_chebyshev_solve(self.ctx, OPS[op], lev0, b.shape[0], scale, flags, None, 0, _ptr(blocks),
+                                                  _ptr(elem_scale), elem_scale.stride(0) if elem_scale is not None else 0,
+                                                  _ptr(b), b.stride(0), len(coef), flat, _ptr(x), x.stride(0),
+                                                  _ptr(pb), pb.stride(0) if pb is not None else 0,
+                                                  _ptr(upd), upd.stride(0) if upd is not None else 0), "block_chebyshev_solve(%s)" % op)
+        return x
+
     def sw_dual_chebyshev(self, coefA, blocks, b1, p1, x1, upd1, coefB, tau, h, u, b0, dinv, p0, x0, upd0):
         """the 1-form mass solve (len(coefA) block-Chebyshev sweeps on Umat: x1, p1 in place) and the upwinded lumped 0-form mass solve (len(coefB)
         Chebyshev sweeps on Phmat_up: x0, p0 in place) of one shallow-water Picard iteration in SHARED launches (mimsem_sw_dual_chebyshev):

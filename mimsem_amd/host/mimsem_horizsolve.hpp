@@ -32,6 +32,7 @@ public:
     // the fixed-length mode off (the CG of the reference's structure from then on; the caller redoes the evaluation).
     // levels_changed() after mimsem_ctx_set_levels: PCSetUp and the interval again.  use_fixed_length(false) keeps the CG.
     static constexpr int MAXLOG = 32;
+    bool whole_solve = true;            // one context: a mass solve is ONE mimsem_block_chebyshev_solve call (false: cheb_steps sweep calls)
     int cheb_steps = 0; bool fixed_length = false; int solves_checked = 0, solves_missed = 0; double worst_rel = 0.0;
 
     // fg: the Coriolis 0-form per level (HorizSolve::coriolis :124-161), device [nk][n0]; nDofs0G: the GLOBAL node count (viscosity() :112-120)
@@ -84,7 +85,7 @@ public:
         }
         const double l1 = 0.90*lo, l2 = 1.05*hi, sg = (std::sqrt(l2/l1) - 1.0)/(std::sqrt(l2/l1) + 1.0), d = 0.5*(l1 + l2), c2 = 0.25*(l2 - l1)*(l2 - l1);
         cheb_steps = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/sg)));
-        coef.clear();
+        coef.clear(); flat.clear();
         double al = 1.0/d;
         coef.emplace_back(al, 0.0);
         for (int k = 1; k < cheb_steps; k++) { const double be = (k == 1 ? 0.5 : 0.25)*c2*al*al; al = 1.0/(d - be/al); coef.emplace_back(al, be); }
@@ -239,10 +240,18 @@ public:
         if (fixed_length) {
             mimsem_ctx* c = mesh->ctx;
             const long long tot = (long long)nk*n1;
-            check(mimsem_memset(c, x, 0, tot*8), "mimsem_memset"); check(mimsem_memset(c, p1, 0, tot*8), "mimsem_memset");
-            bool unsupported = false;
+            bool unsupported = false, whole = false;
             const size_t last = coef.size() - 1;
-            for (size_t k = 0; k < coef.size() && !unsupported; k++) {
+            if (!sh && whole_solve) {
+                // one context: the whole solve as ONE call (the first step has no operator pass and clears nothing): the same bits as the sweeps below
+                if (flat.size() != 2*coef.size()) { flat.clear(); for (const auto& ab : coef) { flat.push_back(ab.first); flat.push_back(ab.second); } }
+                const int rc = mimsem_block_chebyshev_solve(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,
+                                                            (int)coef.size(), flat.data(), x, n1, pb1, n1, upd1, n1);
+                if (rc == MIMSEM_ERR_UNSUPPORTED) whole_solve = false;
+                else { check(rc, "mimsem_block_chebyshev_solve"); whole = true; }
+            }
+            if (!whole) { check(mimsem_memset(c, x, 0, tot*8), "mimsem_memset"); check(mimsem_memset(c, p1, 0, tot*8), "mimsem_memset"); }
+            for (size_t k = 0; k < coef.size() && !unsupported && !whole; k++) {
                 // the update of sweep 0 (x = 0) is P b; the one of the last sweep the preconditioned residual it saw
                 double* upd = k == last ? upd1 : (k == 0 ? pb1 : nullptr);
                 if (sh) {
@@ -292,7 +301,7 @@ private:
     Mesh* mesh; const double* fg; Shard* sh = nullptr; mimsem_ksp* ksp1 = nullptr;
     double *w1 = nullptr, *y1 = nullptr, *z1 = nullptr, *own1n = nullptr;
     int nk = 1, n0 = 0, n1 = 0, n2 = 0; bool have_k2i = false;
-    const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; int slot = 0; bool wanted_fixed = true;
+    const double *blocks1 = nullptr, *escale1 = nullptr; std::vector<std::pair<double, double>> coef; std::vector<double> flat; int slot = 0; bool wanted_fixed = true;
     double *p1 = nullptr, *upd1 = nullptr, *pb1 = nullptr, *pair1 = nullptr, *chk = nullptr, *gt1 = nullptr;
     double *a1 = nullptr, *b1 = nullptr, *c1 = nullptr, *d1 = nullptr, *e1 = nullptr, *g1 = nullptr, *a2 = nullptr, *b2 = nullptr, *c2 = nullptr,
            *m0 = nullptr, *a0 = nullptr, *b0 = nullptr, *scal = nullptr;

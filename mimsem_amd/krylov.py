@@ -344,6 +344,11 @@ class MassSolver:
             es = self.escale[lev0:lev0 + nlev]
             ch.sweep = lambda x, rhs, p, al, be, upd: self.eng.block_chebyshev_sweep(
                 "UMAT", self._blocks_cm, x, rhs, p, al, be, elem_scale=es, lev0=lev0, scale=self.scale, flags=self.flags, upd=upd)
+            # one context: the whole solve as one call (round 6: no operator pass for the first step, no cleared vectors; MIMSEM_CHEB_WHOLE=0, experiments: a call per sweep)
+            ch.whole = None
+            if not self.dist and hasattr(self.eng, "block_chebyshev_solve") and self.eng.n1e <= 30 and experiment("MIMSEM_CHEB_WHOLE", "1") != "0":
+                ch.whole = lambda rhs, coef, pb, upd: self.eng.block_chebyshev_solve(
+                    "UMAT", self._blocks_cm, rhs, coef, elem_scale=es, lev0=lev0, scale=self.scale, flags=self.flags, pb=pb, upd=upd)
             # the calibrated step count holds for the tolerance and the level range it was calibrated on (advisor, round 3): a call that asks
             # for a tighter rtol, or covers levels the calibration did not see, goes back to the bound-based count and re-calibrates
             cal = getattr(self, "_cheb_cal", None)
@@ -873,6 +878,7 @@ class ChebyshevMass:
         self.set_steps(max(2, int(math.ceil(math.log(2.0 / rtol) / math.log(1.0 / sg)))))
         self.p = None
         self.upd = None
+        self.whole = None          # whole(b, coef, pb, upd) -> x: the solve from x = 0 as ONE engine call (Engine.block_chebyshev_solve: no operator pass in the first step, nothing cleared)
 
     def set_steps(self, steps):
         """fix the number of steps (the coefficients of step k depend on the spectral interval only, not on how many steps follow)"""
@@ -893,12 +899,14 @@ class ChebyshevMass:
         """returns x; capturable (fixed shapes and step count, no host synchronisation).  want_residual: self.upd receives the preconditioned
         residual the LAST sweep saw; pb (a tensor like b, zero start only): receives the FIRST sweep's update, which is P b -- the two vectors
         of a convergence check without an extra preconditioner application"""
-        if self.p is None or self.p.shape != b.shape:
-            self.p = torch.zeros_like(b)
+        assert pb is None or x0 is None
         if self.upd is None or self.upd.shape != b.shape:
             self.upd = torch.zeros_like(b)
+        if self.whole is not None and x0 is None:
+            return self.whole(b, self.coef, pb, self.upd if want_residual else None)
+        if self.p is None or self.p.shape != b.shape:
+            self.p = torch.zeros_like(b)
         x = torch.zeros_like(b) if x0 is None else x0.clone()           # (p needs no reset: the first step has beta = 0)
-        assert pb is None or x0 is None
         for k, (alpha, beta) in enumerate(self.coef):
             upd = self.upd if (want_residual and k == self.steps - 1) else (pb if k == 0 else None)
             self.sweep(x, b, self.p, alpha, beta, upd)

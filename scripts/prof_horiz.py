@@ -33,7 +33,8 @@ def rhs():
     dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
     return hs.momentum_rhs_ec(th, dudz, dudz, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk)
 rhs(); torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(3):
+REPS = int(os.environ.get("REPS", "3"))
+for _ in range(REPS):
     rhs()
 torch.cuda.synchronize()
-print("ms/eval", (time.perf_counter() - t0) / 3 * 1e3)
+print("ms/eval", (time.perf_counter() - t0) / REPS * 1e3)

@@ -5,6 +5,7 @@
 //   usage: test_horiz <in.arr> <out.bin> [ksp]
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include "../../mimsem_amd/host/mimsem_horizsolve.hpp"
 #include "../../mimsem_amd/host/sw_io.hpp"
@@ -59,6 +60,17 @@ int main(int argc, char** argv) {
             double e2 = 0.0, r2 = 0.0;
             for (size_t i = 0; i < s1; i++) { e2 += (ha[i] - hb[i])*(ha[i] - hb[i]); r2 += ha[i]*ha[i]; }
             if (!(std::sqrt(e2/r2) < 1.0e-11)) { std::printf("FAIL: CG after the fallback vs fixed-length: %.2e\n", std::sqrt(e2/r2)); return 1; }
+            // the whole solve as one call (the default on one context) and the sweep calls give the same bits
+            if (!hs.whole_solve) { std::printf("FAIL: the whole-solve entry is not in use\n"); return 1; }
+            hs.whole_solve = false;
+            hs.grad(Pi, tB);
+            hs.whole_solve = true;
+            if (!hs.verify()) { std::printf("FAIL: check missed (sweep calls)\n"); return 1; }
+            mesh.to_host(hb.data(), tB, s1);
+            if (std::memcmp(ha.data(), hb.data(), s1*sizeof(double)) != 0) {
+                double worst = 0.0; for (size_t i = 0; i < s1; i++) worst = std::max(worst, std::fabs(ha[i] - hb[i]));
+                if (worst != 0.0) { std::printf("FAIL: whole solve vs sweep calls: max difference %.3e (the same bits expected)\n", worst); return 1; }
+            }
             mimsem_free(tA); mimsem_free(tB);
         }
         FILE* g = std::fopen(argv[2], "wb");

@@ -158,6 +158,54 @@ def test_chebyshev_mass_solver(sphere):
         assert float(torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)) < 1e-13
 
 
+def test_chebyshev_whole_solve_equals_the_sweeps(sphere):
+    """mimsem_block_chebyshev_solve (round 6: the whole fixed-length solve from x = 0 as one call, no element pass for the first step, x and
+    p written rather than updated there) against the same steps as mimsem_block_chebyshev_sweep calls from x = 0: the same bits, for one
+    step, two, an even and an odd count (the experiments build's two-launch form -- MIMSEM_CHEB_PEND=1 -- alternates the iterate between two
+    buffers and must end in the caller's), with and without the check vectors; then through MassSolver (the default path of HorizSolve's
+    mass solves) against PCG"""
+    import torch
+    from mimsem_amd.krylov import MassSolver
+    cs, eng, mats, rng = sphere
+    ms = MassSolver(eng, SCALE, True)
+    cm = ms.blocks.transpose(1, 2).contiguous()
+    b = eng.tensor(rng.standard_normal((eng.nk, cs.nDofs1G)) * 1e3)
+    ms.solve(b)                                                             # (calibration, workspaces)
+    ch = ms._cheb
+    for n in (1, 2, 5, 8, len(ch.coef)):
+        coef = ch.coef[:n]
+        x = torch.zeros_like(b); p = torch.full_like(b, 7.0); u_last = torch.zeros_like(b); u_first = torch.zeros_like(b)
+        for k, (al, be) in enumerate(coef):
+            eng.block_chebyshev_sweep("UMAT", cm, x, b, p, al, be, elem_scale=ms.escale, scale=SCALE, flags=ms.flags,
+                                      upd=u_first if k == 0 else (u_last if k == n - 1 else None))
+        if n == 1:
+            u_last = u_first
+        pb = torch.full_like(b, float("nan")); upd = torch.full_like(b, float("nan")); y = torch.full_like(b, float("nan"))
+        eng.block_chebyshev_solve("UMAT", cm, b, coef, x=y, elem_scale=ms.escale, scale=SCALE, flags=ms.flags, pb=pb, upd=upd)
+        assert torch.equal(y, x), (n, float((y - x).abs().max()))
+        assert torch.equal(pb, u_first) and torch.equal(upd, u_last), n
+        y2 = eng.block_chebyshev_solve("UMAT", cm, b, coef, elem_scale=ms.escale, scale=SCALE, flags=ms.flags)      # no check vectors, own output
+        assert torch.equal(y2, x)
+    # a sub-range of levels, strided rows
+    big = eng.tensor(rng.standard_normal((eng.nk, cs.nDofs1G + 5)))
+    bb = big[1:, :cs.nDofs1G]
+    x = torch.zeros(eng.nk - 1, cs.nDofs1G, dtype=torch.float64, device=eng.device); p = torch.zeros_like(x)
+    for al, be in ch.coef[:4]:
+        eng.block_chebyshev_sweep("UMAT", cm, x, bb, p, al, be, elem_scale=ms.escale[1:], lev0=1, scale=SCALE, flags=ms.flags)
+    y = eng.block_chebyshev_solve("UMAT", cm, bb, ch.coef[:4], elem_scale=ms.escale[1:], lev0=1, scale=SCALE, flags=ms.flags)
+    assert torch.equal(y, x)
+    # the solver class uses it (one context) and agrees with PCG
+    assert ch.whole is not None
+    x1, _ = ms.solve(b)
+    assert ms.verify()
+    ms.chebyshev = False
+    x2, _ = ms.solve(b, rtol=1e-15)
+    assert float(torch.linalg.vector_norm(x1 - x2) / torch.linalg.vector_norm(x2)) < 1e-12
+    import ctypes as C
+    assert eng.L.mimsem_block_chebyshev_solve(eng.ctx, 2, 0, eng.nk, SCALE, 1, None, 0, C.c_void_p(cm.data_ptr()), None, 0, C.c_void_p(b.data_ptr()), b.stride(0),
+                                              2, (C.c_double * 4)(1, 0, 1, 0), C.c_void_p(y.data_ptr()), y.stride(0), None, 0, None, 0) == -2      # only Umat
+
+
 def test_weak_gradient_matches_dense(sphere):
     from mimsem_amd.horizsolve import HorizSolve
     cs, eng, mats, rng = sphere
