@@ -32,6 +32,7 @@ public:
     // the fixed-length mode off (the CG of the reference's structure from then on; the caller redoes the evaluation).
     // levels_changed() after mimsem_ctx_set_levels: PCSetUp and the interval again.  use_fixed_length(false) keeps the CG.
     static constexpr int MAXLOG = 32;
+    double margin_lo = 0.90, margin_hi = 1.05;      // the safety margins in force around the Ritz interval (use_fixed_length)
     bool whole_solve = true;            // one context: a mass solve is ONE mimsem_block_chebyshev_solve call (false: cheb_steps sweep calls)
     int cheb_steps = 0; bool fixed_length = false; int solves_checked = 0, solves_missed = 0; double worst_rel = 0.0;
 
@@ -70,20 +71,28 @@ public:
     void use_fixed_length(bool on) {
         fixed_length = false; wanted_fixed = on;
         if (!on) return;
-        double lo, hi, im;
+        // the interval from TWO Ritz estimates (25 and 40 steps): what the ends still move between them is the measure of their uncertainty
+        double lo = 0.0, hi = 0.0, im = 0.0, lo25 = 0.0, hi25 = 0.0;
+        for (const int steps : {25, 40}) {
+        lo25 = lo; hi25 = hi;
         if (sh) {
             // (the blocks first: the sharded interval is that of the COMPLETED operator, from the host's own Arnoldi process)
             if (mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) throw std::runtime_error("HorizSolve (sharded): no element blocks for this order");
-            sh->ritz((long long)nk*n1, 25, own1n, [&](const double* v, double* w) {
+            sh->ritz((long long)nk*n1, steps, own1n, [&](const double* v, double* w) {
                          check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, v, n1, y1, n1, 1.0), "UMAT"); sh->complete1(y1, nk);
                          check(mimsem_elem_blocks_apply(mesh->ctx, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, y1, n1, w, n1, 1.0), "mimsem_elem_blocks_apply"); sh->complete1(w, nk); },
                      [&](double* v) { sh->complete1(v, nk); }, &lo, &hi, &im, 1234);
-        } else check(mimsem_ksp_ritz(ksp1, 25, &lo, &hi, &im), "mimsem_ksp_ritz");
+        } else check(mimsem_ksp_ritz(ksp1, steps, &lo, &hi, &im), "mimsem_ksp_ritz");
+        }
         if (!(lo > 0.02) || mimsem_ksp_get_pc_blocks(ksp1, &blocks1, &escale1, nullptr) != MIMSEM_OK) {
             if (sh) throw std::runtime_error("HorizSolve (sharded): the spectral interval does not admit the fixed-length solves (no CG on a shard)");
             return;
         }
-        const double l1 = 0.90*lo, l2 = 1.05*hi, sg = (std::sqrt(l2/l1) - 1.0)/(std::sqrt(l2/l1) + 1.0), d = 0.5*(l1 + l2), c2 = 0.25*(l2 - l1)*(l2 - l1);
+        // safety margins (round 6): three times what the ends moved, at least 1 %, at most the 10 % / 5 % of round 5 -- on a smooth thickness
+        // field the Ritz values are exact to 1e-4 and the wide margins cost 3 of 15 steps; every solve is still checked (verify())
+        margin_lo = 1.0 - std::min(0.10, std::max(0.01, 3.0*std::fabs(lo - lo25)/lo));
+        margin_hi = 1.0 + std::min(0.05, std::max(0.01, 3.0*std::fabs(hi - hi25)/hi));
+        const double l1 = margin_lo*lo, l2 = margin_hi*hi, sg = (std::sqrt(l2/l1) - 1.0)/(std::sqrt(l2/l1) + 1.0), d = 0.5*(l1 + l2), c2 = 0.25*(l2 - l1)*(l2 - l1);
         cheb_steps = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/sg)));
         coef.clear(); flat.clear();
         double al = 1.0/d;

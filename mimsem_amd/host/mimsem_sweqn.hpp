@@ -191,6 +191,7 @@ private:
     enum LogKind { K_MASS = 1, K_A = 2, K_PICARD = 3 };
     Mesh* mesh; const double* fg; Shard* sh = nullptr;
     double *y1 = nullptr, *z1 = nullptr, *y0 = nullptr, *yA = nullptr, *zA = nullptr; double widen = 1.0;
+    double marginA[2] = {0.90, 1.05}, marginM[2] = {0.90, 1.05};      // the safety margins in force around the two Ritz intervals (setup)
     void done1(double* v) { if (sh) sh->complete1(v); }      // element-local partial sums of a 1-form / 0-form result completed over the halo (one rank: nothing to do)
     void done0(double* v) { if (sh) sh->complete0(v); }
     // (src/Assembly.h's Umat is built from (Topo*, Geom*); this one from the Mesh of a raw descriptor)
@@ -293,23 +294,38 @@ private:
             return;
         }
         if (!fixed_length) return;
-        double lo, hi_, im;
+        double lo = 0.0, hi_ = 0.0, im = 0.0;
         // (sharded: the host's own Arnoldi process on the COMPLETED operator -- the library's Ritz estimate sees one context's elements only)
-        const double mlo = 1.0 - 0.1*std::min(widen, 4.0), mhi = 1.0 + 0.05*widen;       // safety margins; a re-estimate after a missed check widens them
-        if (sh) sh->ritz(N, 40, sh->ownx, [&](const double* v, double* w) { apply_PA(a, v, w); }, [&](double* v) { sh->complete1(v); }, &lo, &hi_, &im);
-        else kspA.ritz(40, &lo, &hi_, &im);
+        // safety margins around a Ritz interval (round 6; mimsem_amd/krylov.py::ritz_margins): three times what its ends moved between a 25- and
+        // a 40-step estimate, at least 1 % -- round 5 took 10 % / 5 % whatever the estimate's quality, which cost 2 of 31 and 2 of 15 steps; a
+        // re-estimate after a missed check (widen > 1) opens them by 10 % / 5 % per unit
+        double mlo = 0.99, mhi = 1.01, lo25 = 0.0, hi25 = 0.0;
+        auto margins = [&]() {
+            mlo = 1.0 - std::min(0.4, std::max({0.01, 3.0*std::fabs(lo - lo25)/lo, 0.1*(widen - 1.0)}));
+            mhi = 1.0 + std::max({0.01, 3.0*std::fabs(hi_ - hi25)/hi_, 0.05*(widen - 1.0)});
+        };
+        for (const int m : {25, 40}) {
+            lo25 = lo; hi25 = hi_;
+            if (sh) sh->ritz(N, m, sh->ownx, [&](const double* v, double* w) { apply_PA(a, v, w); }, [&](double* v) { sh->complete1(v); }, &lo, &hi_, &im);
+            else kspA.ritz(m, &lo, &hi_, &im);
+        }
         if (!(lo > 0.02 && im <= 0.15*(hi_ - lo))) return;
+        margins(); marginA[0] = mlo; marginA[1] = mhi;
         kspA.pcBlocks(&blocksA);
         const double lminA = mlo*lo, lmaxA = mhi*hi_;
         thetaA = 0.5*(lmaxA + lminA); deltaA = 0.5*(lmaxA - lminA);
         steps_A = std::max(2, (int)std::ceil(std::log(0.5*rtol)/std::log(cheb::interval_rate(lminA, lmaxA))) + 1);
         ksp1.pcBlocks(&blocks1, &escale1);
-        if (sh) sh->ritz(n1, 25, sh->own1, [&](const double* v, double* w) {
+        for (const int m : {25, 40}) {
+        lo25 = lo; hi25 = hi_;
+        if (sh) sh->ritz(n1, m, sh->own1, [&](const double* v, double* w) {
                              check(mimsem_op_apply(mesh->ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, v, 0, y1, 0, 1.0), "UMAT"); sh->complete1(y1);
                              check(mimsem_elem_blocks_apply(mesh->ctx, 1, 1, 0, blocks1, 0, escale1, 0, y1, 0, w, 0, 1.0), "mimsem_elem_blocks_apply"); sh->complete1(w); },
                          [&](double* v) { sh->complete1(v); }, &lo, &hi_, &im, 4321);
-        else ksp1.ritz(25, &lo, &hi_, &im);
+        else ksp1.ritz(m, &lo, &hi_, &im);
+        }
         if (!(lo > 0.02)) return;
+        margins(); marginM[0] = mlo; marginM[1] = mhi;
         const double l1 = mlo*lo, l2 = mhi*hi_;
         steps_M1 = std::max(2, (int)std::ceil(std::log(2.0/rtol)/std::log(1.0/cheb::interval_rate(l1, l2))));
         coefM = cheb::ellipse(0.5*(l1 + l2), 0.25*(l2 - l1)*(l2 - l1), steps_M1);

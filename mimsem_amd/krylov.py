@@ -285,13 +285,21 @@ class MassSolver:
                 # the rank's rows of the global random right-hand side (every level its own draw), ownership-weighted all-reduced inner products
                 b = torch.cat([eng.randn_global(1, 1234 + k, cpu_generator=True) for k in range(eng.nk)], dim=0).contiguous()
                 w1 = eng.weights(1)
-                lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25,
-                                            dot=lambda u, v: eng.allreduce(torch.linalg.vecdot(u * w1, v, dim=1)))
+                lmin, lmax, elo, ehi = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=40, errors=True,
+                                                      dot=lambda u, v: eng.allreduce(torch.linalg.vecdot(u * w1, v, dim=1)))
             else:
                 g = torch.Generator(device="cpu"); g.manual_seed(1234)
                 b = torch.randn(eng.nk, eng.sizes[1], generator=g, dtype=torch.float64).to(eng.device)
-                lmin, lmax = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=25)
-            self._cheb = ChebyshevMass(eng, None, lmin, lmax, rtol=1e-15)
+                lmin, lmax, elo, ehi = lanczos_bounds(lambda v: self.apply(v, 0), lambda r: self.precond(r, 0), b, its=40, errors=True)
+            self.ritz_errors = (elo / lmin, ehi / lmax)
+            # safety margins around the Ritz interval (round 6): as wide as the Ritz values are uncertain -- twice their residual bounds, at
+            # least 1 %, at most the 10 % / 5 % of rounds 3-5.  On a smooth thickness field the extreme Ritz values of 40 steps are exact to
+            # 1e-4 and the old margins cost 2 of 15 steps (profiles/r06_cheb_margin_probe.txt); every solve is still checked (verify()).
+            mg = ritz_margins(lmin, lmax, min(0.10, 2.0 * elo / lmin), min(0.05, 2.0 * ehi / lmax))
+            if experiment("MIMSEM_CHEB_MARGIN", ""):
+                mg = tuple(float(v) for v in experiment("MIMSEM_CHEB_MARGIN", "").split(","))
+            self.margin = mg
+            self._cheb = ChebyshevMass(eng, None, lmin, lmax, rtol=1e-15, margin=mg)
             self._blocks_cm = self.blocks.transpose(1, 2).contiguous()
         return self._cheb
 
@@ -702,11 +710,12 @@ class GraphedRichardson:
         return None
 
 
-def arnoldi_ritz(body, n, m, device, seed=1, eng=None, space=None):
+def arnoldi_ritz(body, n, m, device, seed=1, eng=None, space=None, earlier=None):
     """Ritz values of B = P A from m Arnoldi steps on a random start vector (set-up time: host algebra on the small Hessenberg).
     eng + space (sharded meshes, DistEngine): the start vector is the rank's part of the GLOBAL random vector a single context would draw
     (same seed, same generator -> the same Krylov space), inner products are ownership-weighted and all-reduced -- every rank arrives at
-    the same Hessenberg matrix, hence at the same spectral interval and the same fixed step counts."""
+    the same Hessenberg matrix, hence at the same spectral interval and the same fixed step counts.
+    earlier = m0 < m: returns (values of m steps, values of the first m0 steps) -- how far the ends still move tells how well they are known."""
     import numpy as np
     dist = eng is not None and hasattr(eng, "halo")
     if dist:
@@ -732,7 +741,17 @@ def arnoldi_ritz(body, n, m, device, seed=1, eng=None, space=None):
             k = j + 1
             break
         V[j + 1] = w / H[j + 1, j]
+    if earlier is not None:
+        m0 = min(earlier, k)
+        return np.linalg.eigvals(H[:k, :k]), np.linalg.eigvals(H[:m0, :m0])
     return np.linalg.eigvals(H[:k, :k])
+
+
+def ritz_margins(lo, hi, err_lo, err_hi, widen=1.0):
+    """safety margins (factors for the lower / upper end) around a Ritz interval: as wide as the ends are uncertain (err_*: relative; residual
+    bounds or the movement between two estimates, already scaled by the caller), at least 1 %; a re-estimate after a missed check (widen > 1)
+    opens them by 10 % / 5 % per unit as rounds 5's fixed margins did for widen = 1"""
+    return (1.0 - min(0.4, max(0.01, err_lo, 0.1 * (widen - 1.0))), 1.0 + max(0.01, err_hi, 0.05 * (widen - 1.0)))
 
 
 def chebyshev_ellipse_coefs(d, c2, steps):
@@ -827,10 +846,12 @@ class GraphedChebyshev:
         return self.x.clone(), self.steps, rel
 
 
-def lanczos_bounds(apply_A, precond, b, its=25, dot=None):
+def lanczos_bounds(apply_A, precond, b, its=25, dot=None, errors=False):
     """Extreme eigenvalues of P A (A SPD, P SPD) for every row system of b, from the Lanczos tridiagonal that `its` steps of
     preconditioned CG generate (T_kk = 1/a_k + b_{k-1}/a_{k-1}, T_{k,k+1} = sqrt(b_k)/a_k): Ritz values converge to the ends of
-    the spectrum first.  Returns (lmin, lmax) over all rows.  Setup-time helper (host synchronisation per step)."""
+    the spectrum first.  Returns (lmin, lmax) over all rows.  Setup-time helper (host synchronisation per step).
+    errors: also the residual bounds of the two extreme Ritz values, |beta_k s_ki| (s_ki: last component of the Ritz vector in the Lanczos
+    basis) -- an eigenvalue of P A lies within that distance of each; (lmin, lmax, err_min, err_max), the errors the largest over the rows."""
     import numpy as np
     x = torch.zeros_like(b); r = b.clone(); z = precond(r); p = z.clone()
     if dot is None:                                          # (sharded meshes pass the ownership-weighted, all-reduced row dot)
@@ -850,14 +871,19 @@ def lanczos_bounds(apply_A, precond, b, its=25, dot=None):
     al, be = np.array(al), np.array(be)                     # [k, rows]
     k = al.shape[0]
     lo, hi = np.inf, 0.0
+    elo = ehi = 0.0
     for row in range(al.shape[1]):
         T = np.zeros((k, k))
         for j in range(k):
             T[j, j] = 1.0 / al[j, row] + (be[j - 1, row] / al[j - 1, row] if j > 0 else 0.0)
             if j + 1 < k:
                 T[j, j + 1] = T[j + 1, j] = np.sqrt(max(be[j, row], 0.0)) / al[j, row]
-        ev = np.linalg.eigvalsh(T)
+        ev, S = np.linalg.eigh(T)
         lo, hi = min(lo, ev[0]), max(hi, ev[-1])
+        bk = np.sqrt(max(be[k - 1, row], 0.0)) / al[k - 1, row]           # the off-diagonal entry the next step would add
+        elo, ehi = max(elo, abs(bk * S[k - 1, 0])), max(ehi, abs(bk * S[k - 1, -1]))
+    if errors:
+        return float(lo), float(hi), float(elo), float(ehi)
     return float(lo), float(hi)
 
 

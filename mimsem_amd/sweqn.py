@@ -689,7 +689,7 @@ class _PicardGraph:
 
     def __init__(self, S, dt, q_exact, un, hn, has_bot=False, widen=1.0):
         """widen >= 1: the safety margins around the estimated spectral regions, times widen (a re-estimate after a missed check asks for more)"""
-        from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds
+        from .krylov import ChebyshevMass, GraphedChebyshev, arnoldi_ritz, chebyshev_ellipse_coefs, chebyshev_ellipse_rate, lanczos_bounds, ritz_margins
         self.S, self.dt, self.q_exact = S, dt, q_exact
         self.dist = S.dist                   # sharded: local (ownership-weighted) check norms, one all-reduce per Picard iteration (replay)
         # ... recorded as a hipGraph all the same when the exchanges are kernels only (the one-sided transport of csrc/halo.hip: pack into the
@@ -712,8 +712,10 @@ class _PicardGraph:
         if S._pcA is None or S._pcA[0] != dt:
             S._pcA = (dt, S._coupled_element_blocks(dt))
         body1 = S._krylov_body1(dt)
-        ev = arnoldi_ritz(body1, n1 + n2, 40, dev, eng=eng, space="uh")
+        ev, ev25 = arnoldi_ritz(body1, n1 + n2, 40, dev, eng=eng, space="uh", earlier=25)
         lmin, lmax, imax = float(ev.real.min()), float(ev.real.max()), float(abs(ev.imag).max())
+        # margins (round 6): three times what the ends moved between 25 and 40 Arnoldi steps, at least 1 % (rounds 5: 10 % / 5 % whatever the estimate's quality)
+        mgA = ritz_margins(lmin, lmax, 3.0 * abs(lmin - float(ev25.real.min())) / lmin, 3.0 * abs(lmax - float(ev25.real.max())) / lmax, widen)
         if not (lmin > 0.02 and imax <= 0.15 * (lmax - lmin)):
             raise _NoGraph()
         self.regions = {"A": (lmin, lmax, imax)}
@@ -721,22 +723,23 @@ class _PicardGraph:
         # (a DistEngine has the same call: element pass, exchange, block pass, exchange, update)
         step = lambda ca, cb, x, r, d: eng.sw_operator_precond_chebyshev(ROS_ALPHA * dt, S.grav, H_MEAN, S.fg, blocks, ca, cb, x, r, d)
         self.chA = GraphedChebyshev(eng, (un.shape[0], n1 + n2), body1, lambda r: S.precond_A(r, dt), lmin, lmax, rtol=S.rtol, step=step,
-                                    margin=(1.0 - 0.1 * min(widen, 4.0), 1.0 + 0.05 * widen), space="uh")
+                                    margin=mgA, space="uh")
         self.its["A"] = self.chA.steps
         # ---- M1: real interval of P M1
         cm = S.m1_pre.transpose(1, 2).contiguous()
         if self.dist:
             rb = eng.randn_global(1, 4321, cpu_generator=True).expand(un.shape[0], -1).contiguous()
             w1 = eng.weights(1)
-            l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25, dot=lambda a, b: eng.allreduce(torch.linalg.vecdot(a * w1, b, dim=1)))
+            l1, l2, e1, e2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=40, errors=True, dot=lambda a, b: eng.allreduce(torch.linalg.vecdot(a * w1, b, dim=1)))
         else:
             g = torch.Generator(device="cpu"); g.manual_seed(4321)
             rb = torch.randn(un.shape, generator=g, dtype=torch.float64).to(dev)
-            l1, l2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=25)
+            l1, l2, e1, e2 = lanczos_bounds(S.M1, S.precond_M1, rb, its=40, errors=True)
         self.regions["M1"] = (l1, l2)
+        self.margins = {"A": mgA, "M1": ritz_margins(l1, l2, 2.0 * e1 / l1, 2.0 * e2 / l2, widen)}
         self.cm = cm
         self.chM = ChebyshevMass(eng, lambda x, rhs, p, al, be, upd: eng.block_chebyshev_sweep("UMAT", cm, x, rhs, p, al, be, upd=upd), l1, l2, rtol=S.rtol,
-                                 margin=(1.0 - 0.1 * min(widen, 4.0), 1.0 + 0.05 * widen))
+                                 margin=self.margins["M1"])
         self.its["F"] = self.chM.steps
         # the two vectors of a check (last preconditioned residual | P b) sit side by side: ONE two-row dot per check instead of two
         self.pairM = torch.zeros(2, un.shape[1], dtype=torch.float64, device=dev) if un.shape[0] == 1 else None
