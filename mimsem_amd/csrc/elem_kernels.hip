@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_gather_epilogue(const double* __restric
 
 // block-preconditioned Richardson, middle pass: r_e = (b - gather(ye)) restricted to the element (gathered on the fly through
 // the 1-form plan), z_e = B_e r_e with B_e stored column-major ([c][r]); z_e goes to the second element-local buffer.
-template <int N, int LC>
+template <int N, int LC, bool Y0 = false>
 __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
@@ -706,8 +706,11 @@ __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch,
 #pragma unroll
     for (int l = 0; l < LC; l++) {
         const int lev = min(l0 + l, max(nlev - 1, 0));
-        if (ye) { const double* src = ye + (size_t)lev*yes; a0[l] = src[q0]; a1[l] = src[q1]; }      // (null: the operator result is zero -- the first step of a solve from x = 0)
-        else { a0[l] = 0.0; a1[l] = 0.0; }
+        if constexpr (Y0) { a0[l] = 0.0; a1[l] = 0.0; }        // (the operator result is zero: the first step of a solve from x = 0 -- a compile-time flavour,
+        else {                                                 //  a run-time test of ye in this loop cost the common flavour 15 %: 23.8 -> 27.3 us)
+            const double* src = ye + (size_t)lev*yes;
+            a0[l] = src[q0]; a1[l] = src[q1];
+        }
         bb[l] = b[(size_t)lev*bs + slot];
         es[l] = escale ? escale[(size_t)lev*ess + e] : 1.0;
     }
@@ -727,12 +730,12 @@ __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch,
         if (act && lev < l1) ze[(size_t)lev*zes + (size_t)e*ND + r] = s;
     }
 }
-template <int N, int LC>
+template <int N, int LC, bool Y0 = false>
 __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
         const double* __restrict__ escale, long long ess) {
-    body_blocks_residual<N, LC>(nEl, nlev, lch, i1x, i1y, plan, B, ye, yes, b, bs, ze, zes, escale, ess, blockIdx.x);
+    body_blocks_residual<N, LC, Y0>(nEl, nlev, lch, i1x, i1y, plan, B, ye, yes, b, bs, ze, zes, escale, ess, blockIdx.x);
 }
 
 // ---- two independent Chebyshev sweeps in the SAME launches (round 6) ---------------------------------------------------------------------
@@ -1765,7 +1768,7 @@ static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const dou
         // matrix-core form from a handful of levels on: opt-in (MIMSEM_BLOCKS_MFMA=1).  Measured on HorizSolve's right-hand sides (3 456
         // elements x 30 levels): 25.3 us per launch against 23.8 us for the register-row form below -- the pass is bound by its gathers
         // (three 8-byte loads per DoF and level through the plan), not by the block product, on either kind of ALU
-        if (c->blocks_mfma && nlev >= 6) {
+        if (c->blocks_mfma && nlev >= 6 && ye) {
             const long long witems = (long long)c->nEl*((nlev + 15)/16);
             hipLaunchKernelGGL((k_blocks_residual_mfma<N>), dim3((unsigned)((witems + 3)/4)), dim3(256), 0, c->stream, c->nEl, nlev,
                                c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
@@ -1775,6 +1778,14 @@ static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const dou
     }
     const int lch = std::max(1, std::min(nlev, 8));       // the kernel works through 8 levels per item whether the chunk has them or not
     const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
+    if (!ye) {                                            // zero operator result (mimsem_block_chebyshev_solve, first step): the residual is b
+        if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1, true>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
+                                         c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+        else hipLaunchKernelGGL((k_blocks_residual<N, 8, true>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
+                                c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+        MIMSEM_HIP_TRY(hipGetLastError());
+        return MIMSEM_OK;
+    }
     if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
                                      c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
     else hipLaunchKernelGGL((k_blocks_residual<N, 8>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,

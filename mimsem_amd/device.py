@@ -429,7 +429,7 @@ class Engine:
         nin = {0: self.sizes[0], 1: self.sizes[1], 2: self.sizes[2], 3: self.sizes[1]}[w]
         x2 = x if x.dim() == 2 else x.unsqueeze(0)
         assert x2.shape[1] == nin, (which, x2.shape, nin)          # the C ABI takes raw pointers: lengths are checked here
-        y = torch.zeros(x2.shape[0], nout, dtype=torch.float64, device=self.device)
+        y = torch.empty(x2.shape[0], nout, dtype=torch.float64, device=self.device)      # (every entry is written: faces directly, edges / nodes by the gather pass over all slots)
         check(self.L.mimsem_incidence_apply(self.ctx, w, x2.shape[0], _ptr(x2), x2.stride(0), _ptr(y), y.stride(0)), "incidence")
         return y if x.dim() == 2 else y[0]
 

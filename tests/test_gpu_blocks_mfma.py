@@ -63,6 +63,15 @@ def test_block_sweeps_on_the_matrix_cores(pn, ne, nk):
             # blocks are column-major per element: entry (row i, column c) at [e, c, i]
             np.add.at(z, slots[e], es[k, e] * (B[e].T @ res[slots[e]]))
         assert rel_l2(out[0][2][k], z) < 1e-12, k
+    # the whole solve as one call (mimsem_block_chebyshev_solve: its first step has no operator result -- that block pass always runs on the
+    # register-row form) gives the bits of the sweep calls on either engine
+    coef = [(0.9, 0.0), (0.8, 0.2), (0.85, 0.15), (0.8, 0.1)]
+    for eng in (mf, rr):
+        x = torch.zeros(nk, dm.n1, dtype=torch.float64, device=eng.device); p = torch.zeros_like(x)
+        for al, be in coef:
+            eng.block_chebyshev_sweep("UMAT", eng.tensor(B), x, eng.tensor(b), p, al, be, elem_scale=eng.tensor(es), scale=SCALE, flags=1)
+        y1 = eng.block_chebyshev_solve("UMAT", eng.tensor(B), eng.tensor(b), coef, elem_scale=eng.tensor(es), scale=SCALE, flags=1)
+        assert torch.equal(y1, x)
     # run-to-run reproducible
     x, p = mf.tensor(x0), mf.tensor(p0); upd = torch.zeros_like(x)
     mf.block_chebyshev_sweep("UMAT", mf.tensor(B), x, mf.tensor(b), p, 0.7, 0.3, elem_scale=mf.tensor(es), scale=SCALE, flags=1, upd=upd)
