@@ -896,6 +896,7 @@ def compact_record(out, extras_file=None):
             "horiz_rhs_ms_reusing_grad_theta": _r(_g(out, "horiz_rhs", "ms_per_evaluation_hipgraph_reusing_grad_theta")),
             "horiz_m1_sweep_hbm_frac": _r(_g(out, "horiz_rhs", "m1_sweep_roofline", "frac"), 3),
             "horiz_rhs_ms_cpp_host": _r(_g(out, "horiz_rhs", "cpp_host", "ms_per_evaluation_recorded")),
+            "horiz_rhs_ms_cpp_host_reusing_grad_theta": _r(_g(out, "horiz_rhs", "cpp_host", "ms_per_evaluation_recorded_reusing_grad_theta")),
             "sw_steps_per_s_config3": _r(_g(out, "sw", "config3_galewsky_24x24x6", "steps_per_s")),
             "sw_steps_per_s_config2": _r(_g(out, "sw", "config2_w2_16x16x6", "steps_per_s")),
             "sw_steps_per_s_config3_cpp_host": _r(_g(out, "sw", "config3_galewsky_24x24x6", "cpp_host", "graph", "steps_per_s")),

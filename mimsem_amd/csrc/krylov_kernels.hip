@@ -256,13 +256,15 @@ __global__ __launch_bounds__(256) void k_rowdot_fused(long long n, long long chu
     }
     __syncthreads();
     if (!last || wave != 0) return;
-    double v = (lane < nb) ? __hip_atomic_load(part + (size_t)row*nb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double v = 0.0;
+    for (int i = lane; i < nb; i += 64) v += __hip_atomic_load(part + (size_t)row*nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (nb <= 64: one term per lane)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0) { out[row] = v; __hip_atomic_store(counters + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 __global__ __launch_bounds__(64) void k_rowdot_final(int nb, const double* __restrict__ part, double* __restrict__ out) {
     const int row = blockIdx.x, lane = threadIdx.x;
-    double s = (lane < nb) ? part[(size_t)row*nb + lane] : 0.0;
+    double s = 0.0;
+    for (int i = lane; i < nb; i += 64) s += part[(size_t)row*nb + i];      // (nb <= 64: one term per lane, as before rows longer than 262 144 got more blocks)
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) out[row] = s;
 }
@@ -344,7 +346,10 @@ int mimsem_interface_average(mimsem_ctx* c, int nk, long long n, const double* a
 int mimsem_krylov_rowdot(mimsem_ctx* c, int nrows, long long n, const double* A, long long lda, const double* B, long long ldb, double* out) {
     if (!c || !A || !B || !out || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;
     if (nrows == 0) return MIMSEM_OK;
-    const int nb = (int)std::max<long long>(1, std::min<long long>(RD_BLOCKS, (n + 1023)/1024));
+    // up to 32 blocks per row for rows up to 262 144 entries (the 1-form vectors of a level: unchanged since round 1, the same bits); longer rows
+    // -- a whole [levels x slots] array as ONE row: the C++ HorizSolve's check norms, 2 rows of 1.87 M -- get a block per 8 192 entries
+    // (round 6: 64 blocks on 256 CUs took 66 us per call, 0.5 ms of a 5.7 ms evaluation)
+    const int nb = (int)std::max<long long>(1, std::min<long long>(1024, std::max<long long>(std::min<long long>(RD_BLOCKS, (n + 1023)/1024), (n + 8191)/8192)));
     const long long chunk = (n + nb - 1)/nb;
     int rc = c->ensure_kry((long long)nb*nrows);
     if (rc) return rc;

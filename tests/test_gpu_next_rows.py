@@ -206,6 +206,22 @@ def test_chebyshev_whole_solve_equals_the_sweeps(sphere):
                                               2, (C.c_double * 4)(1, 0, 1, 0), C.c_void_p(y.data_ptr()), y.stride(0), None, 0, None, 0) == -2      # only Umat
 
 
+def test_rowdot_short_and_long_rows(sphere):
+    """mimsem_krylov_rowdot: one launch for up to 8 rows (the last block of a row reduces it), two launches above; rows longer than 262 144 entries
+    get more than 32 blocks (round 6).  Against float64 sums in extended order (torch) on every branch, and run-to-run identical bits."""
+    import torch
+    cs, eng, mats, rng = sphere
+    for nrows, n in ((1, 1), (1, 1000), (2, 93312), (3, 262144), (2, 262145), (2, 1866240), (8, 300001), (9, 300001), (60, 62208), (70, 1500)):
+        A = torch.randn(nrows, n, dtype=torch.float64, device=eng.device)
+        B = torch.randn(nrows, n, dtype=torch.float64, device=eng.device)
+        got = eng.rowdot(A, B)
+        want = (A.double() * B).sum(dim=1)
+        scale = (A.abs() * B.abs()).sum(dim=1)
+        assert bool(((got - want).abs() <= 1e-14 * scale + 1e-300).all()), (nrows, n)
+        for _ in range(3):
+            assert torch.equal(eng.rowdot(A, B), got), (nrows, n)                       # (the arrival counters are left clean: every call the same)
+
+
 def test_weak_gradient_matches_dense(sphere):
     from mimsem_amd.horizsolve import HorizSolve
     cs, eng, mats, rng = sphere
