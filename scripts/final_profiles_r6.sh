@@ -30,4 +30,7 @@ bash scripts/prof_pmc_generic.sh f6box scripts/prof_column_box_p4.py k_schur,k_t
 cat $O/column_pmc_eta.txt $O/column_pmc_s3.txt $O/column_pmc_box.txt | cut -c1-330
 echo "[7] the C++-hosted SW step (<= 20 steps: the profiler's limit, profiles/r06_rocprof_graph_sigsegv.txt)"
 bash scripts/prof_sw_cpp.sh > $O/sw_cpp.txt 2>&1; tail -16 $O/sw_cpp.txt | cut -c1-200
+echo "[8] the kernels of ONE HorizSolve evaluation, Python host and C++ host (differences of two kernel-trace summaries)"
+bash scripts/prof_horiz_per_eval.sh > $O/horiz_per_eval.log 2>&1; cp gpurun_out/prof_he/per_eval.txt $O/horiz_per_eval.txt; head -6 $O/horiz_per_eval.txt | cut -c1-160
+bash scripts/prof_horiz_cpp_per_eval.sh > $O/horiz_cpp_per_eval.log 2>&1; cp gpurun_out/prof_hc/per_eval.txt $O/horiz_cpp_per_eval.txt; head -6 $O/horiz_cpp_per_eval.txt | cut -c1-160
 echo final profiles done
