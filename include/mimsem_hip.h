@@ -605,18 +605,21 @@ int  mimsem_ksp_get_info(const mimsem_ksp* ksp, int* iterations, double* rnorm, 
 int  mimsem_hessenberg_eigenvalues(int n, const double* H, double* wr, double* wi);
 
 
-/* Two INDEPENDENT fixed-length Chebyshev solves of one shallow-water Picard iteration in shared launches (round 6): the 1-form mass system of
- * diagnose_F (src/SWEqn_Picard.cpp:253-284: nA sweeps of {element pass, block pass, gather epilogue}) and the upwinded lumped 0-form mass system
- * of diagnose_q (:322-341: nB sweeps of {element pass, gather epilogue}) read nothing of each other; at the ~3 500 elements of the src/ drivers
- * every launch is a ~5 us dispatch floor, and launch k of both chains goes out as ONE grid (csrc/elem_kernels.hip: k_sw_pair -- the bodies of
- * the very kernels the two sweep entry points below use: the same bits).  Equivalent to nA calls of mimsem_block_chebyshev_sweep(ctx,
- * MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1], p1, 0, x1, 0, last ? upd1 : NULL, 0) and nB calls of
- * mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0, b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0,
- * last ? upd0 : NULL, 0).  coefA / coefB: HOST arrays of (alpha, beta) pairs; single level, scale 1, no flags (the src/ flavour); orders 2..4
- * (MIMSEM_ERR_UNSUPPORTED otherwise: call the two sweeps).  upd1 / upd0 may be NULL.                                                     */
-int mimsem_sw_dual_chebyshev(mimsem_ctx* ctx, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1,
+/* Two INDEPENDENT fixed-length Chebyshev solves of one shallow-water Picard iteration, both from a ZERO initial guess, in shared launches
+ * (round 6): the 1-form mass system of diagnose_F (src/SWEqn_Picard.cpp:253-284: nA steps of {element pass, block pass, gather epilogue}) and the
+ * upwinded lumped 0-form mass system of diagnose_q (:322-341: nB steps of {element pass, gather epilogue}) read nothing of each other; at the
+ * ~3 500 elements of the src/ drivers every launch is a ~5 us dispatch floor, and launch k of both chains goes out as ONE grid
+ * (csrc/elem_kernels.hip: k_sw_pair -- the bodies of the very kernels the two sweep entry points use: the same bits).  Equivalent to, on
+ * x1 = x0 = 0, nA calls of mimsem_block_chebyshev_sweep(ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1],
+ * p1, 0, x1, 0, last ? upd1 : (first ? pb1 : NULL), 0) and nB calls of mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0,
+ * b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0, last ? upd0 : (first ? pb0 : NULL), 0) -- without the first steps' operator passes (Op 0 = 0)
+ * and without cleared vectors: x1, p1, x0, p0 are OUTPUTS / workspaces and need not be initialised.  pb1 / pb0 (may be NULL): the first steps'
+ * preconditioned residuals, P b1 and dinv b0 -- the reference norms of the convergence checks; upd1 / upd0 (may be NULL): the last steps'.
+ * coefA / coefB: HOST arrays of (alpha, beta) pairs; single level, scale 1, no flags (the src/ flavour); orders 2..4 (MIMSEM_ERR_UNSUPPORTED
+ * otherwise: call the sweeps).  3 nA - 1 and 2 nB - 1 launches in max of the two grids.                                                   */
+int mimsem_sw_dual_chebyshev(mimsem_ctx* ctx, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1, double* pb1,
                              int nB, const double* coefB, double tau, const double* h, const double* u, const double* b0, const double* dinv,
-                             double* p0, double* x0, double* upd0);
+                             double* p0, double* x0, double* upd0, double* pb0);
 
 /* ---- halo exchange plan (replaces VecScatter gtol_0/gtol_1, eul/Topo.cpp:145-155) ------------ */
 /* Pack/unpack kernels only: the transport (RCCL send/recv over xGMI) is driven by the host layer

@@ -139,8 +139,8 @@ _SIGS = {
     "mimsem_krylov_gs_control": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_column_solve_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
     "mimsem_column_set_pivot_fallback": (C.c_int, [C.c_void_p, C.c_int]),
-    "mimsem_sw_dual_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                           C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mimsem_sw_dual_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_halo_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_halo_set_peer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mimsem_halo_peer_status": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1613,15 +1613,20 @@ static void sweep_elem_args(mimsem_ctx* c, ElemArgs& a, const double* f, const d
     a.out = out; a.os = os;
 }
 
-// Two independent fixed-length Chebyshev solves of a shallow-water Picard iteration in SHARED launches (round 6; csrc/elem_kernels.hip:
-// k_sw_pair): exactly the sequence
-//     for k < nA: mimsem_block_chebyshev_sweep(ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1], p1, 0, x1, 0, k == nA-1 ? upd1 : NULL, 0)
-//     for k < nB: mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0, b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0, k == nB-1 ? upd0 : NULL, 0)
-// -- the same kernels' bodies, the same bits -- with launch k of the first chain (3 per sweep) and launch k of the second (2 per sweep) in one grid.
-int mimsem_sw_dual_chebyshev(mimsem_ctx* c, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1,
+// Two independent fixed-length Chebyshev solves of a shallow-water Picard iteration, both from x = 0, in SHARED launches (round 6;
+// csrc/elem_kernels.hip: k_sw_pair): exactly the sequence
+//     for k < nA: mimsem_block_chebyshev_sweep(ctx, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, NULL, 0, blocks1, NULL, 0, b1, 0, coefA[2k], coefA[2k+1], p1, 0, x1, 0, k == nA-1 ? upd1 : (k == 0 ? pb1 : NULL), 0)
+//     for k < nB: mimsem_op_chebyshev_sweep(ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h, 0, u, 0, b0, 0, dinv, 0, coefB[2k], coefB[2k+1], p0, 0, x0, 0, k == nB-1 ? upd0 : (k == 0 ? pb0 : NULL), 0)
+// on x1 = x0 = 0 -- the same kernels' bodies, the same bits (up to the sign of a zero) -- with launch k of the first chain and launch k of the second in
+// one grid.  Late in round 6 the chains lost what a zero start makes superfluous: no operator pass in either first step (the block pass takes b1 as its
+// residual, the first q update is dinv b0), x and p WRITTEN there instead of updated (nothing to clear), and the first steps' preconditioned
+// residuals -- P b1 and dinv b0, the reference norms of the checks -- come out as pb1 / pb0 instead of being computed again by the caller:
+// 3 nA - 1 and 2 nB - 1 launches, 8 launches and fills fewer per Picard iteration around them.
+int mimsem_sw_dual_chebyshev(mimsem_ctx* c, int nA, const double* coefA, const double* blocks1, const double* b1, double* p1, double* x1, double* upd1, double* pb1,
                              int nB, const double* coefB, double tau, const double* h, const double* u, const double* b0, const double* dinv,
-                             double* p0, double* x0, double* upd0) {
+                             double* p0, double* x0, double* upd0, double* pb0) {
     if (!c || nA < 1 || nB < 1 || !coefA || !coefB || !blocks1 || !b1 || !p1 || !x1 || !h || !u || !b0 || !dinv || !p0 || !x0) return MIMSEM_ERR_ARG;
+    if ((pb1 && nA < 2 && upd1) || (pb0 && nB < 2 && upd0)) return MIMSEM_ERR_ARG;      // (a one-step solve has ONE preconditioned residual: ask for it once)
     if (c->nEl == 0) return MIMSEM_OK;
     const ElemSizes& es = c->es;
     if (es.n < 2 || es.n > 4) return MIMSEM_ERR_UNSUPPORTED;
@@ -1637,14 +1642,31 @@ int mimsem_sw_dual_chebyshev(mimsem_ctx* c, int nA, const double* coefA, const d
     PairGather gq{yeQ, per0, c->d_g0, c->n0, GatherEpilogue{5, b0, 0, dinv, 0, nullptr, 0}, x0};
     ga.g.p = p1; ga.g.ps = 0; gq.g.p = p0; gq.g.ps = 0;
     c->ev_k1[0] = c->ev_k1[1] = c->ev_k2[0] = c->ev_k2[1] = nullptr;
-    const int LA = 3*nA, LB = 2*nB, L = std::max(LA, LB);
+    // chain A: {block pass on a zero result, epilogue that writes} then (nA - 1) x {element pass, block pass, epilogue};  chain q: {epilogue that
+    // writes, no operator result} then (nB - 1) x {element pass, epilogue}
+    const int LA = 3*nA - 1, LB = 2*nB - 1, L = std::max(LA, LB);
     for (int k = 0; k < L; k++) {
-        const int PA = k < LA ? k%3 : -1, PB = k < LB ? k%2 : -1;
-        if (PA == 2) { const int st = k/3; ga.g.alpha = coefA[2*st]; ga.g.beta = coefA[2*st + 1]; ga.g.upd = st == nA - 1 ? upd1 : nullptr; ga.g.us = 0; }
-        if (PB == 1) { const int st = k/2; gq.g.alpha = coefB[2*st]; gq.g.beta = coefB[2*st + 1]; gq.g.upd = st == nB - 1 ? upd0 : nullptr; gq.g.us = 0; }
+        int PA = -1, PB = -1;
+        if (k < LA) {
+            PA = k == 0 ? 3 : (k == 1 ? 2 : (k - 2)%3);
+            if (PA == 2) {
+                const int st = k == 1 ? 0 : 1 + (k - 2)/3;
+                ga.g.alpha = coefA[2*st]; ga.g.beta = coefA[2*st + 1]; ga.g.zero = st == 0; ga.g.us = 0;
+                ga.g.upd = st == nA - 1 && upd1 ? upd1 : (st == 0 ? pb1 : nullptr);
+            }
+        }
+        if (k < LB) {
+            PB = k == 0 ? 1 : (k - 1)%2;
+            if (PB == 1) {
+                const int st = k == 0 ? 0 : 1 + (k - 1)/2;
+                gq.g.alpha = coefB[2*st]; gq.g.beta = coefB[2*st + 1]; gq.g.zero = st == 0; gq.g.noacc = st == 0; gq.g.us = 0;
+                gq.g.upd = st == nB - 1 && upd0 ? upd0 : (st == 0 ? pb0 : nullptr);
+            }
+        }
         if (PA >= 0 && PB >= 0) rc = launch_sw_pair(c, PA, PB, ea, ba, ga, eq, gq);
         else if (PA == 0) rc = launch_elem_apply(c, MIMSEM_OP_UMAT, ea);                                  // (the longer chain's tail: its own kernels)
         else if (PA == 1) rc = launch_blocks_residual(c, 1, blocks1, yeA, per1, b1, 0, zeA, per1, nullptr, 0);
+        else if (PA == 3) rc = launch_blocks_residual(c, 1, blocks1, nullptr, per1, b1, 0, zeA, per1, nullptr, 0);
         else if (PA == 2) rc = launch_gather_epilogue(c, 1, 1, zeA, per1, ga.g, x1, 0);
         else if (PB == 0) rc = launch_elem_apply(c, MIMSEM_OP_PHMAT_UP, eq);
         else rc = launch_gather_epilogue(c, 0, 1, yeQ, per0, gq.g, x0, 0);

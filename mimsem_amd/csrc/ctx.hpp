@@ -237,7 +237,8 @@ struct GatherEpilogue {
     // mode 4 (round 5): the vector algebra of a Chebyshev step on B = P A with acc = (B d)[s]:  x += d;  r -= acc;  d = alpha d + beta r.
     // d lives in p (in/out), r in cr
     double* cr = nullptr; long long crs = 0;
-    int zero = 0;                    // mode 3, first step of a solve from x = 0: p = d, x = alpha d -- neither is read (mimsem_block_chebyshev_solve)
+    int zero = 0;                    // modes 3, 5, first step of a solve from x = 0: p = d, x = alpha d -- neither is read (mimsem_block_chebyshev_solve, mimsem_sw_dual_chebyshev)
+    int noacc = 0;                   // ... and the operator result is zero: acc = 0, ye is not read (mode 5 without a block pass in between)
 };
 // two independent Chebyshev sweeps in the same launches (elem_kernels.hip: k_sw_pair): the block pass and the gather epilogue of one level
 struct PairBlocks { int nEl, lch; const int *i1x, *i1y, *plan; const double *B, *ye; long long yes; const double* b; double* ze; long long zes; };

@@ -635,8 +635,10 @@ __device__ __forceinline__ void body_gather_epilogue(const double* __restrict__ 
     for (int lev = l0; lev < l1; lev++) {
         const double* src = ye + (size_t)lev*ye_stride;
         double acc = 0.0;
+        if (!g.noacc) {
 #pragma unroll
-        for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
+            for (int k = 0; k < K; k++) if (j[k] >= 0) acc += src[j[k]];
+        }
         const double d = (g.mode == 1 || g.mode == 5) ? g.dinv[(size_t)lev*g.ds + s]*(g.b[(size_t)lev*g.bs + s] - acc) : acc;
         if (g.mode == 4) {           // Chebyshev step on B = P A, acc = (B d)[s]: x += d; r -= acc; d = alpha d + beta r
             double* dp = g.p + (size_t)lev*g.ps + s; double* rp = g.cr + (size_t)lev*g.crs + s;
@@ -745,12 +747,13 @@ __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int 
 // in one grid -- blocks [0, nA) execute phase PA of the mass sweep, blocks [nA, nA + nB) phase PB of the q sweep, the very bodies of the three
 // kernels above (same arithmetic, same bits) -- so the two solves cost max(45, 40) launches instead of 45 + 40.  (Two streams inside the
 // recorded graph were tried in round 5, MIMSEM_SW_FORK: slower -- a cross-stream edge costs more than the nodes it overlaps.)
-template <int N, int PA, int PB, int K0>           // PA: 0 element pass (Umat), 1 block pass, 2 gather epilogue, 3 nothing;  PB: 0 element pass (Phmat_up), 1 gather epilogue, 3 nothing
+template <int N, int PA, int PB, int K0>           // PA: 0 element pass (Umat), 1 block pass, 2 gather epilogue, 3 block pass on a ZERO operator result (first step from x = 0);  PB: 0 element pass (Phmat_up), 1 gather epilogue
 __global__ __launch_bounds__(256) void k_sw_pair(ElemArgs ea, PairBlocks ba, PairGather ga, ElemArgs eq, PairGather gq, unsigned nA) {
     if (blockIdx.x < nA) {
         if constexpr (PA == 0) body_elem_apply<N, MIMSEM_OP_UMAT, false>(ea, blockIdx.x, nA);
         else if constexpr (PA == 1) body_blocks_residual<N, 1>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x);
         else if constexpr (PA == 2) body_gather_epilogue<2>(ga.ye, ga.yes, ga.plan, ga.nslots, 1, ga.g, ga.x, 0, blockIdx.x, 0);
+        else if constexpr (PA == 3) body_blocks_residual<N, 1, true>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x);
     } else {
         const unsigned bid = blockIdx.x - nA, nB = gridDim.x - nA;
         if constexpr (PB == 0) body_elem_apply<N, MIMSEM_OP_PHMAT_UP, false>(eq, bid, nB);
@@ -2065,13 +2068,14 @@ template <int N, int K0>
 static int sw_pair_n(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const PairBlocks& ba, const PairGather& ga, const ElemArgs& eq, const PairGather& gq) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e, LPEb = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPBb = 256/LPEb;
-    const unsigned nA = PA == 0 ? (unsigned)((c->nEl + D::EPB - 1)/D::EPB) : (PA == 1 ? (unsigned)((c->nEl + EPBb - 1)/EPBb) : (unsigned)((ga.nslots + 255)/256));
+    const unsigned nA = PA == 0 ? (unsigned)((c->nEl + D::EPB - 1)/D::EPB) : (PA == 1 || PA == 3 ? (unsigned)((c->nEl + EPBb - 1)/EPBb) : (unsigned)((ga.nslots + 255)/256));
     const unsigned nB = PB == 0 ? (unsigned)((c->nEl + D::EPB - 1)/D::EPB) : (unsigned)((gq.nslots + 255)/256);
 #define MIMSEM_PAIR(A_, B_) hipLaunchKernelGGL((k_sw_pair<N, A_, B_, K0>), dim3(nA + nB), dim3(256), 0, c->stream, ea, ba, ga, eq, gq, nA)
     switch (PA*2 + PB) {
     case 0: MIMSEM_PAIR(0, 0); break;   case 1: MIMSEM_PAIR(0, 1); break;
     case 2: MIMSEM_PAIR(1, 0); break;   case 3: MIMSEM_PAIR(1, 1); break;
     case 4: MIMSEM_PAIR(2, 0); break;   case 5: MIMSEM_PAIR(2, 1); break;
+    case 7: MIMSEM_PAIR(3, 1); break;                                         // (the first launch of two solves from x = 0: the only pairing of phase 3)
     default: return MIMSEM_ERR_ARG;
     }
 #undef MIMSEM_PAIR
@@ -2079,7 +2083,7 @@ static int sw_pair_n(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const Pa
     return MIMSEM_OK;
 }
 int launch_sw_pair(mimsem_ctx* c, int PA, int PB, const ElemArgs& ea, const PairBlocks& ba, const PairGather& ga, const ElemArgs& eq, const PairGather& gq) {
-    if (PA < 0 || PA > 2 || PB < 0 || PB > 1 || (c->G0 != 4 && c->G0 != 8)) return MIMSEM_ERR_ARG;
+    if (PA < 0 || PA > 3 || PB < 0 || PB > 1 || (c->G0 != 4 && c->G0 != 8)) return MIMSEM_ERR_ARG;
     switch (c->es.n*10 + (c->G0 == 4 ? 4 : 8)) {
     case 24: return sw_pair_n<2, 4>(c, PA, PB, ea, ba, ga, eq, gq);   case 28: return sw_pair_n<2, 8>(c, PA, PB, ea, ba, ga, eq, gq);
     case 34: return sw_pair_n<3, 4>(c, PA, PB, ea, ba, ga, eq, gq);   case 38: return sw_pair_n<3, 8>(c, PA, PB, ea, ba, ga, eq, gq);

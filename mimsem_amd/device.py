@@ -317,21 +317,22 @@ class Engine:
                                                   _ptr(upd), upd.stride(0) if upd is not None else 0), "block_chebyshev_solve(%s)" % op)
         return x
 
-    def sw_dual_chebyshev(self, coefA, blocks, b1, p1, x1, upd1, coefB, tau, h, u, b0, dinv, p0, x0, upd0):
-        """the 1-form mass solve (len(coefA) block-Chebyshev sweeps on Umat: x1, p1 in place) and the upwinded lumped 0-form mass solve (len(coefB)
-        Chebyshev sweeps on Phmat_up: x0, p0 in place) of one shallow-water Picard iteration in SHARED launches (mimsem_sw_dual_chebyshev):
-        the same bits as the two sequences of block_chebyshev_sweep / chebyshev_sweep calls.  [1, n] tensors; upd1 / upd0 receive the last
-        sweep's preconditioned residual."""
+    def sw_dual_chebyshev(self, coefA, blocks, b1, p1, x1, upd1, coefB, tau, h, u, b0, dinv, p0, x0, upd0, pb1=None, pb0=None):
+        """the 1-form mass solve (len(coefA) block-Chebyshev steps on Umat) and the upwinded lumped 0-form mass solve (len(coefB) Chebyshev steps
+        on Phmat_up) of one shallow-water Picard iteration, both from x = 0, in SHARED launches (mimsem_sw_dual_chebyshev): the same bits as the
+        two sequences of block_chebyshev_sweep / chebyshev_sweep calls on zero iterates.  [1, n] tensors; x1, p1, x0, p0 are outputs / workspaces
+        (need not be cleared); upd1 / upd0 receive the last step's preconditioned residual, pb1 / pb0 the first's (P b1, dinv b0)."""
         nd = 2 * self.n1e
         for t, n in ((b1, self.sizes[1]), (p1, self.sizes[1]), (x1, self.sizes[1]), (u, self.sizes[1]), (h, self.sizes[2]), (b0, self.sizes[0]), (dinv, self.sizes[0]),
                      (p0, self.sizes[0]), (x0, self.sizes[0])):
             assert t.dim() == 2 and t.shape == (1, n) and t.is_contiguous(), (tuple(t.shape), n)
         assert blocks.shape == (self.nEl, nd, nd) and blocks.is_contiguous()
-        assert upd1 is None or (upd1.shape == x1.shape and upd1.stride(1) == 1) and (upd0 is None or (upd0.shape == x0.shape and upd0.stride(1) == 1))
+        for t, ref in ((upd1, x1), (pb1, x1), (upd0, x0), (pb0, x0)):
+            assert t is None or (t.shape == ref.shape and t.stride(1) == 1)
         ca = np.ascontiguousarray(np.asarray(coefA, dtype=np.float64).reshape(-1, 2))
         cb = np.ascontiguousarray(np.asarray(coefB, dtype=np.float64).reshape(-1, 2))
-        check(self.L.mimsem_sw_dual_chebyshev(self.ctx, ca.shape[0], ca.ctypes.data, _ptr(blocks), _ptr(b1), _ptr(p1), _ptr(x1), _ptr(upd1),
-                                              cb.shape[0], cb.ctypes.data, float(tau), _ptr(h), _ptr(u), _ptr(b0), _ptr(dinv), _ptr(p0), _ptr(x0), _ptr(upd0)),
+        check(self.L.mimsem_sw_dual_chebyshev(self.ctx, ca.shape[0], ca.ctypes.data, _ptr(blocks), _ptr(b1), _ptr(p1), _ptr(x1), _ptr(upd1), _ptr(pb1),
+                                              cb.shape[0], cb.ctypes.data, float(tau), _ptr(h), _ptr(u), _ptr(b0), _ptr(dinv), _ptr(p0), _ptr(x0), _ptr(upd0), _ptr(pb0)),
               "sw_dual_chebyshev")
 
     def apply_ray(self, x, exner, exner_s, dt, lev0=0, scale=1.0, alpha=1.0, flags=0, out=None):

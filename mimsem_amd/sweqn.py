@@ -797,6 +797,12 @@ class _PicardGraph:
         self.S.eng.rowdot_local(pair, pair, out=self.chk[2 * k:2 * k + 2], space=self.SPACE[name])
 
     def m1(self, b):
+        if self.pairM is not None and not self.dist and hasattr(self.S.eng, "block_chebyshev_solve") and self.S.eng.n1e <= 30 and len(self.chM.coef) > 1:
+            # one context: the whole solve from x = 0 as ONE call (no operator pass in the first step, nothing cleared); P b, the check's reference
+            # vector, is the first step's update -- 5 launches fewer than the sweeps + the extra preconditioner application (config 2: no dual solves)
+            x = self.S.eng.block_chebyshev_solve("UMAT", self.cm, b, self.chM.coef, pb=self.pairM[1:2], upd=self.pairM[0:1])
+            self._log_pair("M1", self.pairM)
+            return x
         x = self.chM.solve(b, want_residual=True)
         if self.pairM is not None and self.chM.upd.data_ptr() == self.pairM.data_ptr():
             self.S.precond_M1(b, out=self.pairM[1:2])
@@ -824,12 +830,10 @@ class _PicardGraph:
         """M1 F = hu and M0h_up(h, u) q = rhs0 by their fixed-length Chebyshev iterations in SHARED launches; both checks logged as m1() / q() do"""
         S, eng = self.S, self.S.eng
         dinv = torch.reciprocal(m0h)
-        F = torch.zeros_like(hu); q = torch.zeros_like(rhs0)
-        self.qp.zero_()
-        eng.sw_dual_chebyshev(self.chM.coef, self.cm, hu, self.chM.p, F, self.pairM[0:1], self.qcoef, self.qtau, h, u, rhs0, dinv, self.qp, q, self.pair0[0:1])
-        S.precond_M1(hu, out=self.pairM[1:2])
+        F = torch.empty_like(hu); q = torch.empty_like(rhs0)          # (outputs of solves from x = 0: written, not updated -- nothing to clear)
+        eng.sw_dual_chebyshev(self.chM.coef, self.cm, hu, self.chM.p, F, self.pairM[0:1], self.qcoef, self.qtau, h, u, rhs0, dinv, self.qp, q, self.pair0[0:1],
+                              pb1=self.pairM[1:2], pb0=self.pair0[1:2])      # P hu and dinv rhs0, the checks' reference vectors, are the first steps' updates
         self._log_pair("M1", self.pairM)
-        torch.mul(rhs0, dinv, out=self.pair0[1:2])
         self._log_pair("q", self.pair0)
         return F, q
 

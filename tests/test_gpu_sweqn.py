@@ -527,9 +527,19 @@ def test_dual_chebyshev_solve_equals_the_two_sweep_sequences(sw):
             eng.block_chebyshev_sweep("UMAT", cm, x1, b1, p1, al, be, upd=u1 if k == nA - 1 else None)
         for k, (al, be) in enumerate(coefB):
             eng.chebyshev_sweep("PHMAT_UP", x0, b0, dinv, p0, al, be, f=h, u=u, tau=tau, upd=u0 if k == nB - 1 else None)
-        y1, q1, v1 = eng.zeros(1, n1), eng.zeros(1, n1), eng.zeros(1, n1)
-        y0, q0, v0 = eng.zeros(1, n0), eng.zeros(1, n0), eng.zeros(1, n0)
-        eng.sw_dual_chebyshev(coefA, cm, b1, q1, y1, v1, coefB, tau, h, u, b0, dinv, q0, y0, v0)
+        # the dual entry solves from x = 0 and WRITES x, p in its first steps: poisoned outputs must come back clean
+        nan = lambda n: torch.full((1, n), float("nan"), dtype=torch.float64, device=eng.device)
+        y1, q1, v1, w1 = nan(n1), nan(n1), nan(n1), nan(n1)
+        y0, q0, v0, w0 = nan(n0), nan(n0), nan(n0), nan(n0)
+        many = nA > 1 and nB > 1
+        eng.sw_dual_chebyshev(coefA, cm, b1, q1, y1, v1, coefB, tau, h, u, b0, dinv, q0, y0, v0, pb1=w1 if many else None, pb0=w0 if many else None)
         for a, b, name in ((x1, y1, "x1"), (p1, q1, "p1"), (u1, v1, "upd1"), (x0, y0, "x0"), (p0, q0, "p0"), (u0, v0, "upd0")):
             assert torch.equal(a, b), (nA, nB, name, float((a - b).abs().max()))
         assert float(x1.abs().max()) > 0 and float(x0.abs().max()) > 0
+        if many:
+            # the first steps' preconditioned residuals: P b1 (the element-block preconditioner) and dinv b0
+            assert rel_l2(w1.cpu().numpy(), S.precond_M1(b1).cpu().numpy()) < 1e-14
+            assert torch.equal(w0, b0 * dinv)
+        else:
+            with pytest.raises(Exception):                               # a one-step chain has ONE preconditioned residual: asked for twice
+                eng.sw_dual_chebyshev(coefA, cm, b1, q1, y1, v1, coefB, tau, h, u, b0, dinv, q0, y0, v0, pb1=w1, pb0=w0)
