@@ -542,6 +542,14 @@ int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const doubl
  * interval -- KSPCHEBYSHEV in PETSc's terms; here the [u|h] system of SWEqn::solve (src/SWEqn_Picard.cpp:751-765: KSPSolve(kspA, f, dx)),
  * whose coupled element-block preconditioner leaves P A with Ritz values in [0.35, 1.18] and |Im| < 0.05 -- in ONE pass:
  * x += d;  r -= Bd;  d = a d + b r (the updated r), row by row.  No inner products: a and b follow from the spectral bounds alone. */
+/* ... its start from x = 0 with the preconditioned right-hand side c = P b:  r = s c;  d = r / theta;  x = 0  (theta: the centre of the interval;
+ * s = -1 when c = P f and the system is A dx = -f, as in SWEqn::solve; r may be c itself) -- one launch.                                  */
+int mimsem_krylov_chebyshev_start(mimsem_ctx* ctx, int nrows, long long n, double s, double theta, const double* c, long long ldc,
+                                  double* r, long long ldr, double* d, long long ldd, double* x, long long ldx);
+/* ... and the end of the Picard iteration around it (src/SWEqn_Picard.cpp:757-765: VecAXPY(x, 1.0, dx); VecNorm(dx); VecNorm(x)):
+ * x += dx;  out[0] = dx . dx;  out[1] = x . x (the updated x)  -- one launch; out: device, 2 doubles; the bits of the update followed by two
+ * mimsem_krylov_rowdot calls.                                                                                                            */
+int mimsem_krylov_axpy_dots(mimsem_ctx* ctx, long long n, const double* dx, double* x, double* out);
 int mimsem_krylov_chebyshev_update(mimsem_ctx* ctx, int nrows, long long n, double a, double b, const double* Bd, long long ldBd,
                                    double* x, long long ldx, double* r, long long ldr, double* d, long long ldd);
 int mimsem_krylov_cg_direction(mimsem_ctx* ctx, int nrows, long long n, const double* num, const double* den,

@@ -391,7 +391,70 @@ __global__ __launch_bounds__(256) void k_chebyshev_update(long long n, double a,
     r[row*ldr + i] = rv;
     d[row*ldd + i] = fma(a, dv, b*rv);
 }
+// the start of a Chebyshev solve from x = 0 with the preconditioned right-hand side c = P b (or s = -1: b = -f, c = P f):
+// r = s c;  d = r / theta;  x = 0 -- one launch for what were a negation, a copy, a clear and a scaling
+__global__ __launch_bounds__(256) void k_chebyshev_start(long long n, double s, double inv_theta, const double* cv, long long ldc, double* r, long long ldr,
+                                                         double* d, long long ldd, double* x, long long ldx) {
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = blockIdx.y;
+    const double rv = s*cv[row*ldc + i];
+    r[row*ldr + i] = rv;
+    d[row*ldd + i] = rv*inv_theta;
+    x[row*ldx + i] = 0.0;
+}
+// the end of a Picard iteration: x += dx, out = {dx . dx, x . x (the new x)} -- the update and both norms of the stopping test in ONE launch (the
+// partial sums and their reduction as mimsem_krylov_rowdot's one-launch form: the same bits as the update followed by two rowdot calls)
+__global__ __launch_bounds__(256) void k_axpy_dots(long long n, long long chunk, const double* __restrict__ dx, double* __restrict__ x, double* part,
+                                                   unsigned* counters, double* __restrict__ out) {
+    __shared__ double red[2][4];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = gridDim.x;
+    const long long lo = (long long)blockIdx.x*chunk, hi = min(n, lo + chunk);
+    double s0 = 0.0, s1 = 0.0;
+    for (long long t = lo + tid; t < hi; t += 256) {
+        const double dv = dx[t], xn = x[t] + dv;
+        x[t] = xn;
+        s0 += dv*dv; s1 += xn*xn;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(part + blockIdx.x, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + nb + blockIdx.x, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);                               // (write-through stores acknowledged before the arrival is counted: k_rowdot_fused)
+        last = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nb - 1;
+    }
+    __syncthreads();
+    if (!last || wave > 1) return;
+    double v = 0.0;
+    for (int i = lane; i < nb; i += 64) v += __hip_atomic_load(part + (size_t)wave*nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) out[wave] = v;
+    if (tid == 0) __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 }  // namespace
+int mimsem_krylov_chebyshev_start(mimsem_ctx* c, int nrows, long long n, double s, double theta, const double* cv, long long ldc,
+                                  double* r, long long ldr, double* d, long long ldd, double* x, long long ldx) {
+    if (!c || !cv || !x || !r || !d || nrows < 0 || n < 0 || !(theta != 0.0) || x == r || x == d || r == d || x == cv || d == cv) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_chebyshev_start, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, s, 1.0/theta, cv, ldc, r, ldr, d, ldd, x, ldx);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int mimsem_krylov_axpy_dots(mimsem_ctx* c, long long n, const double* dx, double* x, double* out) {
+    if (!c || !dx || !x || !out || n < 0 || dx == x) return MIMSEM_ERR_ARG;
+    if (n == 0) return mimsem_memset(c, out, 0, 2*sizeof(double));
+    const int nb = (int)std::max<long long>(1, std::min<long long>(1024, std::max<long long>(std::min<long long>(RD_BLOCKS, (n + 1023)/1024), (n + 8191)/8192)));      // (mimsem_krylov_rowdot's blocks)
+    const long long chunk = (n + nb - 1)/nb;
+    int rc = c->ensure_kry(2LL*nb);
+    if (rc) return rc;
+    if (!c->d_rdcnt) return MIMSEM_ERR_STATE;
+    hipLaunchKernelGGL(k_axpy_dots, dim3(nb), dim3(256), 0, c->stream, n, chunk, dx, x, c->d_kry, c->d_rdcnt, out);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
 int mimsem_krylov_chebyshev_update(mimsem_ctx* c, int nrows, long long n, double a, double b, const double* Bd, long long ldb,
                                    double* x, long long ldx, double* r, long long ldr, double* d, long long ldd) {
     if (!c || !Bd || !x || !r || !d || nrows < 0 || n < 0) return MIMSEM_ERR_ARG;

@@ -812,6 +812,16 @@ class Engine:
         check(self.L.mimsem_krylov_cg_update(self.ctx, p.shape[0], p.shape[1], _ptr(num), _ptr(den), _ptr(p), p.stride(0),
                                              _ptr(Ap), Ap.stride(0), _ptr(x), x.stride(0), _ptr(r), r.stride(0)), "cg_update")
 
+    def chebyshev_start(self, c, s, theta, r, d, x):
+        """r = s c ; d = r / theta ; x = 0 row-wise (one launch: mimsem_krylov_chebyshev_start); r may be c"""
+        check(self.L.mimsem_krylov_chebyshev_start(self.ctx, x.shape[0], x.shape[1], float(s), float(theta), _ptr(c), c.stride(0), _ptr(r), r.stride(0),
+                                                   _ptr(d), d.stride(0), _ptr(x), x.stride(0)), "chebyshev_start")
+
+    def axpy_dots(self, dx, x, out):
+        """x += dx ; out[0] = dx . dx ; out[1] = x . x over ALL entries of the (contiguous) tensors (one launch: mimsem_krylov_axpy_dots)"""
+        assert dx.is_contiguous() and x.is_contiguous() and dx.numel() == x.numel() and out.numel() == 2 and out.is_contiguous()
+        check(self.L.mimsem_krylov_axpy_dots(self.ctx, x.numel(), _ptr(dx), _ptr(x), _ptr(out)), "axpy_dots")
+
     def chebyshev_update(self, a, b, Bd, x, r, d):
         """x += d ; r -= Bd ; d = a d + b r  row-wise, in place (one launch: mimsem_krylov_chebyshev_update)"""
         check(self.L.mimsem_krylov_chebyshev_update(self.ctx, x.shape[0], x.shape[1], float(a), float(b), _ptr(Bd), Bd.stride(0),

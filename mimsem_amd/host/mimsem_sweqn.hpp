@@ -432,15 +432,15 @@ private:
         combine(n2, 1.0, hj, 0, nullptr, -1.0, hi, t2b);
         combine(n2, dt, t2, 0, nullptr, 1.0, t2b, t2b);
         check(mimsem_op_apply(c, MIMSEM_OP_WMAT, 0, 1, 1.0, 0, nullptr, 0, t2b, 0, res + n1, 0, 1.0), "WMAT");
-        combine(N, -1.0, res, 0, nullptr, 0.0, nullptr, bA);
         if (inline_fixed) {
+            // A dx = -f: P f first, the sign rides in the start kernel (r = -P f; d = r / theta; dx = 0: one launch for what were a negation, a clear
+            // and a scaling); |P f| = |-P f| is the reference norm of the check
             const double a = ROS_ALPHA*dt, sigma1 = thetaA/deltaA;
-            check(mimsem_sw_blocks_apply(c, 1, blocksA, bA, 0, rA, 0), "mimsem_sw_blocks_apply");
+            check(mimsem_sw_blocks_apply(c, 1, blocksA, res, 0, rA, 0), "mimsem_sw_blocks_apply");
             done1(rA);
             if (sh) { combine(N, 1.0, rA, 1, sh->ownx, 0.0, nullptr, zA); check(mimsem_krylov_rowdot(c, 1, N, zA, N, rA, N, chk + 2*slot + 1), "mimsem_krylov_rowdot"); }
             else check(mimsem_krylov_rowdot(c, 1, N, rA, N, rA, N, chk + 2*slot + 1), "mimsem_krylov_rowdot");
-            zero(N, dx);
-            combine(N, 1.0/thetaA, rA, 0, nullptr, 0.0, nullptr, dA);
+            check(mimsem_krylov_chebyshev_start(c, 1, N, -1.0, thetaA, rA, N, rA, N, dA, N, dx, N), "mimsem_krylov_chebyshev_start");
             double rho = 1.0/sigma1;
             if (sh) {
                 // sharded: a step = P A d with its two exchanges, then ONE update launch  x += d; r -= P A d; d = ca d + cb r  -- no inner product
@@ -474,10 +474,18 @@ private:
             kinds[slot++] = K_A;
         } else {
             if (sh) throw std::runtime_error("SWEqn (sharded): the [u|h] solve exists in the fixed-length mode only");
+            combine(N, -1.0, res, 0, nullptr, 0.0, nullptr, bA);
             kspA.solve(bA, dx);
         }
+        if (!sh) {
+            // x += dx and both norms of the stopping test in ONE launch
+            if (slot >= NSLOT) throw std::runtime_error("SWEqn: check-norm slots exhausted");
+            check(mimsem_krylov_axpy_dots(c, N, dx, x, chk + 2*slot), "mimsem_krylov_axpy_dots");
+            kinds[slot++] = K_PICARD;
+            return;
+        }
         combine(N, 1.0, dx, 0, nullptr, 1.0, x, x);
-        log(K_PICARD, dx, x, N, sh ? sh->ownx : nullptr);
+        log(K_PICARD, dx, x, N, sh->ownx);
     }
 
     // one Picard iteration; returns |dx| / |x|

@@ -804,14 +804,22 @@ class GraphedChebyshev:
         self.graph = None
         self.graph_steps = 0
 
-    def _run(self):
+    def _run(self, neg_of=None, nrm=None):
+        """neg_of = f: solve B x = -P f without forming -f (the Picard iteration's A dx = -f); nrm: where the two check norms go (default self.nrm)"""
         sigma1 = self.theta / self.delta
         rho = 1.0 / sigma1
-        c = self.precond(self.b)
-        self.r.copy_(c)
-        self.x.zero_()
-        torch.mul(c, 1.0 / self.theta, out=self.d)
-        self.eng.rowdot_local(c.reshape(1, -1), c.reshape(1, -1), out=self.nrm[1:2], space=self.space)
+        nrm = self.nrm if nrm is None else nrm
+        loc = getattr(self.eng, "eng", self.eng)              # (element-wise kernels need no halo: a DistEngine's local engine)
+        c = self.precond(self.b if neg_of is None else neg_of)
+        if hasattr(loc, "chebyshev_start"):
+            loc.chebyshev_start(c, 1.0 if neg_of is None else -1.0, self.theta, self.r, self.d, self.x)      # r = +-c; d = r / theta; x = 0: one launch
+        else:
+            if neg_of is not None:
+                c = -c
+            self.r.copy_(c)
+            self.x.zero_()
+            torch.mul(c, 1.0 / self.theta, out=self.d)
+        self.eng.rowdot_local(c.reshape(1, -1), c.reshape(1, -1), out=nrm[1:2], space=self.space)
         for _ in range(self.steps):
             rho_new = 1.0 / (2.0 * sigma1 - rho)
             if self.step is not None:
@@ -820,7 +828,7 @@ class GraphedChebyshev:
                 Bd = self.body(self.d)
                 self.eng.chebyshev_update(rho_new * rho, 2.0 * rho_new / self.delta, Bd, self.x, self.r, self.d)     # x += d; r -= B d; d = rho' rho d + (2 rho'/delta) r
             rho = rho_new
-        self.eng.rowdot_local(self.r.reshape(1, -1), self.r.reshape(1, -1), out=self.nrm[0:1], space=self.space)
+        self.eng.rowdot_local(self.r.reshape(1, -1), self.r.reshape(1, -1), out=nrm[0:1], space=self.space)
 
     def solve(self, b):
         if hasattr(self.eng, "halo"):                      # sharded: the same launches eagerly (the exchanges are not recorded), ONE all-reduce of the two norms

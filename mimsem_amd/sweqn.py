@@ -880,16 +880,17 @@ class _PicardGraph:
         f = S.assemble_residual(self.ui, self.hi, uj, hj, self.dt, self.q_exact, self.bot, qi=None if self.q_exact else self.qi,
                                 qj=qj, it=0 if first else 1, before_q=join, F=F)
         ch = self.chA
-        torch.neg(f, out=ch.b)
-        ch._run()
         k = self.slot; self.slot += 1
         self.names[k] = "A"
-        self.chk[2 * k:2 * k + 2].copy_(ch.nrm)
-        self.x.add_(ch.x)
+        ch._run(neg_of=f, nrm=self.chk[2 * k:2 * k + 2])          # A dx = -f: the sign rides in the start kernel, the check norms go straight into the log
         k = self.slot; self.slot += 1
         self.names[k] = "picard"
-        S.eng.rowdot_local(ch.x.reshape(1, -1), ch.x.reshape(1, -1), out=self.chk[2 * k:2 * k + 1], space="uh")
-        S.eng.rowdot_local(self.x.reshape(1, -1), self.x.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2], space="uh")
+        if not self.dist and hasattr(S.eng, "axpy_dots") and self.x.is_contiguous() and ch.x.is_contiguous():
+            S.eng.axpy_dots(ch.x, self.x, self.chk[2 * k:2 * k + 2])      # x += dx, |dx|^2, |x|^2: one launch
+        else:
+            self.x.add_(ch.x)
+            S.eng.rowdot_local(ch.x.reshape(1, -1), ch.x.reshape(1, -1), out=self.chk[2 * k:2 * k + 1], space="uh")
+            S.eng.rowdot_local(self.x.reshape(1, -1), self.x.reshape(1, -1), out=self.chk[2 * k + 1:2 * k + 2], space="uh")
         self.nslots = self.slot
 
     def replay(self, first):

@@ -222,6 +222,32 @@ def test_rowdot_short_and_long_rows(sphere):
             assert torch.equal(eng.rowdot(A, B), got), (nrows, n)                       # (the arrival counters are left clean: every call the same)
 
 
+def test_chebyshev_start_and_axpy_dots(sphere):
+    """the two one-launch helpers around the [u|h] Chebyshev solve of a Picard iteration (round 6): mimsem_krylov_chebyshev_start (r = s c;
+    d = r / theta; x = 0, also in place on c) and mimsem_krylov_axpy_dots (x += dx with both norms of the stopping test: the bits of the update
+    followed by two rowdot calls)"""
+    import torch
+    cs, eng, mats, rng = sphere
+    for nrows, n in ((1, 93312), (3, 1000), (1, 7)):
+        c = torch.randn(nrows, n, dtype=torch.float64, device=eng.device)
+        r, d, x = (torch.full_like(c, float("nan")) for _ in range(3))
+        eng.chebyshev_start(c, -1.0, 0.77, r, d, x)
+        assert torch.equal(r, -c) and torch.equal(d, (-c) * (1.0 / 0.77)) and not bool(x.any())
+        c2 = c.clone()
+        eng.chebyshev_start(c2, 1.0, 1.3, c2, d, x)                        # in place on c
+        assert torch.equal(c2, c) and torch.equal(d, c * (1.0 / 1.3))
+    for n in (1, 1000, 93312, 300001, 1866240):
+        dx = torch.randn(1, n, dtype=torch.float64, device=eng.device); x0 = torch.randn(1, n, dtype=torch.float64, device=eng.device)
+        x = x0.clone(); out = torch.full((2,), float("nan"), dtype=torch.float64, device=eng.device)
+        eng.axpy_dots(dx, x, out)
+        want_x = x0 + dx
+        assert torch.equal(x, want_x)
+        assert torch.equal(out[0:1], eng.rowdot(dx, dx)) and torch.equal(out[1:2], eng.rowdot(want_x, want_x)), n
+        x = x0.clone(); out2 = torch.zeros_like(out)
+        eng.axpy_dots(dx, x, out2)
+        assert torch.equal(out2, out)                                       # (the arrival counter is left clean)
+
+
 def test_weak_gradient_matches_dense(sphere):
     from mimsem_amd.horizsolve import HorizSolve
     cs, eng, mats, rng = sphere
