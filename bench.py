@@ -1091,7 +1091,9 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    eng.set_profiling(int(os.environ.get('MIMSEM_BENCH_PROF_EVERY', '8')))   # sample every 8th step of the timed region
+    # the live kernel durations of the roofline entry: every n-th step of the timed region goes out with start / stop events (an event-timed
+    # launch costs ~15 us of host time where a plain one costs 2: the samples perturb the region they are taken from) -- at least a dozen samples
+    eng.set_profiling(int(os.environ.get('MIMSEM_BENCH_PROF_EVERY', str(max(1, min(16, a.steps // 12))))))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()

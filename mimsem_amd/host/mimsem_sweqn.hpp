@@ -81,8 +81,8 @@ public:
             if (const char* e = std::getenv("MIMSEM_SW_DUAL")) dual_solves = std::atoi(e) != 0;
         }
         try {
-            for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &y1, &z1}) *p = mesh->device_alloc(n1);
-            for (double** p : {&hi, &hj, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
+            for (double** p : {&ui, &uj_buf, &hu, &F, &fu, &p1, &um, &y1, &z1}) *p = mesh->device_alloc(n1);
+            for (double** p : {&hi, &hj_buf, &Phi, &t2, &t2b, &hm}) *p = mesh->device_alloc(n2);
             for (double** p : {&m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj, &p0, &y0}) *p = mesh->device_alloc(n0);
             for (double** p : {&xsave, &res, &bA, &rA, &dA, &rB, &dB, &yA, &zA}) *p = mesh->device_alloc((size_t)N);
             // the two vectors of a check (last residual | its reference) sit side by side: ONE two-row dot per check instead of two
@@ -125,10 +125,7 @@ public:
     // the diagnostics on their own (device pointers; results in the caller's arrays)
     void diagnose_F(const double* ui_, const double* uj_, const double* hi_, const double* hj_, double* F_) {          // :253-284
         mimsem_ctx* c = mesh->ctx;
-        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, 0, hi_, 0, ui_, 0, hu, 0, 1.0/3.0), "UHMAT");
-        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hi_, 0, uj_, 0, hu, 0, 1.0/6.0), "UHMAT");
-        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj_, 0, ui_, 0, hu, 0, 1.0/6.0), "UHMAT");
-        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj_, 0, uj_, 0, hu, 0, 1.0/3.0), "UHMAT");
+        F_rhs(ui_, uj_, hi_, hj_);
         done1(hu);                                           // (sharded: the four local partial sums, ONE exchange)
         solve_M1(hu, F_);
     }
@@ -183,7 +180,7 @@ public:
 
 private:
     void release() {
-        for (double** p : {&ui, &uj, &hu, &F, &fu, &p1, &um, &hi, &hj, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj,
+        for (double** p : {&ui, &uj_buf, &hu, &F, &fu, &p1, &um, &hi, &hj_buf, &Phi, &t2, &t2b, &hm, &m0, &m0fg, &m0h, &dinv, &ones0, &rhs0, &qi, &qj,
                            &p0, &xsave, &res, &bA, &rA, &dA, &rB, &dB, &chk, &pair1, &pair0, &pairx, &y1, &z1, &y0, &yA, &zA}) { if (*p) mimsem_free(*p); *p = nullptr; }
         t1 = upd1 = t0 = upd0 = x = dx = nullptr;
     }
@@ -201,8 +198,8 @@ private:
     Graph gr[2]; bool have_graph[2] = {false, false}; bool warm[2] = {false, false};
     int n0 = 0, n1 = 0, n2 = 0; long long N = 0;
     double dt = -1.0; bool qx = false; const double* bt = nullptr; bool set_fixed = true; int misses = 0;
-    double *ui = nullptr, *uj = nullptr, *hu = nullptr, *F = nullptr, *fu = nullptr, *t1 = nullptr, *p1 = nullptr, *upd1 = nullptr, *um = nullptr;
-    double *hi = nullptr, *hj = nullptr, *Phi = nullptr, *t2 = nullptr, *t2b = nullptr, *hm = nullptr;
+    double *ui = nullptr, *uj_buf = nullptr, *hu = nullptr, *F = nullptr, *fu = nullptr, *t1 = nullptr, *p1 = nullptr, *upd1 = nullptr, *um = nullptr;
+    double *hi = nullptr, *hj_buf = nullptr, *Phi = nullptr, *t2 = nullptr, *t2b = nullptr, *hm = nullptr;
     double *m0 = nullptr, *m0fg = nullptr, *m0h = nullptr, *dinv = nullptr, *ones0 = nullptr, *rhs0 = nullptr, *t0 = nullptr, *qi = nullptr, *qj = nullptr,
            *p0 = nullptr, *upd0 = nullptr;
     double *x = nullptr, *xsave = nullptr, *res = nullptr, *bA = nullptr, *rA = nullptr, *dA = nullptr, *dx = nullptr, *chk = nullptr;
@@ -244,6 +241,16 @@ private:
     static int apply_m0h_up(void* user, int, const double* xin, long long, double* y, long long) {
         SWEqn* s = (SWEqn*)user;
         return mimsem_op_apply_up(s->mesh->ctx, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, s->q_tau, 0, s->q_h, 0, s->q_u, 0, xin, 0, y, 0, 1.0);
+    }
+
+    // hu = 1/3 M1h(hi) ui + 1/6 M1h(hi) uj + 1/6 M1h(hj) ui + 1/3 M1h(hj) uj (:253-284).  M1h is LINEAR in its thickness field: two applies on the
+    // combined fields hi/3 + hj/6 and hi/6 + hj/3 (two small combines on 2-forms) instead of four applies -- 6 launches instead of 8
+    void F_rhs(const double* ui_, const double* uj_, const double* hi_, const double* hj_) {
+        mimsem_ctx* c = mesh->ctx;
+        combine(n2, 1.0/3.0, hi_, 0, nullptr, 1.0/6.0, hj_, t2);
+        combine(n2, 1.0/6.0, hi_, 0, nullptr, 1.0/3.0, hj_, t2b);
+        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, 0, t2, 0, ui_, 0, hu, 0, 1.0), "UHMAT");
+        check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, t2b, 0, uj_, 0, hu, 0, 1.0), "UHMAT");
     }
 
     // KSPSolve(ksp1, b, x): the 1-form mass
@@ -380,17 +387,16 @@ private:
         mimsem_ctx* c = mesh->ctx;
         slot = 0;
         copy(N, x, xsave);
-        copy(n1, x, uj); copy(n2, x + n1, hj);
+        // the current iterate's halves: views of x where the depth half starts 16-byte aligned (x changes only at the end of the body), else copies
+        const double *uj = x, *hj = x + n1;
+        if (n1 & 1) { copy(n1, x, uj_buf); copy(n2, x + n1, hj_buf); uj = uj_buf; hj = hj_buf; }
         // round 6: the mass-flux solve (diagnose_F: steps_M1 sweeps x 3 launches) and the potential-vorticity solve (diagnose_q: steps_q x 2) read
         // nothing of each other -- mimsem_sw_dual_chebyshev issues launch k of both chains as ONE grid (the same kernels' bodies, the same bits)
         const bool dual = dual_solves && inline_fixed && !sh && !qx && !qcoef.empty() && !escale1;
         bool q_done = false;
         if (dual) {
             const double* uq = first ? ui : uj; const double* hq = first ? hi : hj; double* qdst = first ? qi : qj;
-            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, 0, hi, 0, ui, 0, hu, 0, 1.0/3.0), "UHMAT");                       // the right-hand side of diagnose_F
-            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hi, 0, uj, 0, hu, 0, 1.0/6.0), "UHMAT");
-            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj, 0, ui, 0, hu, 0, 1.0/6.0), "UHMAT");
-            check(mimsem_op_apply(c, MIMSEM_OP_UHMAT, 0, 1, 1.0, MIMSEM_FLAG_ACCUM, hj, 0, uj, 0, hu, 0, 1.0/3.0), "UHMAT");
+            F_rhs(ui, uj, hi, hj);                                                                                                   // the right-hand side of diagnose_F
             check(mimsem_op_apply(c, MIMSEM_OP_UMAT, 0, 1, 1.0, 0, nullptr, 0, uq, 0, t1, 0, 1.0), "UMAT");                          // ... and of diagnose_q
             check(mimsem_incidence_apply(c, 3, 1, t1, 0, rhs0, 0), "E01");
             combine(n0, 1.0, m0fg, 0, nullptr, 1.0, rhs0, rhs0);
