@@ -787,6 +787,20 @@ int mimsem_ctx_create(const mimsem_mesh_desc* d, int device, mimsem_ctx** out) {
         rc = build_plan(d->n1, d->nEl, 2*es.n1e, {d->inds1x, d->inds1y}, {0, es.n1e}, es.n1e, 2, plan);
         if (rc) return fail(rc);
         if ((rc = upload(&c->d_g1, plan.data(), plan.size(), c))) return fail(rc);
+        {
+            // the block passes' own view of that plan (round 6, late): per (element, block row) {slot, first contributor, second contributor}
+            // as ONE 16-byte entry -- the row's chain of dependent loads is {this entry -> the gathered values} instead of {edge map -> plan ->
+            // values}; at the ~3 500 elements of the shallow-water drivers a block pass IS its chain of memory latencies
+            const int nd = 2*es.n1e;
+            std::vector<int> bp((size_t)d->nEl*nd*4, 0);
+            for (int e = 0; e < d->nEl; e++)
+                for (int r = 0; r < nd; r++) {
+                    const int slot = r < es.n1e ? d->inds1x[(size_t)e*es.n1e + r] : d->inds1y[(size_t)e*es.n1e + r - es.n1e];
+                    int* o = &bp[((size_t)e*nd + r)*4];
+                    o[0] = slot; o[1] = plan[(size_t)slot*2]; o[2] = plan[(size_t)slot*2 + 1]; o[3] = 0;
+                }
+            if ((rc = upload(&c->d_bplan, bp.data(), bp.size(), c))) return fail(rc);
+        }
         c->G0 = 4;
         rc = build_plan(d->n0, d->nEl, es.n0e, {d->inds0}, {0}, es.n0e, 4, plan);
         if (rc == MIMSEM_ERR_UNSUPPORTED) { c->G0 = 8; rc = build_plan(d->n0, d->nEl, es.n0e, {d->inds0}, {0}, es.n0e, 8, plan); }
@@ -884,7 +898,7 @@ void mimsem_ctx_destroy(mimsem_ctx* c) {
     (void)hipSetDevice(c->device);
     orphan_graphs(c);
     void* ptrs[] = {c->d_xn, c->d_E, c->d_w, c->d_U, c->d_V, c->d_W, c->d_P, c->d_J, c->d_det, c->d_th, c->d_tI, c->d_tIp, c->d_tIn,
-                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_rdcnt, c->d_cheb, c->d_colratio, c->d_g1, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
+                    c->d_i0, c->d_i1x, c->d_i1y, c->d_i2, c->d_iq, c->d_fperm, c->d_flid, c->d_fslot, c->d_fcnt, c->d_pslot, c->d_ppart, c->d_wlane, c->d_wplan, c->d_wprec, c->d_wnode, c->d_wsing, c->d_wG, c->d_wR, c->d_wfin, c->d_wsslot, c->d_wcnt, c->d_wtfin, c->d_wpart, c->d_wsplit, c->d_colstat, c->d_forceflag, c->d_rdcnt, c->d_cheb, c->d_colratio, c->d_g1, c->d_bplan, c->d_g0, c->d_ye, c->d_col, c->d_lu, c->d_kry,
                     c->d_d0, c->d_d1x, c->d_d1y, c->d_sh0, c->d_sh1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : c->retired) (void)hipFree(p);
@@ -1637,7 +1651,7 @@ int mimsem_sw_dual_chebyshev(mimsem_ctx* c, int nA, const double* coefA, const d
     ElemArgs ea, eq;
     sweep_elem_args(c, ea, nullptr, nullptr, 0.0, x1, yeA, per1);
     sweep_elem_args(c, eq, h, u, tau, x0, yeQ, per0);
-    PairBlocks ba{c->nEl, 1, c->d_i1x, c->d_i1y, c->d_g1, blocks1, yeA, per1, b1, zeA, per1};
+    PairBlocks ba{c->nEl, 1, c->d_i1x, c->d_i1y, c->d_g1, blocks1, yeA, per1, b1, zeA, per1, (const int4*)c->d_bplan};
     PairGather ga{zeA, per1, c->d_g1, c->n1, GatherEpilogue{3, b1, 0, nullptr, 0, nullptr, 0}, x1};
     PairGather gq{yeQ, per0, c->d_g0, c->n0, GatherEpilogue{5, b0, 0, dinv, 0, nullptr, 0}, x0};
     ga.g.p = p1; ga.g.ps = 0; gq.g.p = p0; gq.g.ps = 0;

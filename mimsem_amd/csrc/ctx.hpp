@@ -79,6 +79,7 @@ struct mimsem_ctx {
     int nq = 0;
     // deterministic scatter-add plans: vector slot -> up to K element-local result slots (-1 = none)
     int* d_g1 = nullptr;        // [n1][2]   into ye1[e*2*n1e + j]  (j<n1e: x edge, else y edge)
+    int* d_bplan = nullptr;     // [nEl][2 n1e][4] = {slot, d_g1[slot][0], d_g1[slot][1], 0}: the block passes' view of d_g1, one 16-byte load per block row
     int* d_g0 = nullptr;        // [n0][G0]  into ye0[e*n0e + j]
     int G0 = 4;
     // fused scatter-add of 1-form results: element groups = workgroups, group-local slot ids
@@ -241,7 +242,7 @@ struct GatherEpilogue {
     int noacc = 0;                   // ... and the operator result is zero: acc = 0, ye is not read (mode 5 without a block pass in between)
 };
 // two independent Chebyshev sweeps in the same launches (elem_kernels.hip: k_sw_pair): the block pass and the gather epilogue of one level
-struct PairBlocks { int nEl, lch; const int *i1x, *i1y, *plan; const double *B, *ye; long long yes; const double* b; double* ze; long long zes; };
+struct PairBlocks { int nEl, lch; const int *i1x, *i1y, *plan; const double *B, *ye; long long yes; const double* b; double* ze; long long zes; const int4* bplan; };
 struct PairGather { const double* ye; long long yes; const int* plan; int nslots; GatherEpilogue g; double* x; };
 // phase PA of the 1-form mass sweep (0 element pass, 1 block pass, 2 gather epilogue) and phase PB of the upwinded 0-form sweep (0 element
 // pass, 1 gather epilogue) in ONE launch; orders 2..4

@@ -668,7 +668,7 @@ template <int N, int LC, bool Y0 = false>
 __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
-        const double* __restrict__ escale, long long ess, const unsigned bid) {
+        const double* __restrict__ escale, long long ess, const unsigned bid, const int4* __restrict__ bplan = nullptr) {
     using D = Dims<N>;
     constexpr int ND = 2*D::n1e;
     constexpr int LPE = ND <= 16 ? 16 : (ND <= 32 ? 32 : 64), EPB = 256/LPE;
@@ -685,8 +685,11 @@ __device__ __forceinline__ void body_blocks_residual(int nEl, int nlev, int lch,
     double brow[ND];
     int slot = 0, p0 = -1, p1 = -1;
     if (act) {
-        slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
-        p0 = plan[(size_t)slot*2]; p1 = plan[(size_t)slot*2 + 1];
+        if (bplan) { const int4 t = bplan[(size_t)e*ND + r]; slot = t.x; p0 = t.y; p1 = t.z; }       // {slot, contributors} in one load: one level less in the row's chain of dependent loads
+        else {
+            slot = (r < D::n1e) ? i1x[e*D::n1e + r] : i1y[e*D::n1e + r - D::n1e];
+            p0 = plan[(size_t)slot*2]; p1 = plan[(size_t)slot*2 + 1];
+        }
     }
     // (staging the block through LDS with nine 16-byte loads per lane instead of 24 eight-byte ones was measured: no change, 23.9 us --
     // after the level prefetch the kernel is bound by its 12 broadcast ds_read_b128 + 24 FMAs per level, not by the addresser)
@@ -736,8 +739,8 @@ template <int N, int LC, bool Y0 = false>
 __global__ __launch_bounds__(256) void k_blocks_residual(int nEl, int nlev, int lch, const int* __restrict__ i1x, const int* __restrict__ i1y,
         const int* __restrict__ plan, const double* __restrict__ B, const double* __restrict__ ye, long long yes,
         const double* __restrict__ b, long long bs, double* __restrict__ ze, long long zes,
-        const double* __restrict__ escale, long long ess) {
-    body_blocks_residual<N, LC, Y0>(nEl, nlev, lch, i1x, i1y, plan, B, ye, yes, b, bs, ze, zes, escale, ess, blockIdx.x);
+        const double* __restrict__ escale, long long ess, const int4* __restrict__ bplan) {
+    body_blocks_residual<N, LC, Y0>(nEl, nlev, lch, i1x, i1y, plan, B, ye, yes, b, bs, ze, zes, escale, ess, blockIdx.x, bplan);
 }
 
 // ---- two independent Chebyshev sweeps in the SAME launches (round 6) ---------------------------------------------------------------------
@@ -751,9 +754,9 @@ template <int N, int PA, int PB, int K0>           // PA: 0 element pass (Umat),
 __global__ __launch_bounds__(256) void k_sw_pair(ElemArgs ea, PairBlocks ba, PairGather ga, ElemArgs eq, PairGather gq, unsigned nA) {
     if (blockIdx.x < nA) {
         if constexpr (PA == 0) body_elem_apply<N, MIMSEM_OP_UMAT, false>(ea, blockIdx.x, nA);
-        else if constexpr (PA == 1) body_blocks_residual<N, 1>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x);
+        else if constexpr (PA == 1) body_blocks_residual<N, 1>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x, ba.bplan);
         else if constexpr (PA == 2) body_gather_epilogue<2>(ga.ye, ga.yes, ga.plan, ga.nslots, 1, ga.g, ga.x, 0, blockIdx.x, 0);
-        else if constexpr (PA == 3) body_blocks_residual<N, 1, true>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x);
+        else if constexpr (PA == 3) body_blocks_residual<N, 1, true>(ba.nEl, 1, ba.lch, ba.i1x, ba.i1y, ba.plan, ba.B, ba.ye, ba.yes, ba.b, 0, ba.ze, ba.zes, nullptr, 0, blockIdx.x, ba.bplan);
     } else {
         const unsigned bid = blockIdx.x - nA, nB = gridDim.x - nA;
         if constexpr (PB == 0) body_elem_apply<N, MIMSEM_OP_PHMAT_UP, false>(eq, bid, nB);
@@ -1240,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
         const int* __restrict__ i1x, const int* __restrict__ i1y, const int* __restrict__ i2, const double* __restrict__ B,
         const double* __restrict__ x, long long xs, double* __restrict__ ye, long long yes, double* __restrict__ y, long long ys,
         const double* __restrict__ ye_in, long long yis, const int* __restrict__ plan /* edge entries of x = gather of ye_in (or null) */,
+        const int4* __restrict__ bplan /* per (element, edge row) {slot, contributors}: csrc/api.hip */,
         double ca = 0.0, double cb = 0.0, double* cr = nullptr, long long crs = 0, double* cd = nullptr, long long cds = 0
         /* cd != null (round 5): the 2-form rows finish a Chebyshev step instead of storing their result s = (B d)[slot]:
            y[slot] += d[slot];  r[slot] -= s;  d[slot] = ca d[slot] + cb r[slot]   (y = the iterate) */) {
@@ -1253,12 +1257,20 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
     const bool act = eg < (long long)nEl*nlev && r < ND;
     const int lev = act ? (int)(eg/nEl) : 0, e = act ? (int)(eg%nEl) : 0;
     long long slot = 0;
+    // Round 6, late: at the ~3 500 elements of the shallow-water drivers this launch is a chain of dependent memory latencies -- edge map -> plan
+    // -> gathered values -> (LDS) -> the block row.  The row depends on (e, r) alone: it is requested FIRST and waits in registers; slot and
+    // contributors come as one 16-byte entry: two levels instead of four.
+    double brow[ND];
+    {
+        const double* Be = B + (size_t)e*ND*ND + (r < ND ? r : 0);
+#pragma unroll
+        for (int c = 0; c < ND; c++) brow[c] = Be[(size_t)c*ND];
+    }
     if (act) {
-        if (r < D::n1e) slot = i1x[e*D::n1e + r];
-        else if (r < 2*D::n1e) slot = i1y[e*D::n1e + r - D::n1e];
+        int p0 = -1, p1 = -1;
+        if (r < 2*D::n1e) { const int4 t = bplan[(size_t)e*2*D::n1e + r]; slot = t.x; p0 = t.y; p1 = t.z; }
         else slot = n1 + (i2 ? i2[e*D::n2e + r - 2*D::n1e] : e*D::n2e + r - 2*D::n1e);
         if (ye_in && r < 2*D::n1e) {           // the operator's element-local results, summed on the fly (same order as k_gather_sum)
-            const int p0 = plan[(size_t)slot*2], p1 = plan[(size_t)slot*2 + 1];
             const double* src = ye_in + (size_t)lev*yis;
             double acc = 0.0;
             if (p0 >= 0) acc += src[p0];
@@ -1271,10 +1283,9 @@ __global__ __launch_bounds__(256) void k_sw_blocks_apply(int nEl, int nlev, long
     // (priced in round 6 and declined: the coupled blocks stored as 4-byte entries -- a preconditioner may be approximate -- take the pass + gather
     //  from 9.8 to 8.1 us back to back (scripts/exp/probe_f32_blocks.py on a probe build): 5 % of the step at most, for a second copy of the blocks
     //  and a rounded P in every place that applies it)
-    const double* Be = B + (size_t)e*ND*ND + r;
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < ND; c++) s += Be[(size_t)c*ND]*s_x[el][c];
+    for (int c = 0; c < ND; c++) s += brow[c]*s_x[el][c];
     if (r < 2*D::n1e) ye[(size_t)lev*yes + (size_t)e*2*D::n1e + r] = s;
     else if (cd) {
         double* dp = cd + (size_t)lev*cds + slot; double* rp = cr + (size_t)lev*crs + slot;
@@ -1783,16 +1794,16 @@ static int blocks_residual_n(mimsem_ctx* c, int nlev, const double* B, const dou
     const long long items = (long long)c->nEl*((nlev + lch - 1)/lch);
     if (!ye) {                                            // zero operator result (mimsem_block_chebyshev_solve, first step): the residual is b
         if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1, true>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
-                                         c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+                                         c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess, (const int4*)c->d_bplan);
         else hipLaunchKernelGGL((k_blocks_residual<N, 8, true>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
-                                c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+                                c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess, (const int4*)c->d_bplan);
         MIMSEM_HIP_TRY(hipGetLastError());
         return MIMSEM_OK;
     }
     if (lch == 1) hipLaunchKernelGGL((k_blocks_residual<N, 1>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
-                                     c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+                                     c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess, (const int4*)c->d_bplan);
     else hipLaunchKernelGGL((k_blocks_residual<N, 8>), dim3((unsigned)((items + EPB - 1)/EPB)), dim3(256), 0, c->stream, c->nEl, nlev, lch,
-                            c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess);
+                            c->d_i1x, c->d_i1y, c->d_g1, B, ye, yes, b, bs, ze, zes, escale, ess, (const int4*)c->d_bplan);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
@@ -1951,7 +1962,7 @@ static int sw_blocks_n(mimsem_ctx* c, int nlev, const double* B, const double* x
     const long long total = (long long)c->nEl*nlev;
     const unsigned grid = (unsigned)((total + EPB - 1)/EPB);
     hipLaunchKernelGGL((k_sw_blocks_apply<N>), dim3(grid), dim3(256), 0, c->stream, c->nEl, nlev, (long long)c->n1,
-                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys, ye_in, yis, c->d_g1, ca, cb, cr, crs, cd, cds);
+                       c->d_i1x, c->d_i1y, c->d_i2, B, x, xs, ye, yes, y, ys, ye_in, yis, c->d_g1, (const int4*)c->d_bplan, ca, cb, cr, crs, cd, cds);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }
