@@ -124,7 +124,6 @@ public:
 
     // the diagnostics on their own (device pointers; results in the caller's arrays)
     void diagnose_F(const double* ui_, const double* uj_, const double* hi_, const double* hj_, double* F_) {          // :253-284
-        mimsem_ctx* c = mesh->ctx;
         F_rhs(ui_, uj_, hi_, hj_);
         done1(hu);                                           // (sharded: the four local partial sums, ONE exchange)
         solve_M1(hu, F_);

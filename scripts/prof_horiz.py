@@ -29,7 +29,6 @@ h1 = eng.tensor(rng.uniform(0.8, 1.2, (NK, dm.n2)) * area * dz); h2 = h1 * 1.001
 th = eng.tensor(rng.uniform(290, 310, (NK, dm.n2)) * area * dz); Pi = eng.tensor(rng.uniform(900, 1000, (NK, dm.n2)) * area * dz)
 vz = eng.tensor(rng.standard_normal((NK - 1, dm.n2)) * area); dudz = eng.tensor(rng.standard_normal((NK - 1, dm.n1)) * 1e-3 * ln)
 hs.m1.fixed_its = 14
-PERTURB = os.environ.get("PERTURB")
 def rhs():
     dF, dG, Fk, Gk = hs.advection_rhs_ec(u1, u2, h1, h2, th)
     return hs.momentum_rhs_ec(th, dudz, dudz, vz, vz, Pi, u1, u2, h1, h2, Fx=Fk, Fk=Fk)
