@@ -1092,8 +1092,9 @@ def main():
         step()
     fence()
     # the live kernel durations of the roofline entry: every n-th step of the timed region goes out with start / stop events (an event-timed
-    # launch costs ~15 us of host time where a plain one costs 2: the samples perturb the region they are taken from) -- at least a dozen samples
-    eng.set_profiling(int(os.environ.get('MIMSEM_BENCH_PROF_EVERY', str(max(1, min(16, a.steps // 12))))))
+    # launch costs ~15 us of host time where a plain one costs 2: the samples perturb the region they are taken from): one step in 8 (three
+    # samples at the driver's --steps 20), one in 16 from 200 steps on (a dozen samples and more)
+    eng.set_profiling(int(os.environ.get('MIMSEM_BENCH_PROF_EVERY', str(max(8, min(16, a.steps // 12))))))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
