@@ -68,6 +68,7 @@ public:
     std::vector<double> history;         // |dx| / |x| of the iterations of the last solve()
     int fallbacks = 0;                   // Picard iterations the fixed mode handed to the krylov mode
     int steps_A = 0, steps_M1 = 0, steps_q = 0;
+    int graph_nodes(bool first) const { return have_graph[first ? 0 : 1] ? gr[first ? 0 : 1].nodes() : 0; }      // launches of a recorded Picard iteration (0: not recorded)
     double us_submit = 0.0, us_wait = 0.0; long replays = 0;      // host time inside the graph submissions / waiting for the check norms
 
     // fg: the Coriolis 0-form (SWEqn::coriolis, src/SWEqn_Picard.cpp:95-140), device, n0 entries; it must outlive the object

@@ -49,9 +49,10 @@ int main(int argc, char** argv) {
             check(mimsem_ctx_sync(mesh.ctx), "sync");
             const double el = std::chrono::duration<double>(clk::now() - t0).count();
             std::printf("%s\"%s\": {\"steps_per_s\": %.3f, \"ms_per_step\": %.4f, \"picard_iterations_per_step\": %.2f, \"chebyshev_steps\": [%d, %d, %d], "
-                        "\"iterations_handed_to_ksp\": %d, \"graph_submit_us\": %.1f, \"wait_and_read_us\": %.1f}", mode ? ", " : "", mode == 0 ? "graph" : "ksp_objects",
+                        "\"iterations_handed_to_ksp\": %d, \"graph_submit_us\": %.1f, \"wait_and_read_us\": %.1f, \"graph_nodes_first_iteration\": %d, \"graph_nodes_later_iterations\": %d}",
+                        mode ? ", " : "", mode == 0 ? "graph" : "ksp_objects",
                         cs.nsteps/el, 1e3*el/cs.nsteps, (double)picard/cs.nsteps, sw.steps_A, sw.steps_M1, sw.steps_q, sw.fallbacks,
-                        sw.replays ? sw.us_submit/sw.replays : 0.0, sw.replays ? sw.us_wait/sw.replays : 0.0);
+                        sw.replays ? sw.us_submit/sw.replays : 0.0, sw.replays ? sw.us_wait/sw.replays : 0.0, sw.graph_nodes(true), sw.graph_nodes(false));
             mimsem_free(un); mimsem_free(hn);
         }
         std::printf("}\n");
