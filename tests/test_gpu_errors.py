@@ -197,3 +197,42 @@ def test_set_halo_slots_refused_inside_a_capture(small):
     assert rcs == [0, -4], rcs
     g.replay(); torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.equal(out, eng.apply("UMAT", x, lev0=0, scale=SCALE, flags=1))
+
+
+def test_argument_errors_of_the_round_6_solver_entries(small):
+    """mimsem_block_chebyshev_solve, mimsem_krylov_chebyshev_start, mimsem_krylov_axpy_dots, mimsem_sw_dual_chebyshev: nothing launches on bad
+    arguments; empty inputs are a clean no-op"""
+    from mimsem_amd._lib import OPS
+    eng, dm, P = small
+    L, ctx = eng.L, eng.ctx
+    nd = 2 * eng.n1e
+    b = eng.tensor(np.ones((4, dm.n1))); x = eng.zeros(4, dm.n1); B = eng.zeros(dm.nEl, nd, nd)
+    coef = (C.c_double * 4)(1.0, 0.0, 1.0, 0.1)
+    pb, px, pB = b.data_ptr(), x.data_ptr(), B.data_ptr()
+    solve = lambda op, lev0, nlev, flags, blocks, rhs, nsteps, cf, out: L.mimsem_block_chebyshev_solve(
+        ctx, op, lev0, nlev, SCALE, flags, None, 0, blocks, None, 0, rhs, dm.n1, nsteps, cf, out, dm.n1, None, 0, None, 0)
+    assert solve(OPS["UMAT"], 0, 4, 1, pB, pb, 2, coef, px) == 0
+    assert solve(OPS["UHMAT"], 0, 4, 1, pB, pb, 2, coef, px) == ERR_UNSUPPORTED        # the mass operator only
+    assert solve(OPS["UMAT"], 0, 4, 2, pB, pb, 2, coef, px) == ERR_ARG                 # no accumulate form
+    assert solve(OPS["UMAT"], 0, 5, 1, pB, pb, 2, coef, px) == ERR_ARG                 # levels beyond nk
+    assert solve(OPS["UMAT"], 0, 4, 1, None, pb, 2, coef, px) == ERR_ARG
+    assert solve(OPS["UMAT"], 0, 4, 1, pB, pb, 0, coef, px) == ERR_ARG                 # no steps
+    assert solve(OPS["UMAT"], 0, 4, 1, pB, pb, 2, None, px) == ERR_ARG
+    assert solve(OPS["UMAT"], 0, 4, 1, pB, pb, 2, coef, pb) == ERR_ARG                 # in place on the right-hand side
+    assert solve(OPS["UMAT"], 0, 0, 1, None, None, 2, coef, None) == 0                 # empty batch
+    r = eng.zeros(1, 100); d = eng.zeros(1, 100); v = eng.tensor(np.ones((1, 100))); out = eng.zeros(2)
+    st = lambda th, c, rr, dd, xx: L.mimsem_krylov_chebyshev_start(ctx, 1, 100, 1.0, th, c, 100, rr, 100, dd, 100, xx, 100)
+    assert st(0.8, v.data_ptr(), r.data_ptr(), d.data_ptr(), x.data_ptr()) == 0
+    assert st(0.0, v.data_ptr(), r.data_ptr(), d.data_ptr(), x.data_ptr()) == ERR_ARG   # theta = 0
+    assert st(0.8, v.data_ptr(), r.data_ptr(), r.data_ptr(), x.data_ptr()) == ERR_ARG   # outputs alias
+    assert st(0.8, None, r.data_ptr(), d.data_ptr(), x.data_ptr()) == ERR_ARG
+    assert L.mimsem_krylov_axpy_dots(ctx, 100, v.data_ptr(), v.data_ptr(), out.data_ptr()) == ERR_ARG      # in place
+    assert L.mimsem_krylov_axpy_dots(ctx, 100, v.data_ptr(), r.data_ptr(), None) == ERR_ARG
+    assert L.mimsem_krylov_axpy_dots(ctx, -1, v.data_ptr(), r.data_ptr(), out.data_ptr()) == ERR_ARG
+    out.fill_(7.0)
+    assert L.mimsem_krylov_axpy_dots(ctx, 0, v.data_ptr(), r.data_ptr(), out.data_ptr()) == 0 and not bool(out.any())   # empty: both norms zero
+    p1 = eng.zeros(1, dm.n1); x1 = eng.zeros(1, dm.n1); p0 = eng.zeros(1, dm.n0); x0 = eng.zeros(1, dm.n0); b0 = eng.zeros(1, dm.n0); h = eng.zeros(1, dm.n2)
+    dual = lambda nA, upd1, pb1: L.mimsem_sw_dual_chebyshev(ctx, nA, C.addressof(coef), pB, pb, p1.data_ptr(), x1.data_ptr(), upd1, pb1,
+                                                           2, C.addressof(coef), 1.0, h.data_ptr(), pb, b0.data_ptr(), b0.data_ptr(), p0.data_ptr(), x0.data_ptr(), None, None)
+    assert dual(0, None, None) == ERR_ARG                                               # no steps
+    assert dual(1, r.data_ptr(), d.data_ptr()) == ERR_ARG                               # a one-step chain has one preconditioned residual
