@@ -546,6 +546,12 @@ int mimsem_krylov_cg_update(mimsem_ctx* ctx, int nrows, long long n, const doubl
  * s = -1 when c = P f and the system is A dx = -f, as in SWEqn::solve; r may be c itself) -- one launch.                                  */
 int mimsem_krylov_chebyshev_start(mimsem_ctx* ctx, int nrows, long long n, double s, double theta, const double* c, long long ldc,
                                   double* r, long long ldr, double* d, long long ldd, double* x, long long ldx);
+/* The vector algebra of one Chebyshev step whose operator result y had to be completed over a halo first (sharded meshes; one context uses the
+ * fused sweeps above):  z = dinv (b - y)  -- or z = y when dinv is NULL (y already is the preconditioned residual; b unused) --;  p = z + beta p;
+ * x += alpha p;  upd = z if given.  Row-wise, one launch.                                                                                  */
+int mimsem_krylov_chebyshev_px(mimsem_ctx* ctx, int nrows, long long n, double alpha, double beta, const double* y, long long ldy,
+                               const double* b, long long ldb, const double* dinv, long long lddinv, double* p, long long ldp, double* x, long long ldx,
+                               double* upd, long long ldupd);
 /* ... and the end of the Picard iteration around it (src/SWEqn_Picard.cpp:757-765: VecAXPY(x, 1.0, dx); VecNorm(dx); VecNorm(x)):
  * x += dx;  out[0] = dx . dx;  out[1] = x . x (the updated x)  -- one launch; out: device, 2 doubles; the bits of the update followed by two
  * mimsem_krylov_rowdot calls.                                                                                                            */

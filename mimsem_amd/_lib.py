@@ -141,6 +141,7 @@ _SIGS = {
     "mimsem_column_set_pivot_fallback": (C.c_int, [C.c_void_p, C.c_int]),
     "mimsem_krylov_chebyshev_start": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_krylov_axpy_dots": (C.c_int, [C.c_void_p, c_ll, c_dp, c_dp, c_dp]),
+    "mimsem_krylov_chebyshev_px": (C.c_int, [C.c_void_p, C.c_int, c_ll, C.c_double, C.c_double, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll, c_dp, c_ll]),
     "mimsem_sw_dual_chebyshev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mimsem_halo_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

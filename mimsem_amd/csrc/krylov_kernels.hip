@@ -403,6 +403,22 @@ __global__ __launch_bounds__(256) void k_chebyshev_start(long long n, double s, 
     d[row*ldd + i] = rv*inv_theta;
     x[row*ldx + i] = 0.0;
 }
+// the vector algebra of a Chebyshev step whose operator result had to be COMPLETED over a halo first (sharded meshes: the fused sweeps cannot run
+// across the exchange): z = dinv (b - y) (or z = y when dinv is null: y already is the preconditioned residual); p = z + beta p; x += alpha p;
+// upd = z if given -- one launch for what were up to five element-wise kernels; the arithmetic of k_gather_epilogue's modes 3 / 5
+__global__ __launch_bounds__(256) void k_chebyshev_px(long long n, double alpha, double beta, const double* __restrict__ y, long long ldy,
+                                                      const double* __restrict__ b, long long ldb, const double* __restrict__ dinv, long long ldd,
+                                                      double* __restrict__ p, long long ldp, double* __restrict__ x, long long ldx, double* __restrict__ upd, long long ldu) {
+    const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t row = blockIdx.y;
+    const double yv = y[row*ldy + i];
+    const double z = dinv ? dinv[row*ldd + i]*(b[row*ldb + i] - yv) : yv;
+    const double pn = fma(beta, p[row*ldp + i], z);
+    p[row*ldp + i] = pn;
+    x[row*ldx + i] = fma(alpha, pn, x[row*ldx + i]);
+    if (upd) upd[row*ldu + i] = z;
+}
 // the end of a Picard iteration: x += dx, out = {dx . dx, x . x (the new x)} -- the update and both norms of the stopping test in ONE launch (the
 // partial sums and their reduction as mimsem_krylov_rowdot's one-launch form: the same bits as the update followed by two rowdot calls)
 __global__ __launch_bounds__(256) void k_axpy_dots(long long n, long long chunk, const double* __restrict__ dx, double* __restrict__ x, double* part,
@@ -440,6 +456,15 @@ int mimsem_krylov_chebyshev_start(mimsem_ctx* c, int nrows, long long n, double 
     if (!c || !cv || !x || !r || !d || nrows < 0 || n < 0 || !(theta != 0.0) || x == r || x == d || r == d || x == cv || d == cv) return MIMSEM_ERR_ARG;
     if (nrows == 0 || n == 0) return MIMSEM_OK;
     hipLaunchKernelGGL(k_chebyshev_start, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, s, 1.0/theta, cv, ldc, r, ldr, d, ldd, x, ldx);
+    MIMSEM_HIP_TRY(hipGetLastError());
+    return MIMSEM_OK;
+}
+int mimsem_krylov_chebyshev_px(mimsem_ctx* c, int nrows, long long n, double alpha, double beta, const double* y, long long ldy,
+                               const double* b, long long ldb, const double* dinv, long long ldd, double* p, long long ldp, double* x, long long ldx,
+                               double* upd, long long ldu) {
+    if (!c || !y || !p || !x || nrows < 0 || n < 0 || (dinv && !b) || p == x || y == p || y == x) return MIMSEM_ERR_ARG;
+    if (nrows == 0 || n == 0) return MIMSEM_OK;
+    hipLaunchKernelGGL(k_chebyshev_px, dim3((unsigned)((n + 255)/256), nrows), dim3(256), 0, c->stream, n, alpha, beta, y, ldy, b, ldb, dinv, ldd, p, ldp, x, ldx, upd, ldu);
     MIMSEM_HIP_TRY(hipGetLastError());
     return MIMSEM_OK;
 }

@@ -817,6 +817,13 @@ class Engine:
         check(self.L.mimsem_krylov_chebyshev_start(self.ctx, x.shape[0], x.shape[1], float(s), float(theta), _ptr(c), c.stride(0), _ptr(r), r.stride(0),
                                                    _ptr(d), d.stride(0), _ptr(x), x.stride(0)), "chebyshev_start")
 
+    def chebyshev_px(self, alpha, beta, y, p, x, b=None, dinv=None, upd=None):
+        """z = dinv (b - y) (or y when dinv is None); p = z + beta p; x += alpha p; upd = z -- row-wise, one launch (mimsem_krylov_chebyshev_px: the
+        vector algebra of a Chebyshev step on a sharded mesh, where the operator result is completed over the halo between the passes)"""
+        st = lambda t: t.stride(0) if t is not None else 0
+        check(self.L.mimsem_krylov_chebyshev_px(self.ctx, x.shape[0], x.shape[1], float(alpha), float(beta), _ptr(y), y.stride(0), _ptr(b), st(b), _ptr(dinv), st(dinv),
+                                                _ptr(p), p.stride(0), _ptr(x), x.stride(0), _ptr(upd), st(upd)), "chebyshev_px")
+
     def axpy_dots(self, dx, x, out):
         """x += dx ; out[0] = dx . dx ; out[1] = x . x over ALL entries of the (contiguous) tensors (one launch: mimsem_krylov_axpy_dots)"""
         assert dx.is_contiguous() and x.is_contiguous() and dx.numel() == x.numel() and out.numel() == 2 and out.is_contiguous()

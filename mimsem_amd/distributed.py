@@ -312,10 +312,7 @@ class DistEngine:
         y = self.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags)
         torch.sub(b, y, out=y)
         z = self.blocks_apply(1, blocks, y, transpose=True, elem_scale=elem_scale)       # (column-major storage = the transposed read)
-        self.eng.combine(z, 1.0, None, None, beta, p, out=p)
-        x.add_(p, alpha=alpha)
-        if upd is not None:
-            upd.copy_(z)
+        self.eng.chebyshev_px(alpha, beta, z, p, x, upd=upd)                             # p = z + beta p; x += alpha p; upd = z: one launch
         return x
 
     def chebyshev_sweep(self, op, x, b, dinv, p, alpha, beta, f=None, u=None, tau=0.0, lev0=0, scale=1.0, flags=0, upd=None):
@@ -324,12 +321,7 @@ class DistEngine:
             y = self.apply_up(op, x, f, u, lev0=lev0, scale=scale, tau=tau, flags=flags)
         else:
             y = self.apply(op, x, f=f, lev0=lev0, scale=scale, flags=flags)
-        torch.sub(b, y, out=y)
-        y.mul_(dinv)
-        self.eng.combine(y, 1.0, None, None, beta, p, out=p)
-        x.add_(p, alpha=alpha)
-        if upd is not None:
-            upd.copy_(y)
+        self.eng.chebyshev_px(alpha, beta, y, p, x, b=b, dinv=dinv, upd=upd)             # z = dinv (b - y); p = z + beta p; x += alpha p; upd = z: one launch
         return x
 
     def mdot(self, V, w, k=None, out=None):

@@ -270,9 +270,8 @@ public:
                     comb(n1, -1.0, y1, 0, nullptr, 1.0, b, y1);
                     check(mimsem_elem_blocks_apply(c, 1, nk, 0, blocks1, 0, escale1, mesh->nEl_, y1, n1, z1, n1, 1.0), "mimsem_elem_blocks_apply");
                     sh->complete1(z1, nk);
-                    comb(n1, 1.0, z1, 0, nullptr, coef[k].second, p1, p1);
-                    comb(n1, coef[k].first, p1, 0, nullptr, 1.0, x, x);
-                    if (upd) comb(n1, 1.0, z1, 0, nullptr, 0.0, nullptr, upd);
+                    check(mimsem_krylov_chebyshev_px(c, nk, n1, coef[k].first, coef[k].second, z1, n1, nullptr, 0, nullptr, 0, p1, n1, x, n1, upd, n1),
+                          "mimsem_krylov_chebyshev_px");                  // p = z + beta p; x += alpha p; upd = z: one launch
                     continue;
                 }
                 const int rc = mimsem_block_chebyshev_sweep(c, MIMSEM_OP_UMAT, 0, nk, SCALE, MIMSEM_FLAG_VERT, nullptr, 0, blocks1, escale1, mesh->nEl_, b, n1,

@@ -161,11 +161,8 @@ public:
                 // sharded: the operator pass, its result completed over the halo, then the sweep's algebra  z = dinv (b - Op x); p = z + beta p; x += alpha p
                 check(mimsem_op_apply_up(c, MIMSEM_OP_PHMAT_UP, 0, 1, 1.0, tau, 0, h_, 0, u_, 0, q_, 0, y0, 0, 1.0), "PHMAT_UP");
                 sh->complete0(y0);
-                combine(n0, -1.0, y0, 0, nullptr, 1.0, rhs0, y0);
-                combine(n0, 1.0, y0, 1, dinv, 0.0, nullptr, y0);
-                combine(n0, 1.0, y0, 0, nullptr, qcoef[k].second, p0, p0);
-                combine(n0, qcoef[k].first, p0, 0, nullptr, 1.0, q_, q_);
-                if (k + 1 == qcoef.size()) copy(n0, y0, upd0);
+                check(mimsem_krylov_chebyshev_px(c, 1, n0, qcoef[k].first, qcoef[k].second, y0, n0, rhs0, n0, dinv, n0, p0, n0, q_, n0,
+                                                 k + 1 == qcoef.size() ? upd0 : nullptr, n0), "mimsem_krylov_chebyshev_px");      // one launch for five
             }
             combine(n0, 1.0, rhs0, 1, dinv, 0.0, nullptr, t0);
             log(K_MASS, upd0, t0, n0, sh ? sh->own0 : nullptr);
@@ -283,9 +280,8 @@ private:
                 combine(n1, -1.0, y1, 0, nullptr, 1.0, b, y1);
                 check(mimsem_elem_blocks_apply(c, 1, 1, 0, blocks1, 0, escale1, 0, y1, 0, z1, 0, 1.0), "mimsem_elem_blocks_apply");
                 sh->complete1(z1);
-                combine(n1, 1.0, z1, 0, nullptr, coefM[k].second, p1, p1);
-                combine(n1, coefM[k].first, p1, 0, nullptr, 1.0, out, out);
-                if (k + 1 == coefM.size()) copy(n1, z1, upd1);
+                check(mimsem_krylov_chebyshev_px(c, 1, n1, coefM[k].first, coefM[k].second, z1, n1, nullptr, 0, nullptr, 0, p1, n1, out, n1,
+                                                 k + 1 == coefM.size() ? upd1 : nullptr, n1), "mimsem_krylov_chebyshev_px");      // p = z + beta p; x += alpha p; upd = z
             }
             check(mimsem_elem_blocks_apply(c, 1, 1, 0, blocks1, 0, escale1, 0, b, 0, t1, 0, 1.0), "mimsem_elem_blocks_apply");
             done1(t1);

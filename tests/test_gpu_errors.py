@@ -231,6 +231,11 @@ def test_argument_errors_of_the_round_6_solver_entries(small):
     assert L.mimsem_krylov_axpy_dots(ctx, -1, v.data_ptr(), r.data_ptr(), out.data_ptr()) == ERR_ARG
     out.fill_(7.0)
     assert L.mimsem_krylov_axpy_dots(ctx, 0, v.data_ptr(), r.data_ptr(), out.data_ptr()) == 0 and not bool(out.any())   # empty: both norms zero
+    px_ = lambda yy, bb, dd, pp, xx: L.mimsem_krylov_chebyshev_px(ctx, 1, 100, 0.5, 0.1, yy, 100, bb, 100, dd, 100, pp, 100, xx, 100, None, 0)
+    assert px_(v.data_ptr(), None, None, r.data_ptr(), d.data_ptr()) == 0
+    assert px_(v.data_ptr(), None, v.data_ptr(), r.data_ptr(), d.data_ptr()) == ERR_ARG     # a diagonal without a right-hand side
+    assert px_(v.data_ptr(), None, None, r.data_ptr(), r.data_ptr()) == ERR_ARG             # p and x alias
+    assert px_(None, None, None, r.data_ptr(), d.data_ptr()) == ERR_ARG
     p1 = eng.zeros(1, dm.n1); x1 = eng.zeros(1, dm.n1); p0 = eng.zeros(1, dm.n0); x0 = eng.zeros(1, dm.n0); b0 = eng.zeros(1, dm.n0); h = eng.zeros(1, dm.n2)
     dual = lambda nA, upd1, pb1: L.mimsem_sw_dual_chebyshev(ctx, nA, C.addressof(coef), pB, pb, p1.data_ptr(), x1.data_ptr(), upd1, pb1,
                                                            2, C.addressof(coef), 1.0, h.data_ptr(), pb, b0.data_ptr(), b0.data_ptr(), p0.data_ptr(), x0.data_ptr(), None, None)

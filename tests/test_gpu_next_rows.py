@@ -236,6 +236,16 @@ def test_chebyshev_start_and_axpy_dots(sphere):
         c2 = c.clone()
         eng.chebyshev_start(c2, 1.0, 1.3, c2, d, x)                        # in place on c
         assert torch.equal(c2, c) and torch.equal(d, c * (1.0 / 1.3))
+    # mimsem_krylov_chebyshev_px: the vector algebra of a Chebyshev step on a sharded mesh (z = dinv (b - y) or z = y; p = z + beta p; x += alpha p)
+    for nrows, n in ((1, 5000), (3, 777)):
+        y, b, dinv, p0, x0 = (torch.randn(nrows, n, dtype=torch.float64, device=eng.device) for _ in range(5))
+        for diag in (False, True):
+            p, x, upd = p0.clone(), x0.clone(), torch.full_like(x0, float("nan"))
+            eng.chebyshev_px(0.8, 0.3, y, p, x, b=b if diag else None, dinv=dinv if diag else None, upd=upd)
+            z = dinv * (b - y) if diag else y
+            pn = torch.addcmul(z, p0, torch.tensor(0.3, dtype=torch.float64, device=eng.device))
+            assert torch.equal(upd, z)
+            assert float((p - pn).abs().max()) <= 1e-15 * float(pn.abs().max()) and float((x - (x0 + 0.8 * pn)).abs().max()) <= 1e-15 * float(x0.abs().max() + pn.abs().max())
     for n in (1, 1000, 93312, 300001, 1866240):
         dx = torch.randn(1, n, dtype=torch.float64, device=eng.device); x0 = torch.randn(1, n, dtype=torch.float64, device=eng.device)
         x = x0.clone(); out = torch.full((2,), float("nan"), dtype=torch.float64, device=eng.device)
